@@ -1,0 +1,1240 @@
+/*
+ * gsr_oracle.c -- plain-C CPU restatement of the GS-SR differentiable rasterizer hot path.
+ * TEST INFRASTRUCTURE ONLY (see gsr_oracle.h).  float32 arithmetic throughout, built with
+ * -ffp-contract=off so every +,* is a single IEEE rounding (the reference is built without --use_fast_math).
+ *
+ * Each function cites the reference file:line it follows.  Shorthand for the reference trees:
+ *   3DGS   = submodules/diff-gaussian-rasterization/cuda_rasterizer
+ *   SURFEL = submodules/diff-surfel-rasterization/cuda_rasterizer
+ *   PLANE  = submodules/diff-plane-rasterization/cuda_rasterizer
+ *   FILTER = submodules/scaffold-filter/cuda_rasterizer
+ */
+#include "gsr_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BLOCK_X 16
+#define BLOCK_Y 16
+
+/* ------------------------------------------------------------------ small linear algebra */
+/* m3 mimics a column-major 3x3 (element c[col][row]) so expressions can be restated index-for-index
+   from sources that use that convention. */
+typedef struct { float c[3][3]; } m3;
+typedef struct { float x, y, z; } f3;
+typedef struct { float x, y; } f2;
+
+static m3 m3_cols(float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2)
+{
+    m3 m; m.c[0][0]=a0; m.c[0][1]=a1; m.c[0][2]=a2; m.c[1][0]=b0; m.c[1][1]=b1; m.c[1][2]=b2;
+    m.c[2][0]=c0; m.c[2][1]=c1; m.c[2][2]=c2; return m;
+}
+/* r = a*b: r.col[j] = a * b.col[j];  element (col j,row i) = sum_k a[k][i]*b[j][k], evaluated k=0,1,2 */
+static m3 m3_mul(m3 a, m3 b)
+{
+    m3 r;
+    for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++)
+            r.c[j][i] = a.c[0][i] * b.c[j][0] + a.c[1][i] * b.c[j][1] + a.c[2][i] * b.c[j][2];
+    return r;
+}
+static m3 m3_t(m3 a)
+{
+    m3 r;
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) r.c[j][i] = a.c[i][j];
+    return r;
+}
+static float dot3(const float* a, const float* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+
+/* 3DGS auxiliary.h:58-100 */
+static f3 transformPoint4x3(f3 p, const float* m)
+{
+    f3 t = { m[0]*p.x + m[4]*p.y + m[8]*p.z + m[12],
+             m[1]*p.x + m[5]*p.y + m[9]*p.z + m[13],
+             m[2]*p.x + m[6]*p.y + m[10]*p.z + m[14] };
+    return t;
+}
+static void transformPoint4x4(f3 p, const float* m, float o[4])
+{
+    o[0] = m[0]*p.x + m[4]*p.y + m[8]*p.z + m[12];
+    o[1] = m[1]*p.x + m[5]*p.y + m[9]*p.z + m[13];
+    o[2] = m[2]*p.x + m[6]*p.y + m[10]*p.z + m[14];
+    o[3] = m[3]*p.x + m[7]*p.y + m[11]*p.z + m[15];
+}
+static f3 transformVec4x3(f3 p, const float* m)
+{
+    f3 t = { m[0]*p.x + m[4]*p.y + m[8]*p.z,
+             m[1]*p.x + m[5]*p.y + m[9]*p.z,
+             m[2]*p.x + m[6]*p.y + m[10]*p.z };
+    return t;
+}
+static f3 transformVec4x3Transpose(f3 p, const float* m)
+{
+    f3 t = { m[0]*p.x + m[1]*p.y + m[2]*p.z,
+             m[4]*p.x + m[5]*p.y + m[6]*p.z,
+             m[8]*p.x + m[9]*p.y + m[10]*p.z };
+    return t;
+}
+/* 3DGS auxiliary.h:41-44 -- NB the literals are double, so this is evaluated in double */
+static float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* 3DGS auxiliary.h:46-56 */
+static void getRect(f2 p, int max_radius, int gx, int gy, uint32_t rmin[2], uint32_t rmax[2])
+{
+    rmin[0] = (uint32_t)imin(gx, imax(0, (int)((p.x - max_radius) / BLOCK_X)));
+    rmin[1] = (uint32_t)imin(gy, imax(0, (int)((p.y - max_radius) / BLOCK_Y)));
+    rmax[0] = (uint32_t)imin(gx, imax(0, (int)((p.x + max_radius + BLOCK_X - 1) / BLOCK_X)));
+    rmax[1] = (uint32_t)imin(gy, imax(0, (int)((p.y + max_radius + BLOCK_Y - 1) / BLOCK_Y)));
+}
+
+/* 3DGS auxiliary.h:139-164 (the prefiltered trap is not restated: it aborts the reference) */
+static int in_frustum(int idx, const float* pts, const float* view, f3* p_view)
+{
+    f3 p = { pts[3*idx], pts[3*idx+1], pts[3*idx+2] };
+    *p_view = transformPoint4x3(p, view);
+    return !(p_view->z <= 0.2f);
+}
+
+/* ------------------------------------------------------------------ spherical harmonics */
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f };
+static const float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                -0.5900435899266435f };
+
+/* 3DGS forward.cu:20-71 */
+static void computeColorFromSH(int idx, int deg, int M, const float* means, const float* campos,
+                               const float* shs, uint8_t* clamped, float rgb[3])
+{
+    float dx = means[3*idx] - campos[0], dy = means[3*idx+1] - campos[1], dz = means[3*idx+2] - campos[2];
+    float len = sqrtf(dx*dx + dy*dy + dz*dz);
+    float x = dx / len, y = dy / len, z = dz / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    for (int c = 0; c < 3; c++) {
+        float r = SH_C0 * sh[0*3+c];
+        if (deg > 0) {
+            r = r - SH_C1 * y * sh[1*3+c] + SH_C1 * z * sh[2*3+c] - SH_C1 * x * sh[3*3+c];
+            if (deg > 1) {
+                float xx = x*x, yy = y*y, zz = z*z, xy = x*y, yz = y*z, xz = x*z;
+                r = r + SH_C2[0] * xy * sh[4*3+c] + SH_C2[1] * yz * sh[5*3+c]
+                      + SH_C2[2] * (2.0f*zz - xx - yy) * sh[6*3+c]
+                      + SH_C2[3] * xz * sh[7*3+c] + SH_C2[4] * (xx - yy) * sh[8*3+c];
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.0f*xx - yy) * sh[9*3+c]
+                          + SH_C3[1] * xy * z * sh[10*3+c]
+                          + SH_C3[2] * y * (4.0f*zz - xx - yy) * sh[11*3+c]
+                          + SH_C3[3] * z * (2.0f*zz - 3.0f*xx - 3.0f*yy) * sh[12*3+c]
+                          + SH_C3[4] * x * (4.0f*zz - xx - yy) * sh[13*3+c]
+                          + SH_C3[5] * z * (xx - yy) * sh[14*3+c]
+                          + SH_C3[6] * x * (xx - 3.0f*yy) * sh[15*3+c];
+                }
+            }
+        }
+        r += 0.5f;
+        clamped[3*idx + c] = (r < 0);
+        rgb[c] = r > 0.0f ? r : 0.0f;
+    }
+}
+
+/* 3DGS auxiliary.h:110-120 */
+static f3 dnormvdv(f3 v, f3 dv)
+{
+    float sum2 = v.x*v.x + v.y*v.y + v.z*v.z;
+    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    f3 r;
+    r.x = ((+sum2 - v.x*v.x) * dv.x - v.y*v.x*dv.y - v.z*v.x*dv.z) * invsum32;
+    r.y = (-v.x*v.y*dv.x + (sum2 - v.y*v.y) * dv.y - v.z*v.y*dv.z) * invsum32;
+    r.z = (-v.x*v.z*dv.x - v.y*v.z*dv.y + (sum2 - v.z*v.z) * dv.z) * invsum32;
+    return r;
+}
+
+/* 3DGS backward.cu:20-139 */
+static void computeColorFromSH_bwd(int idx, int deg, int M, const float* means, const float* campos,
+                                   const float* shs, const uint8_t* clamped, const float* dL_dcolor,
+                                   float* dL_dmeans, float* dL_dshs)
+{
+    f3 dir_orig = { means[3*idx] - campos[0], means[3*idx+1] - campos[1], means[3*idx+2] - campos[2] };
+    float len = sqrtf(dir_orig.x*dir_orig.x + dir_orig.y*dir_orig.y + dir_orig.z*dir_orig.z);
+    float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    float* dL_dsh = dL_dshs + (size_t)idx * M * 3;
+    float dRGB[3];
+    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[3*idx+c] * (clamped[3*idx+c] ? 0.0f : 1.0f);
+
+    float dRGBdx[3] = {0,0,0}, dRGBdy[3] = {0,0,0}, dRGBdz[3] = {0,0,0};
+#define SHSET(k, coef) do { float cf_ = (coef); for (int c = 0; c < 3; c++) dL_dsh[(k)*3+c] = cf_ * dRGB[c]; } while (0)
+    SHSET(0, SH_C0);
+    if (deg > 0) {
+        SHSET(1, -SH_C1 * y); SHSET(2, SH_C1 * z); SHSET(3, -SH_C1 * x);
+        for (int c = 0; c < 3; c++) {
+            dRGBdx[c] = -SH_C1 * sh[3*3+c]; dRGBdy[c] = -SH_C1 * sh[1*3+c]; dRGBdz[c] = SH_C1 * sh[2*3+c];
+        }
+        if (deg > 1) {
+            float xx = x*x, yy = y*y, zz = z*z, xy = x*y, yz = y*z, xz = x*z;
+            SHSET(4, SH_C2[0] * xy); SHSET(5, SH_C2[1] * yz); SHSET(6, SH_C2[2] * (2.f*zz - xx - yy));
+            SHSET(7, SH_C2[3] * xz); SHSET(8, SH_C2[4] * (xx - yy));
+            for (int c = 0; c < 3; c++) {
+                dRGBdx[c] += SH_C2[0] * y * sh[4*3+c] + SH_C2[2] * 2.f * -x * sh[6*3+c] + SH_C2[3] * z * sh[7*3+c] + SH_C2[4] * 2.f * x * sh[8*3+c];
+                dRGBdy[c] += SH_C2[0] * x * sh[4*3+c] + SH_C2[1] * z * sh[5*3+c] + SH_C2[2] * 2.f * -y * sh[6*3+c] + SH_C2[4] * 2.f * -y * sh[8*3+c];
+                dRGBdz[c] += SH_C2[1] * y * sh[5*3+c] + SH_C2[2] * 2.f * 2.f * z * sh[6*3+c] + SH_C2[3] * x * sh[7*3+c];
+            }
+            if (deg > 2) {
+                SHSET(9,  SH_C3[0] * y * (3.f*xx - yy));
+                SHSET(10, SH_C3[1] * xy * z);
+                SHSET(11, SH_C3[2] * y * (4.f*zz - xx - yy));
+                SHSET(12, SH_C3[3] * z * (2.f*zz - 3.f*xx - 3.f*yy));
+                SHSET(13, SH_C3[4] * x * (4.f*zz - xx - yy));
+                SHSET(14, SH_C3[5] * z * (xx - yy));
+                SHSET(15, SH_C3[6] * x * (xx - 3.f*yy));
+                for (int c = 0; c < 3; c++) {
+                    dRGBdx[c] += (SH_C3[0] * sh[9*3+c] * 3.f * 2.f * xy + SH_C3[1] * sh[10*3+c] * yz
+                                + SH_C3[2] * sh[11*3+c] * -2.f * xy + SH_C3[3] * sh[12*3+c] * -3.f * 2.f * xz
+                                + SH_C3[4] * sh[13*3+c] * (-3.f*xx + 4.f*zz - yy) + SH_C3[5] * sh[14*3+c] * 2.f * xz
+                                + SH_C3[6] * sh[15*3+c] * 3.f * (xx - yy));
+                    dRGBdy[c] += (SH_C3[0] * sh[9*3+c] * 3.f * (xx - yy) + SH_C3[1] * sh[10*3+c] * xz
+                                + SH_C3[2] * sh[11*3+c] * (-3.f*yy + 4.f*zz - xx) + SH_C3[3] * sh[12*3+c] * -3.f * 2.f * yz
+                                + SH_C3[4] * sh[13*3+c] * -2.f * xy + SH_C3[5] * sh[14*3+c] * -2.f * yz
+                                + SH_C3[6] * sh[15*3+c] * -3.f * 2.f * xy);
+                    dRGBdz[c] += (SH_C3[1] * sh[10*3+c] * xy + SH_C3[2] * sh[11*3+c] * 4.f * 2.f * yz
+                                + SH_C3[3] * sh[12*3+c] * 3.f * (2.f*zz - xx - yy) + SH_C3[4] * sh[13*3+c] * 4.f * 2.f * xz
+                                + SH_C3[5] * sh[14*3+c] * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SHSET
+    f3 dL_ddir = { dot3(dRGBdx, dRGB), dot3(dRGBdy, dRGB), dot3(dRGBdz, dRGB) };
+    f3 dm = dnormvdv(dir_orig, dL_ddir);
+    dL_dmeans[3*idx+0] += dm.x; dL_dmeans[3*idx+1] += dm.y; dL_dmeans[3*idx+2] += dm.z;
+}
+
+/* ------------------------------------------------------------------ EWA preprocess helpers */
+/* 3DGS forward.cu:118-152 (quaternion deliberately NOT normalised) */
+static void computeCov3D(const float* scale, float mod, const float* rot, float* cov3D)
+{
+    m3 S = m3_cols(mod*scale[0],0,0, 0,mod*scale[1],0, 0,0,mod*scale[2]);
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    m3 R = m3_cols(1.f - 2.f*(y*y + z*z), 2.f*(x*y - r*z), 2.f*(x*z + r*y),
+                   2.f*(x*y + r*z), 1.f - 2.f*(x*x + z*z), 2.f*(y*z - r*x),
+                   2.f*(x*z - r*y), 2.f*(y*z + r*x), 1.f - 2.f*(x*x + y*y));
+    m3 Mm = m3_mul(S, R);
+    m3 Sigma = m3_mul(m3_t(Mm), Mm);
+    cov3D[0] = Sigma.c[0][0]; cov3D[1] = Sigma.c[0][1]; cov3D[2] = Sigma.c[0][2];
+    cov3D[3] = Sigma.c[1][1]; cov3D[4] = Sigma.c[1][2]; cov3D[5] = Sigma.c[2][2];
+}
+
+/* 3DGS forward.cu:74-113; also returns T for the backward (backward.cu:144-195 recomputes the same) */
+static void computeCov2D(f3 mean, float fx, float fy, float tan_fovx, float tan_fovy, const float* cov3D,
+                         const float* view, float cov[3], m3* T_out, m3* Vrk_out, f3* t_out,
+                         float* xgm, float* ygm)
+{
+    f3 t = transformPoint4x3(mean, view);
+    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    const float txtz = t.x / t.z, tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    if (xgm) *xgm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    if (ygm) *ygm = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    m3 J = m3_cols(fx / t.z, 0.0f, -(fx * t.x) / (t.z * t.z),
+                   0.0f, fy / t.z, -(fy * t.y) / (t.z * t.z),
+                   0, 0, 0);
+    m3 Wm = m3_cols(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    m3 T = m3_mul(Wm, J);
+    m3 Vrk = m3_cols(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    m3 c2 = m3_mul(m3_mul(m3_t(T), m3_t(Vrk)), T);
+    cov[0] = c2.c[0][0] + 0.3f;   /* low-pass: >= one pixel */
+    cov[1] = c2.c[0][1];
+    cov[2] = c2.c[1][1] + 0.3f;
+    if (T_out) *T_out = T;
+    if (Vrk_out) *Vrk_out = Vrk;
+    if (t_out) *t_out = t;
+}
+
+/* ------------------------------------------------------------------ surfel preprocess helpers */
+/* SURFEL auxiliary.h:215-238 */
+static m3 quat_to_rotmat(const float* q)
+{
+    float s = 1.0f / sqrtf(q[3]*q[3] + q[0]*q[0] + q[1]*q[1] + q[2]*q[2]);
+    float w = q[0]*s, x = q[1]*s, y = q[2]*s, z = q[3]*s;
+    return m3_cols(1.f - 2.f*(y*y + z*z), 2.f*(x*y + w*z), 2.f*(x*z - w*y),
+                   2.f*(x*y - w*z), 1.f - 2.f*(x*x + z*z), 2.f*(y*z + w*x),
+                   2.f*(x*z + w*y), 2.f*(y*z - w*x), 1.f - 2.f*(x*x + y*y));
+}
+/* SURFEL auxiliary.h:241-284; v_R indexed [col][row] */
+static void quat_to_rotmat_vjp(const float* q, m3 v_R, float out[4])
+{
+    float s = 1.0f / sqrtf(q[3]*q[3] + q[0]*q[0] + q[1]*q[1] + q[2]*q[2]);
+    float w = q[0]*s, x = q[1]*s, y = q[2]*s, z = q[3]*s;
+    out[0] = 2.f * (x * (v_R.c[1][2] - v_R.c[2][1]) + y * (v_R.c[2][0] - v_R.c[0][2]) + z * (v_R.c[0][1] - v_R.c[1][0]));
+    out[1] = 2.f * (-2.f * x * (v_R.c[1][1] + v_R.c[2][2]) + y * (v_R.c[0][1] + v_R.c[1][0]) +
+                    z * (v_R.c[0][2] + v_R.c[2][0]) + w * (v_R.c[1][2] - v_R.c[2][1]));
+    out[2] = 2.f * (x * (v_R.c[0][1] + v_R.c[1][0]) - 2.f * y * (v_R.c[0][0] + v_R.c[2][2]) +
+                    z * (v_R.c[1][2] + v_R.c[2][1]) + w * (v_R.c[2][0] - v_R.c[0][2]));
+    out[3] = 2.f * (x * (v_R.c[0][2] + v_R.c[2][0]) + y * (v_R.c[1][2] + v_R.c[2][1]) -
+                    2.f * z * (v_R.c[0][0] + v_R.c[1][1]) + w * (v_R.c[0][1] - v_R.c[1][0]));
+}
+
+/* Pm[k][c] = (world2ndc * ndc2pix) as a 4x3 matrix: column c of the pixel-space homogeneous coordinate.
+   SURFEL forward.cu:99-112 / backward.cu:498-513 */
+static void surfel_P(const float* proj, int W, int H, float Pm[4][3])
+{
+    float n00 = (float)((float)W / 2.0), n03 = (float)((float)(W - 1) / 2.0);
+    float n11 = (float)((float)H / 2.0), n13 = (float)((float)(H - 1) / 2.0);
+    for (int k = 0; k < 4; k++) {
+        /* world2ndc element (row k, col j) = proj[4k + j] */
+        float a0 = proj[4*k+0], a1 = proj[4*k+1], a3 = proj[4*k+3];
+        float a2 = proj[4*k+2];
+        Pm[k][0] = a0 * n00 + a1 * 0.0f + a2 * 0.0f + a3 * n03;
+        Pm[k][1] = a0 * 0.0f + a1 * n11 + a2 * 0.0f + a3 * n13;
+        Pm[k][2] = a0 * 0.0f + a1 * 0.0f + a2 * 0.0f + a3 * 1.0f;
+    }
+}
+
+/* SURFEL forward.cu:75-115.  T stored as three float3: Tu (x coeffs of u,v,1), Tv (y coeffs), Tw (w coeffs) */
+static void compute_transmat(f3 p, const float* scale2, float mod, const float* rot, const float* proj,
+                             const float* view, int W, int H, float T[9], f3* normal)
+{
+    m3 R = quat_to_rotmat(rot);
+    float sx = mod * scale2[0], sy = mod * scale2[1];
+    float L0[3] = { R.c[0][0]*sx, R.c[0][1]*sx, R.c[0][2]*sx };
+    float L1[3] = { R.c[1][0]*sy, R.c[1][1]*sy, R.c[1][2]*sy };
+    float L2[3] = { R.c[2][0], R.c[2][1], R.c[2][2] };
+    float rows[3][4] = { { L0[0], L0[1], L0[2], 0.0f }, { L1[0], L1[1], L1[2], 0.0f }, { p.x, p.y, p.z, 1.0f } };
+    /* (splat2world^T * world2ndc) first, then * ndc2pix -- left-to-right like the source expression */
+    float n00 = (float)((float)W / 2.0), n03 = (float)((float)(W - 1) / 2.0);
+    float n11 = (float)((float)H / 2.0), n13 = (float)((float)(H - 1) / 2.0);
+    for (int r = 0; r < 3; r++) {
+        float h[4];
+        for (int j = 0; j < 4; j++)
+            h[j] = rows[r][0]*proj[0*4+j] + rows[r][1]*proj[1*4+j] + rows[r][2]*proj[2*4+j] + rows[r][3]*proj[3*4+j];
+        float tx = h[0]*n00 + h[1]*0.0f + h[2]*0.0f + h[3]*n03;
+        float ty = h[0]*0.0f + h[1]*n11 + h[2]*0.0f + h[3]*n13;
+        float tw = h[0]*0.0f + h[1]*0.0f + h[2]*0.0f + h[3]*1.0f;
+        T[0 + r] = tx; T[3 + r] = ty; T[6 + r] = tw;
+    }
+    f3 l2 = { L2[0], L2[1], L2[2] };
+    *normal = transformVec4x3(l2, view);
+}
+
+/* SURFEL forward.cu:119-145 */
+static int compute_aabb(const float T[9], float cutoff, f2* point_image, f2* extent)
+{
+    const float* Tu = T; const float* Tv = T + 3; const float* Tw = T + 6;
+    float t[3] = { cutoff*cutoff, cutoff*cutoff, -1.0f };
+    float ww[3] = { Tw[0]*Tw[0], Tw[1]*Tw[1], Tw[2]*Tw[2] };
+    float d = dot3(t, ww);
+    if (d == 0.0f) return 0;
+    float inv = 1 / d;
+    float f[3] = { inv*t[0], inv*t[1], inv*t[2] };
+    float uw[3] = { Tu[0]*Tw[0], Tu[1]*Tw[1], Tu[2]*Tw[2] };
+    float vw[3] = { Tv[0]*Tw[0], Tv[1]*Tw[1], Tv[2]*Tw[2] };
+    float uu[3] = { Tu[0]*Tu[0], Tu[1]*Tu[1], Tu[2]*Tu[2] };
+    float vv[3] = { Tv[0]*Tv[0], Tv[1]*Tv[1], Tv[2]*Tv[2] };
+    float px = dot3(f, uw), py = dot3(f, vw);
+    float h0x = px*px - dot3(f, uu), h0y = py*py - dot3(f, vv);
+    point_image->x = px; point_image->y = py;
+    extent->x = sqrtf(fmaxf(1e-4f, h0x)); extent->y = sqrtf(fmaxf(1e-4f, h0y));
+    return 1;
+}
+
+/* ------------------------------------------------------------------ state */
+struct ref_state {
+    int variant, P, W, H, gx, gy, T, N, R;
+    /* geometry state (3DGS rasterizer_impl.cu:155-170, SURFEL :162-163) */
+    float* depths; uint8_t* clamped; float* means2D; float* cov3D /* or transMat (9) */;
+    float* conic_opacity /* or normal_opacity */; float* rgb; uint32_t* tiles_touched; uint32_t* point_offsets;
+    int32_t* radii;
+    /* binning */
+    uint64_t* keys; uint32_t* point_list;
+    /* image */
+    float* final_T; uint32_t* n_contrib; uint32_t* ranges;
+    float* out_all_map; /* PLANE: kept for backward (all_map_pixels) */
+};
+
+static void* xcalloc(size_t n, size_t s) { void* p = calloc(n ? n : 1, s); if (!p) { fprintf(stderr, "oracle: OOM\n"); abort(); } return p; }
+
+void ref_free(ref_state* st)
+{
+    if (!st) return;
+    free(st->depths); free(st->clamped); free(st->means2D); free(st->cov3D); free(st->conic_opacity);
+    free(st->rgb); free(st->tiles_touched); free(st->point_offsets); free(st->radii);
+    free(st->keys); free(st->point_list); free(st->final_T); free(st->n_contrib); free(st->ranges);
+    free(st->out_all_map);
+    free(st);
+}
+
+/* 3DGS rasterizer_impl.cu:35-50 */
+static uint32_t getHigherMsb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) { step /= 2; if (n >> msb) msb += step; else msb -= step; }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+/* stable LSD radix sort of (key,value) pairs on bits [0,end_bit): semantics of cub::DeviceRadixSort::SortPairs
+   as called at 3DGS rasterizer_impl.cu:303-308 */
+static void radix_sort_pairs(uint64_t* keys, uint32_t* vals, size_t n, int end_bit)
+{
+    uint64_t* k2 = (uint64_t*)xcalloc(n, sizeof(uint64_t));
+    uint32_t* v2 = (uint32_t*)xcalloc(n, sizeof(uint32_t));
+    for (int shift = 0; shift < end_bit; shift += 8) {
+        int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+        uint32_t mask = (1u << bits) - 1u;
+        size_t cnt[257]; memset(cnt, 0, sizeof(cnt));
+        for (size_t i = 0; i < n; i++) cnt[((keys[i] >> shift) & mask) + 1]++;
+        for (int b = 0; b < 256; b++) cnt[b + 1] += cnt[b];
+        for (size_t i = 0; i < n; i++) { size_t d = (keys[i] >> shift) & mask; size_t o = cnt[d]++; k2[o] = keys[i]; v2[o] = vals[i]; }
+        uint64_t* tk = keys; keys = k2; k2 = tk; uint32_t* tv = vals; vals = v2; v2 = tv;
+    }
+    /* after an odd number of passes the result lives in the scratch arrays; copy back */
+    int passes = (end_bit + 7) / 8;
+    if (passes & 1) { memcpy(k2, keys, n * sizeof(uint64_t)); memcpy(v2, vals, n * sizeof(uint32_t)); free(keys); free(vals); }
+    else { free(k2); free(v2); }
+}
+
+/* ------------------------------------------------------------------ forward */
+/* per-gaussian preprocess: EWA = 3DGS forward.cu:156-256 (PLANE forward.cu:156-268 identical);
+   SURFEL = forward.cu:149-251 */
+static void preprocess_one(ref_state* st, const ref_inputs* in, int idx, float fx, float fy)
+{
+    const int W = in->W, H = in->H;
+    st->radii[idx] = 0; st->tiles_touched[idx] = 0;
+    f3 p_view;
+    if (!in_frustum(idx, in->means3D, in->viewmatrix, &p_view)) return;
+    f3 p_orig = { in->means3D[3*idx], in->means3D[3*idx+1], in->means3D[3*idx+2] };
+
+    f2 point_image; float my_radius;
+    uint32_t rmin[2], rmax[2];
+    if (st->variant != REF_SURFEL) {
+        float ph[4]; transformPoint4x4(p_orig, in->projmatrix, ph);
+        float p_w = 1.0f / (ph[3] + 0.0000001f);
+        float projx = ph[0] * p_w, projy = ph[1] * p_w;
+        const float* cov3D;
+        if (in->cov3D_precomp) cov3D = in->cov3D_precomp + 6*idx;
+        else { computeCov3D(in->scales + 3*idx, in->scale_modifier, in->rotations + 4*idx, st->cov3D + 6*idx); cov3D = st->cov3D + 6*idx; }
+        float cov[3];
+        computeCov2D(p_orig, fx, fy, in->tanfovx, in->tanfovy, cov3D, in->viewmatrix, cov, NULL, NULL, NULL, NULL, NULL);
+        float det = (cov[0] * cov[2] - cov[1] * cov[1]);
+        if (det == 0.0f) return;
+        float det_inv = 1.f / det;
+        float conic[3] = { cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv };
+        float mid = 0.5f * (cov[0] + cov[2]);
+        float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        point_image.x = ndc2Pix(projx, W); point_image.y = ndc2Pix(projy, H);
+        getRect(point_image, (int)my_radius, st->gx, st->gy, rmin, rmax);
+        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) return;
+        st->conic_opacity[4*idx+0] = conic[0]; st->conic_opacity[4*idx+1] = conic[1];
+        st->conic_opacity[4*idx+2] = conic[2]; st->conic_opacity[4*idx+3] = in->opacities[idx];
+    } else {
+        float T[9]; f3 normal;
+        if (!in->cov3D_precomp) {
+            compute_transmat(p_orig, in->scales + 2*idx, in->scale_modifier, in->rotations + 4*idx,
+                             in->projmatrix, in->viewmatrix, W, H, T, &normal);
+            memcpy(st->cov3D + 9*idx, T, sizeof(T));
+        } else {
+            memcpy(T, in->cov3D_precomp + 9*idx, sizeof(T));
+            normal.x = 0.0f; normal.y = 0.0f; normal.z = 1.0f;
+        }
+        /* DUAL_VISIABLE, SURFEL forward.cu:209-214 */
+        float cosv = -(p_view.x*normal.x + p_view.y*normal.y + p_view.z*normal.z);
+        if (cosv == 0) return;
+        float mult = cosv > 0 ? 1.f : -1.f;
+        normal.x = mult*normal.x; normal.y = mult*normal.y; normal.z = mult*normal.z;
+        const float cutoff = 3.0f;
+        f2 extent;
+        if (!compute_aabb(T, cutoff, &point_image, &extent)) return;
+        my_radius = ceilf(fmaxf(fmaxf(extent.x, extent.y), cutoff * 0.707106f));
+        getRect(point_image, (int)my_radius, st->gx, st->gy, rmin, rmax);
+        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) return;
+        st->conic_opacity[4*idx+0] = normal.x; st->conic_opacity[4*idx+1] = normal.y;
+        st->conic_opacity[4*idx+2] = normal.z; st->conic_opacity[4*idx+3] = in->opacities[idx];
+    }
+    if (!in->colors_precomp) {
+        float rgb[3];
+        computeColorFromSH(idx, in->D, in->M, in->means3D, in->campos, in->shs, st->clamped, rgb);
+        st->rgb[3*idx] = rgb[0]; st->rgb[3*idx+1] = rgb[1]; st->rgb[3*idx+2] = rgb[2];
+    }
+    st->depths[idx] = p_view.z;
+    st->radii[idx] = (int)my_radius;
+    st->means2D[2*idx] = point_image.x; st->means2D[2*idx+1] = point_image.y;
+    st->tiles_touched[idx] = (rmax[1] - rmin[1]) * (rmax[0] - rmin[0]);
+}
+
+static const float near_n = 0.2f, far_n = 100.0f, FilterInvSquare = 2.0f;
+
+/* blend forward for one pixel of one tile.  EWA: 3DGS forward.cu:261-374.  PLANE: forward.cu:273-407.
+   SURFEL: forward.cu:256-448. */
+static void blend_pixel_fwd(const ref_state* st, const ref_inputs* in, const float* feat, float fx, float fy,
+                            uint32_t px, uint32_t py, uint32_t r0, uint32_t r1,
+                            float* out_color, float* out_others, int32_t* out_observe,
+                            float* out_all_map, float* out_plane_depth)
+{
+    const int W = st->W, H = st->H; const size_t HW = (size_t)H * W;
+    const uint32_t pix_id = (uint32_t)W * py + px;
+    const float pixfx = (float)px, pixfy = (float)py;
+    float T = 1.0f; uint32_t contributor = 0, last_contributor = 0;
+    float C[3] = {0,0,0};
+    /* surfel aux */
+    float Nn[3] = {0,0,0}, Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0, median_contributor = -1;
+    int surf_idx = -1; float median_normal[3] = {0,0,0};
+    /* plane aux */
+    float All_map[5] = {0,0,0,0,0};
+    const float rayx = (pixfx - (float)(W * 0.5f)) / fx, rayy = (pixfy - (float)(H * 0.5f)) / fy;
+
+    for (uint32_t k = r0; k < r1; k++) {
+        const uint32_t id = st->point_list[k];
+        contributor++;
+        float alpha, depth = 0; const float* nor_o = st->conic_opacity + 4*id;
+        if (st->variant != REF_SURFEL) {
+            float dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
+            const float* con_o = nor_o;
+            float power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+            if (power > 0.0f) continue;
+            alpha = fminf(0.99f, con_o[3] * expf(power));
+        } else {
+            const float* Tm = (in->cov3D_precomp ? in->cov3D_precomp : st->cov3D) + 9*id;
+            const float* Tu = Tm; const float* Tv = Tm + 3; const float* Tw = Tm + 6;
+            float kx = pixfx*Tw[0] - Tu[0], ky = pixfx*Tw[1] - Tu[1], kz = pixfx*Tw[2] - Tu[2];
+            float lx = pixfy*Tw[0] - Tv[0], ly = pixfy*Tw[1] - Tv[1], lz = pixfy*Tw[2] - Tv[2];
+            float ppx = ky*lz - kz*ly, ppy = kz*lx - kx*lz, ppz = kx*ly - ky*lx;
+            if (ppz == 0.0f) continue;
+            float sx = ppx / ppz, sy = ppy / ppz;
+            float rho3d = (sx*sx + sy*sy);
+            float dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
+            float rho2d = FilterInvSquare * (dx*dx + dy*dy);
+            float rho = fminf(rho3d, rho2d);
+            depth = (rho3d <= rho2d) ? (sx*Tw[0] + sy*Tw[1]) + Tw[2] : Tw[2];
+            if (depth < near_n) continue;
+            float power = -0.5f * rho;
+            if (power > 0.0f) continue;
+            alpha = fminf(0.99f, nor_o[3] * expf(power));
+        }
+        if (alpha < 1.0f / 255.0f) continue;
+        float test_T = T * (1 - alpha);
+        if (test_T < 0.0001f) break;   /* done = true: nothing after this can contribute */
+        float w = alpha * T;
+        if (st->variant == REF_SURFEL) {
+            float A = 1 - T;
+            float m = far_n / (far_n - near_n) * (1 - near_n / depth);
+            distortion += (m * m * A + M2 - 2 * m * M1) * w;
+            Dd += depth * w; M1 += m * w; M2 += m * m * w;
+            if (T > 0.5f) {
+                median_depth = depth; surf_idx = (int)id;
+                for (int ch = 0; ch < 3; ch++) median_normal[ch] = nor_o[ch];
+                median_contributor = (float)contributor;
+            }
+            for (int ch = 0; ch < 3; ch++) Nn[ch] += nor_o[ch] * w;
+        }
+        for (int ch = 0; ch < 3; ch++) C[ch] += feat[3*id + ch] * alpha * T;
+        if (st->variant == REF_PLANE) {
+            if (in->render_geo)
+                for (int ch = 0; ch < 5; ch++) All_map[ch] += in->all_map[5*id + ch] * alpha * T;
+            if (T > 0.5f) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                out_observe[id] += 1;
+            }
+        }
+        T = test_T;
+        last_contributor = contributor;
+    }
+    st->final_T[pix_id] = T;
+    st->n_contrib[pix_id] = last_contributor;
+    for (int ch = 0; ch < 3; ch++) out_color[ch*HW + pix_id] = C[ch] + T * in->bg[ch];
+    if (st->variant == REF_SURFEL) {
+        /* float -> uint32 conversion of -1 saturates to 0 on the GPU; restated explicitly */
+        st->n_contrib[pix_id + HW] = median_contributor < 0 ? 0u : (uint32_t)median_contributor;
+        st->final_T[pix_id + HW] = M1;
+        st->final_T[pix_id + 2*HW] = M2;
+        out_others[pix_id + 0*HW] = Dd;
+        out_others[pix_id + 1*HW] = 1 - T;
+        for (int ch = 0; ch < 3; ch++) out_others[pix_id + (2+ch)*HW] = Nn[ch];
+        out_others[pix_id + 5*HW] = median_depth;
+        out_others[pix_id + 6*HW] = distortion;
+        out_others[pix_id + 7*HW] = (float)surf_idx;
+        for (int ch = 0; ch < 3; ch++) out_others[pix_id + (8+ch)*HW] = median_normal[ch];
+    }
+    if (st->variant == REF_PLANE && in->render_geo) {
+        for (int ch = 0; ch < 5; ch++) out_all_map[ch*HW + pix_id] = All_map[ch];
+        out_plane_depth[pix_id] = (float)(All_map[4] / -(All_map[0] * rayx + All_map[1] * rayy + All_map[2] + 1.0e-8));
+    }
+}
+
+ref_state* ref_forward(int variant, const ref_inputs* in, float* out_color, int32_t* radii, float* out_others,
+                       int32_t* out_observe, float* out_all_map, float* out_plane_depth)
+{
+    ref_state* st = (ref_state*)xcalloc(1, sizeof(ref_state));
+    const int P = in->P, W = in->W, H = in->H;
+    st->variant = variant; st->P = P; st->W = W; st->H = H;
+    st->gx = (W + BLOCK_X - 1) / BLOCK_X; st->gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    st->T = st->gx * st->gy; st->N = W * H;
+    const size_t HW = (size_t)W * H;
+    const int tm = (variant == REF_SURFEL) ? 9 : 6;
+    st->depths = (float*)xcalloc(P, 4); st->clamped = (uint8_t*)xcalloc((size_t)P*3, 1);
+    st->means2D = (float*)xcalloc((size_t)P*2, 4); st->cov3D = (float*)xcalloc((size_t)P*tm, 4);
+    st->conic_opacity = (float*)xcalloc((size_t)P*4, 4); st->rgb = (float*)xcalloc((size_t)P*3, 4);
+    st->tiles_touched = (uint32_t*)xcalloc(P, 4); st->point_offsets = (uint32_t*)xcalloc(P, 4);
+    st->radii = (int32_t*)xcalloc(P, 4);
+    st->final_T = (float*)xcalloc(HW * (variant == REF_SURFEL ? 3 : 1), 4);
+    st->n_contrib = (uint32_t*)xcalloc(HW * (variant == REF_SURFEL ? 2 : 1), 4);
+    st->ranges = (uint32_t*)xcalloc((size_t)st->T * 2, 4);
+
+    /* 3DGS rasterizer_impl.cu:220-221 */
+    const float focal_y = H / (2.0f * in->tanfovy);
+    const float focal_x = W / (2.0f * in->tanfovx);
+
+    memset(out_color, 0, HW * 3 * 4);
+    if (variant == REF_SURFEL) memset(out_others, 0, HW * 11 * 4);
+    if (variant == REF_PLANE) { memset(out_observe, 0, (size_t)P * 4); memset(out_all_map, 0, HW * 5 * 4); memset(out_plane_depth, 0, HW * 4); }
+
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int i = 0; i < P; i++) preprocess_one(st, in, i, focal_x, focal_y);
+    if (radii) memcpy(radii, st->radii, (size_t)P * 4);
+
+    /* inclusive scan, 3DGS rasterizer_impl.cu:277-281 */
+    uint32_t acc = 0;
+    for (int i = 0; i < P; i++) { acc += st->tiles_touched[i]; st->point_offsets[i] = acc; }
+    st->R = (int)acc;
+    st->keys = (uint64_t*)xcalloc(st->R, 8); st->point_list = (uint32_t*)xcalloc(st->R, 4);
+
+    /* duplicateWithKeys, 3DGS rasterizer_impl.cu:70-111 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int i = 0; i < P; i++) {
+        if (st->radii[i] > 0) {
+            uint32_t off = (i == 0) ? 0 : st->point_offsets[i - 1];
+            uint32_t rmin[2], rmax[2];
+            f2 pxy = { st->means2D[2*i], st->means2D[2*i+1] };
+            getRect(pxy, st->radii[i], st->gx, st->gy, rmin, rmax);
+            uint32_t dbits; memcpy(&dbits, &st->depths[i], 4);
+            for (uint32_t y = rmin[1]; y < rmax[1]; y++)
+                for (uint32_t x = rmin[0]; x < rmax[0]; x++) {
+                    uint64_t key = (uint64_t)(y * (uint32_t)st->gx + x);
+                    key <<= 32; key |= dbits;
+                    st->keys[off] = key; st->point_list[off] = (uint32_t)i; off++;
+                }
+        }
+    }
+    /* sort on bits [0, 32 + msb(T)), 3DGS rasterizer_impl.cu:300-308 */
+    int bit = (int)getHigherMsb((uint32_t)st->T);
+    if (st->R > 0) {
+        /* radix_sort_pairs may swap buffers internally; it guarantees the result ends up in the arrays passed */
+        radix_sort_pairs(st->keys, st->point_list, (size_t)st->R, 32 + bit);
+    }
+    /* identifyTileRanges, 3DGS rasterizer_impl.cu:116-138 */
+    for (int i = 0; i < st->R; i++) {
+        uint32_t cur = (uint32_t)(st->keys[i] >> 32);
+        if (i == 0) st->ranges[2*cur] = 0;
+        else {
+            uint32_t prev = (uint32_t)(st->keys[i-1] >> 32);
+            if (cur != prev) { st->ranges[2*prev+1] = (uint32_t)i; st->ranges[2*cur] = (uint32_t)i; }
+        }
+        if (i == st->R - 1) st->ranges[2*cur+1] = (uint32_t)st->R;
+    }
+
+    const float* feat = in->colors_precomp ? in->colors_precomp : st->rgb;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int tile = 0; tile < st->T; tile++) {
+        uint32_t tx = (uint32_t)(tile % st->gx), ty = (uint32_t)(tile / st->gx);
+        uint32_t r0 = st->ranges[2*tile], r1 = st->ranges[2*tile+1];
+        for (uint32_t ly = 0; ly < BLOCK_Y; ly++)
+            for (uint32_t lx = 0; lx < BLOCK_X; lx++) {
+                uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (px < (uint32_t)W && py < (uint32_t)H)
+                    blend_pixel_fwd(st, in, feat, focal_x, focal_y, px, py, r0, r1, out_color, out_others,
+                                    out_observe, out_all_map, out_plane_depth);
+            }
+    }
+    if (variant == REF_PLANE) {
+        st->out_all_map = (float*)xcalloc(HW * 5, 4);
+        memcpy(st->out_all_map, out_all_map, HW * 5 * 4);
+    }
+    return st;
+}
+
+/* ------------------------------------------------------------------ backward */
+static void atomic_addf(float* p, float v)
+{
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    *p += v;
+}
+
+/* blend backward, one pixel.  EWA: 3DGS backward.cu:399-557.  PLANE: backward.cu:399-614.
+   SURFEL: backward.cu:143-447. */
+static void blend_pixel_bwd(const ref_state* st, const ref_inputs* in, const float* colors, float fx, float fy,
+                            uint32_t px, uint32_t py, uint32_t r0, uint32_t r1, const ref_out_grads* og,
+                            float* dL_dmean2D /*[P,3]*/, float* dL_dmean2D_abs, float* dL_dconic /*[P,4]*/,
+                            float* dL_dnormal3D /*[P,3]*/, float* dL_dtransMat /*[P,9]*/, float* dL_dopacity,
+                            float* dL_dcolors, float* dL_dall_map)
+{
+    const int W = st->W, H = st->H; const size_t HW = (size_t)H * W;
+    const uint32_t pix_id = (uint32_t)W * py + px;
+    const float pixfx = (float)px, pixfy = (float)py;
+    const int toDo = (int)(r1 - r0);
+    const float T_final = st->final_T[pix_id];
+    float T = T_final;
+    uint32_t contributor = (uint32_t)toDo;
+    const int last_contributor = (int)st->n_contrib[pix_id];
+    float accum_rec[3] = {0,0,0}, dL_dpixel[3], last_color[3] = {0,0,0};
+    for (int i = 0; i < 3; i++) dL_dpixel[i] = og->dL_dcolor ? og->dL_dcolor[i*HW + pix_id] : 0.0f;
+    float last_alpha = 0;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+
+    /* PLANE extras, backward.cu:433,460-490 */
+    float accum_all_map[5] = {0,0,0,0,0}, last_all_map[5] = {0,0,0,0,0}, dL_dout_all_map[5] = {0,0,0,0,0};
+    const int geo = (st->variant == REF_PLANE) && in->render_geo;
+    if (geo) {
+        const float rayx = (float)((pixfx - W * 0.5) / fx), rayy = (float)((pixfy - H * 0.5) / fy);
+        for (int i = 0; i < 5; i++) dL_dout_all_map[i] = og->dL_dout_all_map ? og->dL_dout_all_map[i*HW + pix_id] : 0.0f;
+        const float nx = st->out_all_map[pix_id], ny = st->out_all_map[HW + pix_id], nz = st->out_all_map[2*HW + pix_id];
+        const float distance = st->out_all_map[4*HW + pix_id];
+        const float tmp = (float)(nx * rayx + ny * rayy + nz + 1.0e-8);
+        const float dpd = og->dL_dplane_depth ? og->dL_dplane_depth[pix_id] : 0.0f;
+        dL_dout_all_map[4] += (-dpd / tmp);
+        dL_dout_all_map[0] += dpd * (distance / (tmp * tmp) * rayx);
+        dL_dout_all_map[1] += dpd * (distance / (tmp * tmp) * rayy);
+        dL_dout_all_map[2] += dpd * (distance / (tmp * tmp));
+    }
+    /* SURFEL extras, backward.cu:205-243 */
+    float dL_dreg = 0, dL_ddepth = 0, dL_daccum = 0, dL_dnormal2D[3] = {0,0,0}, dL_dmedian_depth = 0;
+    float dL_dmedian_normal2D[3] = {0,0,0};
+    int median_contributor = 0;
+    float last_depth = 0, last_normal[3] = {0,0,0}, accum_depth_rec = 0, accum_alpha_rec = 0, accum_normal_rec[3] = {0,0,0};
+    float final_D = 0, final_D2 = 0, final_A = 0, last_dL_dT = 0;
+    if (st->variant == REF_SURFEL) {
+        median_contributor = (int)st->n_contrib[pix_id + HW];
+        if (og->dL_dothers) {
+            const float* g = og->dL_dothers;
+            dL_ddepth = g[0*HW + pix_id]; dL_daccum = g[1*HW + pix_id]; dL_dreg = g[6*HW + pix_id];
+            for (int i = 0; i < 3; i++) dL_dnormal2D[i] = g[(2+i)*HW + pix_id];
+            dL_dmedian_depth = g[5*HW + pix_id];
+            for (int i = 0; i < 3; i++) dL_dmedian_normal2D[i] = g[(8+i)*HW + pix_id];
+        }
+        final_D = st->final_T[pix_id + HW]; final_D2 = st->final_T[pix_id + 2*HW]; final_A = 1 - T_final;
+    }
+
+    for (int j = 0; j < toDo; j++) {
+        const uint32_t id = st->point_list[r1 - 1 - (uint32_t)j];
+        contributor--;
+        if ((int)contributor >= last_contributor) continue;   /* uint32 vs int compare in the source: both non-negative */
+        const float* nor_o = st->conic_opacity + 4*id;
+        const float dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
+        float G, alpha;
+        /* surfel intersection temporaries */
+        float kx=0,ky=0,kz=0,lx=0,ly=0,lz=0,ppz=0,sx=0,sy=0,rho3d=0,rho2d=0,c_d=0; const float* Tw = NULL;
+        if (st->variant != REF_SURFEL) {
+            const float power = -0.5f * (nor_o[0] * dx * dx + nor_o[2] * dy * dy) - nor_o[1] * dx * dy;
+            if (power > 0.0f) continue;
+            G = expf(power);
+        } else {
+            const float* Tm = (in->cov3D_precomp ? in->cov3D_precomp : st->cov3D) + 9*id;
+            const float* Tu = Tm; const float* Tv = Tm + 3; Tw = Tm + 6;
+            kx = pixfx*Tw[0] - Tu[0]; ky = pixfx*Tw[1] - Tu[1]; kz = pixfx*Tw[2] - Tu[2];
+            lx = pixfy*Tw[0] - Tv[0]; ly = pixfy*Tw[1] - Tv[1]; lz = pixfy*Tw[2] - Tv[2];
+            float ppx = ky*lz - kz*ly, ppy = kz*lx - kx*lz; ppz = kx*ly - ky*lx;
+            if (ppz == 0.0f) continue;
+            sx = ppx / ppz; sy = ppy / ppz;
+            rho3d = (sx*sx + sy*sy);
+            rho2d = FilterInvSquare * (dx*dx + dy*dy);
+            float rho = fminf(rho3d, rho2d);
+            c_d = (rho3d <= rho2d) ? (sx*Tw[0] + sy*Tw[1]) + Tw[2] : Tw[2];
+            if (c_d < near_n) continue;
+            float power = -0.5f * rho;
+            if (power > 0.0f) continue;
+            G = expf(power);
+        }
+        alpha = fminf(0.99f, nor_o[3] * G);
+        if (alpha < 1.0f / 255.0f) continue;
+
+        T = T / (1.f - alpha);
+        const float dchannel_dcolor = alpha * T;
+        float dL_dalpha = 0.0f;
+        for (int ch = 0; ch < 3; ch++) {
+            const float c = colors[3*id + ch];
+            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+            last_color[ch] = c;
+            const float dL_dchannel = dL_dpixel[ch];
+            dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+            atomic_addf(&dL_dcolors[3*id + ch], dchannel_dcolor * dL_dchannel);
+        }
+        if (geo) {
+            for (int ch = 0; ch < 5; ch++) {
+                const float c = in->all_map[5*id + ch];
+                accum_all_map[ch] = last_alpha * last_all_map[ch] + (1.f - last_alpha) * accum_all_map[ch];
+                last_all_map[ch] = c;
+                const float dL_dchannel = dL_dout_all_map[ch];
+                dL_dalpha += (c - accum_all_map[ch]) * dL_dchannel;
+                atomic_addf(&dL_dall_map[5*id + ch], dchannel_dcolor * dL_dchannel);
+            }
+        }
+        float dL_dz = 0.0f;
+        if (st->variant == REF_SURFEL) {
+            float dL_dweight = 0;
+            const float m_d = far_n / (far_n - near_n) * (1 - near_n / c_d);
+            const float dmd_dd = (far_n * near_n) / ((far_n - near_n) * c_d * c_d);
+            if ((int)contributor == median_contributor - 1) dL_dz += dL_dmedian_depth;
+            dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+            dL_dalpha += dL_dweight - last_dL_dT;
+            last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+            const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+            dL_dz += dL_dmd * dmd_dd;
+            accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+            last_depth = c_d;
+            dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+            accum_alpha_rec = (float)(last_alpha * 1.0 + (1.f - last_alpha) * accum_alpha_rec);
+            dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+            for (int ch = 0; ch < 3; ch++) {
+                accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
+                last_normal[ch] = nor_o[ch];
+                dL_dalpha += (nor_o[ch] - accum_normal_rec[ch]) * dL_dnormal2D[ch];
+                atomic_addf(&dL_dnormal3D[3*id + ch], alpha * T * dL_dnormal2D[ch]);
+                /* fork quirk (SURFEL backward.cu:381): median-normal grad goes to EVERY contributing splat */
+                atomic_addf(&dL_dnormal3D[3*id + ch], dL_dmedian_normal2D[ch]);
+            }
+        }
+        dL_dalpha *= T;
+        last_alpha = alpha;
+        float bg_dot_dpixel = 0;
+        for (int i = 0; i < 3; i++) bg_dot_dpixel += in->bg[i] * dL_dpixel[i];
+        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+        const float dL_dG = nor_o[3] * dL_dalpha;
+
+        if (st->variant != REF_SURFEL) {
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * nor_o[0] - gdy * nor_o[1];
+            const float dG_ddely = -gdy * nor_o[2] - gdx * nor_o[1];
+            atomic_addf(&dL_dmean2D[3*id + 0], dL_dG * dG_ddelx * ddelx_dx);
+            atomic_addf(&dL_dmean2D[3*id + 1], dL_dG * dG_ddely * ddely_dy);
+            if (st->variant == REF_PLANE) {
+                atomic_addf(&dL_dmean2D_abs[3*id + 0], fabsf(dL_dG * dG_ddelx * ddelx_dx));
+                atomic_addf(&dL_dmean2D_abs[3*id + 1], fabsf(dL_dG * dG_ddely * ddely_dy));
+            }
+            atomic_addf(&dL_dconic[4*id + 0], -0.5f * gdx * dx * dL_dG);
+            atomic_addf(&dL_dconic[4*id + 1], -0.5f * gdx * dy * dL_dG);
+            atomic_addf(&dL_dconic[4*id + 3], -0.5f * gdy * dy * dL_dG);
+        } else {
+            dL_dz += alpha * T * dL_ddepth;
+            if (rho3d <= rho2d) {
+                const float dL_dsx = dL_dG * -G * sx + dL_dz * Tw[0];
+                const float dL_dsy = dL_dG * -G * sy + dL_dz * Tw[1];
+                const float dsx_pz = dL_dsx / ppz, dsy_pz = dL_dsy / ppz;
+                const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * sx + dsy_pz * sy);
+                /* dL_dk = cross(l, dL_dp); dL_dl = cross(dL_dp, k) */
+                const float dkx = ly*dpz - lz*dpy, dky = lz*dpx - lx*dpz, dkz = lx*dpy - ly*dpx;
+                const float dlx = dpy*kz - dpz*ky, dly = dpz*kx - dpx*kz, dlz = dpx*ky - dpy*kx;
+                float* g = dL_dtransMat + 9*id;
+                atomic_addf(&g[0], -dkx); atomic_addf(&g[1], -dky); atomic_addf(&g[2], -dkz);
+                atomic_addf(&g[3], -dlx); atomic_addf(&g[4], -dly); atomic_addf(&g[5], -dlz);
+                atomic_addf(&g[6], pixfx * dkx + pixfy * dlx + dL_dz * sx);
+                atomic_addf(&g[7], pixfx * dky + pixfy * dly + dL_dz * sy);
+                atomic_addf(&g[8], pixfx * dkz + pixfy * dlz + dL_dz * 1.0f);
+            } else {
+                const float dG_ddelx = -G * FilterInvSquare * dx;
+                const float dG_ddely = -G * FilterInvSquare * dy;
+                atomic_addf(&dL_dmean2D[3*id + 0], dL_dG * dG_ddelx);
+                atomic_addf(&dL_dmean2D[3*id + 1], dL_dG * dG_ddely);
+                atomic_addf(&dL_dtransMat[9*id + 8], dL_dz);
+            }
+        }
+        atomic_addf(&dL_dopacity[id], G * dL_dalpha);
+    }
+}
+
+/* 3DGS backward.cu:144-274 */
+static void computeCov2D_bwd(const ref_inputs* in, int idx, const float* cov3Ds, float h_x, float h_y,
+                             const float* dL_dconics, float* dL_dmeans, float* dL_dcov)
+{
+    const float* cov3D = cov3Ds + 6*idx;
+    f3 mean = { in->means3D[3*idx], in->means3D[3*idx+1], in->means3D[3*idx+2] };
+    float dcx = dL_dconics[4*idx], dcy = dL_dconics[4*idx+1], dcz = dL_dconics[4*idx+3];
+    float cov[3]; m3 T, Vrk; f3 t; float x_grad_mul, y_grad_mul;
+    computeCov2D(mean, h_x, h_y, in->tanfovx, in->tanfovy, cov3D, in->viewmatrix, cov, &T, &Vrk, &t, &x_grad_mul, &y_grad_mul);
+    const float* vm = in->viewmatrix;
+    m3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
+    float a = cov[0], b = cov[1], c = cov[2];
+    float denom = a * c - b * b;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
+        dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
+        dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+        dL_dcov[6*idx+0] = (T.c[0][0]*T.c[0][0]*dL_da + T.c[0][0]*T.c[1][0]*dL_db + T.c[1][0]*T.c[1][0]*dL_dc);
+        dL_dcov[6*idx+3] = (T.c[0][1]*T.c[0][1]*dL_da + T.c[0][1]*T.c[1][1]*dL_db + T.c[1][1]*T.c[1][1]*dL_dc);
+        dL_dcov[6*idx+5] = (T.c[0][2]*T.c[0][2]*dL_da + T.c[0][2]*T.c[1][2]*dL_db + T.c[1][2]*T.c[1][2]*dL_dc);
+        dL_dcov[6*idx+1] = 2*T.c[0][0]*T.c[0][1]*dL_da + (T.c[0][0]*T.c[1][1] + T.c[0][1]*T.c[1][0])*dL_db + 2*T.c[1][0]*T.c[1][1]*dL_dc;
+        dL_dcov[6*idx+2] = 2*T.c[0][0]*T.c[0][2]*dL_da + (T.c[0][0]*T.c[1][2] + T.c[0][2]*T.c[1][0])*dL_db + 2*T.c[1][0]*T.c[1][2]*dL_dc;
+        dL_dcov[6*idx+4] = 2*T.c[0][2]*T.c[0][1]*dL_da + (T.c[0][1]*T.c[1][2] + T.c[0][2]*T.c[1][1])*dL_db + 2*T.c[1][1]*T.c[1][2]*dL_dc;
+    } else {
+        for (int i = 0; i < 6; i++) dL_dcov[6*idx+i] = 0;
+    }
+    float dL_dT00 = 2*(T.c[0][0]*Vrk.c[0][0] + T.c[0][1]*Vrk.c[0][1] + T.c[0][2]*Vrk.c[0][2])*dL_da + (T.c[1][0]*Vrk.c[0][0] + T.c[1][1]*Vrk.c[0][1] + T.c[1][2]*Vrk.c[0][2])*dL_db;
+    float dL_dT01 = 2*(T.c[0][0]*Vrk.c[1][0] + T.c[0][1]*Vrk.c[1][1] + T.c[0][2]*Vrk.c[1][2])*dL_da + (T.c[1][0]*Vrk.c[1][0] + T.c[1][1]*Vrk.c[1][1] + T.c[1][2]*Vrk.c[1][2])*dL_db;
+    float dL_dT02 = 2*(T.c[0][0]*Vrk.c[2][0] + T.c[0][1]*Vrk.c[2][1] + T.c[0][2]*Vrk.c[2][2])*dL_da + (T.c[1][0]*Vrk.c[2][0] + T.c[1][1]*Vrk.c[2][1] + T.c[1][2]*Vrk.c[2][2])*dL_db;
+    float dL_dT10 = 2*(T.c[1][0]*Vrk.c[0][0] + T.c[1][1]*Vrk.c[0][1] + T.c[1][2]*Vrk.c[0][2])*dL_dc + (T.c[0][0]*Vrk.c[0][0] + T.c[0][1]*Vrk.c[0][1] + T.c[0][2]*Vrk.c[0][2])*dL_db;
+    float dL_dT11 = 2*(T.c[1][0]*Vrk.c[1][0] + T.c[1][1]*Vrk.c[1][1] + T.c[1][2]*Vrk.c[1][2])*dL_dc + (T.c[0][0]*Vrk.c[1][0] + T.c[0][1]*Vrk.c[1][1] + T.c[0][2]*Vrk.c[1][2])*dL_db;
+    float dL_dT12 = 2*(T.c[1][0]*Vrk.c[2][0] + T.c[1][1]*Vrk.c[2][1] + T.c[1][2]*Vrk.c[2][2])*dL_dc + (T.c[0][0]*Vrk.c[2][0] + T.c[0][1]*Vrk.c[2][1] + T.c[0][2]*Vrk.c[2][2])*dL_db;
+    float dL_dJ00 = Wm.c[0][0]*dL_dT00 + Wm.c[0][1]*dL_dT01 + Wm.c[0][2]*dL_dT02;
+    float dL_dJ02 = Wm.c[2][0]*dL_dT00 + Wm.c[2][1]*dL_dT01 + Wm.c[2][2]*dL_dT02;
+    float dL_dJ11 = Wm.c[1][0]*dL_dT10 + Wm.c[1][1]*dL_dT11 + Wm.c[1][2]*dL_dT12;
+    float dL_dJ12 = Wm.c[2][0]*dL_dT10 + Wm.c[2][1]*dL_dT11 + Wm.c[2][2]*dL_dT12;
+    float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+    f3 dt = { dL_dtx, dL_dty, dL_dtz };
+    f3 dm = transformVec4x3Transpose(dt, vm);
+    dL_dmeans[3*idx] = dm.x; dL_dmeans[3*idx+1] = dm.y; dL_dmeans[3*idx+2] = dm.z;   /* assignment */
+}
+
+/* 3DGS backward.cu:278-341 (no quaternion-normalisation Jacobian) */
+static void computeCov3D_bwd(int idx, const float* scale, float mod, const float* rot, const float* dL_dcov3Ds,
+                             float* dL_dscales, float* dL_drots)
+{
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    m3 R = m3_cols(1.f - 2.f*(y*y + z*z), 2.f*(x*y - r*z), 2.f*(x*z + r*y),
+                   2.f*(x*y + r*z), 1.f - 2.f*(x*x + z*z), 2.f*(y*z - r*x),
+                   2.f*(x*z - r*y), 2.f*(y*z + r*x), 1.f - 2.f*(x*x + y*y));
+    float s[3] = { mod*scale[0], mod*scale[1], mod*scale[2] };
+    m3 S = m3_cols(s[0],0,0, 0,s[1],0, 0,0,s[2]);
+    m3 Mm = m3_mul(S, R);
+    const float* g = dL_dcov3Ds + 6*idx;
+    m3 dL_dSigma = m3_cols(g[0], 0.5f*g[1], 0.5f*g[2], 0.5f*g[1], g[3], 0.5f*g[4], 0.5f*g[2], 0.5f*g[4], g[5]);
+    m3 M2 = Mm; for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) M2.c[j][i] = 2.0f * Mm.c[j][i];
+    m3 dL_dM = m3_mul(M2, dL_dSigma);
+    m3 Rt = m3_t(R), dL_dMt = m3_t(dL_dM);
+    dL_dscales[3*idx+0] = dot3(Rt.c[0], dL_dMt.c[0]);
+    dL_dscales[3*idx+1] = dot3(Rt.c[1], dL_dMt.c[1]);
+    dL_dscales[3*idx+2] = dot3(Rt.c[2], dL_dMt.c[2]);
+    for (int i = 0; i < 3; i++) { dL_dMt.c[0][i] *= s[0]; dL_dMt.c[1][i] *= s[1]; dL_dMt.c[2][i] *= s[2]; }
+    float* q = dL_drots + 4*idx;
+    q[0] = 2*z*(dL_dMt.c[0][1] - dL_dMt.c[1][0]) + 2*y*(dL_dMt.c[2][0] - dL_dMt.c[0][2]) + 2*x*(dL_dMt.c[1][2] - dL_dMt.c[2][1]);
+    q[1] = 2*y*(dL_dMt.c[1][0] + dL_dMt.c[0][1]) + 2*z*(dL_dMt.c[2][0] + dL_dMt.c[0][2]) + 2*r*(dL_dMt.c[1][2] - dL_dMt.c[2][1]) - 4*x*(dL_dMt.c[2][2] + dL_dMt.c[1][1]);
+    q[2] = 2*x*(dL_dMt.c[1][0] + dL_dMt.c[0][1]) + 2*r*(dL_dMt.c[2][0] - dL_dMt.c[0][2]) + 2*z*(dL_dMt.c[1][2] + dL_dMt.c[2][1]) - 4*y*(dL_dMt.c[2][2] + dL_dMt.c[0][0]);
+    q[3] = 2*r*(dL_dMt.c[0][1] - dL_dMt.c[1][0]) + 2*x*(dL_dMt.c[2][0] + dL_dMt.c[0][2]) + 2*y*(dL_dMt.c[1][2] + dL_dMt.c[2][1]) - 4*z*(dL_dMt.c[1][1] + dL_dMt.c[0][0]);
+}
+
+/* SURFEL backward.cu:450-580 */
+static void compute_transmat_aabb_bwd(const ref_state* st, const ref_inputs* in, int idx, int W, int H,
+                                      const float* dL_dnormals, const float* dL_dmean2Ds, float* dL_dTs,
+                                      float* dL_dmeans, float* dL_dscales, float* dL_drots)
+{
+    const int precomp = (in->scales == NULL);
+    float T[9]; f3 normal = {0,0,0}; float Pm[4][3]; m3 R; f3 p_orig = {0,0,0};
+    const float* rot = NULL; const float* scale = NULL;
+    if (precomp) {
+        memcpy(T, in->cov3D_precomp + 9*idx, sizeof(T));
+    } else {
+        p_orig.x = in->means3D[3*idx]; p_orig.y = in->means3D[3*idx+1]; p_orig.z = in->means3D[3*idx+2];
+        rot = in->rotations + 4*idx; scale = in->scales + 2*idx;
+        R = quat_to_rotmat(rot);
+        /* fork quirk (SURFEL backward.cu:488): scale_modifier is NOT applied in the backward recompute */
+        compute_transmat(p_orig, scale, 1.0f, rot, in->projmatrix, in->viewmatrix, W, H, T, &normal);
+        surfel_P(in->projmatrix, W, H, Pm);
+    }
+    (void)st;
+    float dT[3][3];   /* dT[j] = dL/d(T_j), j: 0=Tu 1=Tv 2=Tw */
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) dT[j][i] = dL_dTs[9*idx + 3*j + i];
+    const float gmx = dL_dmean2Ds[3*idx], gmy = dL_dmean2Ds[3*idx+1];
+    if (gmx != 0 || gmy != 0) {
+        const float* Tu = T; const float* Tv = T + 3; const float* Tw = T + 6;
+        float tv[3] = { 9.0f, 9.0f, -1.0f };
+        float ww[3] = { Tw[0]*Tw[0], Tw[1]*Tw[1], Tw[2]*Tw[2] };
+        float d = dot3(tv, ww);
+        float inv = 1.0f / d;
+        float f[3] = { tv[0]*inv, tv[1]*inv, tv[2]*inv };
+        float dT0[3], dT1[3], dT3[3], dL_df[3];
+        for (int i = 0; i < 3; i++) {
+            dT0[i] = gmx * f[i] * Tw[i];
+            dT1[i] = gmy * f[i] * Tw[i];
+            dT3[i] = gmx * f[i] * Tu[i] + gmy * f[i] * Tv[i];
+            dL_df[i] = gmx * Tu[i] * Tw[i] + gmy * Tv[i] * Tw[i];
+        }
+        float dL_dd = (float)(dot3(dL_df, f) * (-1.0 / d));
+        for (int i = 0; i < 3; i++) {
+            float dd_dT3 = tv[i] * Tw[i] * 2.0f;
+            dT3[i] += dL_dd * dd_dT3;
+            dT[0][i] += dT0[i]; dT[1][i] += dT1[i]; dT[2][i] += dT3[i];
+        }
+        if (precomp) {
+            for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) dL_dTs[9*idx + 3*j + i] = dT[j][i];
+            return;
+        }
+    }
+    if (precomp) return;
+    /* dL_dM = P * transpose(dL_dT): dM[j][k] = sum_c Pm[k][c] * dT[c][j]   (j: 0=L0 row,1=L1 row,2=centre row) */
+    float dM[3][4];
+    for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 4; k++)
+            dM[j][k] = Pm[k][0]*dT[0][j] + Pm[k][1]*dT[1][j] + Pm[k][2]*dT[2][j];
+    f3 dn = { dL_dnormals[3*idx], dL_dnormals[3*idx+1], dL_dnormals[3*idx+2] };
+    f3 dL_dtn = transformVec4x3Transpose(dn, in->viewmatrix);
+    f3 p_view = transformPoint4x3(p_orig, in->viewmatrix);
+    float cosv = -(p_view.x*normal.x + p_view.y*normal.y + p_view.z*normal.z);
+    float mult = cosv > 0 ? 1.f : -1.f;
+    dL_dtn.x *= mult; dL_dtn.y *= mult; dL_dtn.z *= mult;
+    m3 dL_dRS = m3_cols(dM[0][0], dM[0][1], dM[0][2], dM[1][0], dM[1][1], dM[1][2], dL_dtn.x, dL_dtn.y, dL_dtn.z);
+    m3 dL_dR = m3_cols(dL_dRS.c[0][0]*scale[0], dL_dRS.c[0][1]*scale[0], dL_dRS.c[0][2]*scale[0],
+                       dL_dRS.c[1][0]*scale[1], dL_dRS.c[1][1]*scale[1], dL_dRS.c[1][2]*scale[1],
+                       dL_dRS.c[2][0], dL_dRS.c[2][1], dL_dRS.c[2][2]);
+    quat_to_rotmat_vjp(rot, dL_dR, dL_drots + 4*idx);
+    dL_dscales[2*idx+0] = dot3(dL_dRS.c[0], R.c[0]);
+    dL_dscales[2*idx+1] = dot3(dL_dRS.c[1], R.c[1]);
+    dL_dmeans[3*idx+0] = dM[2][0]; dL_dmeans[3*idx+1] = dM[2][1]; dL_dmeans[3*idx+2] = dM[2][2];
+}
+
+void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, ref_in_grads* ig)
+{
+    const int P = st->P, W = st->W, H = st->H, M = in->M;
+    const int surf = st->variant == REF_SURFEL;
+    const int tm = surf ? 9 : 6;
+    memset(ig->dL_dmeans3D, 0, (size_t)P*3*4); memset(ig->dL_dmeans2D, 0, (size_t)P*3*4);
+    if (ig->dL_dmeans2D_abs) memset(ig->dL_dmeans2D_abs, 0, (size_t)P*3*4);
+    memset(ig->dL_dcolors, 0, (size_t)P*3*4); memset(ig->dL_dopacity, 0, (size_t)P*4);
+    memset(ig->dL_dcov3D, 0, (size_t)P*tm*4);
+    if (ig->dL_dsh && M > 0) memset(ig->dL_dsh, 0, (size_t)P*M*3*4);
+    memset(ig->dL_dscales, 0, (size_t)P*(surf ? 2 : 3)*4); memset(ig->dL_drotations, 0, (size_t)P*4*4);
+    if (ig->dL_dall_map) memset(ig->dL_dall_map, 0, (size_t)P*5*4);
+    memset(ig->dL_dconic, 0, (size_t)P*(surf ? 3 : 4)*4);
+
+    const float focal_y = H / (2.0f * in->tanfovy);
+    const float focal_x = W / (2.0f * in->tanfovx);
+    const float* colors = in->colors_precomp ? in->colors_precomp : st->rgb;
+
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int tile = 0; tile < st->T; tile++) {
+        uint32_t tx = (uint32_t)(tile % st->gx), ty = (uint32_t)(tile / st->gx);
+        uint32_t r0 = st->ranges[2*tile], r1 = st->ranges[2*tile+1];
+        for (uint32_t ly = 0; ly < BLOCK_Y; ly++)
+            for (uint32_t lx = 0; lx < BLOCK_X; lx++) {
+                uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (px < (uint32_t)W && py < (uint32_t)H)
+                    blend_pixel_bwd(st, in, colors, focal_x, focal_y, px, py, r0, r1, og,
+                                    ig->dL_dmeans2D, ig->dL_dmeans2D_abs, surf ? NULL : ig->dL_dconic,
+                                    surf ? ig->dL_dconic : NULL, surf ? ig->dL_dcov3D : NULL, ig->dL_dopacity,
+                                    ig->dL_dcolors, ig->dL_dall_map);
+            }
+    }
+
+    if (!surf) {
+        /* BACKWARD::preprocess, 3DGS backward.cu:559-625 */
+        const float* cov3D_ptr = in->cov3D_precomp ? in->cov3D_precomp : st->cov3D;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+        for (int idx = 0; idx < P; idx++) {
+            if (!(st->radii[idx] > 0)) continue;
+            computeCov2D_bwd(in, idx, cov3D_ptr, focal_x, focal_y, ig->dL_dconic, ig->dL_dmeans3D, ig->dL_dcov3D);
+            /* preprocessCUDA bwd, 3DGS backward.cu:346-396 */
+            f3 m = { in->means3D[3*idx], in->means3D[3*idx+1], in->means3D[3*idx+2] };
+            const float* proj = in->projmatrix;
+            float mh[4]; transformPoint4x4(m, proj, mh);
+            float m_w = 1.0f / (mh[3] + 0.0000001f);
+            float mul1 = (proj[0]*m.x + proj[4]*m.y + proj[8]*m.z + proj[12]) * m_w * m_w;
+            float mul2 = (proj[1]*m.x + proj[5]*m.y + proj[9]*m.z + proj[13]) * m_w * m_w;
+            const float gx_ = ig->dL_dmeans2D[3*idx], gy_ = ig->dL_dmeans2D[3*idx+1];
+            float dmx = (proj[0]*m_w - proj[3]*mul1) * gx_ + (proj[1]*m_w - proj[3]*mul2) * gy_;
+            float dmy = (proj[4]*m_w - proj[7]*mul1) * gx_ + (proj[5]*m_w - proj[7]*mul2) * gy_;
+            float dmz = (proj[8]*m_w - proj[11]*mul1) * gx_ + (proj[9]*m_w - proj[11]*mul2) * gy_;
+            ig->dL_dmeans3D[3*idx] += dmx; ig->dL_dmeans3D[3*idx+1] += dmy; ig->dL_dmeans3D[3*idx+2] += dmz;
+            if (in->shs)
+                computeColorFromSH_bwd(idx, in->D, M, in->means3D, in->campos, in->shs, st->clamped,
+                                       ig->dL_dcolors, ig->dL_dmeans3D, ig->dL_dsh);
+            if (in->scales)
+                computeCov3D_bwd(idx, in->scales + 3*idx, in->scale_modifier, in->rotations + 4*idx,
+                                 ig->dL_dcov3D, ig->dL_dscales, ig->dL_drotations);
+        }
+    } else {
+        /* SURFEL backward.cu:582-637.  fork quirk: W,H are re-derived from focal*tan*2 in float32 */
+        const int Wb = (int)(focal_x * in->tanfovx * 2);
+        const int Hb = (int)(focal_y * in->tanfovy * 2);
+        const float* transMats = in->cov3D_precomp ? in->cov3D_precomp : st->cov3D;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+        for (int idx = 0; idx < P; idx++) {
+            if (!(st->radii[idx] > 0)) continue;
+            compute_transmat_aabb_bwd(st, in, idx, Wb, Hb, ig->dL_dconic, ig->dL_dmeans2D, ig->dL_dcov3D,
+                                      ig->dL_dmeans3D, ig->dL_dscales, ig->dL_drotations);
+            if (in->shs)
+                computeColorFromSH_bwd(idx, in->D, M, in->means3D, in->campos, in->shs, st->clamped,
+                                       ig->dL_dcolors, ig->dL_dmeans3D, ig->dL_dsh);
+            /* densification proxy overwrites dL_dmean2D, SURFEL backward.cu:633-636 */
+            float depth = transMats[9*idx + 8];
+            ig->dL_dmeans2D[3*idx+0] = (float)(ig->dL_dcov3D[9*idx + 2] * depth * 0.5 * (float)Wb);
+            ig->dL_dmeans2D[3*idx+1] = (float)(ig->dL_dcov3D[9*idx + 5] * depth * 0.5 * (float)Hb);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ introspection */
+int32_t ref_num_rendered(const ref_state* st) { return st->R; }
+int32_t ref_num_tiles(const ref_state* st) { return st->T; }
+void ref_get_point_list(const ref_state* st, uint32_t* out) { memcpy(out, st->point_list, (size_t)st->R * 4); }
+void ref_get_keys(const ref_state* st, uint64_t* out) { memcpy(out, st->keys, (size_t)st->R * 8); }
+void ref_get_ranges(const ref_state* st, uint32_t* out) { memcpy(out, st->ranges, (size_t)st->T * 8); }
+void ref_get_tiles_touched(const ref_state* st, uint32_t* out) { memcpy(out, st->tiles_touched, (size_t)st->P * 4); }
+void ref_get_geom(const ref_state* st, float* depths, float* means2D, float* conic_opacity, float* rgb, float* cov)
+{
+    size_t P = (size_t)st->P;
+    if (depths) memcpy(depths, st->depths, P*4);
+    if (means2D) memcpy(means2D, st->means2D, P*8);
+    if (conic_opacity) memcpy(conic_opacity, st->conic_opacity, P*16);
+    if (rgb) memcpy(rgb, st->rgb, P*12);
+    if (cov) memcpy(cov, st->cov3D, P*(st->variant == REF_SURFEL ? 9 : 6)*4);
+}
+void ref_get_image_state(const ref_state* st, float* final_T, uint32_t* n_contrib)
+{
+    size_t N = (size_t)st->N;
+    if (final_T) memcpy(final_T, st->final_T, N * (st->variant == REF_SURFEL ? 3 : 1) * 4);
+    if (n_contrib) memcpy(n_contrib, st->n_contrib, N * (st->variant == REF_SURFEL ? 2 : 1) * 4);
+}
+
+/* ------------------------------------------------------------------ scaffold-filter & markVisible */
+/* FILTER forward.cu:268-340 via rasterizer_impl.cu:340-396 */
+void ref_visible_filter(const ref_inputs* in, int32_t* radii)
+{
+    const int P = in->P, W = in->W, H = in->H;
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    const float focal_y = H / (2.0f * in->tanfovy);
+    const float focal_x = W / (2.0f * in->tanfovx);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int idx = 0; idx < P; idx++) {
+        radii[idx] = 0;
+        f3 p_view;
+        if (!in_frustum(idx, in->means3D, in->viewmatrix, &p_view)) continue;
+        f3 p_orig = { in->means3D[3*idx], in->means3D[3*idx+1], in->means3D[3*idx+2] };
+        float ph[4]; transformPoint4x4(p_orig, in->projmatrix, ph);
+        float p_w = 1.0f / (ph[3] + 0.0000001f);
+        float cov3Dl[6]; const float* cov3D;
+        if (in->cov3D_precomp) cov3D = in->cov3D_precomp + 6*idx;
+        else { computeCov3D(in->scales + 3*idx, in->scale_modifier, in->rotations + 4*idx, cov3Dl); cov3D = cov3Dl; }
+        float cov[3];
+        computeCov2D(p_orig, focal_x, focal_y, in->tanfovx, in->tanfovy, cov3D, in->viewmatrix, cov, NULL, NULL, NULL, NULL, NULL);
+        float det = (cov[0] * cov[2] - cov[1] * cov[1]);
+        if (det == 0.0f) continue;
+        float mid = 0.5f * (cov[0] + cov[2]);
+        float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        f2 pi = { ndc2Pix(ph[0] * p_w, W), ndc2Pix(ph[1] * p_w, H) };
+        uint32_t rmin[2], rmax[2];
+        getRect(pi, (int)my_radius, gx, gy, rmin, rmax);
+        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) continue;
+        radii[idx] = (int)my_radius;
+    }
+}
+
+/* 3DGS rasterizer_impl.cu:54-66,141-153 */
+void ref_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
+{
+    (void)projmatrix;
+    for (int i = 0; i < P; i++) { f3 pv; present[i] = (uint8_t)in_frustum(i, means3D, viewmatrix, &pv); }
+}
+
+/* ------------------------------------------------------------------ TSDF (gssr/utils/mesh_utils.py:195-246) */
+/* torch.nn.functional.grid_sample(mode='bilinear', padding_mode='border', align_corners=True) for one sample */
+static float bilinear_border(const float* img, int W, int H, float u, float v)
+{
+    /* align_corners=True: x = (u+1)/2*(W-1); border padding clamps the coordinate into [0, size-1] */
+    float x = ((u + 1.f) / 2.f) * (float)(W - 1);
+    float y = ((v + 1.f) / 2.f) * (float)(H - 1);
+    x = fminf(fmaxf(x, 0.f), (float)(W - 1));
+    y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+    int x0 = (int)floorf(x), y0 = (int)floorf(y);
+    int x1 = x0 + 1, y1 = y0 + 1;
+    /* weights as ATen's grid_sampler: (x1 - x), (x - x0) */
+    float wx1 = x - (float)x0, wy1 = y - (float)y0, wx0 = (float)x1 - x, wy0 = (float)y1 - y;
+    float acc = 0.f;
+    /* out-of-range corners contribute zero (their weight is zero after clamping, restated like the torch kernel) */
+    if (x0 >= 0 && x0 < W && y0 >= 0 && y0 < H) acc += img[(size_t)y0*W + x0] * (wx0 * wy0);
+    if (x1 >= 0 && x1 < W && y0 >= 0 && y0 < H) acc += img[(size_t)y0*W + x1] * (wx1 * wy0);
+    if (x0 >= 0 && x0 < W && y1 >= 0 && y1 < H) acc += img[(size_t)y1*W + x0] * (wx0 * wy1);
+    if (x1 >= 0 && x1 < W && y1 >= 0 && y1 < H) acc += img[(size_t)y1*W + x1] * (wx1 * wy1);
+    return acc;
+}
+
+void ref_tsdf_integrate(int64_t V, const float* points, const float* F, int32_t W, int32_t H, const float* depth,
+                        const float* rgb, float sdf_trunc, const float* trunc_pp, float* tsdf, float* weight,
+                        float* rgb_acc)
+{
+    const size_t HW = (size_t)W * H;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < V; i++) {
+        float x = points[3*i], y = points[3*i+1], z3 = points[3*i+2];
+        /* [x y z 1] @ full_proj_transform (row-vector convention) */
+        float qx = x*F[0] + y*F[4] + z3*F[8] + F[12];
+        float qy = x*F[1] + y*F[5] + z3*F[9] + F[13];
+        float qw = x*F[3] + y*F[7] + z3*F[11] + F[15];
+        float z = qw;
+        float u = qx / qw, v = qy / qw;
+        int mask = (u > -1.f) && (u < 1.f) && (v > -1.f) && (v < 1.f) && (z > 0);
+        float d = bilinear_border(depth, W, H, u, v);
+        float sdf = d - z;
+        float tr = trunc_pp ? trunc_pp[i] : sdf_trunc;
+        mask = mask && (sdf > -tr);
+        if (!mask) continue;
+        float s = sdf / tr; s = fminf(fmaxf(s, -1.0f), 1.0f);
+        float w = weight[i], wp = w + 1;
+        tsdf[i] = (tsdf[i] * w + s) / wp;
+        for (int c = 0; c < 3; c++) {
+            float col = bilinear_border(rgb + c*HW, W, H, u, v);
+            rgb_acc[3*i + c] = (rgb_acc[3*i + c] * w + col) / wp;
+        }
+        weight[i] = wp;
+    }
+}
+
+/* simple-knn (submodules/simple-knn/simple_knn.cu:148-184): mean of the squared distances to the 3 nearest
+   neighbours.  Brute force; the Morton/box pruning of the source is an acceleration structure only. */
+void ref_dist2(int32_t P, const float* pts, float* out)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int i = 0; i < P; i++) {
+        float best[3] = { 3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f };
+        for (int j = 0; j < P; j++) {
+            if (j == i) continue;
+            float dx = pts[3*i] - pts[3*j], dy = pts[3*i+1] - pts[3*j+1], dz = pts[3*i+2] - pts[3*j+2];
+            float d = dx*dx + dy*dy + dz*dz;
+            for (int k = 0; k < 3; k++) if (d < best[k]) { float t = best[k]; best[k] = d; d = t; }
+        }
+        out[i] = (best[0] + best[1] + best[2]) / 3;
+    }
+}
+
+int32_t ref_omp_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,111 @@
+/*
+ * gsr_oracle.h -- CPU restatement of the GS-SR rasterizer hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (gs-sr_amd/) never links, imports or falls back to it.
+ *
+ * PARITY STATUS: "parity unpinned by the reference" -- /root/reference ships no golden vectors, tests or
+ * fixtures for the rasterizers and its CUDA sources cannot be built here (no nvcc, no GPU).  This oracle is
+ * pinned instead by (1) golden vectors generated from the importable reference Python helpers
+ * (tests/golden/make_golden.py: camera matrices, SH evaluation), (2) a float64 torch-autograd restatement of the
+ * forward maths that checks every analytic backward (tests/ref_torch.py), (3) closed-form cases and invariants.
+ *
+ * Variants: 0 = EWA   (submodules/diff-gaussian-rasterization)
+ *           1 = SURFEL(submodules/diff-surfel-rasterization)
+ *           2 = PLANE (submodules/diff-plane-rasterization)
+ */
+#ifndef GSR_ORACLE_H
+#define GSR_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { REF_EWA = 0, REF_SURFEL = 1, REF_PLANE = 2 };
+
+typedef struct ref_inputs {
+    int32_t P, D, M;          /* #gaussians, active SH degree, SH coefficients per gaussian (0 = none) */
+    int32_t W, H;
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t prefiltered;
+    int32_t render_geo;       /* PLANE only */
+    const float* bg;          /* [3] */
+    const float* viewmatrix;  /* [16] row-vector convention (p_view = [p 1] * V) */
+    const float* projmatrix;  /* [16] */
+    const float* campos;      /* [3] */
+    const float* means3D;     /* [P,3] */
+    const float* shs;         /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3] or NULL */
+    const float* opacities;   /* [P] */
+    const float* scales;      /* [P,3] (SURFEL [P,2]) or NULL */
+    const float* rotations;   /* [P,4] wxyz or NULL */
+    const float* cov3D_precomp; /* [P,6] (SURFEL: transMat [P,9]) or NULL */
+    const float* all_map;     /* PLANE [P,5] or NULL */
+} ref_inputs;
+
+typedef struct ref_out_grads {      /* dL/d(outputs); NULL pointers are treated as zeros */
+    const float* dL_dcolor;         /* [3,H,W] */
+    const float* dL_dothers;        /* SURFEL [11,H,W] */
+    const float* dL_dout_all_map;   /* PLANE [5,H,W] */
+    const float* dL_dplane_depth;   /* PLANE [1,H,W] */
+} ref_out_grads;
+
+typedef struct ref_in_grads {       /* all caller-allocated, zero-filled by the callee first */
+    float* dL_dmeans3D;     /* [P,3] */
+    float* dL_dmeans2D;     /* [P,3] */
+    float* dL_dmeans2D_abs; /* PLANE [P,3] or NULL */
+    float* dL_dcolors;      /* [P,3] */
+    float* dL_dopacity;     /* [P] */
+    float* dL_dcov3D;       /* [P,6]  (SURFEL: dL_dtransMat [P,9]) */
+    float* dL_dsh;          /* [P,M,3] or NULL when M==0 */
+    float* dL_dscales;      /* [P,3] (SURFEL [P,2]) */
+    float* dL_drotations;   /* [P,4] */
+    float* dL_dall_map;     /* PLANE [P,5] or NULL */
+    float* dL_dconic;       /* EWA/PLANE [P,4]; SURFEL: dL_dnormal [P,3] -- intermediate, exposed for tests */
+} ref_in_grads;
+
+typedef struct ref_state ref_state;
+
+/* forward: returns an opaque state (owned by the oracle; free with ref_free) holding geometry/binning/image state */
+ref_state* ref_forward(int variant, const ref_inputs* in,
+                       float* out_color /*[3,H,W]*/, int32_t* radii /*[P]*/,
+                       float* out_others /*SURFEL [11,H,W]*/,
+                       int32_t* out_observe /*PLANE [P]*/, float* out_all_map /*PLANE [5,H,W]*/,
+                       float* out_plane_depth /*PLANE [1,H,W]*/);
+void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, ref_in_grads* ig);
+void ref_free(ref_state* st);
+
+/* introspection of intermediate (integer, bit-exact comparable) stages */
+int32_t  ref_num_rendered(const ref_state* st);
+int32_t  ref_num_tiles(const ref_state* st);
+void     ref_get_point_list(const ref_state* st, uint32_t* out /*[R]*/);
+void     ref_get_keys(const ref_state* st, uint64_t* out /*[R] sorted keys*/);
+void     ref_get_ranges(const ref_state* st, uint32_t* out /*[T,2]*/);
+void     ref_get_tiles_touched(const ref_state* st, uint32_t* out /*[P]*/);
+void     ref_get_geom(const ref_state* st, float* depths /*[P]*/, float* means2D /*[P,2]*/,
+                      float* conic_opacity /*[P,4] (SURFEL normal_opacity)*/, float* rgb /*[P,3]*/,
+                      float* cov3D_or_transmat /*[P,6] or [P,9]*/);
+void     ref_get_image_state(const ref_state* st, float* final_T /*[N] (SURFEL [3N])*/,
+                             uint32_t* n_contrib /*[N] (SURFEL [2N])*/);
+
+void ref_visible_filter(const ref_inputs* in, int32_t* radii);   /* scaffold-filter */
+void ref_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present);
+
+/* in-repo TSDF definition (gssr/utils/mesh_utils.py:195-246), one frame, updates tsdf/weight/rgb in place */
+void ref_tsdf_integrate(int64_t V, const float* points /*[V,3]*/, const float* full_proj /*[16]*/,
+                        int32_t W, int32_t H, const float* depth /*[H,W]*/, const float* rgb /*[3,H,W]*/,
+                        float sdf_trunc, const float* sdf_trunc_per_point /*[V] or NULL*/,
+                        float* tsdf /*[V]*/, float* weight /*[V]*/, float* rgb_acc /*[V,3]*/);
+
+/* simple-knn distCUDA2: mean squared distance to the 3 nearest neighbours (brute-force restatement) */
+void ref_dist2(int32_t P, const float* points, float* out);
+
+int32_t ref_omp_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

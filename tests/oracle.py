@@ -1,0 +1,239 @@
+"""ctypes binding of the CPU oracle (oracle/libgsr_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product
+(gs-sr_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+EWA, SURFEL, PLANE = 0, 1, 2
+VARIANT_ID = {"ewa": EWA, "surfel": SURFEL, "plane": PLANE}
+
+_fp = C.POINTER(C.c_float)
+
+
+class RefInputs(C.Structure):
+    _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+                ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+                ("prefiltered", C.c_int32), ("render_geo", C.c_int32),
+                ("bg", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp), ("means3D", _fp),
+                ("shs", _fp), ("colors_precomp", _fp), ("opacities", _fp), ("scales", _fp), ("rotations", _fp),
+                ("cov3D_precomp", _fp), ("all_map", _fp)]
+
+
+class RefOutGrads(C.Structure):
+    _fields_ = [("dL_dcolor", _fp), ("dL_dothers", _fp), ("dL_dout_all_map", _fp), ("dL_dplane_depth", _fp)]
+
+
+class RefInGrads(C.Structure):
+    _fields_ = [(n, _fp) for n in ("dL_dmeans3D", "dL_dmeans2D", "dL_dmeans2D_abs", "dL_dcolors", "dL_dopacity",
+                                   "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dall_map", "dL_dconic")]
+
+
+def build(force=False):
+    so = os.path.join(ORACLE_DIR, "libgsr_oracle.so")
+    src = os.path.join(ORACLE_DIR, "gsr_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.ref_forward.restype = C.c_void_p
+        L.ref_forward.argtypes = [C.c_int, C.POINTER(RefInputs), _fp, C.POINTER(C.c_int32), _fp,
+                                  C.POINTER(C.c_int32), _fp, _fp]
+        L.ref_backward.restype = None
+        L.ref_backward.argtypes = [C.c_void_p, C.POINTER(RefInputs), C.POINTER(RefOutGrads), C.POINTER(RefInGrads)]
+        L.ref_free.argtypes = [C.c_void_p]
+        L.ref_num_rendered.argtypes = [C.c_void_p]; L.ref_num_rendered.restype = C.c_int32
+        L.ref_num_tiles.argtypes = [C.c_void_p]; L.ref_num_tiles.restype = C.c_int32
+        for n in ("ref_get_point_list", "ref_get_keys", "ref_get_ranges", "ref_get_tiles_touched"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_get_geom.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.ref_get_image_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_visible_filter.argtypes = [C.POINTER(RefInputs), C.POINTER(C.c_int32)]
+        L.ref_mark_visible.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_void_p]
+        L.ref_tsdf_integrate.argtypes = [C.c_int64, _fp, _fp, C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp,
+                                         _fp, _fp, _fp]
+        L.ref_dist2.argtypes = [C.c_int32, _fp, _fp]
+        L.ref_omp_threads.restype = C.c_int32
+        _LIB = L
+    return _LIB
+
+
+def _f32(a):
+    if a is None:
+        return None
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(_fp) if a is not None else None
+
+
+class _Keep:
+    """Holds numpy arrays alive next to the ctypes struct that points into them."""
+
+    def __init__(self):
+        self.arrs = []
+
+    def f(self, a):
+        a = _f32(a)
+        if a is not None:
+            self.arrs.append(a)
+        return _p(a)
+
+
+def make_inputs(scene, variant):
+    """scene: dict with the keyword tensors of the reference rasterizer call (see tests/scenes.py)."""
+    k = _Keep()
+    ri = RefInputs()
+    means3D = _f32(scene["means3D"])
+    ri.P = means3D.shape[0]
+    shs = scene.get("shs")
+    ri.M = 0 if shs is None else int(np.asarray(shs).shape[1])
+    ri.D = int(scene.get("sh_degree", 0))
+    ri.W = int(scene["W"]); ri.H = int(scene["H"])
+    ri.tanfovx = float(scene["tanfovx"]); ri.tanfovy = float(scene["tanfovy"])
+    ri.scale_modifier = float(scene.get("scale_modifier", 1.0))
+    ri.prefiltered = 0
+    ri.render_geo = int(bool(scene.get("render_geo", True)))
+    ri.bg = k.f(scene["bg"]); ri.viewmatrix = k.f(scene["viewmatrix"]); ri.projmatrix = k.f(scene["projmatrix"])
+    ri.campos = k.f(scene["campos"]); ri.means3D = k.f(means3D)
+    ri.shs = k.f(shs); ri.colors_precomp = k.f(scene.get("colors_precomp"))
+    ri.opacities = k.f(scene["opacities"]); ri.scales = k.f(scene.get("scales"))
+    ri.rotations = k.f(scene.get("rotations")); ri.cov3D_precomp = k.f(scene.get("cov3D_precomp"))
+    ri.all_map = k.f(scene.get("all_map")) if variant == PLANE else None
+    ri._keep = k
+    return ri
+
+
+class Forward:
+    """Runs the oracle forward; keeps the state for backward/introspection.  Use as a context manager or call .close()."""
+
+    def __init__(self, scene, variant):
+        if isinstance(variant, str):
+            variant = VARIANT_ID[variant]
+        L = lib()
+        self.variant = variant
+        self.ri = make_inputs(scene, variant)
+        P, W, H = self.ri.P, self.ri.W, self.ri.H
+        self.P, self.W, self.H = P, W, H
+        self.color = np.zeros((3, H, W), np.float32)
+        self.radii = np.zeros((P,), np.int32)
+        self.others = np.zeros((11, H, W), np.float32) if variant == SURFEL else None
+        self.observe = np.zeros((P,), np.int32) if variant == PLANE else None
+        self.out_all_map = np.zeros((5, H, W), np.float32) if variant == PLANE else None
+        self.plane_depth = np.zeros((1, H, W), np.float32) if variant == PLANE else None
+        self.st = L.ref_forward(variant, C.byref(self.ri), _p(self.color), self.radii.ctypes.data_as(C.POINTER(C.c_int32)),
+                                _p(self.others),
+                                self.observe.ctypes.data_as(C.POINTER(C.c_int32)) if self.observe is not None else None,
+                                _p(self.out_all_map), _p(self.plane_depth))
+        self.R = L.ref_num_rendered(self.st)
+        self.T = L.ref_num_tiles(self.st)
+
+    def point_list(self):
+        out = np.zeros((self.R,), np.uint32); lib().ref_get_point_list(self.st, out.ctypes.data); return out
+
+    def keys(self):
+        out = np.zeros((self.R,), np.uint64); lib().ref_get_keys(self.st, out.ctypes.data); return out
+
+    def ranges(self):
+        out = np.zeros((self.T, 2), np.uint32); lib().ref_get_ranges(self.st, out.ctypes.data); return out
+
+    def tiles_touched(self):
+        out = np.zeros((self.P,), np.uint32); lib().ref_get_tiles_touched(self.st, out.ctypes.data); return out
+
+    def geom(self):
+        P = self.P
+        d = np.zeros((P,), np.float32); m = np.zeros((P, 2), np.float32); co = np.zeros((P, 4), np.float32)
+        rgb = np.zeros((P, 3), np.float32); cov = np.zeros((P, 9 if self.variant == SURFEL else 6), np.float32)
+        lib().ref_get_geom(self.st, d.ctypes.data, m.ctypes.data, co.ctypes.data, rgb.ctypes.data, cov.ctypes.data)
+        return dict(depths=d, means2D=m, conic_opacity=co, rgb=rgb, cov=cov)
+
+    def image_state(self):
+        N = self.W * self.H
+        k = 3 if self.variant == SURFEL else 1
+        k2 = 2 if self.variant == SURFEL else 1
+        ft = np.zeros((k, self.H, self.W), np.float32); nc = np.zeros((k2, self.H, self.W), np.uint32)
+        lib().ref_get_image_state(self.st, ft.ctypes.data, nc.ctypes.data)
+        return ft, nc
+
+    def backward(self, dL_dcolor=None, dL_dothers=None, dL_dout_all_map=None, dL_dplane_depth=None):
+        P, M = self.P, self.ri.M
+        surf = self.variant == SURFEL
+        k = _Keep()
+        og = RefOutGrads(k.f(dL_dcolor), k.f(dL_dothers), k.f(dL_dout_all_map), k.f(dL_dplane_depth))
+        g = dict(
+            dL_dmeans3D=np.zeros((P, 3), np.float32), dL_dmeans2D=np.zeros((P, 3), np.float32),
+            dL_dmeans2D_abs=np.zeros((P, 3), np.float32), dL_dcolors=np.zeros((P, 3), np.float32),
+            dL_dopacity=np.zeros((P, 1), np.float32), dL_dcov3D=np.zeros((P, 9 if surf else 6), np.float32),
+            dL_dsh=np.zeros((P, max(M, 1), 3), np.float32), dL_dscales=np.zeros((P, 2 if surf else 3), np.float32),
+            dL_drotations=np.zeros((P, 4), np.float32), dL_dall_map=np.zeros((P, 5), np.float32),
+            dL_dconic=np.zeros((P, 3 if surf else 4), np.float32))
+        ig = RefInGrads(*[_p(g[n]) for n, _ in RefInGrads._fields_])
+        lib().ref_backward(self.st, C.byref(self.ri), C.byref(og), C.byref(ig))
+        if M == 0:
+            g["dL_dsh"] = np.zeros((P, 0, 3), np.float32)
+        return g
+
+    def close(self):
+        if self.st:
+            lib().ref_free(self.st); self.st = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def visible_filter(scene):
+    ri = make_inputs(scene, EWA)
+    radii = np.zeros((ri.P,), np.int32)
+    lib().ref_visible_filter(C.byref(ri), radii.ctypes.data_as(C.POINTER(C.c_int32)))
+    return radii
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    m, v, p = _f32(means3D), _f32(viewmatrix), _f32(projmatrix)
+    out = np.zeros((m.shape[0],), np.uint8)
+    lib().ref_mark_visible(m.shape[0], _p(m), _p(v), _p(p), out.ctypes.data)
+    return out.astype(bool)
+
+
+def tsdf_integrate(points, full_proj, depth, rgb, sdf_trunc, tsdf, weight, rgb_acc, trunc_pp=None):
+    pts, F, d, c = _f32(points), _f32(full_proj), _f32(depth), _f32(rgb)
+    H, W = d.shape[-2], d.shape[-1]
+    tp = _f32(trunc_pp)
+    assert tsdf.dtype == np.float32 and weight.dtype == np.float32 and rgb_acc.dtype == np.float32
+    lib().ref_tsdf_integrate(pts.shape[0], _p(pts), _p(F), W, H, _p(d), _p(c), float(sdf_trunc), _p(tp),
+                             _p(tsdf), _p(weight), _p(rgb_acc))
+
+
+def dist2(points):
+    p = _f32(points)
+    out = np.zeros((p.shape[0],), np.float32)
+    lib().ref_dist2(p.shape[0], _p(p), _p(out))
+    return out
+
+
+def omp_threads():
+    return int(lib().ref_omp_threads())
