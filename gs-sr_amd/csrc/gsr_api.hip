@@ -1,0 +1,207 @@
+// gsr_api.hip -- C ABI of libgsrast_hip.so (see include/gsrast.h): arena carving, stage orchestration, errors.
+#include "gsr_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+int gsr_tile_sort_passes(int T);
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void gsr_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* gsr_last_error(void) { return g_err; }
+extern "C" int32_t gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+int gsr_check_launch(const char* what, hipStream_t s, bool debug)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gsr_set_error("%s: launch failed: %s", what, hipGetErrorString(e)); return 1; }
+    if (debug) {   // CHECK_CUDA semantics of the reference (auxiliary.h:166-173)
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { gsr_set_error("%s: %s", what, hipGetErrorString(e)); return 1; }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ arenas
+template <typename T>
+static T* take(char*& p, size_t n)
+{
+    T* r = reinterpret_cast<T*>(p);
+    p += gsr_align(n * sizeof(T));
+    return r;
+}
+
+GeomView gsr_carve_geom(int variant, int P, void* base)
+{
+    GeomView g;
+    char* p = reinterpret_cast<char*>(base);
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    const uint32_t nblk = gsr_div_up((uint32_t)n, GSR_SORT_BLOCK);
+    g.depth_key = take<uint32_t>(p, n);
+    g.tiles_touched = take<uint32_t>(p, n);
+    g.rect = take<ushort4>(p, n);
+    g.cull = take<float4>(p, n);
+    g.rec = take<float4>(p, n * gsr_rec_stride(variant));
+    g.clamped = take<uint32_t>(p, n);
+    g.sorted_idx = take<uint32_t>(p, n);     // == vals_a of the depth sort
+    g.offsets = take<uint32_t>(p, n);
+    g.keys_b = take<uint32_t>(p, n);
+    g.vals_a = g.sorted_idx;
+    g.vals_b = take<uint32_t>(p, n);
+    g.hist = take<uint32_t>(p, (size_t)256 * nblk);
+    g.scan_tmp = take<uint32_t>(p, gsr_div_up((uint32_t)n, GSR_SCAN_BLOCK) + 64);
+    g.counters = take<uint32_t>(p, 64);
+    g.bytes = (size_t)(p - reinterpret_cast<char*>(base));
+    return g;
+}
+
+BinView gsr_carve_bin(int variant, uint32_t R, int W, int H, void* base)
+{
+    (void)variant; (void)W; (void)H;
+    BinView b;
+    char* p = reinterpret_cast<char*>(base);
+    const size_t n = R > 0 ? R : 1;
+    const uint32_t nblk = gsr_div_up((uint32_t)n, GSR_SORT_BLOCK);
+    b.point_list = take<uint32_t>(p, n);
+    b.tile_keys = take<uint32_t>(p, n);
+    b.keys_b = take<uint32_t>(p, n);
+    b.vals_b = take<uint32_t>(p, n);
+    b.hist = take<uint32_t>(p, (size_t)256 * nblk);
+    b.scan_tmp = take<uint32_t>(p, 64);
+    b.bytes = (size_t)(p - reinterpret_cast<char*>(base));
+    return b;
+}
+
+ImgView gsr_carve_img(int variant, int W, int H, void* base)
+{
+    ImgView im;
+    char* p = reinterpret_cast<char*>(base);
+    const size_t N = (size_t)W * H;
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    im.final_T = take<float>(p, N * (variant == GSR_SURFEL ? 3 : 1));
+    im.n_contrib = take<uint32_t>(p, N * (variant == GSR_SURFEL ? 2 : 1));
+    im.ranges = take<uint2>(p, (size_t)gx * gy);
+    im.bytes = (size_t)(p - reinterpret_cast<char*>(base));
+    return im;
+}
+
+extern "C" size_t gsr_geom_bytes(int32_t variant, int32_t P) { return gsr_carve_geom(variant, P, nullptr).bytes; }
+extern "C" size_t gsr_img_bytes(int32_t variant, int32_t W, int32_t H) { return gsr_carve_img(variant, W, H, nullptr).bytes; }
+extern "C" size_t gsr_binning_bytes(int32_t variant, uint32_t R, int32_t W, int32_t H) { return gsr_carve_bin(variant, R, W, H, nullptr).bytes; }
+extern "C" size_t gsr_backward_scratch_bytes(int32_t variant, int32_t P)
+{
+    return gsr_align((size_t)(P > 0 ? P : 1) * gsr_acc_stride(variant) * sizeof(float));
+}
+
+static int check_cfg(const gsr_cfg* cfg, const gsr_inputs* in)
+{
+    if (!cfg || !in) { gsr_set_error("null cfg/inputs"); return 1; }
+    if (cfg->variant < GSR_EWA || cfg->variant > GSR_PLANE) { gsr_set_error("bad variant %d", cfg->variant); return 1; }
+    if (cfg->P < 0 || cfg->W <= 0 || cfg->H <= 0) { gsr_set_error("bad sizes P=%d W=%d H=%d", cfg->P, cfg->W, cfg->H); return 1; }
+    if (cfg->P == 0) return 0;
+    if (!in->means3D || !in->opacities) { gsr_set_error("means3D/opacities must be provided"); return 1; }
+    if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) {
+        gsr_set_error("Please provide excatly one of either SHs or precomputed colors!"); return 1;
+    }
+    const bool has_sr = in->scales && in->rotations;
+    if (has_sr == (in->cov3D_precomp != nullptr) || (!has_sr && (in->scales || in->rotations))) {
+        gsr_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!"); return 1;
+    }
+    if (in->shs && (cfg->M < (cfg->D + 1) * (cfg->D + 1) || cfg->D < 0 || cfg->D > 3)) {
+        gsr_set_error("sh_degree %d needs %d coefficients, got M=%d", cfg->D, (cfg->D + 1) * (cfg->D + 1), cfg->M); return 1;
+    }
+    if (!cfg->bg || !cfg->viewmatrix || !cfg->projmatrix || !cfg->campos) { gsr_set_error("camera tensors missing"); return 1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                                  int32_t* radii, uint32_t* num_rendered_host, void* stream)
+{
+    if (check_cfg(cfg, in)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    *num_rendered_host = 0;
+    if (cfg->P == 0) return 0;
+    GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
+    if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
+    if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1;
+    if (gsr_launch_depth_order(cfg, g, s)) return 1;
+    // the one host<->device sync of the forward (reference: cudaMemcpy of point_offsets[P-1], rasterizer_impl.cu:281)
+    GSR_CHECK(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered");
+    GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
+    return 0;
+}
+
+extern "C" int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                                  void* binning, size_t binning_bytes, void* img, size_t img_bytes,
+                                  uint32_t num_rendered, const gsr_outputs* out, void* stream)
+{
+    if (check_cfg(cfg, in)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    (void)geom_bytes;
+    GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
+    BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, binning);
+    ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, img);
+    if (b.bytes > binning_bytes) { gsr_set_error("binning buffer too small: %zu < %zu", binning_bytes, b.bytes); return 1; }
+    if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
+    if (cfg->P == 0) {
+        // the reference returns the zero-initialised outputs untouched when P == 0 (rasterize_points.cu:79-113)
+        return 0;
+    }
+    if (gsr_launch_binning(cfg, g, b, im, num_rendered, s)) return 1;
+    if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii,
+                            const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                            const void* img, size_t img_bytes, uint32_t num_rendered,
+                            void* scratch, size_t scratch_bytes,
+                            const gsr_out_grads* og, const gsr_in_grads* ig, void* stream)
+{
+    if (check_cfg(cfg, in)) return 1;
+    (void)geom_bytes; (void)binning_bytes; (void)img_bytes;
+    hipStream_t s = (hipStream_t)stream;
+    if (cfg->P == 0) return 0;
+    const size_t need = gsr_backward_scratch_bytes(cfg->variant, cfg->P);
+    if (scratch_bytes < need) { gsr_set_error("backward scratch too small: %zu < %zu", scratch_bytes, need); return 1; }
+    if (cfg->variant == GSR_PLANE && cfg->render_geo && !og->all_map_pixels) { gsr_set_error("PLANE backward needs all_map_pixels"); return 1; }
+    GeomView g = gsr_carve_geom(cfg->variant, cfg->P, const_cast<void*>(geom));
+    BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, const_cast<void*>(binning));
+    ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img));
+    float* acc = reinterpret_cast<float*>(scratch);
+    GSR_CHECK(hipMemsetAsync(acc, 0, need, s), "memset acc");
+    if (num_rendered > 0)
+        if (gsr_launch_blend_bwd(cfg, in, g, b, im, og, acc, s)) return 1;
+    if (gsr_launch_preprocess_bwd(cfg, in, radii, g, acc, ig, s)) return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ debug reads
+extern "C" int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, const void* img,
+                              uint32_t num_rendered, void* dst, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const size_t N = (size_t)cfg->W * cfg->H;
+    const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
+    const void* src = nullptr; size_t bytes = 0;
+    switch (field) {
+    case GSR_DBG_TILES_TOUCHED: { GeomView g = gsr_carve_geom(cfg->variant, cfg->P, const_cast<void*>(geom)); src = g.tiles_touched; bytes = (size_t)cfg->P * 4; break; }
+    case GSR_DBG_POINT_LIST: { BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, const_cast<void*>(binning)); src = b.point_list; bytes = (size_t)num_rendered * 4; break; }
+    case GSR_DBG_TILE_KEYS: { BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, const_cast<void*>(binning)); src = b.tile_keys; bytes = (size_t)num_rendered * 4; break; }
+    case GSR_DBG_RANGES: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.ranges; bytes = (size_t)gx * gy * 8; break; }
+    case GSR_DBG_FINAL_T: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.final_T; bytes = N * 4 * (cfg->variant == GSR_SURFEL ? 3 : 1); break; }
+    case GSR_DBG_N_CONTRIB: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.n_contrib; bytes = N * 4 * (cfg->variant == GSR_SURFEL ? 2 : 1); break; }
+    default: gsr_set_error("unknown debug field %d", field); return 1;
+    }
+    if (bytes) GSR_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s), "debug copy");
+    return 0;
+}

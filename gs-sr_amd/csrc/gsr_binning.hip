@@ -1,0 +1,264 @@
+// gsr_binning.hip -- integer stages between preprocess and blend (all HBM-bound, bit-exact vs the oracle).
+//
+// The reference (3DGS rasterizer_impl.cu:277-314) scans tiles_touched, emits one 64-bit (tile<<32 | depth) key per
+// tile instance and runs a 45-bit stable LSD radix sort over all R instances (6 passes x 24 B/instance).
+// Here the same ORDER -- by tile, then depth bits, ties by gaussian id -- is produced with far less traffic:
+//   1. stable radix sort of the P gaussians by depth bits (4 passes over P << R elements),
+//   2. prefix sum of tiles_touched in that order, duplicate-with-keys in that order (instances are now globally
+//      depth-ordered and carry only a 32-bit tile id),
+//   3. stable radix sort of the R instances by tile id only: ceil(log2 T) bits = 13 @1080p -> 2 passes x 16 B.
+//   4. tile ranges from key boundaries (identifyTileRanges, rasterizer_impl.cu:116-138).
+// Stability of every pass makes the result identical to the reference's single 64-bit sort.
+#include "gsr_common.h"
+
+// ------------------------------------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// inclusive scan across a 64-lane wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide inclusive scan for up to 1024 threads; returns inclusive value, *total = block sum
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* lds /*>=17 words*/, uint32_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t s = wave_incl_scan(v);
+    if (lane == 63) lds[wave] = s;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = (lane < nw) ? lds[lane] : 0;
+        uint32_t ws = wave_incl_scan(w);
+        if (lane < nw) lds[lane] = ws - w;        // exclusive prefix per wave
+        if (lane == nw - 1) lds[16] = ws;
+    }
+    __syncthreads();
+    s += lds[wave];
+    *total = lds[16];
+    __syncthreads();
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ generic scan
+// in-place exclusive scan of n words by ONE block (n is small: histograms, block sums)
+__global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, uint32_t n, uint32_t* total_out)
+{
+    __shared__ uint32_t lds[17];
+    const uint32_t chunk = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t b = threadIdx.x * chunk, e = min(n, b + chunk);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; i++) sum += data[i];
+    uint32_t tot;
+    uint32_t incl = block_incl_scan(sum, lds, &tot);
+    uint32_t run = incl - sum;
+    for (uint32_t i = b; i < e; i++) { uint32_t v = data[i]; data[i] = run; run += v; }
+    if (total_out && threadIdx.x == 0) *total_out = tot;
+}
+
+// ------------------------------------------------------------------------------------------------ radix sort
+// per-block digit histogram, hist[d * nblk + blk]
+__global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                                 uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * GSR_SORT_BLOCK;
+#pragma unroll 4
+    for (int it = 0; it < GSR_SORT_ITEMS; it++) {
+        uint32_t i = base + it * GSR_SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= mask) hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// stable scatter.  Order inside a block is (wave, item, lane): wave w owns keys [w*1024, w*1024+1024).
+__global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                    uint32_t n, int shift, int bits, const uint32_t* __restrict__ hist, uint32_t nblk)
+{
+    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t gbase[256];
+    const uint32_t mask = (1u << bits) - 1u;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * 256; i += GSR_SORT_THREADS) (&cnt[0][0])[i] = 0;
+    if (threadIdx.x <= mask) gbase[threadIdx.x] = hist[threadIdx.x * nblk + blockIdx.x];
+    __syncthreads();
+
+    const uint32_t base = blockIdx.x * GSR_SORT_BLOCK + wave * (GSR_WAVE * GSR_SORT_ITEMS);
+    uint32_t key[GSR_SORT_ITEMS], rank[GSR_SORT_ITEMS];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int it = 0; it < GSR_SORT_ITEMS; it++) {
+        const uint32_t i = base + it * GSR_WAVE + lane;
+        const bool valid = i < n;
+        key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        const uint32_t d = (key[it] >> shift) & mask;
+        // lanes of this wave holding the same digit (invalid lanes form their own group and are ignored)
+        uint64_t peers = __ballot(valid);
+        if (!valid) peers = ~peers;
+        for (int b = 0; b < bits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt);
+        uint32_t old = 0;
+        if (valid && before == 0) old = atomicAdd(&cnt[wave][d], (uint32_t)__popcll(peers));
+        const int leader = __ffsll((unsigned long long)peers) - 1;
+        old = __shfl(old, leader, 64);
+        rank[it] = old + before;
+    }
+    __syncthreads();
+    if (threadIdx.x <= mask) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { uint32_t t = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += t; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < GSR_SORT_ITEMS; it++) {
+        const uint32_t i = base + it * GSR_WAVE + lane;
+        if (i < n) {
+            const uint32_t d = (key[it] >> shift) & mask;
+            const uint32_t pos = gbase[d] + cnt[wave][d] + rank[it];
+            keys_out[pos] = key[it];
+            vals_out[pos] = vals_in ? vals_in[i] : i;
+        }
+    }
+}
+
+int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
+                         int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
+                         bool* result_in_b, hipStream_t s)
+{
+    const uint32_t nblk = gsr_div_up(n, GSR_SORT_BLOCK);
+    // identity_vals: the first pass generates value i for element i instead of reading vals_a
+    uint32_t *kin = keys_a, *vin = identity_vals ? nullptr : vals_a, *kout = keys_b, *vout = vals_b;
+    bool in_b = false;
+    for (int shift = begin_bit; shift < end_bit;) {
+        // balance the digits over the remaining passes
+        int remaining = end_bit - shift;
+        int passes_left = (remaining + bits_per_pass - 1) / bits_per_pass;
+        int bits = (remaining + passes_left - 1) / passes_left;
+        uint32_t mask = (1u << bits) - 1u;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, shift, mask, hist, nblk);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, hist, (mask + 1) * nblk, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, hist, nblk);
+        uint32_t* t;
+        t = kin; kin = kout; kout = t;
+        if (vin == nullptr) { vin = vout; vout = vals_a; }     // first pass generated identity values into vals_b
+        else { t = vin; vin = vout; vout = t; }
+        in_b = !in_b;
+        shift += bits;
+    }
+    if (result_in_b) *result_in_b = in_b;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ depth order
+// offsets[i] = inclusive prefix of tiles_touched[sorted_idx[i]] (block-local), block_sums[blk] = block total
+__global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_local(const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ tiles_touched,
+                                                                  uint32_t P, uint32_t* __restrict__ offsets, uint32_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t lds[17];
+    const uint32_t i = blockIdx.x * GSR_SCAN_BLOCK + threadIdx.x;
+    uint32_t v = (i < P) ? tiles_touched[sorted_idx[i]] : 0;
+    uint32_t tot;
+    uint32_t incl = block_incl_scan(v, lds, &tot);
+    if (i < P) offsets[i] = incl;
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_add(uint32_t P, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_prefix,
+                                                                uint32_t* __restrict__ counters)
+{
+    const uint32_t i = blockIdx.x * GSR_SCAN_BLOCK + threadIdx.x;
+    if (i < P) {
+        uint32_t v = offsets[i] + block_prefix[blockIdx.x];
+        offsets[i] = v;
+        if (i == P - 1) counters[0] = v;       // num_rendered
+    }
+}
+
+int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, hipStream_t s)
+{
+    const uint32_t P = (uint32_t)cfg->P;
+    bool in_b = false;
+    // keys: depth_key (A) <-> keys_b; values: identity -> vals_b <-> vals_a
+    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, 0, 32, 8, true, g.hist, &in_b, s);
+    // 4 passes: keys end in depth_key (A).  values: pass1 -> vals_b, pass2 -> vals_a, pass3 -> vals_b, pass4 -> vals_a
+    // (gsr_radix_sort_pairs alternates vout between vals_b and vals_a), so the ids end in vals_a == sorted_idx.
+    const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
+    hipLaunchKernelGGL(k_offsets_local, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, g.sorted_idx, g.tiles_touched, P, g.offsets, g.scan_tmp);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nblk, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_offsets_add, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, P, g.offsets, g.scan_tmp, g.counters);
+    return gsr_check_launch("depth_order", s, cfg->debug);
+}
+
+// ------------------------------------------------------------------------------------------------ duplicate + ranges
+// duplicateWithKeys (3DGS rasterizer_impl.cu:70-111) over gaussians in depth order; key = tile id only.
+__global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ offsets,
+                                                   const uint32_t* __restrict__ tiles_touched, const ushort4* __restrict__ rect, int gx,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t g = sorted_idx[i];
+    if (tiles_touched[g] == 0) return;
+    uint32_t off = (i == 0) ? 0 : offsets[i - 1];
+    const ushort4 r = rect[g];
+    for (uint32_t y = r.y; y < r.w; y++)
+        for (uint32_t x = r.x; x < r.z; x++) {
+            keys[off] = y * (uint32_t)gx + x;
+            vals[off] = g;
+            off++;
+        }
+}
+
+// identifyTileRanges (3DGS rasterizer_impl.cu:116-138)
+__global__ void __launch_bounds__(256) k_tile_ranges(uint32_t R, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const uint32_t cur = tile_keys[i];
+    if (i == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = tile_keys[i - 1];
+        if (cur != prev) { ranges[prev].y = i; ranges[cur].x = i; }
+    }
+    if (i == R - 1) ranges[cur].y = R;
+}
+
+static int tile_bits(int T)
+{
+    int b = 1;
+    while ((1 << b) < T) b++;
+    return b;
+}
+int gsr_tile_sort_passes(int T) { return (tile_bits(T) + 7) / 8; }
+
+int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, hipStream_t s)
+{
+    const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
+    const int T = gx * gy;
+    GSR_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)T * sizeof(uint2), s), "memset ranges");
+    if (R == 0) return 0;
+    // unsorted instances go to the buffer from which an integral number of passes lands in (tile_keys, point_list)
+    const int passes = gsr_tile_sort_passes(T);
+    uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
+    uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
+    hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up(cfg->P, 256)), dim3(256), 0, s, (uint32_t)cfg->P, g.sorted_idx, g.offsets,
+                       g.tiles_touched, g.rect, gx, k0, v0);
+    bool in_b = false;
+    gsr_radix_sort_pairs(k0, v0, k1, v1, R, 0, tile_bits(T), 8, false, b.hist, &in_b, s);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, b.tile_keys, im.ranges);
+    return gsr_check_launch("binning", s, cfg->debug);
+}

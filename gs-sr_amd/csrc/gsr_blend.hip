@@ -1,0 +1,475 @@
+// gsr_blend.hip -- per-tile alpha blend, forward and backward, for the EWA / PLANE / SURFEL variants.
+//
+// CDNA4 design (not the reference's 16x16-thread / shared-memory-batch / __syncthreads scheme):
+//   * one 64-lane wavefront owns an 8x8 pixel sub-tile (4 waves = one 16x16 tile, same tile list, NO barriers,
+//     each wave terminates on its own as soon as its 64 pixels are saturated);
+//   * the tile's depth-sorted splat list is consumed 64 at a time: lane l fetches instance l's conservative
+//     screen box, tests it against the wave's sub-tile, and a 64-bit ballot gives the queue of splats that can
+//     touch this sub-tile at all -- non-contributing (pixel, splat) pairs are skipped a whole wave at a time;
+//   * the surviving splat's packed record is fetched through a wave-uniform address (scalar/broadcast load of
+//     3-5 dwordx4), so per pair the VALU only does blend maths;
+//   * backward: per-pixel partial gradients are summed across the wave with DPP row reductions and ONE lane issues
+//     the atomics into a packed per-gaussian accumulator (<= 20 floats, one or two cache lines) -- 64x fewer atomics
+//     than one-atomic-per-pixel.
+// Behaviour follows 3DGS forward.cu:261-374 / backward.cu:399-557, PLANE forward.cu:273-407 / backward.cu:399-614,
+// SURFEL forward.cu:256-448 / backward.cu:143-447 (thresholds, ordering, recurrences); see DESIGN.md.
+#include "gsr_common.h"
+
+struct BlendParams {
+    int W, H, gx, gy, variant, render_geo;
+    float fx, fy;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float4* cull;
+    const float4* rec;
+    const float* bg;
+    float* final_T;
+    uint32_t* n_contrib;
+    // forward outputs
+    float* out_color; float* out_others; int32_t* out_observe; float* out_all_map; float* out_plane_depth;
+    // backward inputs
+    const float* dL_dcolor; const float* dL_dothers; const float* dL_dout_all_map; const float* dL_dplane_depth;
+    const float* all_map_pixels;
+    float* acc;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// ---- DPP wave reduction: total of v over the 64 lanes, returned wave-uniform ------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v += dpp_f<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f<0x141, 0xF>(v);   // row_half_mirror
+    v += dpp_f<0x140, 0xF>(v);   // row_mirror        -> every lane holds its row's sum
+    v += dpp_f<0x142, 0xA>(v);   // row_bcast15 into rows 1,3
+    v += dpp_f<0x143, 0xC>(v);   // row_bcast31 into rows 2,3 -> lanes 48..63 hold the wave total
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+__device__ __forceinline__ void atomic_addf(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+static constexpr float NEAR_N = 0.2f, FAR_N = 100.0f, FILTER_INV_SQ = 2.0f;
+
+// =================================================================================================== forward
+template <int V>
+__global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
+{
+    constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
+    const int tile = blockIdx.x;
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ox = tx * GSR_TILE + (wave & 1) * GSR_SUB, oy = ty * GSR_TILE + (wave >> 1) * GSR_SUB;
+    if (ox >= p.W || oy >= p.H) return;                 // wave-uniform: this sub-tile is outside the image
+    const int px = ox + (lane & 7), py = oy + (lane >> 3);
+    const bool inside = px < p.W && py < p.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float scx = (float)ox + 3.5f, scy = (float)oy + 3.5f;
+    const uint2 range = p.ranges[tile];
+    const size_t HW = (size_t)p.W * p.H;
+    const uint32_t pix_id = (uint32_t)p.W * py + px;
+
+    float T = 1.0f;
+    uint32_t last_contributor = 0;
+    float C0 = 0, C1 = 0, C2 = 0;
+    bool done = !inside;
+    // SURFEL
+    float N0 = 0, N1 = 0, N2 = 0, Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+    uint32_t median_contributor = 0; int surf_idx = -1;
+    float mn0 = 0, mn1 = 0, mn2 = 0;
+    // PLANE
+    float A0 = 0, A1 = 0, A2 = 0, A3 = 0, A4 = 0;
+
+    for (uint32_t base = range.x; base < range.y; base += GSR_WAVE) {
+        if (__ballot(!done) == 0) break;
+        const uint32_t i = base + lane;
+        const bool v = i < range.y;
+        const uint32_t id = v ? p.point_list[i] : 0u;
+        float4 cb = make_float4(0, 0, -1, -1);
+        if (v) cb = p.cull[id];
+        const bool hit = v && (cb.z >= 0.f) && !(fabsf(cb.x - scx) > cb.z + 3.5f) && !(fabsf(cb.y - scy) > cb.w + 3.5f);
+        uint64_t m = __ballot(hit);
+        while (m) {
+            const int j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
+            const float4* __restrict__ r = p.rec + (size_t)gid * ST;
+            const uint32_t contributor = base - range.x + (uint32_t)j + 1u;
+            if (V != GSR_SURFEL) {
+                const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+                const float dx = q0.x - pxf, dy = q0.y - pyf;
+                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+                const float alpha = fminf(0.99f, q1.y * __expf(power));
+                bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const float test_T = T * (1 - alpha);
+                const bool stop = ok && (test_T < 0.0001f);
+                done = done || stop;
+                ok = ok && !stop;
+                if (V == GSR_PLANE) {
+                    const uint64_t ob = __ballot(ok && T > 0.5f);
+                    if (ob != 0 && lane == 0) atomicAdd(&p.out_observe[gid], (int)__popcll(ob));
+                }
+                if (ok) {
+                    const float w = alpha * T;
+                    C0 += q1.z * w; C1 += q1.w * w; C2 += q2.x * w;
+                    if (V == GSR_PLANE && p.render_geo) {
+                        const float4 q3 = r[3];
+                        A0 += q2.y * w; A1 += q2.z * w; A2 += q2.w * w; A3 += q3.x * w; A4 += q3.y * w;
+                    }
+                    T = test_T;
+                    last_contributor = contributor;
+                }
+            } else {
+                const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
+                const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
+                const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
+                const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
+                const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
+                const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
+                const float sx = ppx / ppz, sy = ppy / ppz;
+                const float rho3d = sx * sx + sy * sy;
+                const float dx = q2.y - pxf, dy = q2.z - pyf;
+                const float rho2d = FILTER_INV_SQ * (dx * dx + dy * dy);
+                const float rho = fminf(rho3d, rho2d);
+                const float depth = (rho3d <= rho2d) ? (sx * Tw0 + sy * Tw1) + Tw2 : Tw2;
+                const float power = -0.5f * rho;
+                const float alpha = fminf(0.99f, q2.w * __expf(power));
+                bool ok = !done && !(ppz == 0.0f) && !(depth < NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                const float test_T = T * (1 - alpha);
+                const bool stop = ok && (test_T < 0.0001f);
+                done = done || stop;
+                ok = ok && !stop;
+                if (ok) {
+                    const float w = alpha * T;
+                    const float A = 1 - T;
+                    const float mm = FAR_N / (FAR_N - NEAR_N) * (1 - NEAR_N / depth);
+                    distortion += (mm * mm * A + M2 - 2 * mm * M1) * w;
+                    Dd += depth * w; M1 += mm * w; M2 += mm * mm * w;
+                    if (T > 0.5f) {
+                        median_depth = depth; surf_idx = (int)gid;
+                        mn0 = q3.x; mn1 = q3.y; mn2 = q3.z;
+                        median_contributor = contributor;
+                    }
+                    N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
+                    C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
+                    T = test_T;
+                    last_contributor = contributor;
+                }
+            }
+            if (__ballot(!done) == 0) break;
+        }
+    }
+
+    if (inside) {
+        p.final_T[pix_id] = T;
+        p.n_contrib[pix_id] = last_contributor;
+        p.out_color[0 * HW + pix_id] = C0 + T * p.bg[0];
+        p.out_color[1 * HW + pix_id] = C1 + T * p.bg[1];
+        p.out_color[2 * HW + pix_id] = C2 + T * p.bg[2];
+        if (V == GSR_SURFEL) {
+            p.n_contrib[pix_id + HW] = median_contributor;
+            p.final_T[pix_id + HW] = M1;
+            p.final_T[pix_id + 2 * HW] = M2;
+            float* o = p.out_others;
+            o[pix_id + 0 * HW] = Dd;
+            o[pix_id + 1 * HW] = 1 - T;
+            o[pix_id + 2 * HW] = N0; o[pix_id + 3 * HW] = N1; o[pix_id + 4 * HW] = N2;
+            o[pix_id + 5 * HW] = median_depth;
+            o[pix_id + 6 * HW] = distortion;
+            o[pix_id + 7 * HW] = (float)surf_idx;
+            o[pix_id + 8 * HW] = mn0; o[pix_id + 9 * HW] = mn1; o[pix_id + 10 * HW] = mn2;
+        }
+        if (V == GSR_PLANE && p.render_geo) {
+            p.out_all_map[0 * HW + pix_id] = A0; p.out_all_map[1 * HW + pix_id] = A1; p.out_all_map[2 * HW + pix_id] = A2;
+            p.out_all_map[3 * HW + pix_id] = A3; p.out_all_map[4 * HW + pix_id] = A4;
+            const float rayx = (pxf - (float)(p.W * 0.5f)) / p.fx, rayy = (pyf - (float)(p.H * 0.5f)) / p.fy;
+            p.out_plane_depth[pix_id] = (float)(A4 / -(double)((A0 * rayx + A1 * rayy + A2) + 1.0e-8));
+        }
+    }
+}
+
+// =================================================================================================== backward
+// one component: wave-reduce and let lane 63 add it to acc[slot]
+#define GSR_REDUCE_ADD(slot, val)                                         \
+    do {                                                                  \
+        float s_ = wave_sum_to_lane63(val);                               \
+        if (lane == 63) atomic_addf(accg + (slot), s_);                   \
+    } while (0)
+
+template <int V>
+__global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
+{
+    constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
+    constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
+    const int tile = blockIdx.x;
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ox = tx * GSR_TILE + (wave & 1) * GSR_SUB, oy = ty * GSR_TILE + (wave >> 1) * GSR_SUB;
+    if (ox >= p.W || oy >= p.H) return;
+    const int px = ox + (lane & 7), py = oy + (lane >> 3);
+    const bool inside = px < p.W && py < p.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float scx = (float)ox + 3.5f, scy = (float)oy + 3.5f;
+    const uint2 range = p.ranges[tile];
+    const size_t HW = (size_t)p.W * p.H;
+    const uint32_t pix_id = inside ? (uint32_t)p.W * py + px : 0u;
+
+    const float T_final = inside ? p.final_T[pix_id] : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? p.n_contrib[pix_id] : 0u;
+    const uint32_t max_last = wave_max_u32(last_contributor);
+    if (max_last == 0) return;
+
+    float dLp0 = 0, dLp1 = 0, dLp2 = 0;
+    if (inside && p.dL_dcolor) { dLp0 = p.dL_dcolor[pix_id]; dLp1 = p.dL_dcolor[HW + pix_id]; dLp2 = p.dL_dcolor[2 * HW + pix_id]; }
+    const float bg_dot_dpixel = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
+    float ar0 = 0, ar1 = 0, ar2 = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_alpha = 0;
+    const float ddelx_dx = 0.5f * p.W, ddely_dy = 0.5f * p.H;
+
+    // PLANE (backward.cu:433,460-490)
+    const bool geo = (V == GSR_PLANE) && p.render_geo;
+    float dA[5] = { 0, 0, 0, 0, 0 }, accA[5] = { 0, 0, 0, 0, 0 }, lastA[5] = { 0, 0, 0, 0, 0 };
+    if (geo && inside) {
+        const float rayx = (float)((pxf - p.W * 0.5) / p.fx), rayy = (float)((pyf - p.H * 0.5) / p.fy);
+        if (p.dL_dout_all_map)
+            for (int c = 0; c < 5; c++) dA[c] = p.dL_dout_all_map[c * HW + pix_id];
+        const float nx = p.all_map_pixels[pix_id], ny = p.all_map_pixels[HW + pix_id], nz = p.all_map_pixels[2 * HW + pix_id];
+        const float distance = p.all_map_pixels[4 * HW + pix_id];
+        const float tmp = (float)(nx * rayx + ny * rayy + nz + 1.0e-8);
+        const float dpd = p.dL_dplane_depth ? p.dL_dplane_depth[pix_id] : 0.f;
+        dA[4] += (-dpd / tmp);
+        dA[0] += dpd * (distance / (tmp * tmp) * rayx);
+        dA[1] += dpd * (distance / (tmp * tmp) * rayy);
+        dA[2] += dpd * (distance / (tmp * tmp));
+    }
+    // SURFEL (backward.cu:205-243)
+    float dL_dreg = 0, dL_ddepth = 0, dL_daccum = 0, dN0 = 0, dN1 = 0, dN2 = 0, dL_dmedian_depth = 0;
+    float dMN0 = 0, dMN1 = 0, dMN2 = 0;
+    uint32_t median_contributor = 0;
+    float last_depth = 0, ln0 = 0, ln1 = 0, ln2 = 0, accum_depth_rec = 0, accum_alpha_rec = 0, an0 = 0, an1 = 0, an2 = 0;
+    float final_D = 0, final_D2 = 0, final_A = 0, last_dL_dT = 0;
+    if (V == GSR_SURFEL && inside) {
+        median_contributor = p.n_contrib[pix_id + HW];
+        if (p.dL_dothers) {
+            const float* g = p.dL_dothers;
+            dL_ddepth = g[0 * HW + pix_id]; dL_daccum = g[1 * HW + pix_id]; dL_dreg = g[6 * HW + pix_id];
+            dN0 = g[2 * HW + pix_id]; dN1 = g[3 * HW + pix_id]; dN2 = g[4 * HW + pix_id];
+            dL_dmedian_depth = g[5 * HW + pix_id];
+            dMN0 = g[8 * HW + pix_id]; dMN1 = g[9 * HW + pix_id]; dMN2 = g[10 * HW + pix_id];
+        }
+        final_D = p.final_T[pix_id + HW]; final_D2 = p.final_T[pix_id + 2 * HW]; final_A = 1 - T_final;
+    }
+
+    // walk the list back to front, starting at the deepest splat any pixel of this wave used
+    const uint32_t end = range.x + max_last;
+    for (uint32_t top = end; top > range.x; top = (top - range.x > GSR_WAVE) ? top - GSR_WAVE : range.x) {
+        const bool v = (top - range.x) > (uint32_t)lane;
+        const uint32_t i = top - 1u - (uint32_t)lane;               // lane 0 = deepest
+        const uint32_t id = v ? p.point_list[i] : 0u;
+        float4 cb = make_float4(0, 0, -1, -1);
+        if (v) cb = p.cull[id];
+        const bool hit = v && (cb.z >= 0.f) && !(fabsf(cb.x - scx) > cb.z + 3.5f) && !(fabsf(cb.y - scy) > cb.w + 3.5f);
+        uint64_t m = __ballot(hit);
+        while (m) {
+            const int j = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
+            const float4* __restrict__ r = p.rec + (size_t)gid * ST;
+            float* accg = p.acc + (size_t)gid * AS;
+            const uint32_t idx0 = (top - 1u - (uint32_t)j) - range.x;       // 0-based position == reference's `contributor`
+            const bool active = inside && (idx0 < last_contributor);
+
+            if (V != GSR_SURFEL) {
+                const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+                const float dx = q0.x - pxf, dy = q0.y - pyf;
+                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, q1.y * G);
+                const bool ok = active && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(ok) == 0) continue;
+                float g_c0 = 0, g_c1 = 0, g_c2 = 0, g_op = 0, g_mx = 0, g_my = 0, g_ca = 0, g_cb = 0, g_cc = 0;
+                float g_ax = 0, g_ay = 0, g_am[5] = { 0, 0, 0, 0, 0 };
+                if (ok) {
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q1.z; dL_dalpha += (q1.z - ar0) * dLp0; g_c0 = dchannel_dcolor * dLp0;
+                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q1.w; dL_dalpha += (q1.w - ar1) * dLp1; g_c1 = dchannel_dcolor * dLp1;
+                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q2.x; dL_dalpha += (q2.x - ar2) * dLp2; g_c2 = dchannel_dcolor * dLp2;
+                    if (geo) {
+                        const float4 q3 = r[3];
+                        const float am[5] = { q2.y, q2.z, q2.w, q3.x, q3.y };
+#pragma unroll
+                        for (int c = 0; c < 5; c++) {
+                            accA[c] = last_alpha * lastA[c] + (1.f - last_alpha) * accA[c];
+                            lastA[c] = am[c];
+                            dL_dalpha += (am[c] - accA[c]) * dA[c];
+                            g_am[c] = dchannel_dcolor * dA[c];
+                        }
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    const float dL_dG = q1.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+                    const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+                    g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                    g_my = dL_dG * dG_ddely * ddely_dy;
+                    g_ax = fabsf(g_mx); g_ay = fabsf(g_my);
+                    g_ca = -0.5f * gdx * dx * dL_dG;
+                    g_cb = -0.5f * gdx * dy * dL_dG;
+                    g_cc = -0.5f * gdy * dy * dL_dG;
+                    g_op = G * dL_dalpha;
+                }
+                GSR_REDUCE_ADD(0, g_c0); GSR_REDUCE_ADD(1, g_c1); GSR_REDUCE_ADD(2, g_c2);
+                GSR_REDUCE_ADD(3, g_op);
+                GSR_REDUCE_ADD(4, g_mx); GSR_REDUCE_ADD(5, g_my);
+                GSR_REDUCE_ADD(6, g_ca); GSR_REDUCE_ADD(7, g_cb); GSR_REDUCE_ADD(8, g_cc);
+                if (V == GSR_PLANE) {
+                    GSR_REDUCE_ADD(9, g_ax); GSR_REDUCE_ADD(10, g_ay);
+                    if (geo) {
+#pragma unroll
+                        for (int c = 0; c < 5; c++) GSR_REDUCE_ADD(11 + c, g_am[c]);
+                    }
+                }
+            } else {
+                const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
+                const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
+                const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
+                const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
+                const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
+                const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
+                const float sx = ppx / ppz, sy = ppy / ppz;
+                const float rho3d = sx * sx + sy * sy;
+                const float dx = q2.y - pxf, dy = q2.z - pyf;
+                const float rho2d = FILTER_INV_SQ * (dx * dx + dy * dy);
+                const float rho = fminf(rho3d, rho2d);
+                const float c_d = (rho3d <= rho2d) ? (sx * Tw0 + sy * Tw1) + Tw2 : Tw2;
+                const float power = -0.5f * rho;
+                const float G = __expf(power);
+                const float opa = q2.w;
+                const float alpha = fminf(0.99f, opa * G);
+                const bool ok = active && !(ppz == 0.0f) && !(c_d < NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                if (__ballot(ok) == 0) continue;
+                float g_c0 = 0, g_c1 = 0, g_c2 = 0, g_op = 0, g_mx = 0, g_my = 0, g_n0 = 0, g_n1 = 0, g_n2 = 0;
+                float g_T[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+                if (ok) {
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q3.w; dL_dalpha += (q3.w - ar0) * dLp0; g_c0 = dchannel_dcolor * dLp0;
+                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q4.x; dL_dalpha += (q4.x - ar1) * dLp1; g_c1 = dchannel_dcolor * dLp1;
+                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q4.y; dL_dalpha += (q4.y - ar2) * dLp2; g_c2 = dchannel_dcolor * dLp2;
+                    float dL_dz = 0.0f, dL_dweight = 0;
+                    const float m_d = FAR_N / (FAR_N - NEAR_N) * (1 - NEAR_N / c_d);
+                    const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
+                    if (idx0 + 1u == median_contributor) dL_dz += dL_dmedian_depth;      // contributor == median_contributor-1
+                    dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
+                    const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                    dL_dz += dL_dmd * dmd_dd;
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = c_d;
+                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
+                    accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                    dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                    an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = q3.x; dL_dalpha += (q3.x - an0) * dN0;
+                    an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = q3.y; dL_dalpha += (q3.y - an1) * dN1;
+                    an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = q3.z; dL_dalpha += (q3.z - an2) * dN2;
+                    // fork quirk (backward.cu:381): median-normal gradient is added for every contributing splat
+                    g_n0 = alpha * T * dN0 + dMN0; g_n1 = alpha * T * dN1 + dMN1; g_n2 = alpha * T * dN2 + dMN2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    const float dL_dG = opa * dL_dalpha;
+                    dL_dz += alpha * T * dL_ddepth;
+                    if (rho3d <= rho2d) {
+                        const float dL_dsx = dL_dG * -G * sx + dL_dz * Tw0;
+                        const float dL_dsy = dL_dG * -G * sy + dL_dz * Tw1;
+                        const float dsx_pz = dL_dsx / ppz, dsy_pz = dL_dsy / ppz;
+                        const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * sx + dsy_pz * sy);
+                        const float dkx = ly * dpz - lz * dpy, dky = lz * dpx - lx * dpz, dkz = lx * dpy - ly * dpx;   // cross(l, dL_dp)
+                        const float dlx = dpy * kz - dpz * ky, dly = dpz * kx - dpx * kz, dlz = dpx * ky - dpy * kx;   // cross(dL_dp, k)
+                        g_T[0] = -dkx; g_T[1] = -dky; g_T[2] = -dkz;
+                        g_T[3] = -dlx; g_T[4] = -dly; g_T[5] = -dlz;
+                        g_T[6] = pxf * dkx + pyf * dlx + dL_dz * sx;
+                        g_T[7] = pxf * dky + pyf * dly + dL_dz * sy;
+                        g_T[8] = pxf * dkz + pyf * dlz + dL_dz * 1.0f;
+                    } else {
+                        g_mx = dL_dG * (-G * FILTER_INV_SQ * dx);
+                        g_my = dL_dG * (-G * FILTER_INV_SQ * dy);
+                        g_T[8] = dL_dz;
+                    }
+                    g_op = G * dL_dalpha;
+                }
+                GSR_REDUCE_ADD(0, g_c0); GSR_REDUCE_ADD(1, g_c1); GSR_REDUCE_ADD(2, g_c2);
+                GSR_REDUCE_ADD(3, g_op);
+                GSR_REDUCE_ADD(4, g_mx); GSR_REDUCE_ADD(5, g_my);
+                GSR_REDUCE_ADD(6, g_n0); GSR_REDUCE_ADD(7, g_n1); GSR_REDUCE_ADD(8, g_n2);
+#pragma unroll
+                for (int c = 0; c < 9; c++) GSR_REDUCE_ADD(9 + c, g_T[c]);
+            }
+        }
+        if (top == range.x) break;
+    }
+}
+
+// =================================================================================================== launchers
+static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im)
+{
+    BlendParams p = {};
+    p.W = cfg->W; p.H = cfg->H;
+    p.gx = (cfg->W + GSR_TILE - 1) / GSR_TILE; p.gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
+    p.variant = cfg->variant; p.render_geo = cfg->render_geo;
+    p.fy = cfg->H / (2.0f * cfg->tanfovy);
+    p.fx = cfg->W / (2.0f * cfg->tanfovx);
+    p.ranges = im.ranges; p.point_list = b.point_list; p.cull = g.cull; p.rec = g.rec; p.bg = cfg->bg;
+    p.final_T = im.final_T; p.n_contrib = im.n_contrib;
+    return p;
+}
+
+int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
+                         const gsr_outputs* out, hipStream_t s)
+{
+    (void)in;
+    BlendParams p = make_bp(cfg, g, b, im);
+    p.out_color = out->out_color; p.out_others = out->out_others; p.out_observe = out->out_observe;
+    p.out_all_map = out->out_all_map; p.out_plane_depth = out->out_plane_depth;
+    dim3 grid(p.gx * p.gy), block(256);
+    switch (cfg->variant) {
+    case GSR_EWA: hipLaunchKernelGGL(k_blend_fwd<GSR_EWA>, grid, block, 0, s, p); break;
+    case GSR_PLANE: hipLaunchKernelGGL(k_blend_fwd<GSR_PLANE>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(k_blend_fwd<GSR_SURFEL>, grid, block, 0, s, p); break;
+    }
+    return gsr_check_launch("blend_fwd", s, cfg->debug);
+}
+
+int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
+                         const gsr_out_grads* og, float* acc, hipStream_t s)
+{
+    (void)in;
+    BlendParams p = make_bp(cfg, g, b, im);
+    p.dL_dcolor = og->dL_dcolor; p.dL_dothers = og->dL_dothers; p.dL_dout_all_map = og->dL_dout_all_map;
+    p.dL_dplane_depth = og->dL_dplane_depth; p.all_map_pixels = og->all_map_pixels;
+    p.acc = acc;
+    dim3 grid(p.gx * p.gy), block(256);
+    switch (cfg->variant) {
+    case GSR_EWA: hipLaunchKernelGGL(k_blend_bwd<GSR_EWA>, grid, block, 0, s, p); break;
+    case GSR_PLANE: hipLaunchKernelGGL(k_blend_bwd<GSR_PLANE>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(k_blend_bwd<GSR_SURFEL>, grid, block, 0, s, p); break;
+    }
+    return gsr_check_launch("blend_bwd", s, cfg->debug);
+}

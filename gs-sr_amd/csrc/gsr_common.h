@@ -1,0 +1,100 @@
+// gsr_common.h -- private declarations shared by the HIP translation units of libgsrast_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gsrast.h"
+
+#define GSR_TILE 16            // tile edge in pixels (BLOCK_X/BLOCK_Y of the reference, config.h:16-17)
+#define GSR_WAVE 64
+#define GSR_SUB 8              // one wavefront owns an 8x8 sub-tile: 4 waves per 16x16 tile
+
+// record stride (in float4) per variant, see DESIGN.md "data layout in HBM"
+#define GSR_REC_EWA 3
+#define GSR_REC_PLANE 4
+#define GSR_REC_SURFEL 5
+// backward accumulator stride (floats) per variant
+#define GSR_ACC_EWA 12
+#define GSR_ACC_PLANE 16
+#define GSR_ACC_SURFEL 20
+
+// radix sort geometry
+#define GSR_SORT_THREADS 256
+#define GSR_SORT_ITEMS 16
+#define GSR_SORT_BLOCK (GSR_SORT_THREADS * GSR_SORT_ITEMS)   // 4096 keys per block
+#define GSR_SCAN_BLOCK 1024
+
+static inline __host__ __device__ int gsr_rec_stride(int variant)
+{
+    return variant == GSR_EWA ? GSR_REC_EWA : (variant == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
+}
+static inline __host__ __device__ int gsr_acc_stride(int variant)
+{
+    return variant == GSR_EWA ? GSR_ACC_EWA : (variant == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
+}
+
+static inline __host__ __device__ size_t gsr_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline __host__ __device__ uint32_t gsr_div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- arena views -------------------------------------------------------------------------------------------
+struct GeomView {
+    uint32_t* depth_key;      // [P]  bit pattern of view-space depth; 0xFFFFFFFF for culled gaussians
+    uint32_t* tiles_touched;  // [P]
+    ushort4* rect;            // [P]  tile rect {x0,y0,x1,y1}
+    float4* cull;             // [P]  {cx, cy, hx, hy}: conservative pixel-space box of alpha >= 1/255 (hx < 0: none)
+    float4* rec;              // [P * stride] packed blend record
+    uint32_t* clamped;        // [P]  3 bits: SH colour clamped to 0 per channel
+    uint32_t* sorted_idx;     // [P]  gaussian ids in (depth, id) order
+    uint32_t* offsets;        // [P]  inclusive prefix sum of tiles_touched in sorted order
+    uint32_t* keys_b;         // [P]  sort ping-pong
+    uint32_t* vals_a;         // [P]
+    uint32_t* vals_b;         // [P]
+    uint32_t* hist;           // [256 * nblk(P)]
+    uint32_t* scan_tmp;       // [>= nblk]
+    uint32_t* counters;       // [64] misc device scalars; [0] = num_rendered
+    size_t bytes;
+};
+struct BinView {
+    uint32_t* point_list;     // [R] final: gaussian id per instance, sorted by (tile, depth, id)
+    uint32_t* tile_keys;      // [R] final: tile id per instance
+    uint32_t* keys_b;         // [R]
+    uint32_t* vals_b;         // [R]
+    uint32_t* hist;           // [128 * nblk(R)]
+    uint32_t* scan_tmp;
+    size_t bytes;
+};
+struct ImgView {
+    float* final_T;           // [N] (SURFEL [3N]: T, M1, M2)
+    uint32_t* n_contrib;      // [N] (SURFEL [2N]: last, median)
+    uint2* ranges;            // [T]
+    size_t bytes;
+};
+
+GeomView gsr_carve_geom(int variant, int P, void* base);
+BinView gsr_carve_bin(int variant, uint32_t R, int W, int H, void* base);
+ImgView gsr_carve_img(int variant, int W, int H, void* base);
+
+// ---- error plumbing ----------------------------------------------------------------------------------------
+void gsr_set_error(const char* fmt, ...);
+int gsr_check_launch(const char* what, hipStream_t s, bool debug);
+#define GSR_CHECK(call, what)                                                                \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) { gsr_set_error("%s: %s", what, hipGetErrorString(e_)); return 1; } \
+    } while (0)
+
+// ---- stage launchers (each in its own .hip) ------------------------------------------------------------------
+int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s);
+int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, hipStream_t s);     // sorted_idx, offsets, counters[0]
+int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, hipStream_t s);
+int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
+                         const gsr_outputs* out, hipStream_t s);
+int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
+                         const gsr_out_grads* og, float* acc, hipStream_t s);
+int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,
+                              const float* acc, const gsr_in_grads* ig, hipStream_t s);
+
+// generic device-wide primitives (gsr_binning.hip)
+int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
+                         int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
+                         bool* result_in_b, hipStream_t s);

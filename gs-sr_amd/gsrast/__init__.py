@@ -1,0 +1,139 @@
+"""gsrast -- ctypes binding of libgsrast_hip.so (include/gsrast.h) and the shared autograd bridge used by the
+drop-in packages diff_gaussian_rasterization / diff_surfel_rasterization / diff_plane_rasterization /
+scaffold_filter / simple_knn that sit next to this package.
+
+There is NO CPU or PyTorch fallback: every entry point raises if the HIP library is missing or a tensor is not on
+a HIP device (the reference's extensions are CUDA-only in exactly the same way, e.g. CHECK_INPUT in
+diff-surfel-rasterization/rasterize_points.cu:27-29).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgsrast_hip.so")
+
+EWA, SURFEL, PLANE = 0, 1, 2
+ABI_VERSION = 1
+
+_vp = C.c_void_p
+
+
+class Cfg(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32),
+                ("H", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("render_geo", C.c_int32),
+                ("bg", _vp), ("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp)]
+
+
+class Inputs(C.Structure):
+    _fields_ = [(n, _vp) for n in ("means3D", "shs", "colors_precomp", "opacities", "scales", "rotations",
+                                   "cov3D_precomp", "all_map")]
+
+
+class Outputs(C.Structure):
+    _fields_ = [(n, _vp) for n in ("out_color", "out_others", "out_observe", "out_all_map", "out_plane_depth")]
+
+
+class OutGrads(C.Structure):
+    _fields_ = [(n, _vp) for n in ("dL_dcolor", "dL_dothers", "dL_dout_all_map", "dL_dplane_depth", "all_map_pixels")]
+
+
+class InGrads(C.Structure):
+    _fields_ = [(n, _vp) for n in ("dL_dmeans3D", "dL_dmeans2D", "dL_dmeans2D_abs", "dL_dcolors", "dL_dopacity",
+                                   "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dall_map")]
+
+
+EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward_scratch_bytes",
+           "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_visible_filter",
+           "gsr_tsdf_integrate", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
+           "gsr_abi_version"]
+
+_lib = None
+
+
+def lib():
+    """Loads libgsrast_hip.so; fails loudly when it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"gsrast: HIP library not built: {LIB_PATH} (run `make -C gs-sr_amd/csrc` or "
+                           f"`python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    sz = C.c_size_t
+    L.gsr_geom_bytes.restype = sz; L.gsr_geom_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.gsr_img_bytes.restype = sz; L.gsr_img_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.gsr_binning_bytes.restype = sz; L.gsr_binning_bytes.argtypes = [C.c_int32, C.c_uint32, C.c_int32, C.c_int32]
+    L.gsr_backward_scratch_bytes.restype = sz; L.gsr_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.gsr_forward_stage1.restype = C.c_int
+    L.gsr_forward_stage1.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, C.POINTER(C.c_uint32), _vp]
+    L.gsr_forward_stage2.restype = C.c_int
+    L.gsr_forward_stage2.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, sz, _vp, sz, C.c_uint32,
+                                     C.POINTER(Outputs), _vp]
+    L.gsr_backward.restype = C.c_int
+    L.gsr_backward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, _vp, sz, _vp, sz, _vp, sz, C.c_uint32, _vp, sz,
+                               C.POINTER(OutGrads), C.POINTER(InGrads), _vp]
+    L.gsr_mark_visible.restype = C.c_int
+    L.gsr_mark_visible.argtypes = [C.c_int32, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_visible_filter.restype = C.c_int
+    L.gsr_visible_filter.argtypes = [C.POINTER(Cfg), _vp, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_tsdf_integrate.restype = C.c_int
+    L.gsr_tsdf_integrate.argtypes = [C.c_int64, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_dist2_scratch_bytes.restype = sz; L.gsr_dist2_scratch_bytes.argtypes = [C.c_int32]
+    L.gsr_dist2.restype = C.c_int
+    L.gsr_dist2.argtypes = [C.c_int32, _vp, _vp, _vp, sz, _vp]
+    L.gsr_debug_read.restype = C.c_int
+    L.gsr_debug_read.argtypes = [C.POINTER(Cfg), C.c_int32, _vp, _vp, _vp, C.c_uint32, _vp, _vp]
+    L.gsr_last_error.restype = C.c_char_p
+    L.gsr_abi_version.restype = C.c_int32
+    if L.gsr_abi_version() != ABI_VERSION:
+        raise RuntimeError("gsrast: ABI version mismatch between python binding and libgsrast_hip.so")
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().gsr_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"gsrast {what}: {last_error()}")
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dev_f32(t, name, allow_empty=True):
+    """The reference does x.contiguous().data<float>(): float32 required, empty tensor == 'not provided'."""
+    if t is None or t.numel() == 0:
+        if not allow_empty:
+            raise RuntimeError(f"{name} must be provided")
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")          # CHECK_INPUT message of the surfel extension
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected scalar type Float but found {t.dtype}")
+    return t.contiguous()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def make_cfg(variant, P, settings, D, M, render_geo, keep):
+    cfg = Cfg()
+    cfg.variant = variant; cfg.P = P; cfg.D = int(D); cfg.M = int(M)
+    cfg.W = int(settings.image_width); cfg.H = int(settings.image_height)
+    cfg.tanfovx = float(settings.tanfovx); cfg.tanfovy = float(settings.tanfovy)
+    cfg.scale_modifier = float(settings.scale_modifier)
+    cfg.prefiltered = int(bool(settings.prefiltered)); cfg.debug = int(bool(settings.debug))
+    cfg.render_geo = int(bool(render_geo))
+    for name, attr in (("bg", "bg"), ("viewmatrix", "viewmatrix"), ("projmatrix", "projmatrix"), ("campos", "campos")):
+        t = dev_f32(getattr(settings, attr), name, allow_empty=False)
+        keep.append(t)
+        setattr(cfg, name, t.data_ptr())
+    return cfg

@@ -1,0 +1,125 @@
+"""Shared autograd bridge for the three rasterizer variants (the role of _RasterizeGaussians in
+diff_gaussian_rasterization/__init__.py:44-155, diff_surfel_rasterization/__init__.py:44-156,
+diff_plane_rasterization/__init__.py:48-171) on top of the C ABI of libgsrast_hip.so.
+
+Buffer ownership mirrors the reference: outputs and the three opaque byte arenas (geomBuffer, binningBuffer,
+imgBuffer) are torch tensors allocated here; the arenas are saved for backward.
+"""
+import ctypes as C
+
+import torch
+
+from . import (EWA, SURFEL, PLANE, Cfg, Inputs, Outputs, OutGrads, InGrads, lib, check, stream_ptr, dev_f32, ptr,
+               make_cfg)
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+def _bytes(n, device):
+    return torch.empty((max(int(n), 1),), dtype=torch.uint8, device=device)
+
+
+def _prepare(variant, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, all_map, settings):
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    keep = []
+    m3 = dev_f32(means3D, "means3D", allow_empty=True)
+    P = int(means3D.size(0))
+    t = dict(means3D=m3, shs=dev_f32(sh, "sh"), colors_precomp=dev_f32(colors_precomp, "colors"),
+             opacities=dev_f32(opacities, "opacity"), scales=dev_f32(scales, "scales"),
+             rotations=dev_f32(rotations, "rotations"), cov3D_precomp=dev_f32(cov3Ds_precomp, "cov3D_precomp"),
+             all_map=dev_f32(all_map, "all_map") if variant == PLANE else None)
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    render_geo = bool(getattr(settings, "render_geo", False)) and t["all_map"] is not None
+    cfg = make_cfg(variant, P, settings, settings.sh_degree, M, render_geo, keep)
+    inp = Inputs(*[ptr(t[n]) for n, _ in Inputs._fields_])
+    keep.extend(v for v in t.values() if v is not None)
+    return cfg, inp, keep, P, M
+
+
+def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, all_map, settings):
+    """Returns (num_rendered, outputs dict, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    L = lib()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("means3D must be a CUDA tensor")
+    H, W = int(settings.image_height), int(settings.image_width)
+    cfg, inp, keep, P, M = _prepare(variant, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                    all_map, settings)
+    f32 = dict(dtype=torch.float32, device=dev)
+    outs = {}
+    empty_call = (P == 0)
+    mk = torch.zeros if empty_call else torch.empty
+    outs["color"] = mk((3, H, W), **f32)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    if variant == SURFEL:
+        outs["others"] = mk((11, H, W), **f32)
+    if variant == PLANE:
+        outs["observe"] = torch.zeros((P,), dtype=torch.int32, device=dev)
+        geo = bool(cfg.render_geo) and not empty_call
+        outs["all_map"] = (torch.empty if geo else torch.zeros)((5, H, W), **f32)
+        outs["plane_depth"] = (torch.empty if geo else torch.zeros)((1, H, W), **f32)
+    geom = _bytes(L.gsr_geom_bytes(variant, P), dev)
+    img = _bytes(L.gsr_img_bytes(variant, W, H), dev)
+    if empty_call:
+        return 0, outs, radii, geom, _bytes(0, dev), img
+    s = stream_ptr(dev)
+    R = C.c_uint32(0)
+    with torch.cuda.device(dev):
+        check(L.gsr_forward_stage1(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(radii), C.byref(R), s), "forward")
+        binning = _bytes(L.gsr_binning_bytes(variant, R.value, W, H), dev)
+        o = Outputs(ptr(outs["color"]), ptr(outs.get("others")), ptr(outs.get("observe")), ptr(outs.get("all_map")),
+                    ptr(outs.get("plane_depth")))
+        check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
+                                   ptr(img), img.numel(), R.value, C.byref(o), s), "forward")
+    return int(R.value), outs, radii, geom, binning, img
+
+
+def backward(variant, num_rendered, settings, radii, means3D, sh, colors_precomp, opacities, scales, rotations,
+             cov3Ds_precomp, all_map, geom, binning, img, grad_color, grad_others=None, grad_all_map=None,
+             grad_plane_depth=None, all_map_pixels=None):
+    """Returns dict of gradients (tensors shaped like the reference's RasterizeGaussiansBackwardCUDA outputs)."""
+    L = lib()
+    dev = means3D.device
+    cfg, inp, keep, P, M = _prepare(variant, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                    all_map, settings)
+    f32 = dict(dtype=torch.float32, device=dev)
+    mk = torch.zeros if P == 0 else torch.empty
+    g = dict(dL_dmeans3D=mk((P, 3), **f32), dL_dmeans2D=mk((P, 3), **f32),
+             dL_dcolors=mk((P, 3), **f32), dL_dopacity=mk((P, 1), **f32),
+             dL_dcov3D=mk((P, 9 if variant == SURFEL else 6), **f32),
+             dL_dsh=mk((P, M, 3), **f32), dL_dscales=mk((P, 2 if variant == SURFEL else 3), **f32),
+             dL_drotations=mk((P, 4), **f32))
+    if variant == PLANE:
+        g["dL_dmeans2D_abs"] = mk((P, 3), **f32)
+        # without render_geo the all_map channels receive no gradient (PLANE backward.cu:563 is guarded)
+        g["dL_dall_map"] = (mk if cfg.render_geo else torch.zeros)((P, 5), **f32)
+    if P == 0:
+        return g
+    def gd(t, name):
+        return dev_f32(t, name) if t is not None else None
+    og_t = [gd(grad_color, "dL_dout_color"), gd(grad_others, "dL_dout_others"), gd(grad_all_map, "dL_dout_all_map"),
+            gd(grad_plane_depth, "dL_dout_plane_depth"), gd(all_map_pixels, "all_map_pixels")]
+    og = OutGrads(*[ptr(t) for t in og_t])
+    ig = InGrads(ptr(g["dL_dmeans3D"]), ptr(g["dL_dmeans2D"]), ptr(g.get("dL_dmeans2D_abs")), ptr(g["dL_dcolors"]),
+                 ptr(g["dL_dopacity"]), ptr(g["dL_dcov3D"]), ptr(g["dL_dsh"]) if M > 0 else None, ptr(g["dL_dscales"]),
+                 ptr(g["dL_drotations"]), ptr(g.get("dL_dall_map")))
+    scratch = _bytes(L.gsr_backward_scratch_bytes(variant, P), dev)
+    radii_c = radii.contiguous()
+    with torch.cuda.device(dev):
+        check(L.gsr_backward(C.byref(cfg), C.byref(inp), ptr(radii_c), ptr(geom), geom.numel(), ptr(binning),
+                             binning.numel(), ptr(img), img.numel(), int(num_rendered), ptr(scratch), scratch.numel(),
+                             C.byref(og), C.byref(ig), stream_ptr(dev)), "backward")
+    if sh is None or sh.numel() == 0 or M == 0:
+        g["dL_dsh"] = torch.zeros((P, M, 3), **f32)
+    return g
+
+
+def debug_read(variant, field, settings, P, M, num_rendered, geom, binning, img, out):
+    keep = []
+    cfg = make_cfg(variant, P, settings, settings.sh_degree, M, False, keep)
+    check(lib().gsr_debug_read(C.byref(cfg), field, ptr(geom), ptr(binning), ptr(img), int(num_rendered), ptr(out),
+                               stream_ptr(out.device)), "debug_read")
+    return out

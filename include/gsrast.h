@@ -1,0 +1,165 @@
+/*
+ * gsrast.h -- C ABI of libgsrast_hip.so: MI355X-native (gfx950) differentiable Gaussian-splat rasterizer.
+ *
+ * Drop-in boundary for the four CUDA extensions GS-SR imports.  Every entry point names the reference
+ * interface it replaces (paths relative to /root/reference/submodules):
+ *
+ *   gsr_forward_stage1/2   <- _C.rasterize_gaussians            diff-gaussian-rasterization/rasterize_points.cu:35-115
+ *                                                               diff-surfel-rasterization/rasterize_points.cu:39-135
+ *                                                               diff-plane-rasterization/rasterize_points.cu:35-125
+ *                             (CudaRasterizer::Rasterizer::forward, <ext>/cuda_rasterizer/rasterizer_impl.cu:198-352)
+ *   gsr_backward           <- _C.rasterize_gaussians_backward   <ext>/rasterize_points.cu:117-234
+ *                             (CudaRasterizer::Rasterizer::backward, <ext>/cuda_rasterizer/rasterizer_impl.cu:338-448)
+ *   gsr_mark_visible       <- _C.mark_visible                   diff-gaussian-rasterization/rasterize_points.cu:198-217
+ *   gsr_visible_filter     <- _C.rasterize_gaussians_filter     scaffold-filter/rasterize_points.cu:219-283
+ *   gsr_dist2              <- simple_knn._C.distCUDA2           simple-knn/ext.cpp:15-17, simple_knn.cu:186-222
+ *   gsr_tsdf_integrate     <- the per-frame TSDF update of gssr/utils/mesh_utils.py:195-246 (compute_sdf_perframe +
+ *                             the integration step of compute_unbounded_tsdf)
+ *   gsr_*_bytes            <- required<GeometryState/ImageState/BinningState>(), <ext>/cuda_rasterizer/rasterizer_impl.h:21-73
+ *
+ * Conventions
+ *   - All array pointers are DEVICE pointers (HIP) unless marked HOST; plain C types only, no torch types.
+ *   - NULL for an optional input == "not provided" (the reference passes an empty tensor -> nullptr).
+ *   - The caller owns every buffer.  The three scratch arenas (geom, binning, img) must stay alive and unmodified
+ *     between forward and backward of the same call (the reference saves them in the autograd ctx); their internal
+ *     layout is private to the library.
+ *   - Every function returns 0 on success, non-zero on error; gsr_last_error() gives a thread-local message.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  The reference launches on the legacy
+ *     default stream; pass torch.cuda.current_stream().cuda_stream from PyTorch.
+ *   - Matrices follow the reference's row-vector convention: p_view = [x y z 1] * viewmatrix (16 floats, row-major).
+ *   - Layouts: images are CHW float32; radii/out_observe are int32; quaternions are (w,x,y,z).
+ */
+#ifndef GSRAST_H
+#define GSRAST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+enum gsr_variant {
+    GSR_EWA = 0,     /* diff_gaussian_rasterization : 3DGS EWA splats, RGB only                          */
+    GSR_SURFEL = 1,  /* diff_surfel_rasterization   : 2DGS surfels, 11 auxiliary channels                */
+    GSR_PLANE = 2    /* diff_plane_rasterization    : PGSR planes, all_map[5], plane_depth, out_observe  */
+};
+
+/* Per-call camera/state: the GaussianRasterizationSettings NamedTuple
+ * (diff_gaussian_rasterization/__init__.py:157-169; diff_plane_rasterization/__init__.py:173-186 adds render_geo). */
+typedef struct gsr_cfg {
+    int32_t variant;          /* enum gsr_variant */
+    int32_t P;                /* number of gaussians (means3D.size(0)) */
+    int32_t D;                /* sh_degree (active) */
+    int32_t M;                /* SH coefficients per gaussian = sh.size(1); 0 when colors are precomputed */
+    int32_t W, H;             /* image_width, image_height */
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t prefiltered;
+    int32_t debug;            /* synchronise + check after every stage (CHECK_CUDA, auxiliary.h:166-173) */
+    int32_t render_geo;       /* PLANE only */
+    const float* bg;          /* [3]  */
+    const float* viewmatrix;  /* [16] */
+    const float* projmatrix;  /* [16] */
+    const float* campos;      /* [3]  */
+} gsr_cfg;
+
+typedef struct gsr_inputs {
+    const float* means3D;        /* [P,3] */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3]  or NULL */
+    const float* opacities;      /* [P] */
+    const float* scales;         /* [P,3] (SURFEL [P,2]) or NULL */
+    const float* rotations;      /* [P,4] or NULL */
+    const float* cov3D_precomp;  /* [P,6] (SURFEL: transMat_precomp [P,9]) or NULL */
+    const float* all_map;        /* PLANE [P,5] or NULL */
+} gsr_inputs;
+
+typedef struct gsr_outputs {
+    float* out_color;        /* [3,H,W] */
+    float* out_others;       /* SURFEL [11,H,W]: 0 depth*alpha,1 alpha,2-4 normal,5 median depth,6 distortion,7 median idx,8-10 median normal */
+    int32_t* out_observe;    /* PLANE [P]; must be zero-filled by the caller (torch::full(0)) */
+    float* out_all_map;      /* PLANE [5,H,W] */
+    float* out_plane_depth;  /* PLANE [1,H,W] */
+} gsr_outputs;
+
+typedef struct gsr_out_grads {       /* dL/d(outputs); NULL == zeros */
+    const float* dL_dcolor;          /* [3,H,W]  */
+    const float* dL_dothers;         /* SURFEL [11,H,W] */
+    const float* dL_dout_all_map;    /* PLANE [5,H,W] */
+    const float* dL_dplane_depth;    /* PLANE [1,H,W] */
+    const float* all_map_pixels;     /* PLANE [5,H,W]: the forward's out_all_map (saved by the caller) */
+} gsr_out_grads;
+
+typedef struct gsr_in_grads {        /* all written in full by the library (no zero-init required) */
+    float* dL_dmeans3D;     /* [P,3] */
+    float* dL_dmeans2D;     /* [P,3] (z component is always 0) */
+    float* dL_dmeans2D_abs; /* PLANE [P,3] or NULL */
+    float* dL_dcolors;      /* [P,3] */
+    float* dL_dopacity;     /* [P]   */
+    float* dL_dcov3D;       /* [P,6] (SURFEL: dL_dtransMat [P,9]) */
+    float* dL_dsh;          /* [P,M,3] or NULL when M == 0 */
+    float* dL_dscales;      /* [P,3] (SURFEL [P,2]) */
+    float* dL_drotations;   /* [P,4] */
+    float* dL_dall_map;     /* PLANE [P,5] or NULL */
+} gsr_in_grads;
+
+/* ---- scratch sizing (bytes).  binning is sized for a capacity of R tile-instances. */
+size_t gsr_geom_bytes(int32_t variant, int32_t P);
+size_t gsr_img_bytes(int32_t variant, int32_t W, int32_t H);
+size_t gsr_binning_bytes(int32_t variant, uint32_t R, int32_t W, int32_t H);
+/* scratch needed by gsr_backward (gradient accumulators, zeroed by the library) */
+size_t gsr_backward_scratch_bytes(int32_t variant, int32_t P);
+
+/* ---- forward.  stage1 = preprocess + depth ordering + prefix sum; it writes radii and returns the number of
+ * tile instances R in *num_rendered_host (HOST pointer) after synchronising `stream` once -- the same single
+ * host<->device sync the reference performs (rasterizer_impl.cu:281).  The caller then sizes `binning` for R and
+ * calls stage2 = duplicate-with-keys + stable tile sort + tile ranges + per-tile alpha blend. */
+int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                       int32_t* radii /*[P]*/, uint32_t* num_rendered_host, void* stream);
+int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                       void* binning, size_t binning_bytes, void* img, size_t img_bytes,
+                       uint32_t num_rendered, const gsr_outputs* out, void* stream);
+
+/* ---- backward of the same call.  radii is the forward's radii output. */
+int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii,
+                 const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                 const void* img, size_t img_bytes, uint32_t num_rendered,
+                 void* scratch, size_t scratch_bytes,
+                 const gsr_out_grads* og, const gsr_in_grads* ig, void* stream);
+
+/* ---- helpers of the same extensions */
+int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present /*[P] bool*/, void* stream);
+int gsr_visible_filter(const gsr_cfg* cfg, const float* means3D, const float* scales /*[P,3]*/,
+                       const float* rotations, const float* cov3D_precomp, int32_t* radii /*[P]*/, void* stream);
+
+/* ---- adjacent kernels */
+int gsr_tsdf_integrate(int64_t V, const float* points /*[V,3]*/, const float* full_proj /*[16]*/,
+                       int32_t W, int32_t H, const float* depth /*[H,W]*/, const float* rgb /*[3,H,W]*/,
+                       float sdf_trunc, const float* sdf_trunc_per_point /*[V] or NULL*/,
+                       float* tsdf /*[V]*/, float* weight /*[V]*/, float* rgb_acc /*[V,3]*/, void* stream);
+size_t gsr_dist2_scratch_bytes(int32_t P);
+int gsr_dist2(int32_t P, const float* points /*[P,3]*/, float* out /*[P]*/, void* scratch, size_t scratch_bytes,
+              void* stream);
+
+/* ---- introspection for parity tests (copies a private stage result into a caller DEVICE buffer) */
+enum gsr_debug_field {
+    GSR_DBG_TILES_TOUCHED = 0, /* uint32 [P]                                      (from geom)    */
+    GSR_DBG_POINT_LIST = 1,    /* uint32 [R] gaussian ids sorted by (tile, depth) (from binning) */
+    GSR_DBG_RANGES = 2,        /* uint32 [T,2]                                    (from img)     */
+    GSR_DBG_FINAL_T = 3,       /* float  [N] (SURFEL [3,N])                       (from img)     */
+    GSR_DBG_N_CONTRIB = 4,     /* uint32 [N] (SURFEL [2,N])                       (from img)     */
+    GSR_DBG_TILE_KEYS = 5      /* uint32 [R] tile id per sorted instance          (from binning) */
+};
+int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, const void* img,
+                   uint32_t num_rendered, void* dst, void* stream);
+
+const char* gsr_last_error(void);
+int32_t gsr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRAST_H */
