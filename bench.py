@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: train iters/sec + rasterize fwd+bwd ms @ 300k Gaussians, 1920x1080.
+
+A "step" is one training iteration of the hot path on one synthetic tile-scene resident in HBM:
+    drop-in rasterizer forward -> image-space loss -> autograd backward (rasterizer backward) -> fused Adam step.
+Default workload = BASELINE.json configs[1]: scaffold-2dgs => diff_surfel_rasterization with colors_precomp
+(SURVEY.md §8 table), P = 300 000, 1920x1080, synthetic scene of SURVEY.md §8d.  The loss touches every auxiliary
+channel the 2DGS scene uses (rgb L1, alpha, depth, normal, distortion: gssr/scene/twodgs_scene.py:25-35,88-105), so
+every gradient path of the backward kernel is live.  Nothing is skipped inside the timed region.
+
+Multi-GPU: VastGaussian tiles are independent sub-scenes -> one tile per GPU, one process per GPU, no
+data-path collective ("weak" scaling); value = all ranks' iterations / max-over-ranks time.
+
+One JSON line on rank 0, with "roofline" (dominant kernel = blend backward, live HIP-event duration from the library's
+stage profiler, algorithmic bytes of SURVEY.md §8d) and "cpu_baseline" (the CPU oracle, kind "port", N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "gs-sr_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(variant, R, N, T):
+    """blend fwd / bwd algorithmic bytes per launch."""
+    rec = {"ewa": 40, "plane": 60, "surfel": 76}[variant]
+    pix_f = {"ewa": 20, "plane": 44, "surfel": 76}[variant]
+    grad = {"ewa": 44, "plane": 68, "surfel": 72}[variant]
+    pix_b = {"ewa": 20, "plane": 64, "surfel": 76}[variant]
+    fwd = R * rec + N * pix_f + 8 * T
+    bwd = R * rec + R * grad + N * pix_b + 8 * T
+    return fwd, bwd
+
+
+def make_step(variant, sc, device):
+    import hiprun
+    import diff_gaussian_rasterization as dgr
+    import diff_surfel_rasterization as dsr
+    import diff_plane_rasterization as dpr
+    t = hiprun.to_dev(sc, device)
+    rs = hiprun.settings(variant, t)
+    P, W, H = t["means3D"].shape[0], int(t["W"]), int(t["H"])
+    params = {k: t[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations", "colors_precomp")}
+    opt = torch.optim.Adam([{"params": [params["means3D"]], "lr": 1.6e-5}, {"params": [params["colors_precomp"]], "lr": 2.5e-3},
+                            {"params": [params["opacities"]], "lr": 1e-3}, {"params": [params["scales"]], "lr": 5e-4},
+                            {"params": [params["rotations"]], "lr": 1e-4}], eps=1e-15, fused=True)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    gt = torch.rand((3, H, W), generator=g).to(device)
+    gt_normal = torch.nn.functional.normalize(torch.randn((3, H, W), generator=g), dim=0).to(device)
+    all_map = t.get("all_map")
+    state = {}
+
+    def step():
+        means2D = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
+        kw = dict(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], colors_precomp=params["colors_precomp"],
+                  scales=params["scales"], rotations=params["rotations"])
+        if variant == "surfel":
+            color, radii, allmap = dsr.GaussianRasterizer(rs)(**kw)
+            alpha, normal, dist = allmap[1:2], allmap[2:5], allmap[6:7]
+            depth = allmap[0:1] / alpha.clamp_min(1e-6)
+            loss = ((color - gt).abs().mean() + 0.05 * (1 - (normal * gt_normal).sum(0)).mean() + 100.0 * dist.mean()
+                    + 0.01 * depth.mean() + 0.01 * allmap[5:6].mean())
+        elif variant == "plane":
+            m2a = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
+            color, radii, observe, oam, pd = dpr.GaussianRasterizer(rs)(means2D_abs=m2a, all_map=all_map, **kw)
+            loss = (color - gt).abs().mean() + 0.05 * (1 - (oam[0:3] * gt_normal).sum(0)).mean() + 0.01 * pd.mean() + 0.01 * oam[4].mean()
+        else:
+            color, radii = dgr.GaussianRasterizer(rs)(**kw)
+            loss = (color - gt).abs().mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        state["loss"] = loss
+        state["vis"] = radii
+    return step, state
+
+
+def cpu_baseline(variant, sc, og, budget_s=25.0):
+    """Times the CPU oracle (plain-C restatement, OpenMP over all host threads) on the SAME scene: raster fwd+bwd."""
+    import oracle
+    t0 = time.time()
+    with oracle.Forward(sc, variant) as f:
+        f.backward(**og)
+    first = time.time() - t0
+    n, tot = 0, 0.0
+    while tot < budget_s - first and n < 5:
+        t0 = time.time()
+        with oracle.Forward(sc, variant) as f:
+            f.backward(**og)
+        tot += time.time() - t0
+        n += 1
+    per = (tot / n) if n else first
+    return {"value": round(1.0 / per, 4), "unit": "rasterize fwd+bwd iters/s", "cores": oracle.omp_threads(), "kind": "port",
+            "ms_per_iter": round(per * 1e3, 1),
+            "sample": f"{max(n, 1)} x full workload ({variant}, same scene as the GPU run), oracle/gsr_oracle.c with OpenMP; "
+                      f"rasterizer forward+backward only (no loss/optimizer)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--variant", default="surfel", choices=["ewa", "surfel", "plane"])
+    ap.add_argument("--P", type=int, default=300000)
+    ap.add_argument("--W", type=int, default=1920)
+    ap.add_argument("--H", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import gsrast
+    import scenes
+    gsrast.lib()
+    # one independent tile-scene per rank (train_split.py trains tiles independently; seed = tile index)
+    sc = scenes.make_scene(args.variant, args.P, args.W, args.H, seed=rank)
+    step, state = make_step(args.variant, sc, device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    gsrast.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = gsrast.profile_read()
+    gsrast.profile_enable(False)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        import hiprun
+        st = hiprun.run_raw(args.variant, sc, device=device)
+        R = int(st["R"])
+        N = args.W * args.H
+        T = ((args.W + 15) // 16) * ((args.H + 15) // 16)
+        fwd_b, bwd_b = algorithmic_bytes(args.variant, R, N, T)
+        ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items()}
+        dom, dom_bytes = ("blend_bwd", bwd_b) if ms["blend_bwd"] >= ms["blend_fwd"] else ("blend_fwd", fwd_b)
+        achieved = dom_bytes / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get(f"{args.variant}:{dom}")
+            except Exception:
+                traffic = None
+        raster_fwd = ms["preprocess"] + ms["depth_order"] + ms["binning"] + ms["blend_fwd"]
+        raster_bwd = ms["bwd_memset"] + ms["blend_bwd"] + ms["preprocess_bwd"]
+        out = {
+            "metric": "train iters/sec @300k Gaussians 1080p (rasterize fwd+bwd ms and HBM GB/s vs roofline alongside)",
+            "value": round(world * args.steps / elapsed, 3), "unit": "iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1] scaffold-2dgs path: diff_{ {'ewa':'gaussian','surfel':'surfel','plane':'plane'}[args.variant] }_rasterization "
+                                   f"fwd+bwd, colors_precomp, P={args.P}, {args.W}x{args.H}, synthetic scene SURVEY §8d (seed=rank), "
+                                   f"+ image loss + fused Adam",
+                       "variant": args.variant, "P": args.P, "W": args.W, "H": args.H, "tile_instances_R": R,
+                       "visible": int((st["radii"] > 0).sum()), "parallelism": f"{world} independent tile(s), 1 per GPU, no collective"},
+            "rasterize_fwd_ms": round(raster_fwd, 4), "rasterize_bwd_ms": round(raster_bwd, 4),
+            "rasterize_fwd_bwd_ms": round(raster_fwd + raster_bwd, 4),
+            "stage_ms": {k: round(v, 4) for k, v in ms.items()},
+            "roofline": {"kernel": f"k_blend_{'bwd' if dom == 'blend_bwd' else 'fwd'}<{args.variant}>", "bound": "hbm",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(ms[dom], 4),
+                         "note": "blend is VALU/atomic-bound by construction (SURVEY §7-5); HBM fraction reported as BASELINE asks"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            og = scenes.random_out_grads(args.variant, args.W, args.H, seed=0)
+            out["cpu_baseline"] = cpu_baseline(args.variant, sc, og)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,55 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ stage profiler
+// Optional: HIP events recorded on the launch stream around every stage; read back with gsr_profile_read.
+// Used by bench.py for the live kernel durations behind the roofline figure.  Not thread-safe (bench is single-threaded).
+#include <vector>
+struct ProfRec { int label; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<ProfRec> g_prof_free;
+static double g_prof_ms[GSR_PROF_LABELS];
+static uint64_t g_prof_n[GSR_PROF_LABELS];
+
+static void prof_drain()
+{
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            g_prof_ms[r.label] += ms; g_prof_n[r.label] += 1;
+        }
+        g_prof_free.push_back(r);
+    }
+    g_prof.clear();
+}
+struct ProfScope {
+    ProfRec r; bool on; hipStream_t s;
+    ProfScope(int label, hipStream_t s_) : on(g_prof_on), s(s_)
+    {
+        if (!on) return;
+        if (g_prof.size() >= 8192) prof_drain();
+        if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
+        else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
+        r.label = label;
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); g_prof.push_back(r); } }
+};
+extern "C" int gsr_profile_enable(int32_t enable)
+{
+    prof_drain();
+    g_prof_on = enable != 0;
+    for (int i = 0; i < GSR_PROF_LABELS; i++) { g_prof_ms[i] = 0; g_prof_n[i] = 0; }
+    return 0;
+}
+extern "C" int gsr_profile_read(double* ms_total, uint64_t* counts)
+{
+    prof_drain();
+    for (int i = 0; i < GSR_PROF_LABELS; i++) { ms_total[i] = g_prof_ms[i]; counts[i] = g_prof_n[i]; }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ arenas
 template <typename T>
 static T* take(char*& p, size_t n)
@@ -131,8 +180,8 @@ extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void
     if (cfg->P == 0) return 0;
     GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
     if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
-    if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1;
-    if (gsr_launch_depth_order(cfg, g, s)) return 1;
+    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
+    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, s)) return 1; }
     // the one host<->device sync of the forward (reference: cudaMemcpy of point_offsets[P-1], rasterizer_impl.cu:281)
     GSR_CHECK(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered");
     GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
@@ -155,8 +204,8 @@ extern "C" int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void
         // the reference returns the zero-initialised outputs untouched when P == 0 (rasterize_points.cu:79-113)
         return 0;
     }
-    if (gsr_launch_binning(cfg, g, b, im, num_rendered, s)) return 1;
-    if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1;
+    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, num_rendered, s)) return 1; }
+    { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1; }
     return 0;
 }
 
@@ -178,10 +227,12 @@ extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int3
     BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, const_cast<void*>(binning));
     ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img));
     float* acc = reinterpret_cast<float*>(scratch);
-    GSR_CHECK(hipMemsetAsync(acc, 0, need, s), "memset acc");
-    if (num_rendered > 0)
+    { ProfScope ps(GSR_PROF_BWD_MEMSET, s); GSR_CHECK(hipMemsetAsync(acc, 0, need, s), "memset acc"); }
+    if (num_rendered > 0) {
+        ProfScope ps(GSR_PROF_BLEND_BWD, s);
         if (gsr_launch_blend_bwd(cfg, in, g, b, im, og, acc, s)) return 1;
-    if (gsr_launch_preprocess_bwd(cfg, in, radii, g, acc, ig, s)) return 1;
+    }
+    { ProfScope ps(GSR_PROF_PREPROCESS_BWD, s); if (gsr_launch_preprocess_bwd(cfg, in, radii, g, acc, ig, s)) return 1; }
     return 0;
 }
 

@@ -48,7 +48,8 @@ class InGrads(C.Structure):
 EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward_scratch_bytes",
            "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_visible_filter",
            "gsr_tsdf_integrate", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
-           "gsr_abi_version"]
+           "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read"]
+PROF_LABELS = ["preprocess", "depth_order", "binning", "blend_fwd", "bwd_memset", "blend_bwd", "preprocess_bwd", "_"]
 
 _lib = None
 
@@ -86,12 +87,26 @@ def lib():
     L.gsr_dist2.argtypes = [C.c_int32, _vp, _vp, _vp, sz, _vp]
     L.gsr_debug_read.restype = C.c_int
     L.gsr_debug_read.argtypes = [C.POINTER(Cfg), C.c_int32, _vp, _vp, _vp, C.c_uint32, _vp, _vp]
+    L.gsr_profile_enable.restype = C.c_int; L.gsr_profile_enable.argtypes = [C.c_int32]
+    L.gsr_profile_read.restype = C.c_int
+    L.gsr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.gsr_last_error.restype = C.c_char_p
     L.gsr_abi_version.restype = C.c_int32
     if L.gsr_abi_version() != ABI_VERSION:
         raise RuntimeError("gsrast: ABI version mismatch between python binding and libgsrast_hip.so")
     _lib = L
     return L
+
+
+def profile_enable(on=True):
+    lib().gsr_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """-> {label: (total_ms, launches)} accumulated since profile_enable(True)."""
+    ms = (C.c_double * 8)(); n = (C.c_uint64 * 8)()
+    lib().gsr_profile_read(ms, n)
+    return {PROF_LABELS[i]: (ms[i], int(n[i])) for i in range(7)}
 
 
 def last_error():

@@ -43,6 +43,8 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
     """Returns (num_rendered, outputs dict, radii, geomBuffer, binningBuffer, imgBuffer)."""
     L = lib()
     dev = means3D.device
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")     # rasterize_points.cu:57-59
     if dev.type != "cuda":
         raise RuntimeError("means3D must be a CUDA tensor")
     H, W = int(settings.image_height), int(settings.image_width)

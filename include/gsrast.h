@@ -156,6 +156,15 @@ enum gsr_debug_field {
 int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, const void* img,
                    uint32_t num_rendered, void* dst, void* stream);
 
+/* ---- optional stage profiler: HIP events recorded on the launch stream around every stage.
+ * gsr_profile_enable(1) resets and starts, gsr_profile_read returns total milliseconds and launch counts per label. */
+enum gsr_prof_label {
+    GSR_PROF_PREPROCESS = 0, GSR_PROF_DEPTH_ORDER = 1, GSR_PROF_BINNING = 2, GSR_PROF_BLEND_FWD = 3,
+    GSR_PROF_BWD_MEMSET = 4, GSR_PROF_BLEND_BWD = 5, GSR_PROF_PREPROCESS_BWD = 6, GSR_PROF_LABELS = 8
+};
+int gsr_profile_enable(int32_t enable);
+int gsr_profile_read(double* ms_total /*[GSR_PROF_LABELS]*/, uint64_t* counts /*[GSR_PROF_LABELS]*/);
+
 const char* gsr_last_error(void);
 int32_t gsr_abi_version(void);
 

@@ -1,0 +1,107 @@
+"""CPU-side checks of the product boundary (no GPU, no compute calls): the C-ABI library loads, exports every symbol
+include/gsrast.h declares, sizes its arenas sanely, and the python drop-in packages keep the reference's names,
+signatures and error behaviour."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gsrast.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import gsrast
+    L = gsrast.lib()
+    decl = _declared_symbols()
+    assert len(decl) >= 15
+    for s in decl:
+        assert hasattr(L, s), f"libgsrast_hip.so does not export {s}"
+    assert sorted(gsrast.EXPORTS) == decl
+    assert L.gsr_abi_version() == gsrast.ABI_VERSION
+
+
+def test_arena_sizes_scale_linearly():
+    import gsrast
+    L = gsrast.lib()
+    for v in (gsrast.EWA, gsrast.SURFEL, gsrast.PLANE):
+        g1, g2 = L.gsr_geom_bytes(v, 100000), L.gsr_geom_bytes(v, 200000)
+        assert 1.8 < g2 / g1 < 2.2 and g1 / 100000 < 200          # < 200 B per gaussian of private state
+        b = L.gsr_binning_bytes(v, 3000000, 1920, 1080)
+        assert 16 * 3000000 <= b <= 20 * 3000000                   # 4 x u32 per instance (+ histograms)
+        i = L.gsr_img_bytes(v, 1920, 1080)
+        assert i >= 1920 * 1080 * 8
+    assert L.gsr_img_bytes(gsrast.SURFEL, 1920, 1080) > L.gsr_img_bytes(gsrast.EWA, 1920, 1080)
+
+
+def test_dropin_signatures_match_reference():
+    import diff_gaussian_rasterization as dgr
+    import diff_surfel_rasterization as dsr
+    import diff_plane_rasterization as dpr
+    import scaffold_filter as sf
+    base = ["image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+            "sh_degree", "campos", "prefiltered", "debug"]
+    assert list(dgr.GaussianRasterizationSettings._fields) == base
+    assert list(dsr.GaussianRasterizationSettings._fields) == base
+    assert list(sf.GaussianRasterizationSettings._fields) == base
+    assert list(dpr.GaussianRasterizationSettings._fields) == base[:-1] + ["render_geo", "debug"]
+    fwd = ["self", "means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"]
+    assert list(inspect.signature(dgr.GaussianRasterizer.forward).parameters) == fwd
+    assert list(inspect.signature(dsr.GaussianRasterizer.forward).parameters) == fwd
+    assert list(inspect.signature(dpr.GaussianRasterizer.forward).parameters) == \
+        ["self", "means3D", "means2D", "means2D_abs", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp", "all_map"]
+    assert list(inspect.signature(sf.GaussianRasterizer.visible_filter).parameters) == ["self", "means3D", "scales", "rotations", "cov3D_precomp"]
+    assert hasattr(dgr.GaussianRasterizer, "markVisible") and hasattr(dgr, "rasterize_gaussians")
+    from simple_knn._C import distCUDA2
+    assert callable(distCUDA2)
+
+
+def _settings(mod, **kw):
+    z = torch.zeros(3)
+    base = dict(image_height=32, image_width=32, tanfovx=0.5, tanfovy=0.5, bg=z, scale_modifier=1.0, viewmatrix=torch.eye(4),
+                projmatrix=torch.eye(4), sh_degree=0, campos=z, prefiltered=False, debug=False)
+    base.update(kw)
+    return mod.GaussianRasterizationSettings(**base)
+
+
+def test_argument_validation_messages():
+    import diff_gaussian_rasterization as dgr
+    import diff_plane_rasterization as dpr
+    r = dgr.GaussianRasterizer(_settings(dgr))
+    m = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m, torch.zeros(4, 1), scales=m, rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(m, m, torch.zeros(4, 1), shs=torch.zeros(4, 16, 3), colors_precomp=m, scales=m, rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(m, m, torch.zeros(4, 1), colors_precomp=m)
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(m, m, torch.zeros(4, 1), colors_precomp=m, scales=m, rotations=torch.zeros(4, 4), cov3D_precomp=torch.zeros(4, 6))
+    rp = dpr.GaussianRasterizer(_settings(dpr, render_geo=True))
+    with pytest.raises(Exception, match="excatly one of either SHs"):
+        rp(m, m, m, torch.zeros(4, 1), scales=m, rotations=torch.zeros(4, 4))
+
+
+def test_no_cpu_fallback():
+    """The product must fail loudly for host tensors (the reference is CUDA-only too); it never routes to the oracle."""
+    import diff_gaussian_rasterization as dgr
+    r = dgr.GaussianRasterizer(_settings(dgr))
+    m = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        r(m, m, torch.zeros(4, 1), colors_precomp=m, scales=m, rotations=torch.zeros(4, 4))
+    with pytest.raises(RuntimeError, match="dimensions"):
+        r(torch.zeros(4, 2), m, torch.zeros(4, 1), colors_precomp=m, scales=m, rotations=torch.zeros(4, 4))
+    # product sources never reference the oracle
+    for dp, _, fs in os.walk(os.path.join(ROOT, "gs-sr_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                for pat in ("import oracle", "from oracle", "gsr_oracle", "libgsr_oracle", "oracle/"):
+                    assert pat not in txt, (os.path.join(dp, f), pat)

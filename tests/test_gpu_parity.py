@@ -1,0 +1,242 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the drop-in python packages -> C ABI, against the
+CPU oracle on identical inputs.  Bars (BASELINE.json north_star): bit-exact for integer/index work (radii,
+tiles_touched, sorted instance list, tile ranges, out_observe); <=1e-4 on rendered RGB/depth/normal maps; <=1e-3
+relative on gradients."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4
+GRAD_TOL = 1e-3
+
+
+def _hiprun():
+    import hiprun
+    return hiprun
+
+
+def _relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def _img_close(a, b, tol=RGB_TOL, frac=1e-4):
+    """<= tol everywhere, except a vanishing fraction of pixels where a 1-ulp difference in exp() flips one of the
+    reference's discrete gates (alpha<1/255, T<1e-4; SURVEY §7 hard part 1)."""
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    scale = max(1.0, float(np.abs(b).max()))
+    bad = (d > tol * scale).mean()
+    assert bad <= frac, f"{bad:.2e} of pixels differ by more than {tol * scale:.1e} (max {d.max():.3e})"
+
+
+CASES = [
+    ("ewa", "precomp", 4000, 256, 160, 0),
+    ("ewa", "sh", 6000, 330, 190, 1),
+    ("plane", "precomp", 4000, 256, 160, 0),
+    ("plane", "sh", 3000, 200, 120, 1),
+    ("surfel", "precomp", 4000, 256, 160, 0),
+    ("surfel", "sh", 6000, 330, 190, 1),
+]
+
+
+@pytest.mark.parametrize("variant,cm,P,W,H,pose", CASES)
+def test_forward_backward_parity(variant, cm, P, W, H, pose):
+    hr = _hiprun()
+    sc = scenes.make_scene(variant, P, W, H, seed=11, color_mode=cm, bg=(0.2, 0.4, 0.6), pose=pose)
+    og = scenes.random_out_grads(variant, W, H, seed=11, scale=1.0)
+    with oracle.Forward(sc, variant) as f:
+        g = f.backward(**og)
+        st = hr.run_raw(variant, sc)
+        # ---- integer stages: bit-exact
+        assert st["R"] == f.R
+        assert np.array_equal(st["radii"], f.radii)
+        assert np.array_equal(st["tiles_touched"], f.tiles_touched())
+        assert np.array_equal(st["point_list"], f.point_list())
+        assert np.array_equal(st["tile_keys"], (f.keys() >> np.uint64(32)).astype(np.uint32))
+        rr = f.ranges(); touched = rr[:, 1] > rr[:, 0]
+        assert np.array_equal(st["ranges"][touched], rr[touched])
+        assert np.all(st["ranges"][~touched, 0] == st["ranges"][~touched, 1])
+        ft, nc = f.image_state()
+        assert (st["n_contrib"] == nc).mean() > 0.9999
+        # ---- images
+        _img_close(st["color"], f.color)
+        _img_close(st["final_T"], ft)
+        if variant == "surfel":
+            for ch in (0, 1, 2, 3, 4, 5, 6, 8, 9, 10):
+                _img_close(st["others"][ch], f.others[ch])
+            assert (st["others"][7] == f.others[7]).mean() > 0.9999         # median splat index
+        if variant == "plane":
+            assert np.array_equal(st["observe"], f.observe)
+            _img_close(st["all_map"], f.out_all_map)
+            _img_close(st["plane_depth"], f.plane_depth, frac=1e-3)
+        # ---- gradients through the public autograd API
+        res = hr.run(variant, sc, og)
+    gg = res["grads"]
+    pairs = [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"),
+             ("dL_dopacities", "dL_dopacity"), ("dL_dmeans2D", "dL_dmeans2D")]
+    pairs.append(("dL_dshs", "dL_dsh") if cm == "sh" else ("dL_dcolors_precomp", "dL_dcolors"))
+    if variant == "plane":
+        pairs += [("dL_dall_map", "dL_dall_map"), ("dL_dmeans2D_abs", "dL_dmeans2D_abs")]
+    for a, b in pairs:
+        assert _relerr(gg[a].reshape(g[b].shape), g[b]) < GRAD_TOL, (a, _relerr(gg[a].reshape(g[b].shape), g[b]))
+
+
+def test_precomputed_cov3d_and_transmat():
+    hr = _hiprun()
+    # EWA with cov3D_precomp
+    sc = scenes.make_scene("ewa", 2000, 160, 112, seed=3)
+    with oracle.Forward(sc, "ewa") as f:
+        cov = f.geom()["cov"].copy()
+    sc2 = {k: v for k, v in sc.items() if k not in ("scales", "rotations")}
+    sc2["cov3D_precomp"] = cov
+    og = scenes.random_out_grads("ewa", 160, 112, seed=3, scale=1.0)
+    with oracle.Forward(sc2, "ewa") as f:
+        g = f.backward(**og)
+        res = hr.run("ewa", sc2, og)
+        _img_close(res["color"], f.color)
+        assert _relerr(res["grads"]["dL_dcov3D_precomp"], g["dL_dcov3D"]) < GRAD_TOL
+        assert _relerr(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"]) < GRAD_TOL
+    # SURFEL with transMat_precomp (cov3D_precomp slot carries (P,9))
+    ss = scenes.make_scene("surfel", 2000, 160, 112, seed=4)
+    with oracle.Forward(ss, "surfel") as f:
+        T = f.geom()["cov"].copy()
+        vis = f.radii > 0
+    ss2 = {k: v for k, v in ss.items() if k not in ("scales", "rotations")}
+    ss2["cov3D_precomp"] = T
+    ss2["means3D"] = ss["means3D"][vis]; ss2["opacities"] = ss["opacities"][vis]
+    ss2["colors_precomp"] = ss["colors_precomp"][vis]; ss2["cov3D_precomp"] = T[vis]
+    og = scenes.random_out_grads("surfel", 160, 112, seed=4, scale=1.0)
+    with oracle.Forward(ss2, "surfel") as f:
+        g = f.backward(**og)
+        res = hr.run("surfel", ss2, og)
+        _img_close(res["color"], f.color)
+        assert np.array_equal(res["radii"], f.radii)
+        assert _relerr(res["grads"]["dL_dcov3D_precomp"], g["dL_dcov3D"]) < GRAD_TOL
+
+
+@pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
+def test_edge_cases(variant):
+    hr = _hiprun()
+    # ragged image (not a multiple of 16 or 8), huge and tiny splats, scale_modifier, nothing visible, P == 0
+    sc = scenes.make_scene(variant, 1500, 131, 77, seed=5, sigma_px=9.0, scale_modifier=1.3, bg=(1.0, 0.0, 0.5))
+    sc["opacities"][:50] = 0.999      # exercises the 0.99 clamp
+    sc["opacities"][50:100] = 0.002   # below 1/255: never contributes
+    og = scenes.random_out_grads(variant, 131, 77, seed=5, scale=1.0)
+    if variant == "surfel":
+        og["dL_dothers"][8:11] = 0.25   # median-normal quirk path
+    with oracle.Forward(sc, variant) as f:
+        g = f.backward(**og)
+        res = hr.run(variant, sc, og)
+        assert np.array_equal(res["radii"], f.radii)
+        _img_close(res["color"], f.color)
+        assert _relerr(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"]) < GRAD_TOL
+        assert _relerr(res["grads"]["dL_dscales"], g["dL_dscales"]) < GRAD_TOL
+        assert _relerr(res["grads"]["dL_dopacities"].reshape(-1), g["dL_dopacity"].reshape(-1)) < GRAD_TOL
+    # everything behind the camera -> R == 0, background only
+    sb = dict(sc); sb["means3D"] = sc["means3D"].copy(); sb["means3D"][:, 2] = -5.0
+    res = hr.run(variant, sb, og)
+    assert (res["radii"] == 0).all()
+    assert np.allclose(res["color"], np.asarray(sc["bg"])[:, None, None], atol=1e-7)
+    assert all(np.abs(v).max() == 0 for v in res["grads"].values() if v is not None)
+    # P == 0 (reference returns zero-initialised outputs, rasterize_points.cu:79)
+    s0 = {k: (v[:0] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 1500 else v) for k, v in sc.items()}
+    res = hr.run(variant, s0)
+    assert res["color"].shape == (3, 77, 131) and np.abs(res["color"]).max() == 0
+
+
+def test_render_geo_false_plane():
+    hr = _hiprun()
+    sc = scenes.make_scene("plane", 1500, 128, 96, seed=6); sc["render_geo"] = False
+    og = dict(dL_dcolor=scenes.random_out_grads("plane", 128, 96, seed=6, scale=1.0)["dL_dcolor"])
+    with oracle.Forward(sc, "plane") as f:
+        g = f.backward(**og)
+        res = hr.run("plane", sc, og)
+        _img_close(res["color"], f.color)
+        assert np.array_equal(res["observe"], f.observe)            # counted regardless of render_geo
+        assert np.abs(res["out_all_map"]).max() == 0 and np.abs(res["plane_depth"]).max() == 0
+        assert _relerr(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"]) < GRAD_TOL
+
+
+def test_visible_filter_mark_visible_dist2_tsdf():
+    import scaffold_filter
+    from simple_knn._C import distCUDA2
+    from gsrast.tsdf import tsdf_integrate_
+    hr = _hiprun()
+    sc = scenes.make_scene("ewa", 20000, 640, 360, seed=7)
+    t = hr.to_dev(sc)
+    rs = scaffold_filter.GaussianRasterizationSettings(
+        image_height=360, image_width=640, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=t["bg"], scale_modifier=1.0,
+        viewmatrix=t["viewmatrix"], projmatrix=t["projmatrix"], sh_degree=0, campos=t["campos"], prefiltered=False, debug=False)
+    radii = scaffold_filter.GaussianRasterizer(rs).visible_filter(t["means3D"], scales=t["scales"], rotations=t["rotations"])
+    assert np.array_equal(radii.cpu().numpy(), oracle.visible_filter(sc))
+    import diff_gaussian_rasterization as dgr
+    mv = dgr.GaussianRasterizer(hr.settings("ewa", t)).markVisible(t["means3D"])
+    assert np.array_equal(mv.cpu().numpy(), oracle.mark_visible(sc["means3D"], sc["viewmatrix"], sc["projmatrix"]))
+    # distCUDA2
+    pts = sc["means3D"][:3000]
+    d = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+    assert np.allclose(d, oracle.dist2(pts), rtol=1e-5, atol=0)
+    # TSDF: three frames into the same grid
+    rng = np.random.default_rng(0)
+    W, H = 96, 64
+    V = 40000
+    grid = rng.uniform(-1, 1, (V, 3)).astype(np.float32) * np.array([2.0, 1.2, 1.0], np.float32) + np.array([0, 0, 5.0], np.float32)
+    tsdf = np.ones(V, np.float32); wgt = np.ones(V, np.float32); rgb = np.zeros((V, 3), np.float32)
+    tg = torch.ones(V, device="cuda"); wg = torch.ones(V, device="cuda"); cg = torch.zeros((V, 3), device="cuda")
+    for fr in range(3):
+        cam = scenes.make_camera(W, H, 80.0, 80.0, yaw_deg=5.0 * fr, t=(0.1 * fr, 0, 0))
+        depth = rng.uniform(4.0, 6.0, (1, H, W)).astype(np.float32)
+        col = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+        oracle.tsdf_integrate(grid, cam["projmatrix"], depth, col, 0.3, tsdf, wgt, rgb)
+        tsdf_integrate_(torch.from_numpy(grid).cuda(), torch.from_numpy(cam["projmatrix"]).cuda(), torch.from_numpy(depth).cuda(),
+                        torch.from_numpy(col).cuda(), 0.3, tg, cg, wg)
+    assert np.array_equal(wg.cpu().numpy(), wgt)
+    assert np.abs(tg.cpu().numpy() - tsdf).max() < 1e-5
+    assert np.abs(cg.cpu().numpy() - rgb).max() < 1e-5
+    assert (wgt > 1).sum() > 1000
+
+
+@pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
+def test_full_size_properties(variant):
+    """BASELINE full size (300k gaussians, 1920x1080): size-independent properties instead of the (slow) oracle."""
+    hr = _hiprun()
+    P, W, H = 300000, 1920, 1080
+    sc = scenes.make_scene(variant, P, W, H, seed=0)
+    st = hr.run_raw(variant, sc)
+    R = st["R"]
+    assert R == int(st["tiles_touched"].sum())
+    tk, pl = st["tile_keys"].astype(np.int64), st["point_list"].astype(np.int64)
+    assert np.all(np.diff(tk) >= 0)                                           # sorted by tile
+    pv = sc["means3D"] @ sc["viewmatrix"][:3, :3] + sc["viewmatrix"][3, :3]
+    depth_bits = pv[:, 2].astype(np.float32).view(np.uint32).astype(np.int64)
+    same = np.nonzero(np.diff(tk) == 0)[0]
+    d0, d1 = depth_bits[pl[same]], depth_bits[pl[same + 1]]
+    assert np.all(d0 <= d1)                                                   # then by depth
+    assert np.all(pl[same][d0 == d1] < pl[same + 1][d0 == d1])                # ties by gaussian id (stable)
+    counts = np.bincount(tk, minlength=st["ranges"].shape[0])
+    assert np.array_equal(st["ranges"][:, 1] - st["ranges"][:, 0], counts)    # ranges == histogram
+    nz = counts > 0
+    assert np.array_equal(st["ranges"][nz, 0], (np.cumsum(counts) - counts)[nz])
+    assert np.array_equal(np.bincount(pl, minlength=P), st["tiles_touched"])  # every instance emitted exactly once
+    assert (st["final_T"][0] >= 0).all() and (st["final_T"][0] <= 1).all()
+    assert (st["n_contrib"][0] <= counts[(np.arange(H)[:, None] // 16) * ((W + 15) // 16) + np.arange(W)[None] // 16]).all()
+    if variant == "surfel":
+        assert np.abs(st["others"][1] - (1 - st["final_T"][0])).max() < 1e-6
+    # linearity in colour + adjoint identity <R(c), g> == <c, R^T g> (bg = 0): ties forward and backward together
+    og = scenes.random_out_grads(variant, W, H, seed=0, scale=1.0)
+    only_color = dict(dL_dcolor=og["dL_dcolor"])
+    res = hr.run(variant, sc, only_color)
+    lhs = float((res["color"].astype(np.float64) * og["dL_dcolor"]).sum())
+    rhs = float((sc["colors_precomp"].astype(np.float64) * res["grads"]["dL_dcolors_precomp"]).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    sc2 = dict(sc); sc2["colors_precomp"] = (2.0 * sc["colors_precomp"]).astype(np.float32)
+    res2 = hr.run(variant, sc2)
+    assert np.abs(res2["color"] - 2.0 * res["color"]).max() < 2e-5
+    # determinism of the forward
+    res3 = hr.run(variant, sc)
+    assert np.array_equal(res3["color"], res["color"])
