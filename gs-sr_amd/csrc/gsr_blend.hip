@@ -51,6 +51,70 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     v += dpp_f<0x143, 0xC>(v);   // row_bcast31 into rows 2,3 -> lanes 48..63 hold the wave total
     return v;
 }
+// ---- transpose-reduce: K per-lane components -> ONE register, lane (48 + c) holds the wave total of component c.
+// Each level halves the number of live registers instead of running K separate 6-step butterflies:
+//   xor 1, xor 2 : select + quad_perm DPP add          (3 VALU per merge)
+//   xor 4, xor 8 : bank-masked row_shl/row_shr DPP adds (the DPP bank mask does the select)
+//   rows         : lane-wise xor 16 / xor 32 (ds_bpermute)
+// 16 components cost ~45 VALU instead of 16 x 7, and the result feeds a single 16-lane atomic instruction.
+template <int QP>
+__device__ __forceinline__ float merge_quad(float a, float b, bool sel)
+{
+    const float keep = sel ? b : a, give = sel ? a : b;
+    return keep + dpp_f<QP, 0xF>(give);
+}
+template <int SHL, int SHR, int BM_LO, int BM_HI>
+__device__ __forceinline__ float merge_row(float a, float b, bool sel)
+{
+    const float t1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), SHL, 0xF, BM_LO, false));
+    const float t2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), SHR, 0xF, BM_HI, false));
+    return (sel ? b : a) + t1 + t2;
+}
+// lane-wise sum across the four 16-lane rows (every row ends up with the totals).  row_bcast cannot be used here:
+// the lanes of a row hold DIFFERENT components, so the exchange must be lane l <-> l^16, l^32 (ds_bpermute crossbar).
+__device__ __forceinline__ float rows_to_row3(float w)
+{
+    w += __shfl_xor(w, 16, 64);
+    w += __shfl_xor(w, 32, 64);
+    return w;
+}
+// lane 48+c <- total of v[c], c in [0,16)
+__device__ __forceinline__ float reduce16(const float* v, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float r[8], q[4], p[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = merge_quad<0xB1>(v[2 * i], v[2 * i + 1], b0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = merge_quad<0x4E>(r[2 * i], r[2 * i + 1], b1);
+#pragma unroll
+    for (int i = 0; i < 2; i++) p[i] = merge_row<0x104, 0x114, 0x5, 0xA>(q[2 * i], q[2 * i + 1], b2);   // row_shl:4 / row_shr:4
+    const float w = merge_row<0x108, 0x118, 0x3, 0xC>(p[0], p[1], b3);                                   // row_shl:8 / row_shr:8
+    return rows_to_row3(w);
+}
+// lane 56+c (and 48+c) <- total of v[c], c in [0,8)
+__device__ __forceinline__ float reduce8(const float* v, int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float r[4], q[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) r[i] = merge_quad<0xB1>(v[2 * i], v[2 * i + 1], b0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) q[i] = merge_quad<0x4E>(r[2 * i], r[2 * i + 1], b1);
+    float w = merge_row<0x104, 0x114, 0x5, 0xA>(q[0], q[1], b2);
+    w += dpp_f<0x128, 0xF>(w);   // row_ror:8 -> sum over the row, component = lane & 7
+    return rows_to_row3(w);
+}
+// lane 62 <- total of a, lane 63 <- total of b
+__device__ __forceinline__ float reduce2(float a, float b, int lane)
+{
+    float w = merge_quad<0xB1>(a, b, lane & 1);
+    w += dpp_f<0x4E, 0xF>(w);    // xor 2
+    w += dpp_f<0x124, 0xF>(w);   // row_ror:4
+    w += dpp_f<0x128, 0xF>(w);   // row_ror:8
+    return rows_to_row3(w);
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
 #pragma unroll
@@ -59,6 +123,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 }
 
 __device__ __forceinline__ void atomic_addf(float* p, float v) { unsafeAtomicAdd(p, v); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence; blend outputs are tolerance-checked.
+__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 
 static constexpr float NEAR_N = 0.2f, FAR_N = 100.0f, FILTER_INV_SQ = 2.0f;
 
@@ -137,7 +203,8 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
                 const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
                 const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
-                const float sx = ppx / ppz, sy = ppy / ppz;
+                const float rpz = rcp_(ppz);
+                const float sx = ppx * rpz, sy = ppy * rpz;
                 const float rho3d = sx * sx + sy * sy;
                 const float dx = q2.y - pxf, dy = q2.z - pyf;
                 const float rho2d = FILTER_INV_SQ * (dx * dx + dy * dy);
@@ -153,7 +220,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 if (ok) {
                     const float w = alpha * T;
                     const float A = 1 - T;
-                    const float mm = FAR_N / (FAR_N - NEAR_N) * (1 - NEAR_N / depth);
+                    const float mm = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcp_(depth));
                     distortion += (mm * mm * A + M2 - 2 * mm * M1) * w;
                     Dd += depth * w; M1 += mm * w; M2 += mm * mm * w;
                     if (T > 0.5f) {
@@ -301,7 +368,8 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                 float g_c0 = 0, g_c1 = 0, g_c2 = 0, g_op = 0, g_mx = 0, g_my = 0, g_ca = 0, g_cb = 0, g_cc = 0;
                 float g_ax = 0, g_ay = 0, g_am[5] = { 0, 0, 0, 0, 0 };
                 if (ok) {
-                    T = T / (1.f - alpha);
+                    const float r1a = rcp_(1.f - alpha);
+                    T = T * r1a;
                     const float dchannel_dcolor = alpha * T;
                     float dL_dalpha = 0.0f;
                     ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q1.z; dL_dalpha += (q1.z - ar0) * dLp0; g_c0 = dchannel_dcolor * dLp0;
@@ -320,7 +388,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    dL_dalpha += (-T_final * r1a) * bg_dot_dpixel;
                     const float dL_dG = q1.y * dL_dalpha;
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
@@ -333,16 +401,17 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                     g_cc = -0.5f * gdy * dy * dL_dG;
                     g_op = G * dL_dalpha;
                 }
-                GSR_REDUCE_ADD(0, g_c0); GSR_REDUCE_ADD(1, g_c1); GSR_REDUCE_ADD(2, g_c2);
-                GSR_REDUCE_ADD(3, g_op);
-                GSR_REDUCE_ADD(4, g_mx); GSR_REDUCE_ADD(5, g_my);
-                GSR_REDUCE_ADD(6, g_ca); GSR_REDUCE_ADD(7, g_cb); GSR_REDUCE_ADD(8, g_cc);
-                if (V == GSR_PLANE) {
-                    GSR_REDUCE_ADD(9, g_ax); GSR_REDUCE_ADD(10, g_ay);
-                    if (geo) {
-#pragma unroll
-                        for (int c = 0; c < 5; c++) GSR_REDUCE_ADD(11 + c, g_am[c]);
-                    }
+                if (V == GSR_EWA) {
+                    const float v8[8] = { g_c0, g_c1, g_c2, g_op, g_mx, g_my, g_ca, g_cb };
+                    const float w8 = reduce8(v8, lane);
+                    const float w1 = wave_sum_to_lane63(g_cc);
+                    if (lane >= 56 && w8 != 0.f) atomic_addf(accg + (lane - 56), w8);
+                    if (lane == 63 && w1 != 0.f) atomic_addf(accg + 8, w1);
+                } else {
+                    const float v16[16] = { g_c0, g_c1, g_c2, g_op, g_mx, g_my, g_ca, g_cb, g_cc, g_ax, g_ay,
+                                            g_am[0], g_am[1], g_am[2], g_am[3], g_am[4] };
+                    const float w16 = reduce16(v16, lane);
+                    if (lane >= 48 && w16 != 0.f) atomic_addf(accg + (lane - 48), w16);
                 }
             } else {
                 const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
@@ -351,7 +420,8 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
                 const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
                 const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
-                const float sx = ppx / ppz, sy = ppy / ppz;
+                const float rpz = rcp_(ppz);
+                const float sx = ppx * rpz, sy = ppy * rpz;
                 const float rho3d = sx * sx + sy * sy;
                 const float dx = q2.y - pxf, dy = q2.z - pyf;
                 const float rho2d = FILTER_INV_SQ * (dx * dx + dy * dy);
@@ -366,15 +436,17 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                 float g_c0 = 0, g_c1 = 0, g_c2 = 0, g_op = 0, g_mx = 0, g_my = 0, g_n0 = 0, g_n1 = 0, g_n2 = 0;
                 float g_T[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
                 if (ok) {
-                    T = T / (1.f - alpha);
+                    const float r1a = rcp_(1.f - alpha);
+                    T = T * r1a;
                     const float dchannel_dcolor = alpha * T;
                     float dL_dalpha = 0.0f;
                     ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q3.w; dL_dalpha += (q3.w - ar0) * dLp0; g_c0 = dchannel_dcolor * dLp0;
                     ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q4.x; dL_dalpha += (q4.x - ar1) * dLp1; g_c1 = dchannel_dcolor * dLp1;
                     ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q4.y; dL_dalpha += (q4.y - ar2) * dLp2; g_c2 = dchannel_dcolor * dLp2;
                     float dL_dz = 0.0f, dL_dweight = 0;
-                    const float m_d = FAR_N / (FAR_N - NEAR_N) * (1 - NEAR_N / c_d);
-                    const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * c_d * c_d);
+                    const float rcd = rcp_(c_d);
+                    const float m_d = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcd);
+                    const float dmd_dd = ((FAR_N * NEAR_N) / (FAR_N - NEAR_N)) * rcd * rcd;
                     if (idx0 + 1u == median_contributor) dL_dz += dL_dmedian_depth;      // contributor == median_contributor-1
                     dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
                     dL_dalpha += dL_dweight - last_dL_dT;
@@ -393,13 +465,13 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                     g_n0 = alpha * T * dN0 + dMN0; g_n1 = alpha * T * dN1 + dMN1; g_n2 = alpha * T * dN2 + dMN2;
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    dL_dalpha += (-T_final * r1a) * bg_dot_dpixel;
                     const float dL_dG = opa * dL_dalpha;
                     dL_dz += alpha * T * dL_ddepth;
                     if (rho3d <= rho2d) {
                         const float dL_dsx = dL_dG * -G * sx + dL_dz * Tw0;
                         const float dL_dsy = dL_dG * -G * sy + dL_dz * Tw1;
-                        const float dsx_pz = dL_dsx / ppz, dsy_pz = dL_dsy / ppz;
+                        const float dsx_pz = dL_dsx * rpz, dsy_pz = dL_dsy * rpz;
                         const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * sx + dsy_pz * sy);
                         const float dkx = ly * dpz - lz * dpy, dky = lz * dpx - lx * dpz, dkz = lx * dpy - ly * dpx;   // cross(l, dL_dp)
                         const float dlx = dpy * kz - dpz * ky, dly = dpz * kx - dpx * kz, dlz = dpx * ky - dpy * kx;   // cross(dL_dp, k)
@@ -415,15 +487,17 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                     }
                     g_op = G * dL_dalpha;
                 }
-                GSR_REDUCE_ADD(0, g_c0); GSR_REDUCE_ADD(1, g_c1); GSR_REDUCE_ADD(2, g_c2);
-                GSR_REDUCE_ADD(3, g_op);
-                GSR_REDUCE_ADD(4, g_mx); GSR_REDUCE_ADD(5, g_my);
-                GSR_REDUCE_ADD(6, g_n0); GSR_REDUCE_ADD(7, g_n1); GSR_REDUCE_ADD(8, g_n2);
-#pragma unroll
-                for (int c = 0; c < 9; c++) GSR_REDUCE_ADD(9 + c, g_T[c]);
+                // accumulator layout (SURFEL): 0-2 colour, 3 opacity, 4-6 normal, 7-15 transMat, 16-17 mean2D
+                const float v16[16] = { g_c0, g_c1, g_c2, g_op, g_n0, g_n1, g_n2, g_T[0], g_T[1], g_T[2], g_T[3], g_T[4],
+                                        g_T[5], g_T[6], g_T[7], g_T[8] };
+                const float w16 = reduce16(v16, lane);
+                if (lane >= 48 && w16 != 0.f) atomic_addf(accg + (lane - 48), w16);
+                if (__ballot(ok && !(rho3d <= rho2d)) != 0) {      // wave-uniform: any pair on the screen-space filter branch
+                    const float w2 = reduce2(g_mx, g_my, lane);
+                    if (lane >= 62 && w2 != 0.f) atomic_addf(accg + 16 + (lane - 62), w2);
+                }
             }
         }
-        if (top == range.x) break;
     }
 }
 

