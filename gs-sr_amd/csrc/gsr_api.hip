@@ -104,7 +104,7 @@ GeomView gsr_carve_geom(int variant, int P, void* base)
     g.keys_b = take<uint32_t>(p, n);
     g.vals_a = g.sorted_idx;
     g.vals_b = take<uint32_t>(p, n);
-    g.hist = take<uint32_t>(p, (size_t)256 * nblk);
+    g.hist = take<uint32_t>(p, (size_t)256 * nblk + 256);   // histogram matrix + digit totals
     g.scan_tmp = take<uint32_t>(p, gsr_div_up((uint32_t)n, GSR_SCAN_BLOCK) + 64);
     g.counters = take<uint32_t>(p, 64);
     g.bytes = (size_t)(p - reinterpret_cast<char*>(base));
@@ -122,7 +122,7 @@ BinView gsr_carve_bin(int variant, uint32_t R, int W, int H, void* base)
     b.tile_keys = take<uint32_t>(p, n);
     b.keys_b = take<uint32_t>(p, n);
     b.vals_b = take<uint32_t>(p, n);
-    b.hist = take<uint32_t>(p, (size_t)256 * nblk);
+    b.hist = take<uint32_t>(p, (size_t)256 * nblk + 256);
     b.scan_tmp = take<uint32_t>(p, 64);
     b.bytes = (size_t)(p - reinterpret_cast<char*>(base));
     return b;
@@ -170,6 +170,25 @@ static int check_cfg(const gsr_cfg* cfg, const gsr_inputs* in)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ pinned mailbox
+// num_rendered travels through one mapped, pinned host word per device that the last scan kernel writes directly
+// (system-scope store): the forward's single sync is then a bare hipStreamSynchronize, no D2H copy command.
+struct Mailbox { uint32_t* host = nullptr; uint32_t* dev = nullptr; };
+static Mailbox g_mail[64];
+static Mailbox* mailbox()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+    Mailbox& m = g_mail[d];
+    if (!m.host) {
+        void* h = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&h, 256, hipHostMallocMapped) != hipSuccess) return nullptr;
+        if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+        m.host = (uint32_t*)h; m.dev = (uint32_t*)dp;
+    }
+    return &m;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
                                   int32_t* radii, uint32_t* num_rendered_host, void* stream)
@@ -181,10 +200,16 @@ extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void
     GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
     if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
     { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
-    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, s)) return 1; }
+    Mailbox* mb = mailbox();
+    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb ? mb->dev : nullptr, s)) return 1; }
     // the one host<->device sync of the forward (reference: cudaMemcpy of point_offsets[P-1], rasterizer_impl.cu:281)
-    GSR_CHECK(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered");
-    GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
+    if (mb) {
+        GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
+        *num_rendered_host = *(volatile uint32_t*)mb->host;
+    } else {
+        GSR_CHECK(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered");
+        GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
+    }
     return 0;
 }
 

@@ -62,6 +62,24 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, u
     if (total_out && threadIdx.x == 0) *total_out = tot;
 }
 
+// exclusive scan of every row of a [rows x cols] matrix in place, one block per row (coalesced), row totals to tot[].
+// Used on the digit-major histogram hist[d * nblk + blk]: rows = digits, cols = sort blocks.
+__global__ void __launch_bounds__(256) k_scan_rows(uint32_t* __restrict__ data, uint32_t cols, uint32_t* __restrict__ tot)
+{
+    __shared__ uint32_t lds[17];
+    uint32_t* row = data + (size_t)blockIdx.x * cols;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < cols; c0 += 256) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint32_t v = (i < cols) ? row[i] : 0;
+        uint32_t t;
+        const uint32_t incl = block_incl_scan(v, lds, &t);
+        if (i < cols) row[i] = carry + incl - v;
+        carry += t;
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
+}
+
 // ------------------------------------------------------------------------------------------------ radix sort
 // per-block digit histogram, hist[d * nblk + blk]
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift,
@@ -83,14 +101,21 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t*
 // stable scatter.  Order inside a block is (wave, item, lane): wave w owns keys [w*1024, w*1024+1024).
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                    uint32_t n, int shift, int bits, const uint32_t* __restrict__ hist, uint32_t nblk)
+                                                                    uint32_t n, int shift, int bits, const uint32_t* __restrict__ hist, uint32_t nblk,
+                                                                    const uint32_t* __restrict__ digit_tot)
 {
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t gbase[256];
+    __shared__ uint32_t lds[17];
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * 256; i += GSR_SORT_THREADS) (&cnt[0][0])[i] = 0;
-    if (threadIdx.x <= mask) gbase[threadIdx.x] = hist[threadIdx.x * nblk + blockIdx.x];
+    {   // global base of digit d for this block = (#keys with a smaller digit) + (#keys with digit d in earlier blocks)
+        const uint32_t t = (threadIdx.x <= mask) ? digit_tot[threadIdx.x] : 0;
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(t, lds, &tot);
+        if (threadIdx.x <= mask) gbase[threadIdx.x] = (incl - t) + hist[threadIdx.x * nblk + blockIdx.x];
+    }
     __syncthreads();
 
     const uint32_t base = blockIdx.x * GSR_SORT_BLOCK + wave * (GSR_WAVE * GSR_SORT_ITEMS);
@@ -141,6 +166,7 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
                          bool* result_in_b, hipStream_t s)
 {
     const uint32_t nblk = gsr_div_up(n, GSR_SORT_BLOCK);
+    uint32_t* digit_tot = hist + (size_t)256 * nblk;      // 256 words behind the histogram matrix
     // identity_vals: the first pass generates value i for element i instead of reading vals_a
     uint32_t *kin = keys_a, *vin = identity_vals ? nullptr : vals_a, *kout = keys_b, *vout = vals_b;
     bool in_b = false;
@@ -151,8 +177,8 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         int bits = (remaining + passes_left - 1) / passes_left;
         uint32_t mask = (1u << bits) - 1u;
         hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, shift, mask, hist, nblk);
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, hist, (mask + 1) * nblk, (uint32_t*)nullptr);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, hist, nblk);
+        hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, hist, nblk, digit_tot);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, hist, nblk, digit_tot);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         if (vin == nullptr) { vin = vout; vout = vals_a; }     // first pass generated identity values into vals_b
@@ -178,17 +204,20 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_local(const uint32_t
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_add(uint32_t P, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_prefix,
-                                                                uint32_t* __restrict__ counters)
+                                                                uint32_t* __restrict__ counters, uint32_t* __restrict__ host_word)
 {
     const uint32_t i = blockIdx.x * GSR_SCAN_BLOCK + threadIdx.x;
     if (i < P) {
         uint32_t v = offsets[i] + block_prefix[blockIdx.x];
         offsets[i] = v;
-        if (i == P - 1) counters[0] = v;       // num_rendered
+        if (i == P - 1) {                      // num_rendered: device copy + mapped pinned host word (no D2H copy command)
+            counters[0] = v;
+            if (host_word) { __hip_atomic_store(host_word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
     }
 }
 
-int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, hipStream_t s)
+int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s)
 {
     const uint32_t P = (uint32_t)cfg->P;
     bool in_b = false;
@@ -199,7 +228,7 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, hipStream_t s)
     const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
     hipLaunchKernelGGL(k_offsets_local, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, g.sorted_idx, g.tiles_touched, P, g.offsets, g.scan_tmp);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nblk, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_offsets_add, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, P, g.offsets, g.scan_tmp, g.counters);
+    hipLaunchKernelGGL(k_offsets_add, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, P, g.offsets, g.scan_tmp, g.counters, host_word_dev);
     return gsr_check_launch("depth_order", s, cfg->debug);
 }
 

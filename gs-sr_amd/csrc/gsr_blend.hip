@@ -14,9 +14,10 @@
 // Behaviour follows 3DGS forward.cu:261-374 / backward.cu:399-557, PLANE forward.cu:273-407 / backward.cu:399-614,
 // SURFEL forward.cu:256-448 / backward.cu:143-447 (thresholds, ordering, recurrences); see DESIGN.md.
 #include "gsr_common.h"
+#include <cstdlib>
 
 struct BlendParams {
-    int W, H, gx, gy, variant, render_geo;
+    int W, H, gx, gy, variant, render_geo, xcd_remap;
     float fx, fy;
     const uint2* ranges;
     const uint32_t* point_list;
@@ -32,6 +33,15 @@ struct BlendParams {
     const float* all_map_pixels;
     float* acc;
 };
+
+// Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md); give each XCD a contiguous band of tiles so that
+// neighbouring tiles -- which share most of their splats -- hit the same 4 MiB L2.  Bijective for any T; speed only.
+__device__ __forceinline__ int tile_of_block(int b, int T, int remap)
+{
+    if (!remap) return b;
+    const int q = T >> 3, r = T & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -133,7 +143,7 @@ template <int V>
 __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
 {
     constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
-    const int tile = blockIdx.x;
+    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ox = tx * GSR_TILE + (wave & 1) * GSR_SUB, oy = ty * GSR_TILE + (wave >> 1) * GSR_SUB;
@@ -279,7 +289,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
 {
     constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
     constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
-    const int tile = blockIdx.x;
+    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ox = tx * GSR_TILE + (wave & 1) * GSR_SUB, oy = ty * GSR_TILE + (wave >> 1) * GSR_SUB;
@@ -508,6 +518,11 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
     p.W = cfg->W; p.H = cfg->H;
     p.gx = (cfg->W + GSR_TILE - 1) / GSR_TILE; p.gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     p.variant = cfg->variant; p.render_geo = cfg->render_geo;
+    {
+        static int remap = -1;
+        if (remap < 0) { const char* e = getenv("GSR_XCD_REMAP"); remap = e ? (atoi(e) != 0) : 1; }
+        p.xcd_remap = remap;
+    }
     p.fy = cfg->H / (2.0f * cfg->tanfovy);
     p.fx = cfg->W / (2.0f * cfg->tanfovx);
     p.ranges = im.ranges; p.point_list = b.point_list; p.cull = g.cull; p.rec = g.rec; p.bg = cfg->bg;

@@ -20,8 +20,8 @@
 
 // radix sort geometry
 #define GSR_SORT_THREADS 256
-#define GSR_SORT_ITEMS 16
-#define GSR_SORT_BLOCK (GSR_SORT_THREADS * GSR_SORT_ITEMS)   // 4096 keys per block
+#define GSR_SORT_ITEMS 4
+#define GSR_SORT_BLOCK (GSR_SORT_THREADS * GSR_SORT_ITEMS)   // 1024 keys per block: short rank chains, many blocks
 #define GSR_SCAN_BLOCK 1024
 
 static inline __host__ __device__ int gsr_rec_stride(int variant)
@@ -85,7 +85,7 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug);
 
 // ---- stage launchers (each in its own .hip) ------------------------------------------------------------------
 int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s);
-int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, hipStream_t s);     // sorted_idx, offsets, counters[0]
+int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s);   // sorted_idx, offsets, counters[0]
 int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, hipStream_t s);
 int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_outputs* out, hipStream_t s);
