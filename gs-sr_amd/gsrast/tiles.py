@@ -1,0 +1,49 @@
+"""One-tile-per-GPU sharding of VastGaussian-partitioned scenes (replaces the sequential loop of train_split.py:15-38).
+
+Tiles are self-contained sub-scenes (own images, points, anchors, optimiser; split_scene.py:55-82): they shard with NO
+data-path collective.  torch.distributed (RCCL on GPUs, gloo in the CPU tests) is used only for the start/stop barrier
+and the max-over-ranks reduction of elapsed time / aggregation of per-tile iteration counts.
+"""
+import os
+import re
+
+import torch
+import torch.distributed as dist
+
+
+def list_tiles(data_dir):
+    """tile_XXXX sub-directories in sorted order (train_split.py:15-16 uses sorted(os.listdir) filtered on 'tile_')."""
+    return sorted(d for d in os.listdir(data_dir) if re.fullmatch(r"tile_\d+", d) and os.path.isdir(os.path.join(data_dir, d)))
+
+
+def assign_tiles(num_tiles, world_size, rank):
+    """Round-robin: rank r owns tiles r, r+world, ...  (4 tiles on 4 GPUs / 8 on 8 -> exactly one tile per GPU)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    return list(range(rank, num_tiles, world_size))
+
+
+def tile_output_paths(base_output_dir, tile_name):
+    """Per-tile output sub-paths exactly as train_split.py:28-35 rewrites them."""
+    return {k: os.path.join(base_output_dir, tile_name, k) for k in ("chkpnt", "point_cloud", "tb", "config")}
+
+
+def barrier(device=None):
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def reduce_job(elapsed_s, iters_done, device=None):
+    """-> (max elapsed over ranks, total iterations over ranks): the whole-job throughput is total / max."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(elapsed_s), int(iters_done)
+    dev = device if device is not None else torch.device("cpu")
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=dev)
+    n = torch.tensor([int(iters_done)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(n.item())
