@@ -136,6 +136,18 @@ __device__ __forceinline__ void atomic_addf(float* p, float v) { unsafeAtomicAdd
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence; blend outputs are tolerance-checked.
 __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Packed records are written by the preprocess kernel and are read-only in both blend kernels.  Loading them through
+// the constant address space lets the backend use scalar (SMEM) loads for the wave-uniform address even in the
+// backward kernel, where the atomics into `acc` would otherwise defeat the no-clobber analysis.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef const f4_t __attribute__((address_space(4))) * const_rec_ptr;
+__device__ __forceinline__ float4 ldc(const float4* p, int k)
+{
+    const_rec_ptr c = (const_rec_ptr)(p + k);
+    const f4_t v = *c;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 static constexpr float NEAR_N = 0.2f, FAR_N = 100.0f, FILTER_INV_SQ = 2.0f;
 
 // =================================================================================================== forward
@@ -368,7 +380,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
             const bool active = inside && (idx0 < last_contributor);
 
             if (V != GSR_SURFEL) {
-                const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+                const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2);
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
                 const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
                 const float G = __expf(power);
@@ -386,7 +398,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                     ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q1.w; dL_dalpha += (q1.w - ar1) * dLp1; g_c1 = dchannel_dcolor * dLp1;
                     ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q2.x; dL_dalpha += (q2.x - ar2) * dLp2; g_c2 = dchannel_dcolor * dLp2;
                     if (geo) {
-                        const float4 q3 = r[3];
+                        const float4 q3 = ldc(r, 3);
                         const float am[5] = { q2.y, q2.z, q2.w, q3.x, q3.y };
 #pragma unroll
                         for (int c = 0; c < 5; c++) {
@@ -424,7 +436,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                     if (lane >= 48 && w16 != 0.f) atomic_addf(accg + (lane - 48), w16);
                 }
             } else {
-                const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
+                const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2), q3 = ldc(r, 3), q4 = ldc(r, 4);
                 const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
                 const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
