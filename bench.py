@@ -43,6 +43,12 @@ def algorithmic_bytes(variant, R, N, T):
 
 
 def make_step(variant, sc, device):
+    """One training iteration.  All gaussian parameters live in ONE flat leaf z[P,13+] (views: means 3, scales 2|3,
+    rotations 4, opacity 1, colour 3); params = z * lr_scale (per column), optimised by a single fused-Adam group with
+    lr=1: Adam's step is invariant to gradient scale, so the effective per-column learning rates are exactly lr_scale --
+    the per-group rates of gssr/gaussian/*.setup_optimizers -- with one optimizer kernel instead of one per group.
+    The auxiliary-map loss is linear in the 11 (5) channels so autograd hands the rasterizer a dense dL_dothers without
+    materialising one zero-padded [11,H,W] tensor per sliced channel; every gradient path of the backward kernel is live."""
     import hiprun
     import diff_gaussian_rasterization as dgr
     import diff_surfel_rasterization as dsr
@@ -50,30 +56,43 @@ def make_step(variant, sc, device):
     t = hiprun.to_dev(sc, device)
     rs = hiprun.settings(variant, t)
     P, W, H = t["means3D"].shape[0], int(t["W"]), int(t["H"])
-    params = {k: t[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations", "colors_precomp")}
-    opt = torch.optim.Adam([{"params": [params["means3D"]], "lr": 1.6e-5}, {"params": [params["colors_precomp"]], "lr": 2.5e-3},
-                            {"params": [params["opacities"]], "lr": 1e-3}, {"params": [params["scales"]], "lr": 5e-4},
-                            {"params": [params["rotations"]], "lr": 1e-4}], eps=1e-15, fused=True)
+    ns = t["scales"].shape[1]
+    cols = [("means3D", 3, 1.6e-5), ("scales", ns, 5e-4), ("rotations", 4, 1e-4), ("opacities", 1, 1e-3), ("colors_precomp", 3, 2.5e-3)]
+    lr_scale = torch.cat([torch.full((n,), lr, device=device) for _, n, lr in cols])
+    z = (torch.cat([t[k].reshape(P, -1) for k, _, _ in cols], dim=1) / lr_scale).clone().requires_grad_(True)
+    opt = torch.optim.Adam([z], lr=1.0, eps=1e-15, fused=True)
     g = torch.Generator(device="cpu").manual_seed(1234)
     gt = torch.rand((3, H, W), generator=g).to(device)
-    gt_normal = torch.nn.functional.normalize(torch.randn((3, H, W), generator=g), dim=0).to(device)
+    N = float(W * H)
+    gtn = torch.nn.functional.normalize(torch.randn((3, H, W), generator=g), dim=0)
+    if variant == "surfel":
+        wmap = torch.zeros((11, H, W))
+        wmap[0] = 0.01 / N; wmap[1] = 0.01 / N; wmap[2:5] = -0.05 * gtn / N; wmap[5] = 0.01 / N; wmap[6] = 100.0 / N
+        wmap[8:11] = 0.0        # median-normal channels: left without upstream gradient, as in twodgs_scene.py:88-105
+        wmap = wmap.to(device)
+    elif variant == "plane":
+        wmap = torch.zeros((5, H, W)); wmap[0:3] = -0.05 * gtn / N; wmap[3] = 0.01 / N; wmap[4] = 0.01 / N
+        wmap = wmap.to(device)
+        wpd = torch.full((1, H, W), 0.01 / N, device=device)
     all_map = t.get("all_map")
     state = {}
+    offs = [0]
+    for _, n, _ in cols:
+        offs.append(offs[-1] + n)
 
     def step():
+        prm = z * lr_scale
+        v = {k: prm[:, offs[i]:offs[i + 1]] for i, (k, _, _) in enumerate(cols)}
         means2D = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
-        kw = dict(means3D=params["means3D"], means2D=means2D, opacities=params["opacities"], colors_precomp=params["colors_precomp"],
-                  scales=params["scales"], rotations=params["rotations"])
+        kw = dict(means3D=v["means3D"], means2D=means2D, opacities=v["opacities"], colors_precomp=v["colors_precomp"],
+                  scales=v["scales"], rotations=v["rotations"])
         if variant == "surfel":
             color, radii, allmap = dsr.GaussianRasterizer(rs)(**kw)
-            alpha, normal, dist = allmap[1:2], allmap[2:5], allmap[6:7]
-            depth = allmap[0:1] / alpha.clamp_min(1e-6)
-            loss = ((color - gt).abs().mean() + 0.05 * (1 - (normal * gt_normal).sum(0)).mean() + 100.0 * dist.mean()
-                    + 0.01 * depth.mean() + 0.01 * allmap[5:6].mean())
+            loss = (color - gt).abs().mean() + (allmap * wmap).sum()
         elif variant == "plane":
             m2a = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
             color, radii, observe, oam, pd = dpr.GaussianRasterizer(rs)(means2D_abs=m2a, all_map=all_map, **kw)
-            loss = (color - gt).abs().mean() + 0.05 * (1 - (oam[0:3] * gt_normal).sum(0)).mean() + 0.01 * pd.mean() + 0.01 * oam[4].mean()
+            loss = (color - gt).abs().mean() + (oam * wmap).sum() + (pd * wpd).sum()
         else:
             color, radii = dgr.GaussianRasterizer(rs)(**kw)
             loss = (color - gt).abs().mean()

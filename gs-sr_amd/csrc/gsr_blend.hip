@@ -81,12 +81,16 @@ __device__ __forceinline__ float merge_row(float a, float b, bool sel)
     return (sel ? b : a) + t1 + t2;
 }
 // lane-wise sum across the four 16-lane rows (every row ends up with the totals).  row_bcast cannot be used here:
-// the lanes of a row hold DIFFERENT components, so the exchange must be lane l <-> l^16, l^32 (ds_bpermute crossbar).
+// the lanes of a row hold DIFFERENT components, so the exchange must be lane l <-> l^16, l^32.  gfx950 has VALU-only
+// row/half swaps (v_permlane16_swap / v_permlane32_swap), so no trip through the LDS crossbar (ds_bpermute):
+//   permlane16_swap(w,w) -> {[r0,r0,r2,r2], [r1,r1,r3,r3]}, permlane32_swap(w,w) -> {[lo,lo], [hi,hi]}.
 __device__ __forceinline__ float rows_to_row3(float w)
 {
-    w += __shfl_xor(w, 16, 64);
-    w += __shfl_xor(w, 32, 64);
-    return w;
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    u2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+    w = __uint_as_float(a.x) + __uint_as_float(a.y);
+    u2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+    return __uint_as_float(b.x) + __uint_as_float(b.y);
 }
 // lane 48+c <- total of v[c], c in [0,16)
 __device__ __forceinline__ float reduce16(const float* v, int lane)
@@ -148,6 +152,39 @@ __device__ __forceinline__ float4 ldc(const float4* p, int k)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// ---- sub-tile cull: can splat `id` reach alpha >= 1/255 anywhere in the 8x8 block whose first pixel is (ox,oy)?
+// Skipping is result-neutral (a skipped splat fails the reference's alpha gate for every pixel of the block), so the
+// test only has to be conservative.  SURFEL: bounding box of the contribution region.  EWA/PLANE: exact minimum of
+// the conic form q(d) = A dx^2 + 2B dx dy + C dy^2 over the block rectangle (centre inside -> 0, else the best of the
+// four edges, each a clamped 1-D parabola) against 2*ln(255*opacity) (with the safety margin added in preprocess).
+template <int V>
+__device__ __forceinline__ bool cull_hit(const float4* __restrict__ cull, uint32_t id, float ox, float oy)
+{
+    if (V == GSR_SURFEL) {
+        const float4 cb = cull[id];
+        return (cb.z >= 0.f) && !(fabsf(cb.x - (ox + 3.5f)) > cb.z + 3.5f) && !(fabsf(cb.y - (oy + 3.5f)) > cb.w + 3.5f);
+    } else {
+        const float4 a = cull[2 * (size_t)id], b = cull[2 * (size_t)id + 1];
+        const float A = a.z, B = a.w, C = b.x, tt = b.y;
+        if (!(tt > 0.f)) return false;
+        const float X0 = ox - a.x, X1 = X0 + 7.f, Y0 = oy - a.y, Y1 = Y0 + 7.f;
+        if (X0 <= 0.f && X1 >= 0.f && Y0 <= 0.f && Y1 >= 0.f) return true;
+        const float rC = __builtin_amdgcn_rcpf(C), rA = __builtin_amdgcn_rcpf(A);
+        float qmin;
+        {
+            float dy = fminf(fmaxf(-B * X0 * rC, Y0), Y1);
+            qmin = A * X0 * X0 + 2.f * B * X0 * dy + C * dy * dy;
+            dy = fminf(fmaxf(-B * X1 * rC, Y0), Y1);
+            qmin = fminf(qmin, A * X1 * X1 + 2.f * B * X1 * dy + C * dy * dy);
+            float dx = fminf(fmaxf(-B * Y0 * rA, X0), X1);
+            qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * Y0 + C * Y0 * Y0);
+            dx = fminf(fmaxf(-B * Y1 * rA, X0), X1);
+            qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * Y1 + C * Y1 * Y1);
+        }
+        return !(qmin > tt);      // NaN -> keep
+    }
+}
+
 static constexpr float NEAR_N = 0.2f, FAR_N = 100.0f, FILTER_INV_SQ = 2.0f;
 
 // =================================================================================================== forward
@@ -163,7 +200,6 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
     const int px = ox + (lane & 7), py = oy + (lane >> 3);
     const bool inside = px < p.W && py < p.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float scx = (float)ox + 3.5f, scy = (float)oy + 3.5f;
     const uint2 range = p.ranges[tile];
     const size_t HW = (size_t)p.W * p.H;
     const uint32_t pix_id = (uint32_t)p.W * py + px;
@@ -184,9 +220,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         const uint32_t i = base + lane;
         const bool v = i < range.y;
         const uint32_t id = v ? p.point_list[i] : 0u;
-        float4 cb = make_float4(0, 0, -1, -1);
-        if (v) cb = p.cull[id];
-        const bool hit = v && (cb.z >= 0.f) && !(fabsf(cb.x - scx) > cb.z + 3.5f) && !(fabsf(cb.y - scy) > cb.w + 3.5f);
+        const bool hit = v && cull_hit<V>(p.cull, id, (float)ox, (float)oy);
         uint64_t m = __ballot(hit);
         while (m) {
             const int j = __ffsll((unsigned long long)m) - 1;
@@ -309,7 +343,6 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
     const int px = ox + (lane & 7), py = oy + (lane >> 3);
     const bool inside = px < p.W && py < p.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float scx = (float)ox + 3.5f, scy = (float)oy + 3.5f;
     const uint2 range = p.ranges[tile];
     const size_t HW = (size_t)p.W * p.H;
     const uint32_t pix_id = inside ? (uint32_t)p.W * py + px : 0u;
@@ -366,9 +399,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
         const bool v = (top - range.x) > (uint32_t)lane;
         const uint32_t i = top - 1u - (uint32_t)lane;               // lane 0 = deepest
         const uint32_t id = v ? p.point_list[i] : 0u;
-        float4 cb = make_float4(0, 0, -1, -1);
-        if (v) cb = p.cull[id];
-        const bool hit = v && (cb.z >= 0.f) && !(fabsf(cb.x - scx) > cb.z + 3.5f) && !(fabsf(cb.y - scy) > cb.w + 3.5f);
+        const bool hit = v && cull_hit<V>(p.cull, id, (float)ox, (float)oy);
         uint64_t m = __ballot(hit);
         while (m) {
             const int j = __ffsll((unsigned long long)m) - 1;

@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
 
     int radius_out = 0; uint32_t tiles = 0, key = 0xFFFFFFFFu, clamped = 0;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, cull = make_float4(0, 0, -1, -1);
+    float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, cull0 = q0, cull1 = make_float4(0, -1, 0, 0);
 
     const float3 p_orig = make_float3(p.means3D[3 * idx], p.means3D[3 * idx + 1], p.means3D[3 * idx + 2]);
     const float3 p_view = xform_point4x3(p_orig, view);
@@ -88,10 +88,9 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
             const float* am = p.all_map + 5 * idx;
             q2.y = am[0]; q2.z = am[1]; q2.w = am[2]; q3.x = am[3]; q3.y = am[4];
         }
-        // conservative box of {power >= -tau}: |dx| <= sqrt(2 tau cov_xx), |dy| <= sqrt(2 tau cov_yy)
-        float tt = two_tau(o);
-        if (tt > 0) cull = make_float4(pix, piy, sqrtf(tt * cv.a) * 1.001f + 0.01f, sqrtf(tt * cv.c) * 1.001f + 0.01f);
-        else cull = make_float4(pix, piy, -1.f, -1.f);
+        // cull record for the blend kernels: conic form + 2*tau (the pair contributes iff dT Q d <= 2 tau)
+        cull0 = make_float4(pix, piy, conA, conB);
+        cull1 = make_float4(conC, two_tau(o), 0.f, 0.f);
     } while (0);
 
     p.radii[idx] = radius_out;
@@ -99,7 +98,8 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
     p.g.depth_key[idx] = key;
     p.g.tiles_touched[idx] = tiles;
     p.g.rect[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
-    p.g.cull[idx] = cull;
+    p.g.cull[2 * (size_t)idx] = cull0;
+    p.g.cull[2 * (size_t)idx + 1] = cull1;
     p.g.clamped[idx] = clamped;
     const int st = (p.variant == GSR_PLANE) ? GSR_REC_PLANE : GSR_REC_EWA;
     float4* rec = p.g.rec + (size_t)idx * st;
