@@ -82,7 +82,8 @@ def make_step(variant, sc, device):
 
     def step():
         prm = z * lr_scale
-        v = {k: prm[:, offs[i]:offs[i + 1]] for i, (k, _, _) in enumerate(cols)}
+        parts = torch.split(prm, [n for _, n, _ in cols], dim=1)       # backward = one cat, not one zero-pad per slice
+        v = {k: parts[i] for i, (k, _, _) in enumerate(cols)}
         means2D = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
         kw = dict(means3D=v["means3D"], means2D=means2D, opacities=v["opacities"], colors_precomp=v["colors_precomp"],
                   scales=v["scales"], rotations=v["rotations"])

@@ -149,6 +149,8 @@ extern "C" size_t gsr_backward_scratch_bytes(int32_t variant, int32_t P)
     return gsr_align((size_t)(P > 0 ? P : 1) * gsr_acc_stride(variant) * sizeof(float));
 }
 
+extern "C" uint32_t gsr_binning_capacity(int32_t variant, size_t bytes, int32_t W, int32_t H);
+
 static int check_cfg(const gsr_cfg* cfg, const gsr_inputs* in)
 {
     if (!cfg || !in) { gsr_set_error("null cfg/inputs"); return 1; }
@@ -173,7 +175,7 @@ static int check_cfg(const gsr_cfg* cfg, const gsr_inputs* in)
 // ------------------------------------------------------------------------------------------------ pinned mailbox
 // num_rendered travels through one mapped, pinned host word per device that the last scan kernel writes directly
 // (system-scope store): the forward's single sync is then a bare hipStreamSynchronize, no D2H copy command.
-struct Mailbox { uint32_t* host = nullptr; uint32_t* dev = nullptr; };
+struct Mailbox { uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev[16] = {}; unsigned next = 0; };
 static Mailbox g_mail[64];
 static Mailbox* mailbox()
 {
@@ -182,8 +184,10 @@ static Mailbox* mailbox()
     Mailbox& m = g_mail[d];
     if (!m.host) {
         void* h = nullptr; void* dp = nullptr;
-        if (hipHostMalloc(&h, 256, hipHostMallocMapped) != hipSuccess) return nullptr;
+        if (hipHostMalloc(&h, 16 * 64, hipHostMallocMapped) != hipSuccess) return nullptr;     // 16 slots, one cache line each
         if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+        for (int i = 0; i < 16; i++)
+            if (hipEventCreateWithFlags(&m.ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
         m.host = (uint32_t*)h; m.dev = (uint32_t*)dp;
     }
     return &m;
@@ -201,11 +205,12 @@ extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void
     if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
     { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
     Mailbox* mb = mailbox();
-    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb ? mb->dev : nullptr, s)) return 1; }
+    const unsigned slot = mb ? (mb->next++ & 15u) : 0u;
+    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb ? mb->dev + 16 * slot : nullptr, s)) return 1; }
     // the one host<->device sync of the forward (reference: cudaMemcpy of point_offsets[P-1], rasterizer_impl.cu:281)
     if (mb) {
         GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
-        *num_rendered_host = *(volatile uint32_t*)mb->host;
+        *num_rendered_host = *(volatile uint32_t*)(mb->host + 16 * slot);
     } else {
         GSR_CHECK(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered");
         GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
@@ -221,16 +226,64 @@ extern "C" int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void
     hipStream_t s = (hipStream_t)stream;
     (void)geom_bytes;
     GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
-    BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, binning);
+    // the arena layout is always derived from the capacity implied by binning_bytes (forward, backward and debug agree)
+    const uint32_t cap = gsr_binning_capacity(cfg->variant, binning_bytes, cfg->W, cfg->H);
+    if (cap < num_rendered) { gsr_set_error("binning buffer too small: holds %u instances, need %u", cap, num_rendered); return 1; }
+    BinView b = gsr_carve_bin(cfg->variant, cap, cfg->W, cfg->H, binning);
     ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, img);
-    if (b.bytes > binning_bytes) { gsr_set_error("binning buffer too small: %zu < %zu", binning_bytes, b.bytes); return 1; }
     if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
     if (cfg->P == 0) {
         // the reference returns the zero-initialised outputs untouched when P == 0 (rasterize_points.cu:79-113)
         return 0;
     }
-    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, num_rendered, s)) return 1; }
+    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, num_rendered, nullptr, s)) return 1; }
     { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1; }
+    return 0;
+}
+
+// Largest instance count whose binning arena fits in `bytes` (inverse of gsr_binning_bytes).
+extern "C" uint32_t gsr_binning_capacity(int32_t variant, size_t bytes, int32_t W, int32_t H)
+{
+    uint64_t lo = 0, hi = 0xFFFFFFFFull;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi + 1) >> 1;
+        if (gsr_binning_bytes(variant, (uint32_t)mid, W, H) <= bytes) lo = mid; else hi = mid - 1;
+    }
+    return (uint32_t)lo;
+}
+
+// Single-call forward without a GPU idle gap: stage 2 is enqueued right behind stage 1 against a caller-provided
+// binning arena of some CAPACITY (the kernels read the exact instance count from device memory), and the host only
+// waits on an event recorded after stage 1 to learn num_rendered.  *overflow_host = 1 when num_rendered exceeds the
+// capacity: the outputs are then incomplete and the caller must re-run gsr_forward_stage2 with a large-enough arena
+// (geom is intact; PLANE callers must re-zero out_observe first).  Exact same results as stage1 + stage2 otherwise.
+extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                           void* binning, size_t binning_bytes, void* img, size_t img_bytes, int32_t* radii,
+                           const gsr_outputs* out, uint32_t* num_rendered_host, int32_t* overflow_host, void* stream)
+{
+    if (check_cfg(cfg, in)) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    *num_rendered_host = 0; *overflow_host = 0;
+    if (cfg->P == 0) return 0;
+    Mailbox* mb = mailbox();
+    if (!mb) { gsr_set_error("gsr_forward: pinned mailbox unavailable, use stage1/stage2"); return 1; }
+    GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
+    if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
+    const uint32_t cap = gsr_binning_capacity(cfg->variant, binning_bytes, cfg->W, cfg->H);
+    if (cap == 0) { gsr_set_error("binning buffer too small"); return 1; }
+    BinView b = gsr_carve_bin(cfg->variant, cap, cfg->W, cfg->H, binning);
+    ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, img);
+    if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
+    const unsigned slot = mb->next++ & 15u;
+    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
+    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s)) return 1; }
+    GSR_CHECK(hipEventRecord(mb->ev[slot], s), "event record");
+    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s)) return 1; }
+    { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1; }
+    GSR_CHECK(hipEventSynchronize(mb->ev[slot]), "stage1 event sync");
+    const uint32_t R = *(volatile uint32_t*)(mb->host + 16 * slot);
+    *num_rendered_host = R;
+    *overflow_host = (R > cap) ? 1 : 0;
     return 0;
 }
 
@@ -242,14 +295,15 @@ extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int3
                             const gsr_out_grads* og, const gsr_in_grads* ig, void* stream)
 {
     if (check_cfg(cfg, in)) return 1;
-    (void)geom_bytes; (void)binning_bytes; (void)img_bytes;
+    (void)geom_bytes; (void)img_bytes;
     hipStream_t s = (hipStream_t)stream;
     if (cfg->P == 0) return 0;
     const size_t need = gsr_backward_scratch_bytes(cfg->variant, cfg->P);
     if (scratch_bytes < need) { gsr_set_error("backward scratch too small: %zu < %zu", scratch_bytes, need); return 1; }
     if (cfg->variant == GSR_PLANE && cfg->render_geo && !og->all_map_pixels) { gsr_set_error("PLANE backward needs all_map_pixels"); return 1; }
     GeomView g = gsr_carve_geom(cfg->variant, cfg->P, const_cast<void*>(geom));
-    BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, const_cast<void*>(binning));
+    BinView b = gsr_carve_bin(cfg->variant, gsr_binning_capacity(cfg->variant, binning_bytes, cfg->W, cfg->H), cfg->W, cfg->H,
+                              const_cast<void*>(binning));
     ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img));
     float* acc = reinterpret_cast<float*>(scratch);
     { ProfScope ps(GSR_PROF_BWD_MEMSET, s); GSR_CHECK(hipMemsetAsync(acc, 0, need, s), "memset acc"); }
@@ -262,17 +316,18 @@ extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int3
 }
 
 // ------------------------------------------------------------------------------------------------ debug reads
-extern "C" int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, const void* img,
-                              uint32_t num_rendered, void* dst, void* stream)
+extern "C" int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, size_t binning_bytes,
+                              const void* img, uint32_t num_rendered, void* dst, void* stream)
 {
+    const uint32_t bcap = gsr_binning_capacity(cfg->variant, binning_bytes, cfg->W, cfg->H);
     hipStream_t s = (hipStream_t)stream;
     const size_t N = (size_t)cfg->W * cfg->H;
     const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     const void* src = nullptr; size_t bytes = 0;
     switch (field) {
     case GSR_DBG_TILES_TOUCHED: { GeomView g = gsr_carve_geom(cfg->variant, cfg->P, const_cast<void*>(geom)); src = g.tiles_touched; bytes = (size_t)cfg->P * 4; break; }
-    case GSR_DBG_POINT_LIST: { BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, const_cast<void*>(binning)); src = b.point_list; bytes = (size_t)num_rendered * 4; break; }
-    case GSR_DBG_TILE_KEYS: { BinView b = gsr_carve_bin(cfg->variant, num_rendered, cfg->W, cfg->H, const_cast<void*>(binning)); src = b.tile_keys; bytes = (size_t)num_rendered * 4; break; }
+    case GSR_DBG_POINT_LIST: { BinView b = gsr_carve_bin(cfg->variant, bcap, cfg->W, cfg->H, const_cast<void*>(binning)); src = b.point_list; bytes = (size_t)num_rendered * 4; break; }
+    case GSR_DBG_TILE_KEYS: { BinView b = gsr_carve_bin(cfg->variant, bcap, cfg->W, cfg->H, const_cast<void*>(binning)); src = b.tile_keys; bytes = (size_t)num_rendered * 4; break; }
     case GSR_DBG_RANGES: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.ranges; bytes = (size_t)gx * gy * 8; break; }
     case GSR_DBG_FINAL_T: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.final_T; bytes = N * 4 * (cfg->variant == GSR_SURFEL ? 3 : 1); break; }
     case GSR_DBG_N_CONTRIB: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.n_contrib; bytes = N * 4 * (cfg->variant == GSR_SURFEL ? 2 : 1); break; }

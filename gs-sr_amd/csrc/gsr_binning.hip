@@ -82,10 +82,11 @@ __global__ void __launch_bounds__(256) k_scan_rows(uint32_t* __restrict__ data, 
 
 // ------------------------------------------------------------------------------------------------ radix sort
 // per-block digit histogram, hist[d * nblk + blk]
-__global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift,
-                                                                 uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk)
+__global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                                 int shift, uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk)
 {
     __shared__ uint32_t h[256];
+    if (n_dev) n = min(n, *n_dev);       // device-side element count (speculative forward): n is then the capacity
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * GSR_SORT_BLOCK;
@@ -101,9 +102,10 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t*
 // stable scatter.  Order inside a block is (wave, item, lane): wave w owns keys [w*1024, w*1024+1024).
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                                    uint32_t n, int shift, int bits, const uint32_t* __restrict__ hist, uint32_t nblk,
-                                                                    const uint32_t* __restrict__ digit_tot)
+                                                                    uint32_t n, const uint32_t* __restrict__ n_dev, int shift, int bits,
+                                                                    const uint32_t* __restrict__ hist, uint32_t nblk, const uint32_t* __restrict__ digit_tot)
 {
+    if (n_dev) n = min(n, *n_dev);
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t gbase[256];
     __shared__ uint32_t lds[17];
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     }
 }
 
-int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
+int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
                          bool* result_in_b, hipStream_t s)
 {
@@ -176,9 +178,9 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         int passes_left = (remaining + bits_per_pass - 1) / bits_per_pass;
         int bits = (remaining + passes_left - 1) / passes_left;
         uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, shift, mask, hist, nblk);
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, n_dev, shift, mask, hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, hist, nblk, digit_tot);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, shift, bits, hist, nblk, digit_tot);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         if (vin == nullptr) { vin = vout; vout = vals_a; }     // first pass generated identity values into vals_b
@@ -222,7 +224,7 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
     const uint32_t P = (uint32_t)cfg->P;
     bool in_b = false;
     // keys: depth_key (A) <-> keys_b; values: identity -> vals_b <-> vals_a
-    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, 0, 32, 8, true, g.hist, &in_b, s);
+    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, 8, true, g.hist, &in_b, s);
     // 4 passes: keys end in depth_key (A).  values: pass1 -> vals_b, pass2 -> vals_a, pass3 -> vals_b, pass4 -> vals_a
     // (gsr_radix_sort_pairs alternates vout between vals_b and vals_a), so the ids end in vals_a == sorted_idx.
     const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
@@ -236,7 +238,7 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
 // duplicateWithKeys (3DGS rasterizer_impl.cu:70-111) over gaussians in depth order; key = tile id only.
 __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ tiles_touched, const ushort4* __restrict__ rect, int gx,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -246,15 +248,18 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
     const ushort4 r = rect[g];
     for (uint32_t y = r.y; y < r.w; y++)
         for (uint32_t x = r.x; x < r.z; x++) {
-            keys[off] = y * (uint32_t)gx + x;
-            vals[off] = g;
+            if (off < cap) {                     // cap == R normally; smaller only when a speculative forward overflowed
+                keys[off] = y * (uint32_t)gx + x;
+                vals[off] = g;
+            }
             off++;
         }
 }
 
 // identifyTileRanges (3DGS rasterizer_impl.cu:116-138)
-__global__ void __launch_bounds__(256) k_tile_ranges(uint32_t R, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges)
+__global__ void __launch_bounds__(256) k_tile_ranges(uint32_t R, const uint32_t* __restrict__ n_dev, const uint32_t* __restrict__ tile_keys, uint2* __restrict__ ranges)
 {
+    if (n_dev) R = min(R, *n_dev);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const uint32_t cur = tile_keys[i];
@@ -274,7 +279,9 @@ static int tile_bits(int T)
 }
 int gsr_tile_sort_passes(int T) { return (tile_bits(T) + 7) / 8; }
 
-int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, hipStream_t s)
+// R is the exact instance count, or -- when n_dev != nullptr -- the CAPACITY of the binning arena while the exact count
+// is read on the device from *n_dev (speculative forward: the host has not seen it yet).
+int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s)
 {
     const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     const int T = gx * gy;
@@ -285,9 +292,9 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up(cfg->P, 256)), dim3(256), 0, s, (uint32_t)cfg->P, g.sorted_idx, g.offsets,
-                       g.tiles_touched, g.rect, gx, k0, v0);
+                       g.tiles_touched, g.rect, gx, k0, v0, R);
     bool in_b = false;
-    gsr_radix_sort_pairs(k0, v0, k1, v1, R, 0, tile_bits(T), 8, false, b.hist, &in_b, s);
-    hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, b.tile_keys, im.ranges);
+    gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s);
+    hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
     return gsr_check_launch("binning", s, cfg->debug);
 }

@@ -86,7 +86,7 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug);
 // ---- stage launchers (each in its own .hip) ------------------------------------------------------------------
 int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s);
 int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s);   // sorted_idx, offsets, counters[0]
-int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, hipStream_t s);
+int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s);
 int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_outputs* out, hipStream_t s);
 int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
@@ -95,6 +95,6 @@ int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const in
                               const float* acc, const gsr_in_grads* ig, hipStream_t s);
 
 // generic device-wide primitives (gsr_binning.hip)
-int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
+int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
                          bool* result_in_b, hipStream_t s);

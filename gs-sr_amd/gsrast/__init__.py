@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgsrast_hip.so")
 
 EWA, SURFEL, PLANE = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = C.c_void_p
 
@@ -48,7 +48,7 @@ class InGrads(C.Structure):
 EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward_scratch_bytes",
            "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_visible_filter",
            "gsr_tsdf_integrate", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
-           "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read"]
+           "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward"]
 PROF_LABELS = ["preprocess", "depth_order", "binning", "blend_fwd", "bwd_memset", "blend_bwd", "preprocess_bwd", "_"]
 
 _lib = None
@@ -73,6 +73,10 @@ def lib():
     L.gsr_forward_stage2.restype = C.c_int
     L.gsr_forward_stage2.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, sz, _vp, sz, C.c_uint32,
                                      C.POINTER(Outputs), _vp]
+    L.gsr_binning_capacity.restype = C.c_uint32; L.gsr_binning_capacity.argtypes = [C.c_int32, sz, C.c_int32, C.c_int32]
+    L.gsr_forward.restype = C.c_int
+    L.gsr_forward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, sz, _vp, sz, _vp, C.POINTER(Outputs),
+                              C.POINTER(C.c_uint32), C.POINTER(C.c_int32), _vp]
     L.gsr_backward.restype = C.c_int
     L.gsr_backward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, _vp, sz, _vp, sz, _vp, sz, C.c_uint32, _vp, sz,
                                C.POINTER(OutGrads), C.POINTER(InGrads), _vp]
@@ -86,7 +90,7 @@ def lib():
     L.gsr_dist2.restype = C.c_int
     L.gsr_dist2.argtypes = [C.c_int32, _vp, _vp, _vp, sz, _vp]
     L.gsr_debug_read.restype = C.c_int
-    L.gsr_debug_read.argtypes = [C.POINTER(Cfg), C.c_int32, _vp, _vp, _vp, C.c_uint32, _vp, _vp]
+    L.gsr_debug_read.argtypes = [C.POINTER(Cfg), C.c_int32, _vp, _vp, sz, _vp, C.c_uint32, _vp, _vp]
     L.gsr_profile_enable.restype = C.c_int; L.gsr_profile_enable.argtypes = [C.c_int32]
     L.gsr_profile_read.restype = C.c_int
     L.gsr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]

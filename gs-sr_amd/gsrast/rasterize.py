@@ -6,6 +6,7 @@ Buffer ownership mirrors the reference: outputs and the three opaque byte arenas
 imgBuffer) are torch tensors allocated here; the arenas are saved for backward.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -15,6 +16,12 @@ from . import (EWA, SURFEL, PLANE, Cfg, Inputs, Outputs, OutGrads, InGrads, lib,
 
 def cpu_deep_copy_tuple(input_tuple):
     return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+# Expected number of tile instances per (device, variant, W, H): sizes the binning arena of the NEXT forward so that
+# stage 2 can be enqueued without waiting for the host to learn num_rendered (gsr_forward).  GSR_SPECULATIVE=0 disables.
+_R_HINT = {}
+_SPECULATIVE = os.environ.get("GSR_SPECULATIVE", "1") != "0"
 
 
 def _bytes(n, device):
@@ -69,13 +76,29 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
         return 0, outs, radii, geom, _bytes(0, dev), img
     s = stream_ptr(dev)
     R = C.c_uint32(0)
+    o = Outputs(ptr(outs["color"]), ptr(outs.get("others")), ptr(outs.get("observe")), ptr(outs.get("all_map")),
+                ptr(outs.get("plane_depth")))
+    key = (dev.index, variant, W, H)
+    hint = _R_HINT.get(key) if (_SPECULATIVE and not cfg.debug) else None
     with torch.cuda.device(dev):
-        check(L.gsr_forward_stage1(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(radii), C.byref(R), s), "forward")
-        binning = _bytes(L.gsr_binning_bytes(variant, R.value, W, H), dev)
-        o = Outputs(ptr(outs["color"]), ptr(outs.get("others")), ptr(outs.get("observe")), ptr(outs.get("all_map")),
-                    ptr(outs.get("plane_depth")))
-        check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
-                                   ptr(img), img.numel(), R.value, C.byref(o), s), "forward")
+        if hint is not None:
+            # steady state: one call, no GPU idle gap at the sync (arena sized from the previous call + 25 % head-room)
+            binning = _bytes(L.gsr_binning_bytes(variant, int(hint * 1.25) + 16384, W, H), dev)
+            ovf = C.c_int32(0)
+            check(L.gsr_forward(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(), ptr(img),
+                                img.numel(), ptr(radii), C.byref(o), C.byref(R), C.byref(ovf), s), "forward")
+            if ovf.value:
+                binning = _bytes(L.gsr_binning_bytes(variant, R.value, W, H), dev)
+                if "observe" in outs:
+                    outs["observe"].zero_()
+                check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
+                                           ptr(img), img.numel(), R.value, C.byref(o), s), "forward")
+        else:
+            check(L.gsr_forward_stage1(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(radii), C.byref(R), s), "forward")
+            binning = _bytes(L.gsr_binning_bytes(variant, R.value, W, H), dev)
+            check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
+                                       ptr(img), img.numel(), R.value, C.byref(o), s), "forward")
+    _R_HINT[key] = int(R.value)
     return int(R.value), outs, radii, geom, binning, img
 
 
@@ -122,6 +145,6 @@ def backward(variant, num_rendered, settings, radii, means3D, sh, colors_precomp
 def debug_read(variant, field, settings, P, M, num_rendered, geom, binning, img, out):
     keep = []
     cfg = make_cfg(variant, P, settings, settings.sh_degree, M, False, keep)
-    check(lib().gsr_debug_read(C.byref(cfg), field, ptr(geom), ptr(binning), ptr(img), int(num_rendered), ptr(out),
-                               stream_ptr(out.device)), "debug_read")
+    check(lib().gsr_debug_read(C.byref(cfg), field, ptr(geom), ptr(binning), binning.numel(), ptr(img), int(num_rendered),
+                               ptr(out), stream_ptr(out.device)), "debug_read")
     return out

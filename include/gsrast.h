@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 enum gsr_variant {
     GSR_EWA = 0,     /* diff_gaussian_rasterization : 3DGS EWA splats, RGB only                          */
@@ -122,6 +122,17 @@ int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, siz
                        void* binning, size_t binning_bytes, void* img, size_t img_bytes,
                        uint32_t num_rendered, const gsr_outputs* out, void* stream);
 
+/* ---- single-call forward without the GPU idle gap at the sync.  `binning` is an arena of ANY capacity
+ * (gsr_binning_capacity(bytes) instances, e.g. sized from the previous iteration's num_rendered with head-room):
+ * stage 2 is enqueued right behind stage 1 and reads the exact instance count on the device; the host waits only on an
+ * event recorded after stage 1 and returns num_rendered.  *overflow_host = 1 iff num_rendered > capacity: outputs are
+ * then incomplete and the caller re-runs gsr_forward_stage2 with a large-enough arena (geom stays valid; PLANE callers
+ * re-zero out_observe first).  Results are identical to stage1 + stage2. */
+uint32_t gsr_binning_capacity(int32_t variant, size_t binning_bytes, int32_t W, int32_t H);
+int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                void* binning, size_t binning_bytes, void* img, size_t img_bytes, int32_t* radii /*[P]*/,
+                const gsr_outputs* out, uint32_t* num_rendered_host, int32_t* overflow_host, void* stream);
+
 /* ---- backward of the same call.  radii is the forward's radii output. */
 int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii,
                  const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
@@ -153,8 +164,8 @@ enum gsr_debug_field {
     GSR_DBG_N_CONTRIB = 4,     /* uint32 [N] (SURFEL [2,N])                       (from img)     */
     GSR_DBG_TILE_KEYS = 5      /* uint32 [R] tile id per sorted instance          (from binning) */
 };
-int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, const void* img,
-                   uint32_t num_rendered, void* dst, void* stream);
+int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, size_t binning_bytes,
+                   const void* img, uint32_t num_rendered, void* dst, void* stream);
 
 /* ---- optional stage profiler: HIP events recorded on the launch stream around every stage.
  * gsr_profile_enable(1) resets and starts, gsr_profile_read returns total milliseconds and launch counts per label. */

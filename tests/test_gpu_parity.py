@@ -161,6 +161,34 @@ def test_edge_cases(variant):
     assert res["color"].shape == (3, 77, 131) and np.abs(res["color"]).max() == 0
 
 
+@pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
+def test_speculative_forward_matches_exact_and_survives_overflow(variant):
+    """gsr_forward (stage 2 enqueued against a capacity guessed from the previous call) must give bit-identical results
+    to stage1+stage2, including when the guess is too small (overflow -> redo; PLANE re-zeroes out_observe)."""
+    from gsrast import rasterize as rz
+    hr = _hiprun()
+    W, H = 208, 144
+    small = scenes.make_scene(variant, 300, W, H, seed=21, sigma_px=2.0)
+    big = scenes.make_scene(variant, 9000, W, H, seed=22, sigma_px=12.0)      # R(big) >> 1.25 * R(small) + 16384
+    key = (torch.cuda.current_device(), hr.VID[variant], W, H)
+    rz._R_HINT.pop(key, None)
+    exact = hr.run_raw(variant, big)                                           # no hint -> stage1 + stage2
+    assert rz._R_HINT[key] == exact["R"] and exact["R"] > 60000
+    spec = hr.run_raw(variant, big)                                            # hint fits -> single call
+    rz._R_HINT[key] = 100                                                      # force an overflow on the next call
+    ovf = hr.run_raw(variant, big)
+    for other in (spec, ovf):
+        assert other["R"] == exact["R"]
+        for k in ("color", "radii", "point_list", "tile_keys", "ranges", "final_T", "n_contrib"):
+            assert np.array_equal(other[k], exact[k]), k
+        if variant == "plane":
+            assert np.array_equal(other["observe"], exact["observe"])
+    hr.run_raw(variant, small)                                                 # shrinking is fine too
+    with oracle.Forward(big, variant) as f:
+        assert np.array_equal(ovf["point_list"], f.point_list())
+        _img_close(ovf["color"], f.color)
+
+
 def test_render_geo_false_plane():
     hr = _hiprun()
     sc = scenes.make_scene("plane", 1500, 128, 96, seed=6); sc["render_geo"] = False
