@@ -69,39 +69,186 @@ extern "C" int gsr_tsdf_integrate(int64_t V, const float* points, const float* f
     return gsr_check_launch("tsdf_integrate", (hipStream_t)stream, false);
 }
 
-// ---- distCUDA2 (simple-knn/simple_knn.cu:148-184).  Exact 3-NN by LDS-tiled all-pairs: every block owns 256 query
-// points and streams all points through LDS in tiles of 256.  O(P^2) but init-time only; the reference's Morton/box
-// pruning yields the same exact answer.
-__global__ void __launch_bounds__(256) k_dist2(int P, const float* __restrict__ pts, float* __restrict__ out)
+// ---- dense-grid Open3D-style integration (see include/gsrast.h; parity unpinned).  One thread per voxel, z fastest:
+// consecutive lanes walk a voxel column, so tsdf/weight/color accesses are coalesced 4/4/12-B streams.
+struct DenseTsdfParams {
+    int nx, ny, nz, W, H;
+    float ox, oy, oz, vl, trunc, dtrunc, fx, fy, cx, cy;
+    float E[12];
+};
+__global__ void __launch_bounds__(256) k_tsdf_dense(DenseTsdfParams p, const float* __restrict__ depth, const float* __restrict__ rgb,
+                                                    float* __restrict__ tsdf, float* __restrict__ weight, float* __restrict__ color)
 {
-    __shared__ float sx[256], sy[256], sz[256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    float px = 0, py = 0, pz = 0;
-    if (i < P) { px = pts[3 * i]; py = pts[3 * i + 1]; pz = pts[3 * i + 2]; }
-    float b0 = 3.402823466e+38f, b1 = b0, b2 = b0;
-    for (int t = 0; t < P; t += 256) {
-        const int j = t + threadIdx.x;
-        __syncthreads();
-        if (j < P) { sx[threadIdx.x] = pts[3 * j]; sy[threadIdx.x] = pts[3 * j + 1]; sz[threadIdx.x] = pts[3 * j + 2]; }
-        __syncthreads();
-        const int n = min(256, P - t);
-        for (int k = 0; k < n; k++) {
-            if (t + k == i) continue;
-            const float dx = sx[k] - px, dy = sy[k] - py, dz = sz[k] - pz;
-            float d = dx * dx + dy * dy + dz * dz;
-            if (b0 > d) { float tmp = b0; b0 = d; d = tmp; }
-            if (b1 > d) { float tmp = b1; b1 = d; d = tmp; }
-            if (b2 > d) { b2 = d; }
-        }
-    }
-    if (i < P) out[i] = (b0 + b1 + b2) / 3.0f;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t V = (int64_t)p.nx * p.ny * p.nz;
+    if (i >= V) return;
+    const int iz = (int)(i % p.nz), iy = (int)((i / p.nz) % p.ny), ix = (int)(i / ((int64_t)p.nz * p.ny));
+    const float x = p.ox + p.vl * ((float)ix + 0.5f), y = p.oy + p.vl * ((float)iy + 0.5f), z = p.oz + p.vl * ((float)iz + 0.5f);
+    const float xc = p.E[0] * x + p.E[1] * y + p.E[2] * z + p.E[3];
+    const float yc = p.E[4] * x + p.E[5] * y + p.E[6] * z + p.E[7];
+    const float zc = p.E[8] * x + p.E[9] * y + p.E[10] * z + p.E[11];
+    if (!(zc > 0.f)) return;
+    const float uf = xc * p.fx / zc + p.cx + 0.5f, vf = yc * p.fy / zc + p.cy + 0.5f;
+    if (!(uf >= 0.f && uf < (float)p.W && vf >= 0.f && vf < (float)p.H)) return;
+    const int u = (int)uf, v = (int)vf;
+    const float d = depth[(size_t)v * p.W + u];
+    if (!(d > 0.f) || d > p.dtrunc) return;
+    const float rx = ((float)u - p.cx) / p.fx, ry = ((float)v - p.cy) / p.fy;
+    const float sdf = (d - zc) * sqrtf(rx * rx + ry * ry + 1.0f);
+    if (!(sdf > -p.trunc)) return;
+    const float t = fminf(1.0f, sdf / p.trunc);
+    const float w = weight[i], wp = w + 1.0f;
+    tsdf[i] = (tsdf[i] * w + t) / wp;
+    const size_t HW = (size_t)p.W * p.H;
+#pragma unroll
+    for (int c = 0; c < 3; c++) color[3 * i + c] = (color[3 * i + c] * w + rgb[c * HW + (size_t)v * p.W + u]) / wp;
+    weight[i] = wp;
 }
 
-extern "C" size_t gsr_dist2_scratch_bytes(int32_t P) { (void)P; return 256; }
+extern "C" int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* origin, float voxel_length, float sdf_trunc,
+                                        float depth_trunc, int32_t W, int32_t H, const float* depth, const float* rgb, float fx, float fy,
+                                        float cx, float cy, const float* extrinsic, float* tsdf, float* weight, float* color, void* stream)
+{
+    const int64_t V = (int64_t)nx * ny * nz;
+    if (V <= 0) return 0;
+    if ((V + 255) / 256 > 0x7FFFFFFF) { gsr_set_error("tsdf: grid too large"); return 1; }
+    DenseTsdfParams p;
+    p.nx = nx; p.ny = ny; p.nz = nz; p.W = W; p.H = H;
+    p.ox = origin[0]; p.oy = origin[1]; p.oz = origin[2]; p.vl = voxel_length; p.trunc = sdf_trunc; p.dtrunc = depth_trunc;
+    p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy;
+    for (int k = 0; k < 12; k++) p.E[k] = extrinsic[k];
+    hipLaunchKernelGGL(k_tsdf_dense, dim3((uint32_t)((V + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, depth, rgb, tsdf, weight, color);
+    return gsr_check_launch("tsdf_integrate_dense", (hipStream_t)stream, false);
+}
+
+// ---- distCUDA2 (simple-knn/simple_knn.cu:186-222): mean squared distance to the 3 nearest neighbours.
+// Same strategy as the reference (Morton order -> boxes of consecutive points -> box-pruned exact search), built from
+// this library's own primitives: float min/max by order-preserving integer atomics, the stable LSD radix sort of
+// gsr_binning.hip on the 30-bit Morton code, 256-point boxes.  The pruning is conservative, so the result is the exact
+// 3-NN (bit-identical to an all-pairs search).
+#define GSR_KNN_BOX 256
+__device__ __forceinline__ uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+__global__ void k_knn_init(uint32_t* mm) { if (threadIdx.x < 3) mm[threadIdx.x] = 0xFFFFFFFFu; else if (threadIdx.x < 6) mm[threadIdx.x] = 0u; }
+
+__global__ void __launch_bounds__(256) k_knn_minmax(int P, const float* __restrict__ pts, uint32_t* __restrict__ mm)
+{
+    __shared__ uint32_t s[6];
+    if (threadIdx.x < 3) s[threadIdx.x] = 0xFFFFFFFFu; else if (threadIdx.x < 6) s[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x)
+        for (int c = 0; c < 3; c++) { uint32_t o = f2ord(pts[3 * i + c]); atomicMin(&s[c], o); atomicMax(&s[3 + c], o); }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&mm[threadIdx.x], s[threadIdx.x]); else if (threadIdx.x < 6) atomicMax(&mm[threadIdx.x], s[threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t prep_morton(uint32_t x)
+{
+    x = (x | (x << 16)) & 0x030000FF; x = (x | (x << 8)) & 0x0300F00F; x = (x | (x << 4)) & 0x030C30C3; x = (x | (x << 2)) & 0x09249249;
+    return x;
+}
+// simple_knn.cu:55-61
+__global__ void __launch_bounds__(256) k_knn_morton(int P, const float* __restrict__ pts, const uint32_t* __restrict__ mm, uint32_t* __restrict__ codes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    uint32_t m[3];
+    for (int c = 0; c < 3; c++) {
+        const float lo = ord2f(mm[c]), hi = ord2f(mm[3 + c]);
+        const float t = (hi > lo) ? (pts[3 * i + c] - lo) / (hi - lo) : 0.f;
+        m[c] = prep_morton((uint32_t)(t * ((1 << 10) - 1)));
+    }
+    codes[i] = m[0] | (m[1] << 1) | (m[2] << 2);
+}
+
+// per-box bounds of GSR_KNN_BOX consecutive points in Morton order (simple_knn.cu:79-118)
+__global__ void __launch_bounds__(GSR_KNN_BOX) k_knn_boxes(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order, float* __restrict__ boxes)
+{
+    __shared__ uint32_t s[6];
+    if (threadIdx.x < 3) s[threadIdx.x] = 0xFFFFFFFFu; else if (threadIdx.x < 6) s[threadIdx.x] = 0u;
+    __syncthreads();
+    const int i = blockIdx.x * GSR_KNN_BOX + threadIdx.x;
+    if (i < P) {
+        const uint32_t id = order[i];
+        for (int c = 0; c < 3; c++) { uint32_t o = f2ord(pts[3 * id + c]); atomicMin(&s[c], o); atomicMax(&s[3 + c], o); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) boxes[6 * blockIdx.x + threadIdx.x] = ord2f(s[threadIdx.x]);
+}
+
+__device__ __forceinline__ void knn_update(float px, float py, float pz, float qx, float qy, float qz, float& b0, float& b1, float& b2)
+{
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    float d = dx * dx + dy * dy + dz * dz;
+    if (b0 > d) { const float t = b0; b0 = d; d = t; }
+    if (b1 > d) { const float t = b1; b1 = d; d = t; }
+    if (b2 > d) { b2 = d; }
+}
+
+// simple_knn.cu:148-184
+__global__ void __launch_bounds__(256) k_knn_dist(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
+                                                  const float* __restrict__ boxes, int nbox, float* __restrict__ out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const uint32_t me = order[idx];
+    const float px = pts[3 * me], py = pts[3 * me + 1], pz = pts[3 * me + 2];
+    const float FMAX = 3.402823466e+38f;
+    float b0 = FMAX, b1 = FMAX, b2 = FMAX;
+    for (int i = max(0, idx - 3); i <= min(P - 1, idx + 3); i++) {
+        if (i == idx) continue;
+        const uint32_t q = order[i];
+        knn_update(px, py, pz, pts[3 * q], pts[3 * q + 1], pts[3 * q + 2], b0, b1, b2);
+    }
+    const float reject = b2;
+    b0 = FMAX; b1 = FMAX; b2 = FMAX;
+    for (int b = 0; b < nbox; b++) {
+        const float* bx = boxes + 6 * b;
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+        if (px < bx[0] || px > bx[3]) ddx = fminf(fabsf(px - bx[0]), fabsf(px - bx[3]));
+        if (py < bx[1] || py > bx[4]) ddy = fminf(fabsf(py - bx[1]), fabsf(py - bx[4]));
+        if (pz < bx[2] || pz > bx[5]) ddz = fminf(fabsf(pz - bx[2]), fabsf(pz - bx[5]));
+        const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
+        if (dist > reject || dist > b2) continue;
+        const int e = min(P, (b + 1) * GSR_KNN_BOX);
+        for (int i = b * GSR_KNN_BOX; i < e; i++) {
+            if (i == idx) continue;
+            const uint32_t q = order[i];
+            knn_update(px, py, pz, pts[3 * q], pts[3 * q + 1], pts[3 * q + 2], b0, b1, b2);
+        }
+    }
+    out[me] = (b0 + b1 + b2) / 3.0f;
+}
+
+struct KnnScratch { uint32_t *mm, *keys_a, *keys_b, *vals_a, *vals_b, *hist; float* boxes; size_t bytes; };
+static KnnScratch knn_carve(int P, void* base)
+{
+    KnnScratch k; char* p = (char*)base;
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    const uint32_t nblk = gsr_div_up((uint32_t)n, GSR_SORT_BLOCK), nbox = gsr_div_up((uint32_t)n, GSR_KNN_BOX);
+    auto take = [&](size_t bytes) { char* r = p; p += gsr_align(bytes); return r; };
+    k.mm = (uint32_t*)take(64); k.keys_a = (uint32_t*)take(n * 4); k.keys_b = (uint32_t*)take(n * 4);
+    k.vals_a = (uint32_t*)take(n * 4); k.vals_b = (uint32_t*)take(n * 4);
+    k.hist = (uint32_t*)take(((size_t)256 * nblk + 256) * 4); k.boxes = (float*)take((size_t)nbox * 6 * 4);
+    k.bytes = (size_t)(p - (char*)base);
+    return k;
+}
+extern "C" size_t gsr_dist2_scratch_bytes(int32_t P) { return knn_carve(P, nullptr).bytes; }
 extern "C" int gsr_dist2(int32_t P, const float* points, float* out, void* scratch, size_t scratch_bytes, void* stream)
 {
-    (void)scratch; (void)scratch_bytes;
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(k_dist2, dim3(gsr_div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, P, points, out);
-    return gsr_check_launch("dist2", (hipStream_t)stream, false);
+    hipStream_t s = (hipStream_t)stream;
+    KnnScratch k = knn_carve(P, scratch);
+    if (k.bytes > scratch_bytes) { gsr_set_error("dist2 scratch too small: %zu < %zu", scratch_bytes, k.bytes); return 1; }
+    const int nbox = (int)gsr_div_up((uint32_t)P, GSR_KNN_BOX);
+    hipLaunchKernelGGL(k_knn_init, dim3(1), dim3(64), 0, s, k.mm);
+    hipLaunchKernelGGL(k_knn_minmax, dim3(min(1024u, gsr_div_up((uint32_t)P, 256))), dim3(256), 0, s, P, points, k.mm);
+    hipLaunchKernelGGL(k_knn_morton, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, points, k.mm, k.keys_a);
+    bool in_b = false;
+    gsr_radix_sort_pairs(k.keys_a, k.vals_a, k.keys_b, k.vals_b, (uint32_t)P, nullptr, 0, 30, 8, true, k.hist, &in_b, s);
+    const uint32_t* order = in_b ? k.vals_b : k.vals_a;
+    hipLaunchKernelGGL(k_knn_boxes, dim3(nbox), dim3(GSR_KNN_BOX), 0, s, P, points, order, k.boxes);
+    hipLaunchKernelGGL(k_knn_dist, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, points, order, k.boxes, nbox, out);
+    return gsr_check_launch("dist2", s, false);
 }

@@ -151,6 +151,18 @@ int gsr_tsdf_integrate(int64_t V, const float* points /*[V,3]*/, const float* fu
                        int32_t W, int32_t H, const float* depth /*[H,W]*/, const float* rgb /*[3,H,W]*/,
                        float sdf_trunc, const float* sdf_trunc_per_point /*[V] or NULL*/,
                        float* tsdf /*[V]*/, float* weight /*[V]*/, float* rgb_acc /*[V,3]*/, void* stream);
+/* Dense-grid, Open3D-style integration (the bounded path of gssr/utils/mesh_utils.py:138-179 calls
+ * o3d.pipelines.integration.ScalableTSDFVolume.integrate, Open3D 0.18.0 -- NOT vendored in the reference, so the voxel
+ * update is restated from Open3D's published UniformTSDFVolume algorithm and its parity is UNPINNED):
+ * voxel centre p = origin + voxel_length*(idx+0.5); p_cam = extrinsic*p (row-major 4x4 world->camera); skip z<=0;
+ * (u,v) = (int)(fx*x/z + cx + 0.5, fy*y/z + cy + 0.5) nearest pixel; d = depth[v,u], skip d<=0 or d>depth_trunc;
+ * sdf = (d - z) * sqrt(((u-cx)/fx)^2 + ((v-cy)/fy)^2 + 1); if sdf > -sdf_trunc: t = min(1, sdf/sdf_trunc);
+ * tsdf = (tsdf*w + t)/(w+1); color = (color*w + rgb[:,v,u])/(w+1); w += 1.  Arrays are [nx,ny,nz] x-major, initial 0. */
+int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* origin /*[3] HOST*/, float voxel_length,
+                             float sdf_trunc, float depth_trunc, int32_t W, int32_t H, const float* depth /*[H,W]*/,
+                             const float* rgb /*[3,H,W]*/, float fx, float fy, float cx, float cy,
+                             const float* extrinsic /*[16] HOST, row-major world->camera*/,
+                             float* tsdf, float* weight, float* color /*[nx,ny,nz,3]*/, void* stream);
 size_t gsr_dist2_scratch_bytes(int32_t P);
 int gsr_dist2(int32_t P, const float* points /*[P,3]*/, float* out /*[P]*/, void* scratch, size_t scratch_bytes,
               void* stream);

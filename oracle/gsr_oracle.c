@@ -1211,6 +1211,40 @@ void ref_tsdf_integrate(int64_t V, const float* points, const float* F, int32_t 
     }
 }
 
+/* Open3D 0.18.0 (pinned at requirements.txt:6, absent from /root/reference): UniformTSDFVolume::Integrate restated from
+   its published algorithm; call sites gssr/utils/mesh_utils.py:154-178, extract_mesh_split.py:91-119.  PARITY UNPINNED. */
+void ref_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* origin, float vl, float trunc, float dtrunc,
+                              int32_t W, int32_t H, const float* depth, const float* rgb, float fx, float fy, float cx, float cy,
+                              const float* E, float* tsdf, float* weight, float* color)
+{
+    const int64_t V = (int64_t)nx * ny * nz;
+    const size_t HW = (size_t)W * H;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < V; i++) {
+        const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((int64_t)nz * ny));
+        const float x = origin[0] + vl * ((float)ix + 0.5f), y = origin[1] + vl * ((float)iy + 0.5f), z = origin[2] + vl * ((float)iz + 0.5f);
+        const float xc = E[0]*x + E[1]*y + E[2]*z + E[3];
+        const float yc = E[4]*x + E[5]*y + E[6]*z + E[7];
+        const float zc = E[8]*x + E[9]*y + E[10]*z + E[11];
+        if (!(zc > 0.f)) continue;
+        const float uf = xc * fx / zc + cx + 0.5f, vf = yc * fy / zc + cy + 0.5f;
+        if (!(uf >= 0.f && uf < (float)W && vf >= 0.f && vf < (float)H)) continue;
+        const int u = (int)uf, v = (int)vf;
+        const float d = depth[(size_t)v * W + u];
+        if (!(d > 0.f) || d > dtrunc) continue;
+        const float rx = ((float)u - cx) / fx, ry = ((float)v - cy) / fy;
+        const float sdf = (d - zc) * sqrtf(rx*rx + ry*ry + 1.0f);
+        if (!(sdf > -trunc)) continue;
+        const float t = fminf(1.0f, sdf / trunc);
+        const float w = weight[i], wp = w + 1.0f;
+        tsdf[i] = (tsdf[i] * w + t) / wp;
+        for (int c = 0; c < 3; c++) color[3*i + c] = (color[3*i + c] * w + rgb[c*HW + (size_t)v * W + u]) / wp;
+        weight[i] = wp;
+    }
+}
+
 /* simple-knn (submodules/simple-knn/simple_knn.cu:148-184): mean of the squared distances to the 3 nearest
    neighbours.  Brute force; the Morton/box pruning of the source is an acceleration structure only. */
 void ref_dist2(int32_t P, const float* pts, float* out)

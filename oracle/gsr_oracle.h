@@ -100,6 +100,12 @@ void ref_tsdf_integrate(int64_t V, const float* points /*[V,3]*/, const float* f
                         float sdf_trunc, const float* sdf_trunc_per_point /*[V] or NULL*/,
                         float* tsdf /*[V]*/, float* weight /*[V]*/, float* rgb_acc /*[V,3]*/);
 
+/* dense-grid Open3D-style integration (Open3D 0.18.0 UniformTSDFVolume algorithm restated; NOT in /root/reference:
+   parity unpinned) -- see include/gsrast.h gsr_tsdf_integrate_dense for the definition */
+void ref_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* origin, float voxel_length, float sdf_trunc,
+                              float depth_trunc, int32_t W, int32_t H, const float* depth, const float* rgb, float fx, float fy,
+                              float cx, float cy, const float* extrinsic, float* tsdf, float* weight, float* color);
+
 /* simple-knn distCUDA2: mean squared distance to the 3 nearest neighbours (brute-force restatement) */
 void ref_dist2(int32_t P, const float* points, float* out);
 

@@ -64,6 +64,8 @@ def lib():
         L.ref_mark_visible.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_void_p]
         L.ref_tsdf_integrate.argtypes = [C.c_int64, _fp, _fp, C.c_int32, C.c_int32, _fp, _fp, C.c_float, _fp,
                                          _fp, _fp, _fp]
+        L.ref_tsdf_integrate_dense.argtypes = [C.c_int32] * 3 + [_fp, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, _fp, _fp,
+                                               C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp, _fp]
         L.ref_dist2.argtypes = [C.c_int32, _fp, _fp]
         L.ref_omp_threads.restype = C.c_int32
         _LIB = L
@@ -226,6 +228,14 @@ def tsdf_integrate(points, full_proj, depth, rgb, sdf_trunc, tsdf, weight, rgb_a
     assert tsdf.dtype == np.float32 and weight.dtype == np.float32 and rgb_acc.dtype == np.float32
     lib().ref_tsdf_integrate(pts.shape[0], _p(pts), _p(F), W, H, _p(d), _p(c), float(sdf_trunc), _p(tp),
                              _p(tsdf), _p(weight), _p(rgb_acc))
+
+
+def tsdf_integrate_dense(dims, origin, voxel_length, sdf_trunc, depth_trunc, depth, rgb, fx, fy, cx, cy, extrinsic, tsdf, weight, color):
+    o, d, c, E = _f32(origin), _f32(depth), _f32(rgb), _f32(extrinsic)
+    H, W = d.shape[-2], d.shape[-1]
+    lib().ref_tsdf_integrate_dense(int(dims[0]), int(dims[1]), int(dims[2]), _p(o), float(voxel_length), float(sdf_trunc),
+                                   float(depth_trunc), W, H, _p(d), _p(c), float(fx), float(fy), float(cx), float(cy), _p(E),
+                                   _p(tsdf), _p(weight), _p(color))
 
 
 def dist2(points):

@@ -43,6 +43,32 @@ def test_tile_sharding_world2_gloo():
         mp.spawn(_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
 
 
+def _merge_worker(rank, world, port):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "gs-sr_amd"))
+    from gsrast.tsdf import merge_volumes_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    # two "frames" integrated sequentially on one rank vs one frame per rank + merge: same weighted average
+    obs = torch.rand(2, 4, 5, 6, generator=g); seen = torch.rand(2, 4, 5, 6, generator=g) > 0.3
+    col = torch.rand(2, 4, 5, 6, 3, generator=g)
+    tsdf = torch.where(seen[rank], obs[rank], torch.zeros(4, 5, 6)); w = seen[rank].float()
+    c = torch.where(seen[rank].unsqueeze(-1), col[rank], torch.zeros(4, 5, 6, 3))
+    merge_volumes_(tsdf, w, c)
+    wt = seen.float().sum(0)
+    exp = torch.where(wt > 0, (obs * seen).sum(0) / wt.clamp_min(1), torch.zeros(4, 5, 6))
+    assert torch.allclose(w, wt) and torch.allclose(tsdf, exp, atol=1e-6)
+    assert torch.allclose(c, torch.where((wt > 0).unsqueeze(-1), (col * seen.unsqueeze(-1)).sum(0) / wt.clamp_min(1).unsqueeze(-1),
+                                         torch.zeros(4, 5, 6, 3)), atol=1e-6)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_tsdf_volume_merge_world2_gloo():
+    mp.spawn(_merge_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def test_assign_tiles_covers_configs():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -241,6 +241,33 @@ def test_visible_filter_mark_visible_dist2_tsdf():
     assert (wgt > 1).sum() > 1000
 
 
+def test_dist2_morton_pruned_is_exact_and_dense_tsdf():
+    from simple_knn._C import distCUDA2
+    from gsrast.tsdf import DenseTSDFVolume
+    rng = np.random.default_rng(3)
+    # clustered + duplicated points: the box pruning must still return the exact 3-NN
+    pts = np.concatenate([rng.normal(0, 1, (20000, 3)), rng.normal(5, 0.01, (5000, 3)), np.zeros((7, 3))]).astype(np.float32)
+    d = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+    assert np.array_equal(d, oracle.dist2(pts))
+    # dense Open3D-style volume, 4 frames
+    dims, origin, vl, trunc = (48, 40, 56), (-1.2, -1.0, 3.0), 0.05, 0.25
+    vol = DenseTSDFVolume(origin, vl, dims, trunc)
+    t = np.zeros(dims, np.float32); w = np.zeros(dims, np.float32); c = np.zeros(dims + (3,), np.float32)
+    W, H, fx, fy = 128, 96, 110.0, 105.0
+    for fr in range(4):
+        a = 0.1 * fr
+        E = np.array([[np.cos(a), 0, np.sin(a), 0.05 * fr], [0, 1, 0, -0.02 * fr], [-np.sin(a), 0, np.cos(a), 0.1], [0, 0, 0, 1]], np.float32)
+        depth = rng.uniform(3.5, 5.5, (1, H, W)).astype(np.float32)
+        depth[0, :5] = 0.0
+        rgb = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+        q = (np.clip(rgb, 0, 1) * 255).astype(np.uint8).astype(np.float32)
+        oracle.tsdf_integrate_dense(dims, origin, vl, trunc, 5.2, depth, q, fx, fy, W / 2, H / 2, E, t, w, c)
+        vol.integrate(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), fx, fy, W / 2, H / 2, E, depth_trunc=5.2)
+    assert np.array_equal(vol.weight.cpu().numpy(), w) and (w > 0).sum() > 5000
+    assert np.abs(vol.tsdf.cpu().numpy() - t).max() < 1e-5
+    assert np.abs(vol.color.cpu().numpy() - c).max() < 1e-3
+
+
 @pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
 def test_full_size_properties(variant):
     """BASELINE full size (300k gaussians, 1920x1080): size-independent properties instead of the (slow) oracle."""

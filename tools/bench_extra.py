@@ -1,0 +1,49 @@
+"""HBM-bound adjacent kernels on the GPU box: TSDF integrate (both definitions), distCUDA2, visible_filter.  Prints JSON."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gs-sr_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import scenes, hiprun
+from gsrast.tsdf import tsdf_integrate_, DenseTSDFVolume
+from simple_knn._C import distCUDA2
+import scaffold_filter
+
+
+def timeit(fn, n=20, w=3):
+    for _ in range(w): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+
+
+out = {}
+W, H = 1920, 1080
+cam = scenes.make_camera(W, H, 1600.0, 1600.0)
+depth = torch.rand(1, H, W, device="cuda") * 2 + 4; rgb = torch.rand(3, H, W, device="cuda")
+n = 512
+g = torch.stack(torch.meshgrid(torch.linspace(-3, 3, n), torch.linspace(-1.7, 1.7, n), torch.linspace(3.5, 6.5, n), indexing="ij"), -1).reshape(-1, 3).cuda().contiguous()
+V = g.shape[0]
+ts = torch.ones(V, device="cuda"); ws = torch.ones(V, device="cuda"); cs = torch.zeros(V, 3, device="cuda")
+F = torch.from_numpy(cam["projmatrix"]).cuda()
+t = timeit(lambda: tsdf_integrate_(g, F, depth, rgb, 0.05, ts, cs, ws))
+touched = float((ws > 1).float().mean())
+alg = V * 12 + touched * V * 40
+out["tsdf_points"] = {"voxels": V, "ms": round(t * 1e3, 3), "touched_frac": round(touched / 1.0, 3), "algorithmic_GBps": round(alg / t / 1e9, 1)}
+vol = DenseTSDFVolume((-3, -1.7, 3.5), 6.0 / n, (n, n // 2, n), 0.05)
+E = np.eye(4, dtype=np.float32)
+t = timeit(lambda: vol.integrate(rgb, depth, 1600.0, 1600.0, W / 2, H / 2, E, quantize_rgb8=False))
+Vd = n * (n // 2) * n
+tf = float((vol.weight > 0).float().mean())
+out["tsdf_dense"] = {"voxels": Vd, "ms": round(t * 1e3, 3), "touched_frac": round(tf, 3), "algorithmic_GBps": round((tf * Vd * 40) / t / 1e9, 1),
+                     "streamed_GBps_lower_bound": round((Vd * 4) / t / 1e9, 1)}
+sc = scenes.make_scene("ewa", 300000, W, H, seed=0)
+pts = torch.from_numpy(sc["means3D"]).cuda()
+t = timeit(lambda: distCUDA2(pts), n=5, w=1)
+out["distCUDA2_300k"] = {"ms": round(t * 1e3, 3)}
+td = hiprun.to_dev(sc)
+rs = scaffold_filter.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=td["bg"],
+        scale_modifier=1.0, viewmatrix=td["viewmatrix"], projmatrix=td["projmatrix"], sh_degree=0, campos=td["campos"], prefiltered=False, debug=False)
+rr = scaffold_filter.GaussianRasterizer(rs)
+t = timeit(lambda: rr.visible_filter(td["means3D"], td["scales"], td["rotations"]), n=50)
+out["visible_filter_300k"] = {"ms": round(t * 1e3, 4), "algorithmic_GBps": round(300000 * 44 / t / 1e9, 1)}
+print(json.dumps(out))
