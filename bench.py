@@ -53,6 +53,7 @@ def make_step(variant, sc, device):
     import diff_gaussian_rasterization as dgr
     import diff_surfel_rasterization as dsr
     import diff_plane_rasterization as dpr
+    from gsrast.losses import l1_plus_linear
     t = hiprun.to_dev(sc, device)
     rs = hiprun.settings(variant, t)
     P, W, H = t["means3D"].shape[0], int(t["W"]), int(t["H"])
@@ -89,14 +90,14 @@ def make_step(variant, sc, device):
                   scales=v["scales"], rotations=v["rotations"])
         if variant == "surfel":
             color, radii, allmap = dsr.GaussianRasterizer(rs)(**kw)
-            loss = (color - gt).abs().mean() + (allmap * wmap).sum()
+            loss = l1_plus_linear(color, gt, allmap, wmap)
         elif variant == "plane":
             m2a = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
             color, radii, observe, oam, pd = dpr.GaussianRasterizer(rs)(means2D_abs=m2a, all_map=all_map, **kw)
-            loss = (color - gt).abs().mean() + (oam * wmap).sum() + (pd * wpd).sum()
+            loss = l1_plus_linear(color, gt, oam, wmap) + (pd * wpd).sum()
         else:
             color, radii = dgr.GaussianRasterizer(rs)(**kw)
-            loss = (color - gt).abs().mean()
+            loss = l1_plus_linear(color, gt)
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)

@@ -121,6 +121,51 @@ extern "C" int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, cons
     return gsr_check_launch("tsdf_integrate_dense", (hipStream_t)stream, false);
 }
 
+// ---- fused L1 + linear-aux loss (forward value + dL/dcolor in one streaming pass; float4 loads, grid-stride)
+__global__ void __launch_bounds__(256) k_loss_l1_linear(int64_t n4c, int64_t nc, const float* __restrict__ color, const float* __restrict__ gt,
+                                                        float* __restrict__ dcol, int64_t n4a, int64_t na, const float* __restrict__ aux,
+                                                        const float* __restrict__ waux, float inv_n, float* __restrict__ loss_out)
+{
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < n4c; i += stride) {
+        const float4 c = reinterpret_cast<const float4*>(color)[i], g = reinterpret_cast<const float4*>(gt)[i];
+        const float d0 = c.x - g.x, d1 = c.y - g.y, d2 = c.z - g.z, d3 = c.w - g.w;
+        acc += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+        auto sg = [inv_n](float d) { return d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f); };
+        reinterpret_cast<float4*>(dcol)[i] = make_float4(sg(d0), sg(d1), sg(d2), sg(d3));
+    }
+    for (int64_t i = 4 * n4c + t0; i < nc; i += stride) {          // tail
+        const float d = color[i] - gt[i];
+        acc += fabsf(d);
+        dcol[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
+    }
+    acc *= inv_n;
+    for (int64_t i = t0; i < n4a; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(aux)[i], w = reinterpret_cast<const float4*>(waux)[i];
+        acc += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+    }
+    for (int64_t i = 4 * n4a + t0; i < na; i += stride) acc += aux[i] * waux[i];
+    // block reduction, one atomic per block
+    __shared__ float red[4];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+extern "C" int gsr_loss_l1_linear(int64_t n_color, const float* color, const float* gt, float* dL_dcolor, int64_t n_aux, const float* aux,
+                                  const float* waux, float* loss_out, void* stream)
+{
+    if (n_color <= 0) return 0;
+    const bool al = (((uintptr_t)color | (uintptr_t)gt | (uintptr_t)dL_dcolor | (uintptr_t)aux | (uintptr_t)waux) & 15) == 0;
+    const int64_t n4c = al ? n_color / 4 : 0, n4a = (al && n_aux > 0) ? n_aux / 4 : 0;
+    hipLaunchKernelGGL(k_loss_l1_linear, dim3(2048), dim3(256), 0, (hipStream_t)stream, n4c, n_color, color, gt, dL_dcolor, n4a,
+                       n_aux > 0 ? n_aux : 0, aux, waux, 1.0f / (float)n_color, loss_out);
+    return gsr_check_launch("loss_l1_linear", (hipStream_t)stream, false);
+}
+
 // ---- distCUDA2 (simple-knn/simple_knn.cu:186-222): mean squared distance to the 3 nearest neighbours.
 // Same strategy as the reference (Morton order -> boxes of consecutive points -> box-pruned exact search), built from
 // this library's own primitives: float min/max by order-preserving integer atomics, the stable LSD radix sort of

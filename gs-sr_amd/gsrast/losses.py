@@ -1,0 +1,34 @@
+"""Fused image-side loss kernels that run right behind the rasterizer."""
+import torch
+
+from . import lib, check, ptr, stream_ptr, dev_f32
+
+
+class _L1PlusLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, gt, aux, waux):
+        c = dev_f32(color, "color", allow_empty=False)
+        g = dev_f32(gt, "gt", allow_empty=False)
+        a = dev_f32(aux, "aux") if aux is not None else None
+        w = dev_f32(waux, "waux") if waux is not None else None
+        if (a is None) != (w is None) or (a is not None and a.numel() != w.numel()):
+            raise RuntimeError("aux and waux must both be given and have the same number of elements")
+        dcol = torch.empty_like(c)
+        loss = torch.zeros((), dtype=torch.float32, device=c.device)
+        check(lib().gsr_loss_l1_linear(c.numel(), ptr(c), ptr(g), ptr(dcol), a.numel() if a is not None else 0, ptr(a), ptr(w),
+                                       ptr(loss), stream_ptr(c.device)), "loss_l1_linear")
+        ctx.save_for_backward(dcol, w if w is not None else torch.empty(0, device=c.device))
+        ctx.has_aux = a is not None
+        ctx.aux_shape = aux.shape if aux is not None else None
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dcol, w = ctx.saved_tensors
+        return dcol * g, None, (w.reshape(ctx.aux_shape) * g) if ctx.has_aux else None, None
+
+
+def l1_plus_linear(color, gt, aux=None, waux=None):
+    """mean|color - gt| + sum(aux * waux), forward value and dL/dcolor in ONE streaming HIP kernel.
+    Equivalent torch: (color - gt).abs().mean() + (aux * waux).sum()."""
+    return _L1PlusLinear.apply(color, gt, aux, waux)

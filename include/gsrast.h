@@ -163,6 +163,12 @@ int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* or
                              const float* rgb /*[3,H,W]*/, float fx, float fy, float cx, float cy,
                              const float* extrinsic /*[16] HOST, row-major world->camera*/,
                              float* tsdf, float* weight, float* color /*[nx,ny,nz,3]*/, void* stream);
+/* Fused image-side loss right behind the rasterizer (the L1 term of gssr/scene/vanilla_scene.py:63-69
+ * plus a linear functional of the auxiliary maps): loss = mean|color - gt| + sum(aux * waux); one streaming pass
+ * writes dL/dcolor = sign(color-gt)/n and accumulates the scalar into *loss_out (device, caller zero-fills).
+ * dL/daux is waux itself, so nothing is written for it. */
+int gsr_loss_l1_linear(int64_t n_color, const float* color, const float* gt, float* dL_dcolor,
+                       int64_t n_aux, const float* aux, const float* waux, float* loss_out, void* stream);
 size_t gsr_dist2_scratch_bytes(int32_t P);
 int gsr_dist2(int32_t P, const float* points /*[P,3]*/, float* out /*[P]*/, void* scratch, size_t scratch_bytes,
               void* stream);

@@ -241,6 +241,23 @@ def test_visible_filter_mark_visible_dist2_tsdf():
     assert (wgt > 1).sum() > 1000
 
 
+def test_fused_loss_matches_torch():
+    from gsrast.losses import l1_plus_linear
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for shape_c, shape_a in (((3, 77, 131), (11, 77, 131)), ((3, 64, 64), None)):
+        c = torch.rand(shape_c, generator=g).cuda().requires_grad_(True)
+        gt = torch.rand(shape_c, generator=g).cuda()
+        a = torch.randn(shape_a, generator=g).cuda().requires_grad_(True) if shape_a else None
+        w = torch.randn(shape_a, generator=g).cuda() if shape_a else None
+        ref = (c - gt).abs().mean() + ((a * w).sum() if a is not None else 0.0)
+        gr = torch.autograd.grad(ref * 1.7, [c] + ([a] if a is not None else []))
+        out = l1_plus_linear(c, gt, a, w)
+        go = torch.autograd.grad(out * 1.7, [c] + ([a] if a is not None else []))
+        assert abs(float(out) - float(ref)) <= 1e-4 * max(1.0, abs(float(ref)))
+        for x, y in zip(go, gr):
+            assert torch.allclose(x, y, atol=1e-7, rtol=1e-5)
+
+
 def test_dist2_morton_pruned_is_exact_and_dense_tsdf():
     from simple_knn._C import distCUDA2
     from gsrast.tsdf import DenseTSDFVolume
