@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgsrast_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libgsrast_hip.so")   # override: experiments only
 
 EWA, SURFEL, PLANE = 0, 1, 2
 ABI_VERSION = 2
