@@ -554,13 +554,14 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                         const float dL_dsy = dL_dG * -G * sy + dL_dz * Tw1;
                         const float dsx_pz = dL_dsx * rpz, dsy_pz = dL_dsy * rpz;
                         const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * sx + dsy_pz * sy);
-                        const float dkx = ly * dpz - lz * dpy, dky = lz * dpx - lx * dpz, dkz = lx * dpy - ly * dpx;   // cross(l, dL_dp)
-                        const float dlx = dpy * kz - dpz * ky, dly = dpz * kx - dpx * kz, dlz = dpx * ky - dpy * kx;   // cross(dL_dp, k)
-                        g_T[0] = -dkx; g_T[1] = -dky; g_T[2] = -dkz;
-                        g_T[3] = -dlx; g_T[4] = -dly; g_T[5] = -dlz;
-                        g_T[6] = pxf * dkx + pyf * dlx + dL_dz * sx;
-                        g_T[7] = pxf * dky + pyf * dly + dL_dz * sy;
-                        g_T[8] = pxf * dkz + pyf * dlz + dL_dz * 1.0f;
+                        // dL_dTu = -cross(l, dL_dp) = cross(dL_dp, l); dL_dTv = -cross(dL_dp, k) = cross(k, dL_dp)  (no sign flips)
+                        const float tux = dpy * lz - dpz * ly, tuy = dpz * lx - dpx * lz, tuz = dpx * ly - dpy * lx;
+                        const float tvx = ky * dpz - kz * dpy, tvy = kz * dpx - kx * dpz, tvz = kx * dpy - ky * dpx;
+                        g_T[0] = tux; g_T[1] = tuy; g_T[2] = tuz;
+                        g_T[3] = tvx; g_T[4] = tvy; g_T[5] = tvz;
+                        g_T[6] = dL_dz * sx - (pxf * tux + pyf * tvx);
+                        g_T[7] = dL_dz * sy - (pxf * tuy + pyf * tvy);
+                        g_T[8] = dL_dz - (pxf * tuz + pyf * tvz);
                     } else {
                         g_mx = dL_dG * (-G * FILTER_INV_SQ * dx);
                         g_my = dL_dG * (-G * FILTER_INV_SQ * dy);
