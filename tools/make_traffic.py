@@ -8,12 +8,18 @@ import collections, csv, glob, json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
+files = []
+for d in glob.glob(os.path.join(out, "pmc_*", "*")):
+    cands = sorted(glob.glob(os.path.join(d, "*_counter_collection.csv")), key=os.path.getmtime)
+    if cands:
+        files.append(cands[-1])          # newest pass only (gpurun_out accumulates across calls)
+for f in files:
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if not (k.startswith("void k_") or k.startswith("k_")):
             continue
-        agg[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        name = k.split("(")[0].replace("void ", "").replace(", false>", ">").replace(", true>", ",mfma>")
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = {"k_blend_fwd<0>": "ewa:blend_fwd", "k_blend_fwd<1>": "surfel:blend_fwd", "k_blend_fwd<2>": "plane:blend_fwd",
          "k_blend_bwd<0>": "ewa:blend_bwd", "k_blend_bwd<1>": "surfel:blend_bwd", "k_blend_bwd<2>": "plane:blend_bwd"}
 traffic = {}
