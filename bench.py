@@ -58,7 +58,9 @@ def make_step(variant, sc, device):
     rs = hiprun.settings(variant, t)
     P, W, H = t["means3D"].shape[0], int(t["W"]), int(t["H"])
     ns = t["scales"].shape[1]
-    cols = [("means3D", 3, 1.6e-5), ("scales", ns, 5e-4), ("rotations", 4, 1e-4), ("opacities", 1, 1e-3), ("colors_precomp", 3, 2.5e-3)]
+    use_sh = t.get("shs") is not None
+    cols = [("means3D", 3, 1.6e-5), ("scales", ns, 5e-4), ("rotations", 4, 1e-4), ("opacities", 1, 1e-3)]
+    cols.append(("shs", 48, 2.5e-3) if use_sh else ("colors_precomp", 3, 2.5e-3))
     lr_scale = torch.cat([torch.full((n,), lr, device=device) for _, n, lr in cols])
     z = (torch.cat([t[k].reshape(P, -1) for k, _, _ in cols], dim=1) / lr_scale).clone().requires_grad_(True)
     opt = torch.optim.Adam([z], lr=1.0, eps=1e-15, fused=True)
@@ -86,8 +88,11 @@ def make_step(variant, sc, device):
         parts = torch.split(prm, [n for _, n, _ in cols], dim=1)       # backward = one cat, not one zero-pad per slice
         v = {k: parts[i] for i, (k, _, _) in enumerate(cols)}
         means2D = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
-        kw = dict(means3D=v["means3D"], means2D=means2D, opacities=v["opacities"], colors_precomp=v["colors_precomp"],
-                  scales=v["scales"], rotations=v["rotations"])
+        kw = dict(means3D=v["means3D"], means2D=means2D, opacities=v["opacities"], scales=v["scales"], rotations=v["rotations"])
+        if use_sh:
+            kw["shs"] = v["shs"].reshape(P, 16, 3)
+        else:
+            kw["colors_precomp"] = v["colors_precomp"]
         if variant == "surfel":
             color, radii, allmap = dsr.GaussianRasterizer(rs)(**kw)
             loss = l1_plus_linear(color, gt, allmap, wmap)
@@ -136,6 +141,8 @@ def main():
     ap.add_argument("--P", type=int, default=300000)
     ap.add_argument("--W", type=int, default=1920)
     ap.add_argument("--H", type=int, default=1080)
+    ap.add_argument("--color-mode", default="precomp", choices=["precomp", "sh"],
+                    help="precomp = scaffold/octree path (configs 2-5, default); sh = vanilla path with degree-3 SH (config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -158,7 +165,7 @@ def main():
     import scenes
     gsrast.lib()
     # one independent tile-scene per rank (train_split.py trains tiles independently; seed = tile index)
-    sc = scenes.make_scene(args.variant, args.P, args.W, args.H, seed=rank)
+    sc = scenes.make_scene(args.variant, args.P, args.W, args.H, seed=rank, color_mode=args.color_mode)
     step, state = make_step(args.variant, sc, device)
 
     from gsrast import tiles
@@ -205,7 +212,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1] scaffold-2dgs path: diff_{ {'ewa':'gaussian','surfel':'surfel','plane':'plane'}[args.variant] }_rasterization "
-                                   f"fwd+bwd, colors_precomp, P={args.P}, {args.W}x{args.H}, synthetic scene SURVEY §8d (seed=rank), "
+                                   f"fwd+bwd, {'SH deg 3' if args.color_mode == 'sh' else 'colors_precomp'}, P={args.P}, {args.W}x{args.H}, synthetic scene SURVEY §8d (seed=rank), "
                                    f"+ image loss + fused Adam",
                        "variant": args.variant, "P": args.P, "W": args.W, "H": args.H, "tile_instances_R": R,
                        "visible": int((st["radii"] > 0).sum()), "parallelism": f"{world} independent tile(s), 1 per GPU, no collective"},

@@ -34,6 +34,14 @@ def _img_close(a, b, tol=RGB_TOL, frac=1e-4):
     assert bad <= frac, f"{bad:.2e} of pixels differ by more than {tol * scale:.1e} (max {d.max():.3e})"
 
 
+def _counts_close(a, b):
+    """out_observe counts (pixel, splat) pairs that pass the FLOAT gate T > 0.5: integer-valued, but a 1-ulp difference in T
+    can move single pairs across the gate.  Equal everywhere except a vanishing number of +-1/2 differences."""
+    a = np.asarray(a, np.int64); b = np.asarray(b, np.int64)
+    d = np.abs(a - b)
+    assert d.max() <= 2 and (d > 0).sum() <= max(2, int(1e-3 * a.size)), (int(d.max()), int((d > 0).sum()))
+
+
 def _grad_close(a, b, tol=GRAD_TOL, frac=2e-3):
     """Gradient parity: relative L2 error <= tol AND at most `frac` of the elements off by more than tol*max|ref|.
     A handful of outliers is inherent: one-ulp differences (FMA contraction, exp) flip discrete gates / the surfel
@@ -83,7 +91,7 @@ def test_forward_backward_parity(variant, cm, P, W, H, pose):
                 _img_close(st["others"][ch], f.others[ch])
             assert (st["others"][7] == f.others[7]).mean() > 0.9999         # median splat index
         if variant == "plane":
-            assert np.array_equal(st["observe"], f.observe)
+            _counts_close(st["observe"], f.observe)
             _img_close(st["all_map"], f.out_all_map)
             _img_close(st["plane_depth"], f.plane_depth, frac=1e-3)
         # ---- gradients through the public autograd API
@@ -96,6 +104,34 @@ def test_forward_backward_parity(variant, cm, P, W, H, pose):
         pairs += [("dL_dall_map", "dL_dall_map"), ("dL_dmeans2D_abs", "dL_dmeans2D_abs")]
     for a, b in pairs:
         _grad_close(gg[a], g[b])
+
+
+@pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
+@pytest.mark.parametrize("seed,W,H,fx,fy,sigma,bg", [
+    (101, 400, 225, 333.0, 333.0, 4.0, (0.0, 0.0, 0.0)),      # the loader's 1600x900 cap, scaled
+    (102, 97, 61, 70.0, 95.0, 2.5, (1.0, 1.0, 1.0)),          # odd size, fx != fy, white background
+    (103, 512, 48, 300.0, 300.0, 7.0, (0.3, 0.0, 0.9)),       # wide strip: many tile columns, 3 rows
+])
+def test_varied_cameras(variant, seed, W, H, fx, fy, sigma, bg):
+    hr = _hiprun()
+    sc = scenes.make_scene(variant, 2500, W, H, fx=fx, fy=fy, seed=seed, sigma_px=sigma, bg=bg, pose=seed % 2)
+    og = scenes.random_out_grads(variant, W, H, seed=seed, scale=1.0)
+    with oracle.Forward(sc, variant) as f:
+        g = f.backward(**og)
+        st = hr.run_raw(variant, sc)
+        assert st["R"] == f.R and np.array_equal(st["radii"], f.radii)
+        assert np.array_equal(st["point_list"], f.point_list())
+        _img_close(st["color"], f.color)
+        if variant == "surfel":
+            for ch in (0, 1, 2, 3, 4, 5, 6):
+                _img_close(st["others"][ch], f.others[ch])
+        if variant == "plane":
+            _counts_close(st["observe"], f.observe)
+            _img_close(st["plane_depth"], f.plane_depth, frac=1e-3)
+        res = hr.run(variant, sc, og)
+    for a, b in (("dL_dmeans3D", "dL_dmeans3D"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"),
+                 ("dL_dopacities", "dL_dopacity"), ("dL_dcolors_precomp", "dL_dcolors")):
+        _grad_close(res["grads"][a], g[b])
 
 
 def test_precomputed_cov3d_and_transmat():
@@ -197,7 +233,7 @@ def test_render_geo_false_plane():
         g = f.backward(**og)
         res = hr.run("plane", sc, og)
         _img_close(res["color"], f.color)
-        assert np.array_equal(res["observe"], f.observe)            # counted regardless of render_geo
+        _counts_close(res["observe"], f.observe)                    # counted regardless of render_geo
         assert np.abs(res["out_all_map"]).max() == 0 and np.abs(res["plane_depth"]).max() == 0
         _grad_close(res["grads"]["dL_dmeans3D"], g["dL_dmeans3D"])
 
@@ -253,7 +289,7 @@ def test_fused_loss_matches_torch():
         gr = torch.autograd.grad(ref * 1.7, [c] + ([a] if a is not None else []))
         out = l1_plus_linear(c, gt, a, w)
         go = torch.autograd.grad(out * 1.7, [c] + ([a] if a is not None else []))
-        assert abs(float(out) - float(ref)) <= 1e-4 * max(1.0, abs(float(ref)))
+        assert abs(float(out.detach()) - float(ref.detach())) <= 1e-4 * max(1.0, abs(float(ref.detach())))
         for x, y in zip(go, gr):
             assert torch.allclose(x, y, atol=1e-7, rtol=1e-5)
 
