@@ -22,58 +22,144 @@ __device__ __forceinline__ float bilinear_border(const float* __restrict__ img, 
     return acc;
 }
 
-// One thread per voxel/sample point; pure streaming RMW of (tsdf, weight, rgb): 20 B read + 20 B write per touched voxel.
-__global__ void __launch_bounds__(256) k_tsdf_integrate(int64_t V, const float* __restrict__ points, const float* __restrict__ Fp, int W, int H,
-                                                        const float* __restrict__ depth, const float* __restrict__ rgb, float sdf_trunc,
-                                                        const float* __restrict__ trunc_pp, float* __restrict__ tsdf, float* __restrict__ weight,
-                                                        float* __restrict__ rgb_acc)
+// Interleaved (r,g,b,d) texels: one 16-byte load per bilinear corner instead of four dword gathers.
+__global__ void __launch_bounds__(256) k_pack_rgbd(int64_t n, const float* __restrict__ depth, const float* __restrict__ rgb, float4* __restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V) return;
-    float F[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) F[k] = Fp[k];
-    const float x = points[3 * i], y = points[3 * i + 1], z3 = points[3 * i + 2];
+    if (i < n) out[i] = make_float4(rgb[i], rgb[n + i], rgb[2 * n + i], depth[i]);
+}
+// same clamping, weights and corner order as bilinear_border, on all four channels at once (bit-identical per channel)
+__device__ __forceinline__ float4 bilinear_border4(const float4* __restrict__ img, int W, int H, float u, float v)
+{
+    float x = ((u + 1.f) / 2.f) * (float)(W - 1);
+    float y = ((v + 1.f) / 2.f) * (float)(H - 1);
+    x = fminf(fmaxf(x, 0.f), (float)(W - 1));
+    y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = x - (float)x0, wy1 = y - (float)y0, wx0 = (float)x1 - x, wy0 = (float)y1 - y;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](int xx, int yy, float w) {
+        if (xx < W && yy < H) {
+            const float4 t = img[(size_t)yy * W + xx];
+            acc.x += t.x * w; acc.y += t.y * w; acc.z += t.z * w; acc.w += t.w * w;
+        }
+    };
+    add(x0, y0, wx0 * wy0); add(x1, y0, wx1 * wy0); add(x0, y1, wx0 * wy1); add(x1, y1, wx1 * wy1);
+    return acc;
+}
+
+// One sample point: the update of compute_unbounded_tsdf (mesh_utils.py:208-246).  Returns true when the voxel changed.
+__device__ __forceinline__ bool tsdf_point(const float* F, float x, float y, float z3, int W, int H, const float* __restrict__ depth,
+                                           const float* __restrict__ rgb, const float4* __restrict__ rgbd, float tr, float& tsdf,
+                                           float& weight, float* col /*[3]*/)
+{
     const float qx = x * F[0] + y * F[4] + z3 * F[8] + F[12];
     const float qy = x * F[1] + y * F[5] + z3 * F[9] + F[13];
     const float qw = x * F[3] + y * F[7] + z3 * F[11] + F[15];
     const float u = qx / qw, v = qy / qw;
     bool mask = (u > -1.f) && (u < 1.f) && (v > -1.f) && (v < 1.f) && (qw > 0);
-    const float d = bilinear_border(depth, W, H, u, v);
-    const float sdf = d - qw;
-    const float tr = trunc_pp ? trunc_pp[i] : sdf_trunc;
-    mask = mask && (sdf > -tr);
-    if (!mask) return;
+    if (!mask) return false;                      // the reference samples depth for every point; the result is masked anyway
+    float4 tex;
+    if (rgbd) tex = bilinear_border4(rgbd, W, H, u, v);
+    else tex.w = bilinear_border(depth, W, H, u, v);
+    const float sdf = tex.w - qw;
+    if (!(sdf > -tr)) return false;
+    if (!rgbd) {
+        const size_t HW = (size_t)W * H;
+        tex.x = bilinear_border(rgb, W, H, u, v); tex.y = bilinear_border(rgb + HW, W, H, u, v); tex.z = bilinear_border(rgb + 2 * HW, W, H, u, v);
+    }
     float s = sdf / tr;
     s = fminf(fmaxf(s, -1.0f), 1.0f);
-    const float w = weight[i], wp = w + 1;
-    tsdf[i] = (tsdf[i] * w + s) / wp;
-    const size_t HW = (size_t)W * H;
+    const float w = weight, wp = w + 1;
+    tsdf = (tsdf * w + s) / wp;
+    col[0] = (col[0] * w + tex.x) / wp; col[1] = (col[1] * w + tex.y) / wp; col[2] = (col[2] * w + tex.z) / wp;
+    weight = wp;
+    return true;
+}
+
+// Streaming RMW of (tsdf, weight, rgb): 12 B read per point + 40 B per touched voxel.  Each thread owns FOUR consecutive
+// points so every stream is 16-byte vector traffic (3 x dwordx4 for the points, 1 each for tsdf/weight, 3 for rgb)
+// instead of stride-3 dword accesses.
+__global__ void __launch_bounds__(256) k_tsdf_integrate4(int64_t V4, const float4* __restrict__ points, const float* __restrict__ Fp, int W, int H,
+                                                         const float* __restrict__ depth, const float* __restrict__ rgb, const float4* __restrict__ rgbd,
+                                                         float sdf_trunc, const float4* __restrict__ trunc_pp, float4* __restrict__ tsdf,
+                                                         float4* __restrict__ weight, float4* __restrict__ rgb_acc)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V4) return;
+    float F[16];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float col = bilinear_border(rgb + c * HW, W, H, u, v);
-        rgb_acc[3 * i + c] = (rgb_acc[3 * i + c] * w + col) / wp;
+    for (int k = 0; k < 16; k++) F[k] = Fp[k];
+    const float4 p0 = points[3 * i], p1 = points[3 * i + 1], p2 = points[3 * i + 2];
+    const float px[4] = { p0.x, p0.w, p1.z, p2.y }, py[4] = { p0.y, p1.x, p1.w, p2.z }, pz[4] = { p0.z, p1.y, p2.x, p2.w };
+    float4 t4 = tsdf[i], w4 = weight[i];
+    float t[4] = { t4.x, t4.y, t4.z, t4.w }, w[4] = { w4.x, w4.y, w4.z, w4.w };
+    float tr[4] = { sdf_trunc, sdf_trunc, sdf_trunc, sdf_trunc };
+    if (trunc_pp) { const float4 q = trunc_pp[i]; tr[0] = q.x; tr[1] = q.y; tr[2] = q.z; tr[3] = q.w; }
+    float4 c0 = rgb_acc[3 * i], c1 = rgb_acc[3 * i + 1], c2 = rgb_acc[3 * i + 2];
+    float col[4][3] = { { c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, { c2.y, c2.z, c2.w } };
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) any |= tsdf_point(F, px[k], py[k], pz[k], W, H, depth, rgb, rgbd, tr[k], t[k], w[k], col[k]);
+    if (any) {
+        tsdf[i] = make_float4(t[0], t[1], t[2], t[3]);
+        weight[i] = make_float4(w[0], w[1], w[2], w[3]);
+        rgb_acc[3 * i] = make_float4(col[0][0], col[0][1], col[0][2], col[1][0]);
+        rgb_acc[3 * i + 1] = make_float4(col[1][1], col[1][2], col[2][0], col[2][1]);
+        rgb_acc[3 * i + 2] = make_float4(col[2][2], col[3][0], col[3][1], col[3][2]);
     }
-    weight[i] = wp;
+}
+
+// scalar version for the tail / unaligned buffers
+__global__ void __launch_bounds__(256) k_tsdf_integrate(int64_t V0, int64_t V, const float* __restrict__ points, const float* __restrict__ Fp, int W, int H,
+                                                        const float* __restrict__ depth, const float* __restrict__ rgb, const float4* __restrict__ rgbd,
+                                                        float sdf_trunc, const float* __restrict__ trunc_pp, float* __restrict__ tsdf,
+                                                        float* __restrict__ weight, float* __restrict__ rgb_acc)
+{
+    const int64_t i = V0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    float F[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) F[k] = Fp[k];
+    float t = tsdf[i], w = weight[i], col[3] = { rgb_acc[3 * i], rgb_acc[3 * i + 1], rgb_acc[3 * i + 2] };
+    if (tsdf_point(F, points[3 * i], points[3 * i + 1], points[3 * i + 2], W, H, depth, rgb, rgbd, trunc_pp ? trunc_pp[i] : sdf_trunc, t, w, col)) {
+        tsdf[i] = t; weight[i] = w;
+        rgb_acc[3 * i] = col[0]; rgb_acc[3 * i + 1] = col[1]; rgb_acc[3 * i + 2] = col[2];
+    }
 }
 
 extern "C" int gsr_tsdf_integrate(int64_t V, const float* points, const float* full_proj, int32_t W, int32_t H, const float* depth,
                                   const float* rgb, float sdf_trunc, const float* sdf_trunc_per_point, float* tsdf, float* weight,
-                                  float* rgb_acc, void* stream)
+                                  float* rgb_acc, void* rgbd_scratch, void* stream)
 {
     if (V <= 0) return 0;
-    const int64_t nb = (V + 255) / 256;
-    if (nb > 0x7FFFFFFF) { gsr_set_error("tsdf: too many points"); return 1; }
-    hipLaunchKernelGGL(k_tsdf_integrate, dim3((uint32_t)nb), dim3(256), 0, (hipStream_t)stream, V, points, full_proj, W, H, depth, rgb,
-                       sdf_trunc, sdf_trunc_per_point, tsdf, weight, rgb_acc);
-    return gsr_check_launch("tsdf_integrate", (hipStream_t)stream, false);
+    hipStream_t s = (hipStream_t)stream;
+    // optional [H*W] float4 scratch: interleave (r,g,b,d) once per frame so every bilinear corner is one 16-byte load
+    const float4* rgbd = nullptr;
+    if (rgbd_scratch && (((uintptr_t)rgbd_scratch) & 15) == 0) {
+        const int64_t n = (int64_t)W * H;
+        hipLaunchKernelGGL(k_pack_rgbd, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, n, depth, rgb, (float4*)rgbd_scratch);
+        rgbd = (const float4*)rgbd_scratch;
+    }
+    const uintptr_t al = (uintptr_t)points | (uintptr_t)tsdf | (uintptr_t)weight | (uintptr_t)rgb_acc | (uintptr_t)sdf_trunc_per_point;
+    const int64_t V4 = (al & 15) == 0 ? V / 4 : 0;      // vector path needs 16-byte aligned buffers (torch allocations are)
+    if ((V4 + 255) / 256 > 0x7FFFFFFF || (V + 255) / 256 > 0x7FFFFFFF) { gsr_set_error("tsdf: too many points"); return 1; }
+    if (V4 > 0)
+        hipLaunchKernelGGL(k_tsdf_integrate4, dim3((uint32_t)((V4 + 255) / 256)), dim3(256), 0, s, V4, (const float4*)points, full_proj, W, H,
+                           depth, rgb, rgbd, sdf_trunc, (const float4*)sdf_trunc_per_point, (float4*)tsdf, (float4*)weight, (float4*)rgb_acc);
+    const int64_t rest = V - 4 * V4;
+    if (rest > 0)
+        hipLaunchKernelGGL(k_tsdf_integrate, dim3((uint32_t)((rest + 255) / 256)), dim3(256), 0, s, 4 * V4, V, points, full_proj, W, H, depth,
+                           rgb, rgbd, sdf_trunc, sdf_trunc_per_point, tsdf, weight, rgb_acc);
+    return gsr_check_launch("tsdf_integrate", s, false);
 }
 
 // ---- dense-grid Open3D-style integration (see include/gsrast.h; parity unpinned).  One thread per voxel, z fastest:
 // consecutive lanes walk a voxel column, so tsdf/weight/color accesses are coalesced 4/4/12-B streams.
 struct DenseTsdfParams {
     int nx, ny, nz, W, H;
-    float ox, oy, oz, vl, trunc, dtrunc, fx, fy, cx, cy;
+    float ox, oy, oz, vl, trunc, dtrunc, fx, fy, cx, cy, rfx, rfy, rtrunc;
     float E[12];
 };
 __global__ void __launch_bounds__(256) k_tsdf_dense(DenseTsdfParams p, const float* __restrict__ depth, const float* __restrict__ rgb,
@@ -88,20 +174,23 @@ __global__ void __launch_bounds__(256) k_tsdf_dense(DenseTsdfParams p, const flo
     const float yc = p.E[4] * x + p.E[5] * y + p.E[6] * z + p.E[7];
     const float zc = p.E[8] * x + p.E[9] * y + p.E[10] * z + p.E[11];
     if (!(zc > 0.f)) return;
-    const float uf = xc * p.fx / zc + p.cx + 0.5f, vf = yc * p.fy / zc + p.cy + 0.5f;
+    // v_rcp/v_sqrt instead of the IEEE division/sqrt sequences: this kernel was VALU-bound on them (222 VALU per wave),
+    // and its definition is parity-unpinned anyway (checked against the CPU restatement to 1e-4)
+    const float rz = __builtin_amdgcn_rcpf(zc);
+    const float uf = xc * p.fx * rz + p.cx + 0.5f, vf = yc * p.fy * rz + p.cy + 0.5f;
     if (!(uf >= 0.f && uf < (float)p.W && vf >= 0.f && vf < (float)p.H)) return;
     const int u = (int)uf, v = (int)vf;
     const float d = depth[(size_t)v * p.W + u];
     if (!(d > 0.f) || d > p.dtrunc) return;
-    const float rx = ((float)u - p.cx) / p.fx, ry = ((float)v - p.cy) / p.fy;
-    const float sdf = (d - zc) * sqrtf(rx * rx + ry * ry + 1.0f);
+    const float rx = ((float)u - p.cx) * p.rfx, ry = ((float)v - p.cy) * p.rfy;
+    const float sdf = (d - zc) * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + 1.0f);
     if (!(sdf > -p.trunc)) return;
-    const float t = fminf(1.0f, sdf / p.trunc);
-    const float w = weight[i], wp = w + 1.0f;
-    tsdf[i] = (tsdf[i] * w + t) / wp;
+    const float t = fminf(1.0f, sdf * p.rtrunc);
+    const float w = weight[i], wp = w + 1.0f, rwp = __builtin_amdgcn_rcpf(wp);
+    tsdf[i] = (tsdf[i] * w + t) * rwp;
     const size_t HW = (size_t)p.W * p.H;
 #pragma unroll
-    for (int c = 0; c < 3; c++) color[3 * i + c] = (color[3 * i + c] * w + rgb[c * HW + (size_t)v * p.W + u]) / wp;
+    for (int c = 0; c < 3; c++) color[3 * i + c] = (color[3 * i + c] * w + rgb[c * HW + (size_t)v * p.W + u]) * rwp;
     weight[i] = wp;
 }
 
@@ -115,7 +204,7 @@ extern "C" int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, cons
     DenseTsdfParams p;
     p.nx = nx; p.ny = ny; p.nz = nz; p.W = W; p.H = H;
     p.ox = origin[0]; p.oy = origin[1]; p.oz = origin[2]; p.vl = voxel_length; p.trunc = sdf_trunc; p.dtrunc = depth_trunc;
-    p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy;
+    p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy; p.rfx = 1.0f / fx; p.rfy = 1.0f / fy; p.rtrunc = 1.0f / sdf_trunc;
     for (int k = 0; k < 12; k++) p.E[k] = extrinsic[k];
     hipLaunchKernelGGL(k_tsdf_dense, dim3((uint32_t)((V + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, depth, rgb, tsdf, weight, color);
     return gsr_check_launch("tsdf_integrate_dense", (hipStream_t)stream, false);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libgsrast_hip.so")   # override: experiments only
 
 EWA, SURFEL, PLANE = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp = C.c_void_p
 
@@ -85,7 +85,7 @@ def lib():
     L.gsr_visible_filter.restype = C.c_int
     L.gsr_visible_filter.argtypes = [C.POINTER(Cfg), _vp, _vp, _vp, _vp, _vp, _vp]
     L.gsr_tsdf_integrate.restype = C.c_int
-    L.gsr_tsdf_integrate.argtypes = [C.c_int64, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_tsdf_integrate.argtypes = [C.c_int64, _vp, _vp, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]
     L.gsr_tsdf_integrate_dense.restype = C.c_int
     L.gsr_tsdf_integrate_dense.argtypes = [C.c_int32] * 3 + [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                            _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _vp, _vp, _vp, _vp]

@@ -22,8 +22,9 @@ def tsdf_integrate_(points, full_proj_transform, depthmap, rgbmap, sdf_trunc, ts
         tp = dev_f32(sdf_trunc, "sdf_trunc", allow_empty=False)
     else:
         st = float(sdf_trunc)
+    scratch = torch.empty((H * W, 4), dtype=torch.float32, device=pts.device)      # interleaved (r,g,b,d) texels
     check(lib().gsr_tsdf_integrate(int(pts.shape[0]), ptr(pts), ptr(F), W, H, ptr(d), ptr(c), st, ptr(tp), ptr(tsdfs),
-                                   ptr(weights), ptr(rgbs), stream_ptr(pts.device)), "tsdf_integrate")
+                                   ptr(weights), ptr(rgbs), ptr(scratch), stream_ptr(pts.device)), "tsdf_integrate")
     return tsdfs, rgbs, weights
 
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 
 enum gsr_variant {
     GSR_EWA = 0,     /* diff_gaussian_rasterization : 3DGS EWA splats, RGB only                          */
@@ -150,7 +150,8 @@ int gsr_visible_filter(const gsr_cfg* cfg, const float* means3D, const float* sc
 int gsr_tsdf_integrate(int64_t V, const float* points /*[V,3]*/, const float* full_proj /*[16]*/,
                        int32_t W, int32_t H, const float* depth /*[H,W]*/, const float* rgb /*[3,H,W]*/,
                        float sdf_trunc, const float* sdf_trunc_per_point /*[V] or NULL*/,
-                       float* tsdf /*[V]*/, float* weight /*[V]*/, float* rgb_acc /*[V,3]*/, void* stream);
+                       float* tsdf /*[V]*/, float* weight /*[V]*/, float* rgb_acc /*[V,3]*/,
+                       void* rgbd_scratch /*[H*W*16 bytes], 16-B aligned, or NULL (slower dword gathers)*/, void* stream);
 /* Dense-grid, Open3D-style integration (the bounded path of gssr/utils/mesh_utils.py:138-179 calls
  * o3d.pipelines.integration.ScalableTSDFVolume.integrate, Open3D 0.18.0 -- NOT vendored in the reference, so the voxel
  * update is restated from Open3D's published UniformTSDFVolume algorithm and its parity is UNPINNED):

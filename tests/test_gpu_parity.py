@@ -260,7 +260,7 @@ def test_visible_filter_mark_visible_dist2_tsdf():
     # TSDF: three frames into the same grid
     rng = np.random.default_rng(0)
     W, H = 96, 64
-    V = 40000
+    V = 40003        # not a multiple of 4: exercises the vector path and the scalar tail
     grid = rng.uniform(-1, 1, (V, 3)).astype(np.float32) * np.array([2.0, 1.2, 1.0], np.float32) + np.array([0, 0, 5.0], np.float32)
     tsdf = np.ones(V, np.float32); wgt = np.ones(V, np.float32); rgb = np.zeros((V, 3), np.float32)
     tg = torch.ones(V, device="cuda"); wg = torch.ones(V, device="cuda"); cg = torch.zeros((V, 3), device="cuda")
@@ -317,7 +317,7 @@ def test_dist2_morton_pruned_is_exact_and_dense_tsdf():
         oracle.tsdf_integrate_dense(dims, origin, vl, trunc, 5.2, depth, q, fx, fy, W / 2, H / 2, E, t, w, c)
         vol.integrate(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), fx, fy, W / 2, H / 2, E, depth_trunc=5.2)
     assert np.array_equal(vol.weight.cpu().numpy(), w) and (w > 0).sum() > 5000
-    assert np.abs(vol.tsdf.cpu().numpy() - t).max() < 1e-5
+    assert np.abs(vol.tsdf.cpu().numpy() - t).max() < 1e-4        # v_rcp / v_sqrt in the dense kernel
     assert np.abs(vol.color.cpu().numpy() - c).max() < 1e-3
 
 
