@@ -42,6 +42,21 @@ def algorithmic_bytes(variant, R, N, T):
     return fwd, bwd
 
 
+def stage_bytes(variant, color_mode, P, R, N, T):
+    """Algorithmic bytes per launch of every stage (sort passes as implemented here:
+    4 depth passes over P (key+value, read+write) and ceil(log2 T / 8) tile passes over R)."""
+    sh = 192 if color_mode == "sh" else 12
+    fwd_b, bwd_b = algorithmic_bytes(variant, R, N, T)
+    pre = P * ((12 + 8 + 16 + 4 + sh) + (4 + 8 + 4 + 36 + 16 + 4)) if variant == "surfel" else \
+        P * ((12 + 12 + 16 + 4 + sh) + (4 + 8 + 4 + 24 + 16 + 12 + 4 + 3))
+    tile_bits = max(1, (T - 1).bit_length())
+    tile_passes = (tile_bits + 7) // 8
+    acc = {"ewa": 48, "plane": 64, "surfel": 80}[variant]
+    pre_bwd = P * (acc + 12 + 16 + 8 + (2 * 192 if color_mode == "sh" else 0) + 12 + 12 + 12 + 4 + 36 + 8 + 16)
+    return {"preprocess": pre, "depth_order": 4 * 16 * P + 8 * P, "binning": 20 * P + 8 * R + tile_passes * 16 * R + 4 * R + 8 * T,
+            "blend_fwd": fwd_b, "bwd_memset": P * acc, "blend_bwd": bwd_b, "preprocess_bwd": pre_bwd}
+
+
 def make_step(variant, sc, device):
     """One training iteration.  All gaussian parameters live in ONE flat leaf z[P,13+] (views: means 3, scales 2|3,
     rotations 4, opacity 1, colour 3); params = z * lr_scale (per column), optimised by a single fused-Adam group with
@@ -219,6 +234,8 @@ def main():
             "rasterize_fwd_ms": round(raster_fwd, 4), "rasterize_bwd_ms": round(raster_bwd, 4),
             "rasterize_fwd_bwd_ms": round(raster_fwd + raster_bwd, 4),
             "stage_ms": {k: round(v, 4) for k, v in ms.items()},
+            "stage_algorithmic_GBps": {k: round(b / (ms[k] * 1e-3) / 1e9, 1) for k, b in
+                                       stage_bytes(args.variant, args.color_mode, args.P, R, N, T).items() if ms.get(k, 0) > 0},
             "roofline": {"kernel": f"k_blend_{'bwd' if dom == 'blend_bwd' else 'fwd'}<{args.variant}>", "bound": "hbm",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
