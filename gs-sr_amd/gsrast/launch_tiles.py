@@ -1,0 +1,115 @@
+"""Tile-parallel launcher: one worker process per GPU, one VastGaussian tile at a time per worker.
+
+Replaces the sequential loop of the reference (train_split.py:24-38: deep-copy the config per tile, rewrite the four relative
+output dirs to tile_%04d/<dir>, call train.main) by N concurrent workers.  Tiles are independent sub-scenes, so there is no data-path
+collective; torch.distributed (RCCL on GPUs / gloo on CPU) carries only the start/stop barrier and the (max elapsed, sum iterations)
+reduction that yields the whole-job it/s.
+
+    python -m gsrast.launch_tiles --data <source_path> --output <dir> --gpus 4 --entry mypkg.train:train_tile [--backend nccl]
+
+`--entry module:function` names the per-tile trainer: `function(tile_dir, out_paths, device, tile_index) -> iterations_done`.
+For the reference that function is a 5-line shim around `train.main(tile_config)`.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import tiles
+
+
+def resolve_entry(spec):
+    mod, _, fn = spec.partition(":")
+    if not mod or not fn:
+        raise ValueError("--entry must be module:function")
+    return getattr(importlib.import_module(mod), fn)
+
+
+def tile_dirnames(num_tiles):
+    """tile_%04d, the naming train_split.py:17 gives config_of_tiles (index order, not directory-name order)."""
+    return ["tile_%04d" % i for i in range(num_tiles)]
+
+
+def worker(args):
+    """Body of one rank.  Returns the job summary dict on rank 0, None elsewhere."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    use_gpu = args.backend == "nccl"
+    if use_gpu:
+        if not torch.cuda.is_available():
+            raise RuntimeError("launch_tiles: backend nccl needs a HIP device (use --backend gloo for CPU-only dry runs)")
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        device = torch.device("cuda", torch.cuda.current_device())
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    entry = resolve_entry(args.entry)
+    names = tiles.list_tiles(args.data)
+    out_names = tile_dirnames(len(names))
+    mine = tiles.assign_tiles(len(names), world, rank)
+    tiles.barrier(device)
+    t0 = time.perf_counter()
+    iters = 0
+    done = []
+    for i in mine:
+        paths = tiles.tile_output_paths(args.output, out_names[i])
+        for p in paths.values():
+            os.makedirs(p, exist_ok=True)
+        iters += int(entry(os.path.join(args.data, names[i]), paths, device, i))
+        done.append(i)
+    tiles.barrier(device)
+    elapsed = time.perf_counter() - t0
+    t_max, n_sum = tiles.reduce_job(elapsed, iters, device if use_gpu else None)
+    summary = None
+    if rank == 0:
+        summary = {"tiles": len(names), "workers": world, "elapsed_s": t_max, "iterations": n_sum,
+                   "iters_per_s": (n_sum / t_max) if t_max > 0 else 0.0}
+        print(json.dumps(summary), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return summary
+
+
+def spawn(args):
+    """Parent: start one child per GPU with the torchrun environment contract (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*)."""
+    n = args.gpus
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(args.port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "gsrast.launch_tiles", "--data", args.data, "--output", args.output, "--entry", args.entry,
+               "--backend", args.backend, "--gpus", str(n), "--_child"]
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--data", required=True, help="partitioned scene directory holding tile_* sub-directories")
+    ap.add_argument("--output", required=True)
+    ap.add_argument("--entry", required=True, help="module:function(tile_dir, out_paths, device, tile_index) -> iterations")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--port", type=int, default=29531)
+    ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+    if args._child or "RANK" in os.environ or args.gpus == 1:
+        worker(args)
+        return 0
+    return spawn(args)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

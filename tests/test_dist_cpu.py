@@ -77,3 +77,32 @@ def test_assign_tiles_covers_configs():
     assert [tiles.assign_tiles(4, 4, r) for r in range(4)] == [[0], [1], [2], [3]]          # BASELINE config 4
     assert [tiles.assign_tiles(8, 8, r) for r in range(8)] == [[r] for r in range(8)]       # BASELINE config 5
     assert sorted(sum((tiles.assign_tiles(8, 3, r) for r in range(3)), [])) == list(range(8))
+
+
+def test_launch_tiles_two_workers_gloo():
+    """gsrast.launch_tiles: 3 tiles over 2 worker processes (gloo): every tile trained once, output dirs as train_split.py:28-35."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        data = os.path.join(tmp, "scene"); out = os.path.join(tmp, "out")
+        for i in (3, 1, 7):
+            os.makedirs(os.path.join(data, f"tile_{i:04d}"))
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "gs-sr_amd"), os.path.join(root, "tests"),
+                                                            os.environ.get("PYTHONPATH", "")]))
+        env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+        r = subprocess.run([sys.executable, "-m", "gsrast.launch_tiles", "--data", data, "--output", out, "--gpus", "2",
+                            "--backend", "gloo", "--port", str(_free_port()), "--entry", "tile_entry_fixture:train_tile"],
+                           env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        summary = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert summary["tiles"] == 3 and summary["workers"] == 2 and summary["iterations"] == 21
+        ranks = set()
+        for k, src in enumerate(("tile_0001", "tile_0003", "tile_0007")):      # sorted source tiles -> tile_%04d index dirs
+            for sub in ("chkpnt", "point_cloud", "tb", "config"):
+                assert os.path.isdir(os.path.join(out, f"tile_{k:04d}", sub))
+            txt = open(os.path.join(out, f"tile_{k:04d}", "chkpnt", "done.txt")).read().split()
+            assert txt[0] == src and int(txt[1]) == k and txt[2] == "cpu"
+            ranks.add(txt[3])
+        assert ranks == {"rank0", "rank1"}
