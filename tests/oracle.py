@@ -38,8 +38,8 @@ class RefInGrads(C.Structure):
 
 def build(force=False):
     so = os.path.join(ORACLE_DIR, "libgsr_oracle.so")
-    src = os.path.join(ORACLE_DIR, "gsr_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so
 

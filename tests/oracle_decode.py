@@ -1,0 +1,82 @@
+"""ctypes binding of the neural-Gaussian decode oracle (oracle/gsd_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+
+import numpy as np
+
+import oracle
+
+_fp = C.POINTER(C.c_float)
+PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app")
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("Na", "Nv", "k", "A", "dist_o", "dist_c", "dist_k", "level")]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, _fp) for n in PARAM_NAMES]
+
+
+class Inputs(C.Structure):
+    _fields_ = [("anchor", _fp), ("feat", _fp), ("offset", _fp), ("scaling", _fp), ("level", _fp), ("opacity_scale", _fp),
+                ("vis_idx", C.POINTER(C.c_int32)), ("campos", _fp)]
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_fp)
+
+
+def _pack(case):
+    """case: dict from decode_cases.make_case -> (cfg, inputs struct, params struct, keep-alive list)"""
+    k = case["k"]
+    arr = {n: _f(case[n]) for n in ("anchor", "feat", "offset", "scaling", "level", "opacity_scale", "campos")}
+    vis = np.ascontiguousarray(case["vis_idx"], dtype=np.int32)
+    par = {n: _f(case["params"].get(n)) for n in PARAM_NAMES}
+    A = 0 if par["app"] is None else par["app"].size
+    cfg = Cfg(arr["anchor"].shape[0], vis.size, k, A, int(case["dist_o"]), int(case["dist_c"]), int(case["dist_k"]),
+              int(arr["level"] is not None))
+    inp = Inputs(_p(arr["anchor"]), _p(arr["feat"]), _p(arr["offset"]), _p(arr["scaling"]), _p(arr["level"]), _p(arr["opacity_scale"]),
+                 vis.ctypes.data_as(C.POINTER(C.c_int32)), _p(arr["campos"]))
+    prm = Params(*[_p(par[n]) for n in PARAM_NAMES])
+    return cfg, inp, prm, (arr, vis, par)
+
+
+def forward(case):
+    L = oracle.lib()
+    L.refd_forward.restype = C.c_int64
+    cfg, inp, prm, keep = _pack(case)
+    n = cfg.Nv * cfg.k
+    out = {"neural_opacity": np.zeros(n, np.float32), "mask": np.zeros(n, np.uint8), "xyz": np.zeros((n, 3), np.float32),
+           "color": np.zeros((n, 3), np.float32), "opacity": np.zeros(n, np.float32), "scaling": np.zeros((n, 3), np.float32),
+           "rot": np.zeros((n, 4), np.float32)}
+    P = L.refd_forward(C.byref(cfg), C.byref(inp), C.byref(prm), _p(out["neural_opacity"]),
+                       out["mask"].ctypes.data_as(C.POINTER(C.c_uint8)), _p(out["xyz"]), _p(out["color"]), _p(out["opacity"]),
+                       _p(out["scaling"]), _p(out["rot"]))
+    for n_ in ("xyz", "color", "opacity", "scaling", "rot"):
+        out[n_] = out[n_][:P].copy()
+    out["P"] = int(P)
+    return out
+
+
+def backward(case, mask, dL):
+    """dL: dict xyz/color/opacity/scaling/rot (compacted rows) -> dict of gradients (anchor, feat, offset, scaling, params...)."""
+    L = oracle.lib()
+    L.refd_backward.restype = None
+    cfg, inp, prm, keep = _pack(case)
+    par = keep[2]
+    g = {n: (None if par[n] is None else np.zeros_like(par[n])) for n in PARAM_NAMES}
+    gp = Params(*[_p(g[n]) for n in PARAM_NAMES])
+    Na, k = cfg.Na, cfg.k
+    out = {"anchor": np.zeros((Na, 3), np.float32), "feat": np.zeros((Na, 32), np.float32), "offset": np.zeros((Na, k, 3), np.float32),
+           "scaling": np.zeros((Na, 6), np.float32)}
+    d = {n: _f(dL[n]) for n in ("xyz", "color", "opacity", "scaling", "rot")}
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    L.refd_backward(C.byref(cfg), C.byref(inp), C.byref(prm), m.ctypes.data_as(C.POINTER(C.c_uint8)), _p(d["xyz"]), _p(d["color"]),
+                    _p(d["opacity"]), _p(d["scaling"]), _p(d["rot"]), _p(out["anchor"]), _p(out["feat"]), _p(out["offset"]),
+                    _p(out["scaling"]), C.byref(gp))
+    out.update({n: g[n] for n in PARAM_NAMES if g[n] is not None})
+    return out

@@ -1,0 +1,57 @@
+"""float64 torch transcription of generate_neural_gaussians (gssr/scene/scaffold_scene.py:27-120, octree_scene.py:26-133) used to pin
+the C oracle (forward values and autograd gradients).  TEST INFRASTRUCTURE ONLY.  The op sequence mirrors the reference's: boolean-mask
+gathers, cat of [feat, ob_view, (ob_dist), (level)], three Sequential(Linear, ReLU, Linear, act) heads, concatenated masking, split."""
+import torch
+import torch.nn.functional as Fn
+
+
+def decode(case, dtype=torch.float64, mask_override=None):
+    """-> (outputs dict, leaves dict).  Leaves require grad; outputs are torch tensors (compacted like the reference)."""
+    t = lambda a: None if a is None else torch.tensor(a, dtype=dtype)
+    k = case["k"]
+    leaves = {n: t(case[n]).requires_grad_(True) for n in ("anchor", "feat", "offset", "scaling")}
+    par = {n: t(v).requires_grad_(True) for n, v in case["params"].items() if v is not None}
+    vis = torch.tensor(case["vis_idx"], dtype=torch.long)
+    campos = t(case["campos"])
+    anchor = leaves["anchor"][vis]; feat = leaves["feat"][vis]
+    grid_offsets = leaves["offset"][vis]; grid_scaling = leaves["scaling"][vis]
+    ob_view = anchor - campos
+    ob_dist = ob_view.norm(dim=1, keepdim=True)
+    ob_view = ob_view / ob_dist
+    lvl = [] if case["level"] is None else [t(case["level"])[vis].unsqueeze(1)]
+    with_dist = torch.cat([feat, ob_view, ob_dist] + lvl, dim=1)
+    wo_dist = torch.cat([feat, ob_view] + lvl, dim=1)
+    pick = lambda flag: with_dist if flag else wo_dist
+
+    def head(x, W1, b1, W2, b2):
+        return Fn.linear(torch.relu(Fn.linear(x, par[W1], par[b1])), par[W2], par[b2])
+    neural_opacity = torch.tanh(head(pick(case["dist_o"]), "W1o", "b1o", "W2o", "b2o"))
+    if case["opacity_scale"] is not None:
+        neural_opacity = neural_opacity * t(case["opacity_scale"])[vis].unsqueeze(1)
+    neural_opacity = neural_opacity.reshape([-1, 1])
+    mask = (neural_opacity > 0.0).view(-1) if mask_override is None else torch.tensor(mask_override, dtype=torch.bool)
+    opacity = neural_opacity[mask]
+    xk = pick(case["dist_k"])
+    if "app" in par:
+        xk = torch.cat([xk, par["app"].unsqueeze(0).expand(xk.shape[0], -1)], dim=1)
+    color = torch.sigmoid(head(xk, "W1k", "b1k", "W2k", "b2k")).reshape([anchor.shape[0] * k, 3])
+    scale_rot = head(pick(case["dist_c"]), "W1c", "b1c", "W2c", "b2c").reshape([anchor.shape[0] * k, 7])
+    offsets = grid_offsets.view([-1, 3])
+    concatenated = torch.cat([grid_scaling, anchor], dim=-1)
+    rep = concatenated.unsqueeze(1).expand(-1, k, -1).reshape(-1, 9)          # repeat 'n c -> (n k) c'
+    masked = torch.cat([rep, color, scale_rot, offsets], dim=-1)[mask]
+    scaling_repeat, repeat_anchor, color, scale_rot, offsets = masked.split([6, 3, 3, 7, 3], dim=-1)
+    scaling = scaling_repeat[:, 3:] * torch.sigmoid(scale_rot[:, :3])
+    rot = Fn.normalize(scale_rot[:, 3:7])
+    xyz = repeat_anchor + offsets * scaling_repeat[:, :3]
+    out = {"xyz": xyz, "color": color, "opacity": opacity.view(-1), "scaling": scaling, "rot": rot,
+           "neural_opacity": neural_opacity.view(-1), "mask": mask}
+    leaves.update(par)
+    return out, leaves
+
+
+def backward(out, leaves, dL):
+    loss = sum((out[n] * torch.tensor(dL[n], dtype=out[n].dtype)).sum() for n in ("xyz", "color", "opacity", "scaling", "rot"))
+    names = list(leaves)
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    return {n: (None if g is None else g.numpy()) for n, g in zip(names, grads)}
