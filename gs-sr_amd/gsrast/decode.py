@@ -1,0 +1,181 @@
+"""Fused neural-Gaussian decode (include/gsdecode.h) behind a torch.autograd.Function.
+
+Drop-in for the body of ScaffoldScene.generate_neural_gaussians (gssr/scene/scaffold_scene.py:27-120) and
+OctreeScene.generate_neural_gaussians (gssr/scene/octree_scene.py:26-133): same inputs, same returned tuple
+`(xyz, color, opacity, scaling, rot, neural_opacity, mask)`, same gradients to anchors, features, offsets, scalings, the three MLP heads
+and the appearance embedding row.  HIP only: there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import check, dev_f32, lib, ptr, stream_ptr
+
+_vp = C.c_void_p
+PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app")
+EXPORTS = ["gsd_compact_scratch_bytes", "gsd_compact_visible", "gsd_forward_scratch_bytes", "gsd_forward_stage1", "gsd_forward_stage2",
+           "gsd_backward_scratch_bytes", "gsd_backward"]
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("Na", "Nv", "k", "A", "dist_o", "dist_c", "dist_k", "level")]
+
+
+class Inputs(C.Structure):
+    _fields_ = [(n, _vp) for n in ("anchor", "feat", "offset", "scaling", "level", "opacity_scale", "vis_idx", "campos")]
+
+
+class Params(C.Structure):
+    _fields_ = [(n, _vp) for n in PARAM_NAMES]
+
+
+class Outputs(C.Structure):
+    _fields_ = [(n, _vp) for n in ("xyz", "color", "opacity", "scaling", "rot")]
+
+
+class OutGrads(C.Structure):
+    _fields_ = [(n, _vp) for n in ("xyz", "color", "opacity", "scaling", "rot")]
+
+
+class InGrads(C.Structure):
+    _fields_ = [("anchor", _vp), ("feat", _vp), ("offset", _vp), ("scaling", _vp), ("params", Params)]
+
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = lib()
+    if not _bound:
+        sz = C.c_size_t
+        L.gsd_compact_scratch_bytes.restype = sz; L.gsd_compact_scratch_bytes.argtypes = [C.c_int32]
+        L.gsd_compact_visible.restype = C.c_int
+        L.gsd_compact_visible.argtypes = [_vp, C.c_int32, _vp, C.POINTER(C.c_uint32), _vp, sz, _vp]
+        L.gsd_forward_scratch_bytes.restype = sz; L.gsd_forward_scratch_bytes.argtypes = [C.c_int32]
+        L.gsd_forward_stage1.restype = C.c_int
+        L.gsd_forward_stage1.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, _vp, C.POINTER(C.c_uint32), _vp, sz, _vp]
+        L.gsd_forward_stage2.restype = C.c_int
+        L.gsd_forward_stage2.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, C.c_uint32, C.POINTER(Outputs), _vp, sz, _vp]
+        L.gsd_backward_scratch_bytes.restype = sz; L.gsd_backward_scratch_bytes.argtypes = [C.POINTER(Cfg)]
+        L.gsd_backward.restype = C.c_int
+        L.gsd_backward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, C.c_uint32, C.POINTER(OutGrads),
+                                   C.POINTER(InGrads), _vp, sz, _vp]
+        _bound = True
+    return L
+
+
+def compact_visible(visible_mask):
+    """nonzero(visible_mask) as int32 indices (ascending), computed on the device with one synchronisation for the count."""
+    if not visible_mask.is_cuda:
+        raise RuntimeError("visible_mask must be a CUDA tensor")
+    m = visible_mask.contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else (m != 0).view(torch.uint8)
+    Na = m.numel()
+    L = _lib()
+    idx = torch.empty(Na, dtype=torch.int32, device=m.device)
+    scratch = torch.empty(L.gsd_compact_scratch_bytes(Na), dtype=torch.uint8, device=m.device)
+    n = C.c_uint32(0)
+    check(L.gsd_compact_visible(ptr(m), Na, ptr(idx), C.byref(n), ptr(scratch), scratch.numel(), stream_ptr(m.device)), "compact_visible")
+    return idx[: n.value]
+
+
+def _structs(flags, Na, Nv, tensors, params):
+    k, A, dist_o, dist_c, dist_k, has_level = flags
+    cfg = Cfg(Na, Nv, k, A, int(dist_o), int(dist_c), int(dist_k), int(has_level))
+    inp = Inputs(*[ptr(tensors[n]) for n in ("anchor", "feat", "offset", "scaling", "level", "opacity_scale", "vis_idx", "campos")])
+    prm = Params(*[ptr(params[n]) for n in PARAM_NAMES])
+    return cfg, inp, prm
+
+
+class _NeuralDecode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flags, vis_idx, campos, level, opacity_scale, anchor, feat, offset, scaling, *params):
+        L = _lib()
+        dev = anchor.device
+        k = flags[0]
+        t = {"anchor": dev_f32(anchor, "anchor", False), "feat": dev_f32(feat, "feat", False), "offset": dev_f32(offset, "offset", False),
+             "scaling": dev_f32(scaling, "scaling", False), "level": dev_f32(level, "level"), "opacity_scale": dev_f32(opacity_scale, "opacity_scale"),
+             "vis_idx": vis_idx.contiguous(), "campos": dev_f32(campos, "campos", False)}
+        if t["vis_idx"].dtype != torch.int32:
+            raise RuntimeError("vis_idx must be int32")
+        prm = {n: dev_f32(p, n) for n, p in zip(PARAM_NAMES, params)}
+        Na, Nv = t["anchor"].shape[0], t["vis_idx"].numel()
+        cfg, inp, cp = _structs(flags, Na, Nv, t, prm)
+        nop = torch.empty(Nv * k, 1, dtype=torch.float32, device=dev)
+        mask = torch.empty(Nv * k, dtype=torch.uint8, device=dev)
+        row_offset = torch.empty(max(Nv, 1), dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.gsd_forward_scratch_bytes(Nv), dtype=torch.uint8, device=dev)
+        P = C.c_uint32(0)
+        s = stream_ptr(dev)
+        check(L.gsd_forward_stage1(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(mask), ptr(row_offset), C.byref(P), ptr(scratch),
+                                   scratch.numel(), s), "decode stage1")
+        n = P.value
+        xyz = torch.empty(n, 3, dtype=torch.float32, device=dev); color = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        opacity = torch.empty(n, 1, dtype=torch.float32, device=dev); scl = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        rot = torch.empty(n, 4, dtype=torch.float32, device=dev)
+        out = Outputs(ptr(xyz), ptr(color), ptr(opacity), ptr(scl), ptr(rot))
+        check(L.gsd_forward_stage2(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(row_offset), n, C.byref(out), ptr(scratch),
+                                   scratch.numel(), s), "decode stage2")
+        ctx.flags, ctx.n = flags, n
+        ctx.save_for_backward(t["anchor"], t["feat"], t["offset"], t["scaling"], t["level"], t["opacity_scale"], t["vis_idx"], t["campos"],
+                              nop, row_offset, *[prm[nm] for nm in PARAM_NAMES])
+        mask_b = mask.view(torch.bool)
+        ctx.mark_non_differentiable(nop, mask_b)
+        return xyz, color, opacity, scl, rot, nop, mask_b
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_color, g_opacity, g_scaling, g_rot, _g_nop, _g_mask):
+        L = _lib()
+        sv = ctx.saved_tensors
+        names = ("anchor", "feat", "offset", "scaling", "level", "opacity_scale", "vis_idx", "campos")
+        t = dict(zip(names, sv[:8]))
+        nop, row_offset = sv[8], sv[9]
+        prm = dict(zip(PARAM_NAMES, sv[10:]))
+        dev = t["anchor"].device
+        Na, Nv, n = t["anchor"].shape[0], t["vis_idx"].numel(), ctx.n
+        cfg, inp, cp = _structs(ctx.flags, Na, Nv, t, prm)
+
+        def og(g, cols):
+            return torch.zeros(n, cols, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
+        gx, gc, go, gs, gr = og(g_xyz, 3), og(g_color, 3), og(g_opacity, 1), og(g_scaling, 3), og(g_rot, 4)
+        ogr = OutGrads(ptr(gx), ptr(gc), ptr(go), ptr(gs), ptr(gr))
+        d_anchor = torch.zeros_like(t["anchor"]); d_feat = torch.zeros_like(t["feat"])
+        d_offset = torch.zeros_like(t["offset"]); d_scaling = torch.zeros_like(t["scaling"])
+        gp = {nm: (None if prm[nm] is None else torch.empty_like(prm[nm])) for nm in PARAM_NAMES}
+        ig = InGrads(ptr(d_anchor), ptr(d_feat), ptr(d_offset), ptr(d_scaling), Params(*[ptr(gp[nm]) for nm in PARAM_NAMES]))
+        scratch = torch.empty(L.gsd_backward_scratch_bytes(C.byref(cfg)), dtype=torch.uint8, device=dev)
+        check(L.gsd_backward(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(row_offset), n, C.byref(ogr), C.byref(ig), ptr(scratch),
+                             scratch.numel(), stream_ptr(dev)), "decode backward")
+        return (None, None, None, None, None, d_anchor, d_feat, d_offset, d_scaling, *[gp[nm] for nm in PARAM_NAMES])
+
+
+def _head(mlp):
+    """nn.Sequential(Linear, ReLU, Linear[, act]) or a (W1, b1, W2, b2) tuple -> the four tensors."""
+    if isinstance(mlp, (tuple, list)):
+        return tuple(mlp)
+    return mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
+
+
+def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_color, campos, visible_mask=None, vis_idx=None,
+                     appearance=None, level=None, opacity_scale=None, add_opacity_dist=False, add_cov_dist=False, add_color_dist=False,
+                     use_feat_bank=False):
+    """-> (xyz, color, opacity, scaling, rot, neural_opacity, mask), the `is_training=True` tuple of the reference.
+
+    anchor (Na,3), feat (Na,32), offset (Na,k,3), scaling (Na,6) = get_scaling; `appearance` = embedding_appearance row of this camera
+    ((A,) tensor, keeps its autograd link to the embedding table); `level` (Na,) or (Na,1) when add_level; `opacity_scale` (Na,) = the
+    Octree progressive ratio with prog[~transition_mask] = 1.  `visible_mask` (bool, Na) or `vis_idx` (int32 indices) selects the anchors."""
+    if use_feat_bank:
+        raise NotImplementedError("gsrast.decode: use_feat_bank=True is not covered by the fused kernel")
+    if feat.shape[1] != 32:
+        raise NotImplementedError("gsrast.decode: feat_dim must be 32")
+    Na, k = offset.shape[0], offset.shape[1]
+    if vis_idx is None:
+        vis_idx = torch.arange(Na, dtype=torch.int32, device=anchor.device) if visible_mask is None else compact_visible(visible_mask)
+    heads = _head(mlp_opacity) + _head(mlp_cov) + _head(mlp_color)
+    A = 0 if appearance is None else appearance.numel()
+    lvl = None if level is None else level.reshape(-1)
+    osc = None if opacity_scale is None else opacity_scale.reshape(-1)
+    flags = (int(k), int(A), bool(add_opacity_dist), bool(add_cov_dist), bool(add_color_dist), lvl is not None)
+    app = None if appearance is None else appearance.reshape(-1)
+    return _NeuralDecode.apply(flags, vis_idx, campos, lvl, osc, anchor, feat, offset, scaling, *heads, app)

@@ -5,13 +5,13 @@ import torch
 import torch.nn.functional as Fn
 
 
-def decode(case, dtype=torch.float64, mask_override=None):
+def decode(case, dtype=torch.float64, mask_override=None, device="cpu"):
     """-> (outputs dict, leaves dict).  Leaves require grad; outputs are torch tensors (compacted like the reference)."""
-    t = lambda a: None if a is None else torch.tensor(a, dtype=dtype)
+    t = lambda a: None if a is None else torch.tensor(a, dtype=dtype, device=device)
     k = case["k"]
     leaves = {n: t(case[n]).requires_grad_(True) for n in ("anchor", "feat", "offset", "scaling")}
     par = {n: t(v).requires_grad_(True) for n, v in case["params"].items() if v is not None}
-    vis = torch.tensor(case["vis_idx"], dtype=torch.long)
+    vis = torch.tensor(case["vis_idx"], dtype=torch.long, device=device)
     campos = t(case["campos"])
     anchor = leaves["anchor"][vis]; feat = leaves["feat"][vis]
     grid_offsets = leaves["offset"][vis]; grid_scaling = leaves["scaling"][vis]
@@ -29,7 +29,7 @@ def decode(case, dtype=torch.float64, mask_override=None):
     if case["opacity_scale"] is not None:
         neural_opacity = neural_opacity * t(case["opacity_scale"])[vis].unsqueeze(1)
     neural_opacity = neural_opacity.reshape([-1, 1])
-    mask = (neural_opacity > 0.0).view(-1) if mask_override is None else torch.tensor(mask_override, dtype=torch.bool)
+    mask = (neural_opacity > 0.0).view(-1) if mask_override is None else torch.tensor(mask_override, dtype=torch.bool, device=device)
     opacity = neural_opacity[mask]
     xk = pick(case["dist_k"])
     if "app" in par:
@@ -50,8 +50,8 @@ def decode(case, dtype=torch.float64, mask_override=None):
     return out, leaves
 
 
-def backward(out, leaves, dL):
-    loss = sum((out[n] * torch.tensor(dL[n], dtype=out[n].dtype)).sum() for n in ("xyz", "color", "opacity", "scaling", "rot"))
+def backward(out, leaves, dL, device="cpu"):
+    loss = sum((out[n] * torch.tensor(dL[n], dtype=out[n].dtype, device=device)).sum() for n in ("xyz", "color", "opacity", "scaling", "rot"))
     names = list(leaves)
     grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
-    return {n: (None if g is None else g.numpy()) for n, g in zip(names, grads)}
+    return {n: (None if g is None else g.cpu().numpy()) for n, g in zip(names, grads)}

@@ -1,0 +1,98 @@
+"""GPU parity of the fused neural-Gaussian decode (gsrast.decode -> include/gsdecode.h) against the C oracle and, at full size, against
+the torch transcription of the reference's op chain running on the same device."""
+import numpy as np
+import pytest
+import torch
+
+import decode_cases
+import oracle_decode
+import ref_decode_torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GRAD_LEAVES = ("anchor", "feat", "offset", "scaling")
+
+
+def _run_hip(case, dL=None):
+    from gsrast import decode
+    t = lambda a: None if a is None else torch.tensor(a, device=DEV)
+    leaves = {n: t(case[n]).requires_grad_(True) for n in GRAD_LEAVES}
+    par = {n: (None if v is None else t(v).requires_grad_(True)) for n, v in case["params"].items()}
+    vis = torch.tensor(case["vis_idx"], dtype=torch.int32, device=DEV)
+    out = decode.neural_gaussians(leaves["anchor"], leaves["feat"], leaves["offset"], leaves["scaling"],
+                                  (par["W1o"], par["b1o"], par["W2o"], par["b2o"]), (par["W1c"], par["b1c"], par["W2c"], par["b2c"]),
+                                  (par["W1k"], par["b1k"], par["W2k"], par["b2k"]), t(case["campos"]), vis_idx=vis, appearance=par["app"],
+                                  level=t(case["level"]), opacity_scale=t(case["opacity_scale"]), add_opacity_dist=case["dist_o"],
+                                  add_cov_dist=case["dist_c"], add_color_dist=case["dist_k"])
+    names = ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask")
+    res = dict(zip(names, out))
+    grads = None
+    if dL is not None:
+        loss = sum((res[n].reshape(dL[n].shape) * torch.tensor(dL[n], device=DEV)).sum() for n in ("xyz", "color", "opacity", "scaling", "rot"))
+        loss.backward()
+        grads = {n: leaves[n].grad.cpu().numpy() for n in GRAD_LEAVES}
+        grads.update({n: p.grad.cpu().numpy() for n, p in par.items() if p is not None})
+    return {n: v.detach().cpu().numpy() for n, v in res.items()}, grads
+
+
+CASES = [dict(), dict(A=0, k=5), dict(dist_o=True, dist_c=True, dist_k=True, seed=1), dict(level=True, progressive=True, seed=2),
+         dict(dist_k=True, level=True, A=16, k=12, seed=3), dict(k=16, A=64, seed=4), dict(k=1, seed=5, vis_frac=1.0)]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_decode_matches_oracle(kw):
+    case = decode_cases.make_case(Na=3000, **kw)
+    o = oracle_decode.forward(case)
+    dL = decode_cases.make_out_grads(o["P"], seed=kw.get("seed", 0))
+    h, _ = _run_hip(case)
+    mism = h["mask"].astype(bool) != o["mask"].astype(bool)
+    assert not (mism & (np.abs(o["neural_opacity"]) > 1e-5)).any()          # the gate may only differ where tanh(.) is ~0
+    np.testing.assert_allclose(h["neural_opacity"].reshape(-1), o["neural_opacity"], rtol=1e-5, atol=2e-6)
+    if mism.any():
+        pytest.skip("opacity gate flipped on a ~0 value for this seed; compaction differs by construction")
+    assert h["xyz"].shape[0] == o["P"]
+    for n in ("xyz", "color", "scaling", "rot"):
+        np.testing.assert_allclose(h[n], o[n], rtol=1e-5, atol=2e-6, err_msg=n)
+    np.testing.assert_allclose(h["opacity"].reshape(-1), o["opacity"], rtol=1e-5, atol=2e-6)
+    _, g = _run_hip(case, dL)
+    go = oracle_decode.backward(case, o["mask"], dL)
+    for n, r in go.items():
+        scale = np.abs(r).max() + 1e-12
+        err = np.abs(g[n].reshape(r.shape) - r).max() / scale
+        assert err < 1e-4, (n, err)
+
+
+def test_decode_compact_visible_and_empty():
+    from gsrast import decode
+    g = torch.Generator().manual_seed(3)
+    m = (torch.rand(100003, generator=g) < 0.37).to(DEV)
+    idx = decode.compact_visible(m)
+    assert torch.equal(idx.long(), torch.nonzero(m).view(-1))
+    assert decode.compact_visible(torch.zeros(77, dtype=torch.bool, device=DEV)).numel() == 0
+    # no visible anchors: empty outputs, zero gradients
+    case = decode_cases.make_case(Na=50, seed=9)
+    case["vis_idx"] = np.zeros(0, np.int32)
+    h, g_ = _run_hip(case, decode_cases.make_out_grads(0))
+    assert h["xyz"].shape == (0, 3) and h["mask"].size == 0
+    assert all(not np.any(v) for v in g_.values())
+
+
+def test_decode_full_size_vs_torch_chain():
+    """100k anchors / 1M candidate Gaussians: the HIP decode against the reference's op chain run by torch on the same GPU (fp32)."""
+    case = decode_cases.make_case(Na=100000, seed=11, vis_frac=0.6)
+    h, _ = _run_hip(case)
+    mask = h["mask"].astype(bool)
+    ref, leaves = ref_decode_torch.decode(case, dtype=torch.float32, mask_override=mask, device=DEV)
+    P = int(mask.sum())
+    assert h["xyz"].shape[0] == P and 0.3 < P / mask.size < 0.7
+    nop = ref["neural_opacity"].detach().cpu().numpy()
+    assert not ((nop > 0) != mask)[np.abs(nop) > 1e-5].any()
+    for n in ("xyz", "color", "scaling", "rot"):
+        np.testing.assert_allclose(h[n], ref[n].detach().cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=n)
+    dL = decode_cases.make_out_grads(P, seed=11)
+    _, g = _run_hip(case, dL)
+    gr = ref_decode_torch.backward(ref, leaves, dL, device=DEV)
+    for n, v in g.items():
+        r = gr[n]
+        rel = np.linalg.norm((v.reshape(r.shape) - r).ravel()) / (np.linalg.norm(r.ravel()) + 1e-20)
+        assert rel < 1e-4, (n, rel)
