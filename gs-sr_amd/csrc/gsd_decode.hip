@@ -25,7 +25,9 @@
 typedef const float __attribute__((address_space(4))) * cfp;     // constant address space: wave-uniform index -> scalar load
 #define CW(p) ((cfp)(p))
 
-// column blocks of the feature-major backward scratch (units: columns of ld floats each)
+// column blocks of the backward scratch.  Layout is TILE-major: element (column c, anchor v) lives at ((v/16)*SC_COLS + c)*16 + v%16,
+// so the 16-anchor tile a wave produces is one contiguous 26 KB block (a column-major [c][Nv] layout made every wave stream into
+// 416 different pages and ran the producer at <0.6 TB/s), and k_wgrad still reads 16 consecutive anchors of a column as 4 float4.
 #define SC_X 0               // 48 (37 used)
 #define SC_H 48              // 3 x 32
 #define SC_P1 144            // dpre1: 3 x 32
@@ -40,70 +42,10 @@ typedef const float __attribute__((address_space(4))) * cfp;     // constant add
 struct DecArgs {
     gsd_cfg cfg;
     gsd_inputs in;
-    const float* W1p;
-    const float *W2o, *b2o, *W2c, *b2c, *W2k, *b2k;
 };
 
 // ------------------------------------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-
-__device__ __forceinline__ void load_x(const DecArgs& p, int a, float (&x)[GSD_XC], float (&vw)[3], float& dist)
-{
-    const float4* f4 = reinterpret_cast<const float4*>(p.in.feat + (size_t)a * GSD_FEAT);
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const float4 t = f4[q];
-        x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
-    }
-    const float r0 = p.in.anchor[3 * a] - p.in.campos[0], r1 = p.in.anchor[3 * a + 1] - p.in.campos[1],
-                r2 = p.in.anchor[3 * a + 2] - p.in.campos[2];
-    dist = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
-    vw[0] = r0 / dist; vw[1] = r1 / dist; vw[2] = r2 / dist;
-    x[32] = vw[0]; x[33] = vw[1]; x[34] = vw[2];
-    x[35] = dist;
-    x[36] = p.in.level ? p.in.level[a] : 0.0f;
-}
-
-// h = relu(W1p[head] [x;1])
-template <int HEAD>
-__device__ __forceinline__ void layer1(cfp W1p, const float (&x)[GSD_XC], float (&h)[32])
-{
-    cfp w = W1p + HEAD * 32 * GSD_W1LD;
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        float s = 0.0f;
-#pragma unroll
-        for (int i = 0; i < GSD_XC; i++) s = fmaf(w[j * GSD_W1LD + i], x[i], s);
-        s += w[j * GSD_W1LD + GSD_XC];
-        h[j] = fmaxf(s, 0.0f);
-    }
-}
-
-// dx += W1p[head]^T dpre1
-template <int HEAD>
-__device__ __forceinline__ void layer1_bwd(cfp W1p, const float (&g)[32], float (&dx)[GSD_XC])
-{
-    cfp w = W1p + HEAD * 32 * GSD_W1LD;
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-#pragma unroll
-        for (int i = 0; i < GSD_XC; i++) dx[i] = fmaf(w[j * GSD_W1LD + i], g[j], dx[i]);
-    }
-}
-
-__device__ __forceinline__ float dot32(cfp w, const float (&h)[32])
-{
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; i++) s = fmaf(w[i], h[i], s);
-    return s;
-}
-
-__device__ __forceinline__ void axpy32(cfp w, float g, float (&dh)[32])
-{
-#pragma unroll
-    for (int i = 0; i < 32; i++) dh[i] = fmaf(w[i], g, dh[i]);
-}
 
 // ------------------------------------------------------------------------------------------------ scan (exclusive, in place)
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
@@ -158,6 +100,46 @@ __global__ void __launch_bounds__(1024) k_scan_add(uint32_t* __restrict__ data, 
     if (i < n) data[i] += sums[blockIdx.x];
 }
 
+// k_scan_block + k_scan_sums in one launch: the block that finishes last (ticket counter, zeroed by k_pack_img) scans the block sums
+__global__ void __launch_bounds__(1024) k_scan_block_last(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ sums,
+                                                          uint32_t* __restrict__ total /*[0] total, [1] ticket*/)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t is_last;
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t v = i < n ? data[i] : 0u;
+    const uint32_t incl = wave_scan_incl(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wsum[w];
+    if (i < n) data[i] = base + incl - v;
+    if (threadIdx.x == 1023) {
+        sums[blockIdx.x] = base + incl;
+        __threadfence();
+        is_last = atomicAdd(&total[1], 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const uint32_t nblk = gridDim.x;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < nblk; c0 += 1024u) {
+        const uint32_t q = c0 + threadIdx.x;
+        const uint32_t sv = q < nblk ? __hip_atomic_load(&sums[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t sincl = wave_scan_incl(sv);
+        __syncthreads();
+        if (lane == 63) wsum[wave] = sincl;
+        __syncthreads();
+        uint32_t b2 = 0, all = 0;
+        for (int w = 0; w < 16; w++) { if (w < wave) b2 += wsum[w]; all += wsum[w]; }
+        if (q < nblk) sums[q] = carry + b2 + sincl - sv;
+        carry += all;
+    }
+    if (threadIdx.x == 0) { total[0] = carry; total[1] = 0u; }
+}
+
 // data[0..n) -> exclusive prefix in place, *total_dev = sum.  sums: >= div_up(n,1024) words.
 static void launch_scan(uint32_t* data, uint32_t n, uint32_t* sums, uint32_t* total_dev, hipStream_t s)
 {
@@ -180,245 +162,499 @@ __global__ void __launch_bounds__(256) k_scatter_idx(const uint8_t* __restrict__
     if (i < n && mask[i]) out[pos[i]] = (int32_t)i;
 }
 
-// ------------------------------------------------------------------------------------------------ weight repack
+// ------------------------------------------------------------------------------------------------ weight image (MFMA operand order)
+// v_mfma_f32_16x16x4_f32: lane l = (i = l & 15, kk = l >> 4) supplies A[m = i][k = kk] and B[k = kk][n = i]; it receives
+// D[m = 4 kk + r][n = i] in acc[r].  All activations are kept TRANSPOSED, as [feature][anchor] tiles in D layout (16 anchors per
+// tile on i, feature 16 t + 4 kk + r on (t, kk, r)), so that the output tile of one layer is directly the B operand of the next:
+// at contraction step (t, r) lane (i, kk) contributes feature 16 t + 4 kk + r and the weight operand must hold W[m][16 t + 4 kk + r].
+// k_pack_img writes every weight operand of forward and backward in exactly that per-lane order ("slots" of 64 floats); the kernels
+// copy the slots they need into LDS once per block and read them with conflict-free ds_read_b32.
+//   layer-2 output rows are re-grouped so that the epilogue is lane-local: cov head 8 rows per offset (7 used) -> lane (kk even) holds
+//   (s0,s1,s2,q0), lane kk+1 holds (q1,q2,q3,-) of offset 2 ot + kk/2; colour head 4 rows per offset (3 used) -> lane kk holds offset
+//   4 ot + kk; opacity head: lane kk holds offsets 4 kk .. 4 kk + 3.
+#define IMG_W1F 0        // [h 3][ht 2][t 3][r 4]     A[m = hidden][k = x column]
+#define IMG_W2F_O 72     // [ht 2][r 4]               A[m = out row][k = hidden]
+#define IMG_W2F_C 80     // [ot 8][ht 2][r 4]
+#define IMG_W2F_K 144    // [ot 4][ht 2][r 4]
+#define IMG_B2_O 176     // [r 4]                     bias in D layout
+#define IMG_B2_C 180     // [ot 8][r 4]
+#define IMG_B2_K 212     // [ot 4][r 4]
+#define IMG_W2T_O 228    // [ht 2][r 4]               A[m = hidden][k = out row]
+#define IMG_W2T_C 236    // [ht 2][ot 8][r 4]
+#define IMG_W2T_K 300    // [ht 2][ot 4][r 4]
+#define IMG_W1T 332      // [h 3][xt 3][ht 2][r 4]    A[m = x column][k = hidden]
+#define IMG_SLOTS 404
+#define IMG_FLOATS (IMG_SLOTS * 64)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct PackArgs {
     gsd_cfg cfg;
-    const float *W1o, *b1o, *W1c, *b1c, *W1k, *b1k, *app;
-    float* W1p;
+    const float *W1o, *b1o, *W2o, *b2o, *W1c, *b1c, *W2c, *b2c, *W1k, *b1k, *W2k, *b2k, *app;
+    float* img;
+    uint32_t* ticket;       // scan ticket counter to clear, or NULL
 };
-__global__ void __launch_bounds__(256) k_pack(PackArgs p)
+
+// packed layer-1 weight: columns feat 0..31, view 32..34, dist 35, level 36, 37 = bias + appearance contribution, 38.. = 0
+__device__ float w1p(const PackArgs& p, int head, int j, int c)
 {
     const int lv = p.cfg.level ? 1 : 0;
-    for (int e = threadIdx.x; e < 3 * 32 * GSD_W1LD; e += 256) {
-        const int head = e / (32 * GSD_W1LD), j = (e / GSD_W1LD) % 32, c = e % GSD_W1LD;
-        const float* W = head == 0 ? p.W1o : (head == 1 ? p.W1c : p.W1k);
-        const float* b = head == 0 ? p.b1o : (head == 1 ? p.b1c : p.b1k);
-        const int dist = head == 0 ? p.cfg.dist_o : (head == 1 ? p.cfg.dist_c : p.cfg.dist_k);
-        const int A = head == 2 ? p.cfg.A : 0;
-        const int in = 35 + (dist ? 1 : 0) + lv + A;
+    const float* W = head == 0 ? p.W1o : (head == 1 ? p.W1c : p.W1k);
+    const float* b = head == 0 ? p.b1o : (head == 1 ? p.b1c : p.b1k);
+    const int dist = head == 0 ? p.cfg.dist_o : (head == 1 ? p.cfg.dist_c : p.cfg.dist_k);
+    const int A = head == 2 ? p.cfg.A : 0;
+    const int in = 35 + (dist ? 1 : 0) + lv + A;
+    if (c < 35) return W[j * in + c];
+    if (c == 35) return dist ? W[j * in + 35] : 0.0f;
+    if (c == 36) return lv ? W[j * in + 35 + (dist ? 1 : 0)] : 0.0f;
+    if (c == GSD_XC) {
         float v = 0.0f;
-        if (c < 35) v = W[j * in + c];
-        else if (c == 35) v = dist ? W[j * in + 35] : 0.0f;
-        else if (c == 36) v = lv ? W[j * in + 35 + (dist ? 1 : 0)] : 0.0f;
-        else if (c == GSD_XC) {
-            v = 0.0f;
-            const int base = 35 + (dist ? 1 : 0) + lv;
-            for (int i = 0; i < A; i++) v = fmaf(W[j * in + base + i], p.app[i], v);     // appearance is the same for every anchor
-            v += b[j];
-        }
-        p.W1p[e] = v;
+        const int base = 35 + (dist ? 1 : 0) + lv;
+        for (int i = 0; i < A; i++) v = fmaf(W[j * in + base + i], p.app[i], v);       // appearance is the same for every anchor
+        return v + b[j];
     }
+    return 0.0f;
+}
+// layer-2 rows in the re-grouped order: head 0: rho = offset; head 1: rho = 8 j + c (c < 7); head 2: rho = 4 j + c (c < 3)
+__device__ float w2row(const PackArgs& p, int head, int rho, int hid, bool bias)
+{
+    const int k = p.cfg.k;
+    int j, c, per;
+    if (head == 0) { j = rho; c = 0; per = 1; }
+    else if (head == 1) { j = rho >> 3; c = rho & 7; per = 7; }
+    else { j = rho >> 2; c = rho & 3; per = 3; }
+    if (j >= k || c >= per) return 0.0f;
+    const int row = per * j + c;
+    const float* W = head == 0 ? p.W2o : (head == 1 ? p.W2c : p.W2k);
+    const float* b = head == 0 ? p.b2o : (head == 1 ? p.b2c : p.b2k);
+    return bias ? b[row] : W[row * 32 + hid];
+}
+
+__global__ void __launch_bounds__(256) k_pack_img(PackArgs p)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e == 0 && p.ticket) *p.ticket = 0u;
+    if (e >= IMG_FLOATS) return;
+    const int slot = e >> 6, l = e & 63, m = l & 15, kk = l >> 4;
+    float v;
+    if (slot < IMG_W2F_O) {
+        const int s = slot - IMG_W1F, r = s & 3, t = (s >> 2) % 3, ht = (s / 12) & 1, h = s / 24;
+        v = w1p(p, h, 16 * ht + m, 16 * t + 4 * kk + r);
+    } else if (slot < IMG_B2_O) {
+        int head, s;
+        if (slot < IMG_W2F_C) { head = 0; s = slot - IMG_W2F_O; }
+        else if (slot < IMG_W2F_K) { head = 1; s = slot - IMG_W2F_C; }
+        else { head = 2; s = slot - IMG_W2F_K; }
+        const int r = s & 3, ht = (s >> 2) & 1, ot = s >> 3;
+        v = w2row(p, head, 16 * ot + m, 16 * ht + 4 * kk + r, false);
+    } else if (slot < IMG_W2T_O) {
+        int head, s;
+        if (slot < IMG_B2_C) { head = 0; s = slot - IMG_B2_O; }
+        else if (slot < IMG_B2_K) { head = 1; s = slot - IMG_B2_C; }
+        else { head = 2; s = slot - IMG_B2_K; }
+        const int r = s & 3, ot = s >> 2;
+        v = w2row(p, head, 16 * ot + 4 * kk + r, 0, true);
+    } else if (slot < IMG_W1T) {
+        int head, s, not_;
+        if (slot < IMG_W2T_C) { head = 0; s = slot - IMG_W2T_O; not_ = 1; }
+        else if (slot < IMG_W2T_K) { head = 1; s = slot - IMG_W2T_C; not_ = 8; }
+        else { head = 2; s = slot - IMG_W2T_K; not_ = 4; }
+        const int r = s & 3, ot = (s >> 2) % not_, ht = (s >> 2) / not_;
+        v = w2row(p, head, 16 * ot + 4 * kk + r, 16 * ht + m, false);
+    } else {
+        const int s = slot - IMG_W1T, r = s & 3, ht = (s >> 2) & 1, xt = (s >> 3) % 3, h = s / 24;
+        const int col = 16 * xt + m;
+        v = col < GSD_XC ? w1p(p, h, 16 * ht + 4 * kk + r, col) : 0.0f;
+    }
+    p.img[e] = v;
+}
+
+// copy `count` consecutive slots of the global image into LDS (dst slot index given), all threads of the block
+__device__ __forceinline__ void img_to_lds(float* lds, int dst_slot, const float* __restrict__ img, int src_slot, int count)
+{
+    const float4* s = reinterpret_cast<const float4*>(img + (size_t)src_slot * 64);
+    float4* d = reinterpret_cast<float4*>(lds + (size_t)dst_slot * 64);
+    for (int i = threadIdx.x; i < count * 16; i += blockDim.x) d[i] = s[i];
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// B-operand tiles of x = [feat 32 | view 3, dist | level, 1, 0, 0 | 0...] for anchor `a` (all zero for padding anchors)
+__device__ __forceinline__ void load_xb(const DecArgs& p, int a, bool active, int kk, f32x4 (&xb)[3], float (&vw)[3], float& dist)
+{
+    const float4* f4 = reinterpret_cast<const float4*>(p.in.feat + (size_t)a * GSD_FEAT);
+    const float4 f0 = f4[kk], f1 = f4[4 + kk];
+    const float r0 = p.in.anchor[3 * a] - p.in.campos[0], r1 = p.in.anchor[3 * a + 1] - p.in.campos[1],
+                r2 = p.in.anchor[3 * a + 2] - p.in.campos[2];
+    dist = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+    vw[0] = r0 / dist; vw[1] = r1 / dist; vw[2] = r2 / dist;
+    const float lv = p.in.level ? p.in.level[a] : 0.0f;
+    const float am = active ? 1.0f : 0.0f;
+    xb[0] = (f32x4){f0.x, f0.y, f0.z, f0.w} * am;
+    xb[1] = (f32x4){f1.x, f1.y, f1.z, f1.w} * am;
+    xb[2] = (kk == 0 ? (f32x4){vw[0], vw[1], vw[2], dist} : (kk == 1 ? (f32x4){lv, 1.0f, 0.0f, 0.0f} : (f32x4){0.f, 0.f, 0.f, 0.f})) * am;
+}
+
+// pre1^T tiles of one head: acc[ht][r] = pre-activation of hidden unit 16 ht + 4 kk + r.  w1: LDS slots [ht 2][t 3][r 4] of that head
+__device__ __forceinline__ void layer1_mfma(const float* w1, int lane, const f32x4 (&xb)[3], f32x4 (&acc)[2])
+{
+#pragma unroll
+    for (int ht = 0; ht < 2; ht++) {
+        acc[ht] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[ht] = MFMA(w1[((ht * 3 + t) * 4 + r) * 64 + lane], xb[t][r], acc[ht]);
+    }
+}
+// one 16-row output tile of layer 2: w2 = LDS slots [ht 2][r 4] of that tile, bias = LDS slots [r 4]
+__device__ __forceinline__ f32x4 layer2_mfma(const float* w2, const float* bias, int lane, const f32x4 (&hb)[2])
+{
+    f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ht = 0; ht < 2; ht++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) y = MFMA(w2[(ht * 4 + r) * 64 + lane], hb[ht][r], y);
+#pragma unroll
+    for (int r = 0; r < 4; r++) y[r] += bias[r * 64 + lane];
+    return y;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) { return (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+
+__device__ __forceinline__ uint32_t mask_bits(const float* __restrict__ nop, int v, int k, bool active)
+{
+    uint32_t m = 0;
+    if (active)
+        for (int j = 0; j < k; j++) m |= nop[(size_t)v * k + j] > 0.0f ? (1u << j) : 0u;
+    return m;
 }
 
 // ------------------------------------------------------------------------------------------------ forward stage 1: opacity head
-__global__ void __launch_bounds__(GSD_BLOCK) k_decode_opacity(DecArgs p, float* __restrict__ neural_opacity, uint8_t* __restrict__ mask,
-                                                              uint32_t* __restrict__ counts)
+// LDS: [W1F head 0: 24][W2F_O: 8][B2_O: 4]
+__global__ void __launch_bounds__(GSD_BLOCK) k_dec_opacity(DecArgs p, const float* __restrict__ img, float* __restrict__ neural_opacity,
+                                                           uint8_t* __restrict__ mask, uint32_t* __restrict__ counts, int n_tiles)
 {
-    const int v = blockIdx.x * GSD_BLOCK + threadIdx.x;
-    const bool active = v < p.cfg.Nv;
-    const int a = p.in.vis_idx[active ? v : 0];
-    float x[GSD_XC], vw[3], dist, h[32];
-    load_x(p, a, x, vw, dist);
-    layer1<0>(CW(p.W1p), x, h);
-    const float sc = p.in.opacity_scale ? p.in.opacity_scale[a] : 1.0f;
-    const int k = p.cfg.k;
-    uint32_t cnt = 0;
-    for (int j = 0; j < k; j++) {
-        float o = tanhf(dot32(CW(p.W2o) + j * 32, h) + CW(p.b2o)[j]);
-        if (p.in.opacity_scale) o *= sc;
-        if (active) {
-            neural_opacity[(size_t)v * k + j] = o;
-            mask[(size_t)v * k + j] = o > 0.0f ? 1 : 0;
+    __shared__ float lds[36 * 64];
+    img_to_lds(lds, 0, img, IMG_W1F, 24);
+    img_to_lds(lds, 24, img, IMG_W2F_O, 8);
+    img_to_lds(lds, 32, img, IMG_B2_O, 4);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kk = lane >> 4, k = p.cfg.k;
+    for (int tile = blockIdx.x * (GSD_BLOCK / 64) + wave; tile < n_tiles; tile += gridDim.x * (GSD_BLOCK / 64)) {
+        const int v = tile * 16 + n;
+        const bool active = v < p.cfg.Nv;
+        const int a = p.in.vis_idx[active ? v : 0];
+        f32x4 xb[3], acc[2], hb[2];
+        float vw[3], dist;
+        load_xb(p, a, active, kk, xb, vw, dist);
+        layer1_mfma(lds, lane, xb, acc);
+        hb[0] = relu4(acc[0]); hb[1] = relu4(acc[1]);
+        const f32x4 y = layer2_mfma(lds + 24 * 64, lds + 32 * 64, lane, hb);
+        const float osc = p.in.opacity_scale ? p.in.opacity_scale[a] : 1.0f;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = 4 * kk + r;
+            float o = tanhf(y[r]);
+            if (p.in.opacity_scale) o *= osc;
+            if (active && j < k) {
+                neural_opacity[(size_t)v * k + j] = o;
+                mask[(size_t)v * k + j] = o > 0.0f ? 1 : 0;
+                cnt += o > 0.0f ? 1u : 0u;
+            }
         }
-        cnt += o > 0.0f ? 1u : 0u;
+        cnt += __shfl_xor(cnt, 16, 64);
+        cnt += __shfl_xor(cnt, 32, 64);
+        if (active && kk == 0) counts[v] = cnt;
     }
-    if (active) counts[v] = cnt;
 }
 
 // ------------------------------------------------------------------------------------------------ forward stage 2: cov + colour heads
-__global__ void __launch_bounds__(GSD_BLOCK) k_decode_emit(DecArgs p, const float* __restrict__ neural_opacity,
-                                                           const uint32_t* __restrict__ row_offset, gsd_outputs out)
+// blockIdx.y = 0: cov head (+ xyz, opacity), 1: colour head.  LDS: [W1F 24][W2F 8 NOT][B2 4 NOT], NOT = 8 / 4 -> 30 KB / 18 KB
+template <int HEAD>
+__device__ __forceinline__ void emit_head(const DecArgs& p, const float* __restrict__ img, const float* __restrict__ neural_opacity,
+                                          const uint32_t* __restrict__ row_offset, const gsd_outputs& out, int n_tiles, float* lds)
 {
-    const int v = blockIdx.x * GSD_BLOCK + threadIdx.x;
-    const bool active = v < p.cfg.Nv;
-    const int a = p.in.vis_idx[active ? v : 0];
-    const int k = p.cfg.k;
-    float x[GSD_XC], vw[3], dist, h[32];
-    load_x(p, a, x, vw, dist);
-    const uint32_t row0 = active ? row_offset[v] : 0u;
-    float S[6], A3[3];
+    constexpr int NOT = HEAD == 1 ? 8 : 4;
+    constexpr int L_W2F = 24, L_B2 = L_W2F + 8 * NOT;
+    img_to_lds(lds, 0, img, IMG_W1F + 24 * HEAD, 24);
+    img_to_lds(lds, L_W2F, img, HEAD == 1 ? IMG_W2F_C : IMG_W2F_K, 8 * NOT);
+    img_to_lds(lds, L_B2, img, HEAD == 1 ? IMG_B2_C : IMG_B2_K, 4 * NOT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kk = lane >> 4, k = p.cfg.k;
+    const int n_ot = HEAD == 1 ? (k + 1) >> 1 : (k + 3) >> 2;
+    for (int tile = blockIdx.x * (GSD_BLOCK / 64) + wave; tile < n_tiles; tile += gridDim.x * (GSD_BLOCK / 64)) {
+        const int v = tile * 16 + n;
+        const bool active = v < p.cfg.Nv;
+        const int a = p.in.vis_idx[active ? v : 0];
+        f32x4 xb[3], acc[2], hb[2];
+        float vw[3], dist;
+        load_xb(p, a, active, kk, xb, vw, dist);
+        const uint32_t row0 = active ? row_offset[v] : 0u;
+        const uint32_t mbits = mask_bits(neural_opacity, v, k, active);
+        float S[6], A3[3];
+        if (HEAD == 1) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) S[i] = p.in.scaling[(size_t)a * 6 + i];
+            for (int i = 0; i < 6; i++) S[i] = p.in.scaling[(size_t)a * 6 + i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) A3[i] = p.in.anchor[3 * a + i];
-    uint32_t mbits = 0;
-    for (int j = 0; j < k; j++) mbits |= (active && neural_opacity[(size_t)v * k + j] > 0.0f) ? (1u << j) : 0u;
-
-    layer1<1>(CW(p.W1p), x, h);
-    for (int j = 0; j < k; j++) {
-        float sr[7];
+            for (int i = 0; i < 3; i++) A3[i] = p.in.anchor[3 * a + i];
+        }
+        layer1_mfma(lds, lane, xb, acc);
+        hb[0] = relu4(acc[0]); hb[1] = relu4(acc[1]);
+#pragma unroll 1
+        for (int ot = 0; ot < n_ot; ot++) {
+            const f32x4 y = layer2_mfma(lds + (L_W2F + ot * 8) * 64, lds + (L_B2 + ot * 4) * 64, lane, hb);
+            if (HEAD == 1) {     // lane pair (kk even, kk odd) = (s0 s1 s2 q0 | q1 q2 q3 -) of offset 2 ot + kk/2
+                const int j = 2 * ot + (kk >> 1), half = kk & 1;
+                const float own = half ? (y[0] * y[0] + y[1] * y[1] + y[2] * y[2]) : (y[3] * y[3]);
+                const float nn = own + __shfl_xor(own, 16, 64);
+                const float q0 = __shfl_xor(y[3], 16, 64);
+                if (j < k && ((mbits >> j) & 1u)) {
+                    const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
+                    if (half == 0) {
+                        const float* off = p.in.offset + ((size_t)a * k + j) * 3;
 #pragma unroll
-        for (int r = 0; r < 7; r++) sr[r] = dot32(CW(p.W2c) + (7 * j + r) * 32, h) + CW(p.b2c)[7 * j + r];
-        if (mbits & (1u << j)) {
-            const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
-            const float* off = p.in.offset + ((size_t)a * k + j) * 3;
+                        for (int i = 0; i < 3; i++) {
+                            out.xyz[(size_t)row * 3 + i] = A3[i] + off[i] * S[i];
+                            out.scaling[(size_t)row * 3 + i] = S[3 + i] * sigmoid_(y[i]);
+                        }
+                        out.opacity[row] = neural_opacity[(size_t)v * k + j];
+                    } else {
+                        const float nrm = fmaxf(sqrtf(nn), 1e-12f);
+                        reinterpret_cast<float4*>(out.rot)[row] = make_float4(q0 / nrm, y[0] / nrm, y[1] / nrm, y[2] / nrm);
+                    }
+                }
+            } else {             // lane kk = offset 4 ot + kk, rows (r, g, b, -)
+                const int j = 4 * ot + kk;
+                if (j < k && ((mbits >> j) & 1u)) {
+                    const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                out.xyz[(size_t)row * 3 + i] = A3[i] + off[i] * S[i];
-                out.scaling[(size_t)row * 3 + i] = S[3 + i] * sigmoid_(sr[i]);
+                    for (int r = 0; r < 3; r++) out.color[(size_t)row * 3 + r] = sigmoid_(y[r]);
+                }
             }
-            float n = sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]);
-            n = fmaxf(n, 1e-12f);
-            reinterpret_cast<float4*>(out.rot)[row] = make_float4(sr[3] / n, sr[4] / n, sr[5] / n, sr[6] / n);
-            out.opacity[row] = neural_opacity[(size_t)v * k + j];
         }
     }
-    layer1<2>(CW(p.W1p), x, h);
-    for (int j = 0; j < k; j++) {
-        float c[3];
+}
+__global__ void __launch_bounds__(GSD_BLOCK) k_dec_emit(DecArgs p, const float* __restrict__ img, const float* __restrict__ neural_opacity,
+                                                        const uint32_t* __restrict__ row_offset, gsd_outputs out, int n_tiles)
+{
+    __shared__ float lds[120 * 64];
+    if (blockIdx.y == 0) emit_head<1>(p, img, neural_opacity, row_offset, out, n_tiles, lds);
+    else emit_head<2>(p, img, neural_opacity, row_offset, out, n_tiles, lds);
+}
+
+// ------------------------------------------------------------------------------------------------ backward, per anchor tile
+// Split by head (blockIdx.y) so that each block needs only its head's operands in LDS (17 / 52 / 32 KB -> several blocks per CU) and a
+// small register state: forward recompute -> lane-local layer-2 pre-activation gradients -> dH = W2^T dY -> dpre1 = dH * relu'.
+// x, h, dpre1, dpre2 go to the tile-major scratch for the weight-gradient contraction (k_wgrad); k_dec_bwd_dx then forms
+// dX = [W1o; W1c; W1k]^T dpre1 from the same scratch and writes the per-anchor gradients.
+#define SC_AT(sc, tile, col, n) (sc)[((size_t)(tile) * SC_COLS + (col)) * 16 + (n)]
+#define SC_GEO (SC_X + 38)    // 9 spare x columns: dA[3], dS[6] of the geometry, written by the cov head
+__device__ __forceinline__ void store_tile(float* __restrict__ sc, int tile, int col0, int kk, int n, f32x4 t)
+{
 #pragma unroll
-        for (int r = 0; r < 3; r++) c[r] = sigmoid_(dot32(CW(p.W2k) + (3 * j + r) * 32, h) + CW(p.b2k)[3 * j + r]);
-        if (mbits & (1u << j)) {
-            const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
+    for (int r = 0; r < 4; r++) SC_AT(sc, tile, col0 + 4 * kk + r, n) = t[r];
+}
+
+struct BwdArgs {
+    DecArgs d;
+    const float* img; const float* neural_opacity; const uint32_t* row_offset;
+    gsd_out_grads og;
+    float* d_offset; float* sc; int n_tiles;
+};
+
+// LDS slot map of one head: [W1F 24][W2F 8*NOT][B2 4*NOT][W2T 2*4*NOT][...]; NOT = 1 / 8 / 4 layer-2 row tiles
+template <int HEAD>
+__device__ __forceinline__ void bwd_head(const BwdArgs& p, float* lds)
+{
+    constexpr int NOT = HEAD == 0 ? 1 : (HEAD == 1 ? 8 : 4);
+    constexpr int L_W2F = 24, L_B2 = L_W2F + 8 * NOT, L_W2T = L_B2 + 4 * NOT;
+    constexpr int G_W2F = HEAD == 0 ? IMG_W2F_O : (HEAD == 1 ? IMG_W2F_C : IMG_W2F_K);
+    constexpr int G_B2 = HEAD == 0 ? IMG_B2_O : (HEAD == 1 ? IMG_B2_C : IMG_B2_K);
+    constexpr int G_W2T = HEAD == 0 ? IMG_W2T_O : (HEAD == 1 ? IMG_W2T_C : IMG_W2T_K);
+    img_to_lds(lds, 0, p.img, IMG_W1F + 24 * HEAD, 24);
+    img_to_lds(lds, L_W2F, p.img, G_W2F, 8 * NOT);
+    img_to_lds(lds, L_B2, p.img, G_B2, 4 * NOT);
+    img_to_lds(lds, L_W2T, p.img, G_W2T, 8 * NOT);
+    __syncthreads();
+    const DecArgs& d = p.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kk = lane >> 4, k = d.cfg.k;
+    const int n_ot = HEAD == 0 ? 1 : (HEAD == 1 ? (k + 1) >> 1 : (k + 3) >> 2);
+    float* __restrict__ sc = p.sc;
+    for (int tile = blockIdx.x * (GSD_BLOCK / 64) + wave; tile < p.n_tiles; tile += gridDim.x * (GSD_BLOCK / 64)) {
+        const int v = tile * 16 + n;
+        const bool active = v < d.cfg.Nv;
+        const int a = d.in.vis_idx[active ? v : 0];
+        f32x4 xb[3], acc[2], hb[2], dh[2];
+        float vw[3], dist;
+        load_xb(d, a, active, kk, xb, vw, dist);
+        if (HEAD == 0) {
 #pragma unroll
-            for (int r = 0; r < 3; r++) out.color[(size_t)row * 3 + r] = c[r];
+            for (int t = 0; t < 3; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (16 * t + 4 * kk + r < 38) SC_AT(sc, tile, SC_X + 16 * t + 4 * kk + r, n) = xb[t][r];
+        }
+        const uint32_t row0 = active ? p.row_offset[v] : 0u;
+        const uint32_t mbits = mask_bits(p.neural_opacity, v, k, active);
+        layer1_mfma(lds, lane, xb, acc);
+        hb[0] = relu4(acc[0]); hb[1] = relu4(acc[1]);
+        dh[0] = dh[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float S[6], dS[6] = {0, 0, 0, 0, 0, 0}, dA[3] = {0, 0, 0};
+        if (HEAD == 1) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) S[i] = d.in.scaling[(size_t)a * 6 + i];
+        }
+        const float osc = (HEAD == 0 && d.in.opacity_scale) ? d.in.opacity_scale[a] : 1.0f;
+#pragma unroll 1
+        for (int ot = 0; ot < n_ot; ot++) {
+            const f32x4 y = layer2_mfma(lds + (L_W2F + ot * 8) * 64, lds + (L_B2 + ot * 4) * 64, lane, hb);
+            f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (HEAD == 0) {                 // opacity = tanh(.) * scale; lane kk = offsets 4 kk .. 4 kk + 3
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = 4 * kk + r;
+                    if (j < k && ((mbits >> j) & 1u)) {
+                        const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
+                        const float t = tanhf(y[r]);
+                        g[r] = p.og.opacity[row] * osc * (1.0f - t * t);
+                    }
+                }
+                store_tile(sc, tile, SC_P2O, kk, n, g);
+            } else if (HEAD == 1) {          // lane pair = (s0 s1 s2 q0 | q1 q2 q3 -) of offset 2 ot + kk/2; also xyz = anchor + offset*S[0:3]
+                const int j = 2 * ot + (kk >> 1), half = kk & 1;
+                const bool m = j < k && ((mbits >> j) & 1u);
+                const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
+                float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m) gr = reinterpret_cast<const float4*>(p.og.rot)[row];
+                const float own_sq = half ? (y[0] * y[0] + y[1] * y[1] + y[2] * y[2]) : (y[3] * y[3]);
+                const float own_dot = half ? (y[0] * gr.y + y[1] * gr.z + y[2] * gr.w) : (y[3] * gr.x);
+                const float nn = own_sq + __shfl_xor(own_sq, 16, 64);
+                const float qd = own_dot + __shfl_xor(own_dot, 16, 64);          // q . gr
+                if (m) {
+                    const float nrm = sqrtf(nn);
+                    const bool ok = nrm > 1e-12f;
+                    const float inv = ok ? 1.0f / nrm : 1e12f;                    // clamped norm: d rot = gr / eps
+                    const float dot = ok ? qd * inv * inv : 0.0f;                 // (rhat . gr) / n
+                    if (half == 0) {
+                        const float* off = d.in.offset + ((size_t)a * k + j) * 3;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) {
+                            const float gx = p.og.xyz[(size_t)row * 3 + i];
+                            dA[i] += gx;
+                            p.d_offset[((size_t)a * k + j) * 3 + i] = gx * S[i];
+                            dS[i] = fmaf(gx, off[i], dS[i]);
+                            const float sg = sigmoid_(y[i]);
+                            const float gs = p.og.scaling[(size_t)row * 3 + i];
+                            g[i] = gs * S[3 + i] * sg * (1.0f - sg);
+                            dS[3 + i] = fmaf(gs, sg, dS[3 + i]);
+                        }
+                        g[3] = (gr.x - y[3] * dot) * inv;
+                    } else {
+                        g[0] = (gr.y - y[0] * dot) * inv; g[1] = (gr.z - y[1] * dot) * inv; g[2] = (gr.w - y[2] * dot) * inv;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {                                     // scratch keeps the ORIGINAL row order 7 j + c
+                    const int c = 4 * half + r;
+                    if (j < k && c < 7) SC_AT(sc, tile, SC_P2C + 7 * j + c, n) = g[r];
+                }
+            } else {                         // colour = sigmoid(.); lane kk = offset 4 ot + kk
+                const int j = 4 * ot + kk;
+                if (j < k && ((mbits >> j) & 1u)) {
+                    const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const float c = sigmoid_(y[r]);
+                        g[r] = p.og.color[(size_t)row * 3 + r] * c * (1.0f - c);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+                    if (j < k) SC_AT(sc, tile, SC_P2K + 3 * j + r, n) = g[r];
+            }
+#pragma unroll
+            for (int ht = 0; ht < 2; ht++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) dh[ht] = MFMA(lds[(L_W2T + (ht * NOT + ot) * 4 + r) * 64 + lane], g[r], dh[ht]);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 2; ht++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) dh[ht][r] = acc[ht][r] > 0.0f ? dh[ht][r] : 0.0f;
+            store_tile(sc, tile, SC_H + 32 * HEAD + 16 * ht, kk, n, hb[ht]);
+            store_tile(sc, tile, SC_P1 + 32 * HEAD + 16 * ht, kk, n, dh[ht]);
+        }
+        if (HEAD == 1) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { dA[i] += __shfl_xor(dA[i], 16, 64); dA[i] += __shfl_xor(dA[i], 32, 64); }
+#pragma unroll
+            for (int i = 0; i < 6; i++) { dS[i] += __shfl_xor(dS[i], 16, 64); dS[i] += __shfl_xor(dS[i], 32, 64); }
+            if (kk == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) SC_AT(sc, tile, SC_GEO + i, n) = dA[i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) SC_AT(sc, tile, SC_GEO + 3 + i, n) = dS[i];
+            }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------ backward, per anchor
-__global__ void __launch_bounds__(GSD_BLOCK) k_decode_bwd(DecArgs p, const float* __restrict__ neural_opacity,
-                                                          const uint32_t* __restrict__ row_offset, gsd_out_grads og, float* __restrict__ d_anchor,
-                                                          float* __restrict__ d_feat, float* __restrict__ d_offset, float* __restrict__ d_scaling,
-                                                          float* __restrict__ sc, size_t ld)
+#define BWD_LDS_SLOTS 208     // the cov head: 24 + 64 + 32 + 64 + 24
+__global__ void __launch_bounds__(GSD_BLOCK) k_dec_bwd_heads(BwdArgs p)
 {
-    const int v = blockIdx.x * GSD_BLOCK + threadIdx.x;        // grid covers the padded anchor count: inactive lanes store zeros
-    const bool active = v < p.cfg.Nv;
-    const float am = active ? 1.0f : 0.0f;
-    const int a = p.in.vis_idx[active ? v : 0];
-    const int k = p.cfg.k;
-    float x[GSD_XC], vw[3], dist, h[32], dh[32], dx[GSD_XC];
-    load_x(p, a, x, vw, dist);
-    const uint32_t row0 = active ? row_offset[v] : 0u;
-    float S[6], dS[6] = {0, 0, 0, 0, 0, 0}, dA[3] = {0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 6; i++) S[i] = p.in.scaling[(size_t)a * 6 + i];
-    uint32_t mbits = 0;
-    for (int j = 0; j < k; j++) mbits |= (active && neural_opacity[(size_t)v * k + j] > 0.0f) ? (1u << j) : 0u;
-    const float osc = p.in.opacity_scale ? p.in.opacity_scale[a] : 1.0f;
-#pragma unroll
-    for (int i = 0; i < GSD_XC; i++) { dx[i] = 0.0f; sc[(size_t)(SC_X + i) * ld + v] = x[i] * am; }
+    extern __shared__ float lds[];
+    if (blockIdx.y == 0) bwd_head<0>(p, lds);
+    else if (blockIdx.y == 1) bwd_head<1>(p, lds);
+    else bwd_head<2>(p, lds);
+}
 
-    // ---- head o: opacity = tanh(.) * scale
-    layer1<0>(CW(p.W1p), x, h);
+// dX^T = [W1o; W1c; W1k]^T dpre1 (96 -> 48 x columns) per 16-anchor tile, then the per-anchor gradients
+__global__ void __launch_bounds__(GSD_BLOCK) k_dec_bwd_dx(DecArgs p, const float* __restrict__ img, const float* __restrict__ sc,
+                                                         float* __restrict__ d_anchor, float* __restrict__ d_feat, float* __restrict__ d_scaling,
+                                                         int n_tiles)
+{
+    __shared__ float lds[72 * 64];
+    img_to_lds(lds, 0, img, IMG_W1T, 72);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kk = lane >> 4;
+    for (int tile = blockIdx.x * (GSD_BLOCK / 64) + wave; tile < n_tiles; tile += gridDim.x * (GSD_BLOCK / 64)) {
+        const int v = tile * 16 + n;
+        if (tile * 16 >= p.cfg.Nv) continue;
+        const bool active = v < p.cfg.Nv;
+        const int a = p.in.vis_idx[active ? v : 0];
+        f32x4 dx[3];
 #pragma unroll
-    for (int i = 0; i < 32; i++) dh[i] = 0.0f;
-    for (int j = 0; j < k; j++) {
-        float g = 0.0f;
-        if (mbits & (1u << j)) {
-            const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
-            const float t = tanhf(dot32(CW(p.W2o) + j * 32, h) + CW(p.b2o)[j]);
-            g = og.opacity[row] * osc * (1.0f - t * t);
-        }
-        sc[(size_t)(SC_P2O + j) * ld + v] = g;
-        axpy32(CW(p.W2o) + j * 32, g, dh);
-    }
+        for (int xt = 0; xt < 3; xt++) dx[xt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
-        dh[i] = h[i] > 0.0f ? dh[i] : 0.0f;
-        sc[(size_t)(SC_H + i) * ld + v] = h[i] * am;
-        sc[(size_t)(SC_P1 + i) * ld + v] = dh[i];
-    }
-    layer1_bwd<0>(CW(p.W1p), dh, dx);
-
-    // ---- head c: scaling_out = S[3:6]*sigmoid(sr[0:3]), rot = normalize(sr[3:7]); also the geometry xyz = anchor + offset*S[0:3]
-    layer1<1>(CW(p.W1p), x, h);
+        for (int h = 0; h < 3; h++)
 #pragma unroll
-    for (int i = 0; i < 32; i++) dh[i] = 0.0f;
-    for (int j = 0; j < k; j++) {
-        float g[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (mbits & (1u << j)) {
-            const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
-            float sr[7];
+            for (int ht = 0; ht < 2; ht++) {
+                f32x4 g;
 #pragma unroll
-            for (int r = 0; r < 7; r++) sr[r] = dot32(CW(p.W2c) + (7 * j + r) * 32, h) + CW(p.b2c)[7 * j + r];
-            const float* off = p.in.offset + ((size_t)a * k + j) * 3;
+                for (int r = 0; r < 4; r++) g[r] = SC_AT(sc, tile, SC_P1 + 32 * h + 16 * ht + 4 * kk + r, n);
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const float gx = og.xyz[(size_t)row * 3 + i];
-                dA[i] += gx;
-                d_offset[((size_t)a * k + j) * 3 + i] = gx * S[i];
-                dS[i] = fmaf(gx, off[i], dS[i]);
-                const float sg = sigmoid_(sr[i]);
-                const float gs = og.scaling[(size_t)row * 3 + i];
-                g[i] = gs * S[3 + i] * sg * (1.0f - sg);
-                dS[3 + i] = fmaf(gs, sg, dS[3 + i]);
+                for (int xt = 0; xt < 3; xt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dx[xt] = MFMA(lds[(((h * 3 + xt) * 2 + ht) * 4 + r) * 64 + lane], g[r], dx[xt]);
             }
-            const float4 gr = reinterpret_cast<const float4*>(og.rot)[row];
-            const float n = sqrtf(sr[3] * sr[3] + sr[4] * sr[4] + sr[5] * sr[5] + sr[6] * sr[6]);
-            if (n > 1e-12f) {
-                const float inv = 1.0f / n;
-                const float r0 = sr[3] * inv, r1 = sr[4] * inv, r2 = sr[5] * inv, r3 = sr[6] * inv;
-                const float dot = r0 * gr.x + r1 * gr.y + r2 * gr.z + r3 * gr.w;
-                g[3] = (gr.x - r0 * dot) * inv; g[4] = (gr.y - r1 * dot) * inv; g[5] = (gr.z - r2 * dot) * inv; g[6] = (gr.w - r3 * dot) * inv;
-            } else {
-                g[3] = gr.x / 1e-12f; g[4] = gr.y / 1e-12f; g[5] = gr.z / 1e-12f; g[6] = gr.w / 1e-12f;
-            }
-        } else if (active) {
+        if (active) {
+            float4* f4 = reinterpret_cast<float4*>(d_feat + (size_t)a * GSD_FEAT);
+            f4[kk] = make_float4(dx[0][0], dx[0][1], dx[0][2], dx[0][3]);
+            f4[4 + kk] = make_float4(dx[1][0], dx[1][1], dx[1][2], dx[1][3]);
+            if (kk == 0) {       // x columns 32..35 = view, dist
+                const float r0 = p.in.anchor[3 * a] - p.in.campos[0], r1 = p.in.anchor[3 * a + 1] - p.in.campos[1],
+                            r2 = p.in.anchor[3 * a + 2] - p.in.campos[2];
+                const float dist = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+                const float vw[3] = {r0 / dist, r1 / dist, r2 / dist};
+                const float vd = vw[0] * dx[2][0] + vw[1] * dx[2][1] + vw[2] * dx[2][2];
 #pragma unroll
-            for (int i = 0; i < 3; i++) d_offset[((size_t)a * k + j) * 3 + i] = 0.0f;
-        }
+                for (int i = 0; i < 3; i++)
+                    d_anchor[3 * a + i] = SC_AT(sc, tile, SC_GEO + i, n) + (dx[2][i] - vw[i] * vd) / dist + dx[2][3] * vw[i];
 #pragma unroll
-        for (int r = 0; r < 7; r++) {
-            sc[(size_t)(SC_P2C + 7 * j + r) * ld + v] = g[r];
-            axpy32(CW(p.W2c) + (7 * j + r) * 32, g[r], dh);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-        dh[i] = h[i] > 0.0f ? dh[i] : 0.0f;
-        sc[(size_t)(SC_H + 32 + i) * ld + v] = h[i] * am;
-        sc[(size_t)(SC_P1 + 32 + i) * ld + v] = dh[i];
-    }
-    layer1_bwd<1>(CW(p.W1p), dh, dx);
-
-    // ---- head k: colour = sigmoid(.)
-    layer1<2>(CW(p.W1p), x, h);
-#pragma unroll
-    for (int i = 0; i < 32; i++) dh[i] = 0.0f;
-    for (int j = 0; j < k; j++) {
-        float g[3] = {0, 0, 0};
-        if (mbits & (1u << j)) {
-            const uint32_t row = row0 + __popc(mbits & ((1u << j) - 1u));
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const float c = sigmoid_(dot32(CW(p.W2k) + (3 * j + r) * 32, h) + CW(p.b2k)[3 * j + r]);
-                g[r] = og.color[(size_t)row * 3 + r] * c * (1.0f - c);
+                for (int i = 0; i < 6; i++) d_scaling[(size_t)a * 6 + i] = SC_AT(sc, tile, SC_GEO + 3 + i, n);
             }
         }
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            sc[(size_t)(SC_P2K + 3 * j + r) * ld + v] = g[r];
-            axpy32(CW(p.W2k) + (3 * j + r) * 32, g[r], dh);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-        dh[i] = h[i] > 0.0f ? dh[i] : 0.0f;
-        sc[(size_t)(SC_H + 64 + i) * ld + v] = h[i] * am;
-        sc[(size_t)(SC_P1 + 64 + i) * ld + v] = dh[i];
-    }
-    layer1_bwd<2>(CW(p.W1p), dh, dx);
-
-    if (active) {
-        float4* f4 = reinterpret_cast<float4*>(d_feat + (size_t)a * GSD_FEAT);
-#pragma unroll
-        for (int q = 0; q < 8; q++) f4[q] = make_float4(dx[4 * q], dx[4 * q + 1], dx[4 * q + 2], dx[4 * q + 3]);
-        const float vd = vw[0] * dx[32] + vw[1] * dx[33] + vw[2] * dx[34];
-#pragma unroll
-        for (int i = 0; i < 3; i++) d_anchor[3 * a + i] = dA[i] + (dx[32 + i] - vw[i] * vd) / dist + dx[35] * vw[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) d_scaling[(size_t)a * 6 + i] = dS[i];
     }
 }
 
@@ -431,8 +667,6 @@ struct WgArgs {
     float* bias_part;       // [n_prob][WG_WAVES][16]
     WgProblem prob[WG_MAXPROB];
 };
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 __global__ void __launch_bounds__(64) k_wgrad(WgArgs p)
 {
     const WgProblem pr = p.prob[blockIdx.y];
@@ -441,10 +675,11 @@ __global__ void __launch_bounds__(64) k_wgrad(WgArgs p)
 #pragma unroll
     for (int nb = 0; nb < 3; nb++) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
-    const float* colA = p.sc + (size_t)(pr.a_col + i) * p.ld + 16 * kk;
-    const float* colB = p.sc + (size_t)(pr.b_col + i) * p.ld + 16 * kk;
+    // chunk c = anchors 64 c .. 64 c + 63 = tiles 4 c .. 4 c + 3; lane (i, kk) reads the 16 anchors of tile 4 c + kk for its column
+    const float* colA = p.sc + ((size_t)kk * SC_COLS + pr.a_col + i) * 16;
+    const float* colB = p.sc + ((size_t)kk * SC_COLS + pr.b_col + i) * 16;
     for (int c = blockIdx.x; c < p.n_chunks; c += gridDim.x) {
-        const size_t o = (size_t)c * 64;
+        const size_t o = (size_t)c * 4 * SC_COLS * 16;
         float4 a4[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) a4[q] = reinterpret_cast<const float4*>(colA + o)[q];
@@ -455,7 +690,7 @@ __global__ void __launch_bounds__(64) k_wgrad(WgArgs p)
             if (nb < pr.nb) {
                 float4 b4[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) b4[q] = reinterpret_cast<const float4*>(colB + (size_t)(16 * nb) * p.ld + o)[q];
+                for (int q = 0; q < 4; q++) b4[q] = reinterpret_cast<const float4*>(colB + (size_t)(16 * nb) * 16 + o)[q];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].x, b4[q].x, acc[nb], 0, 0, 0);
@@ -481,13 +716,38 @@ __global__ void __launch_bounds__(64) k_wgrad(WgArgs p)
 struct WgOut {
     gsd_cfg cfg;
     gsd_params g;           // destinations
-    const float* part; const float* bias_part; int n_waves;
+    const float* part; const float* bias_part; int n_waves; int n_prob;
     // per problem: head (0 o, 1 c, 2 k), layer (1 or 2), first output row of the 16-row group
     int head[WG_MAXPROB], layer[WG_MAXPROB], row0[WG_MAXPROB], nb[WG_MAXPROB];
+    // appearance: dW1k[:, app cols] = db1k (x) app;  dapp = W1k[:, app cols]^T db1k  (db1k from the two layer-1 problems of head k)
+    const float* W1k; const float* app; int app_prob[2];
 };
 __global__ void __launch_bounds__(256) k_wgrad_reduce(WgOut p)
 {
     const int pi = blockIdx.x, nbsel = blockIdx.y;
+    if (pi == p.n_prob) {                               // the appearance block
+        __shared__ float db[32];
+        if (nbsel != 0 || p.cfg.A == 0) return;
+        if (threadIdx.x < 32) {
+            const int q = p.app_prob[threadIdx.x >> 4];
+            float s = 0.0f;
+#pragma unroll 8
+            for (int w = 0; w < p.n_waves; w++) s += p.bias_part[((size_t)q * WG_WAVES + w) * 16 + (threadIdx.x & 15)];
+            db[threadIdx.x] = s;
+        }
+        __syncthreads();
+        const int A = p.cfg.A, base = 35 + (p.cfg.dist_k ? 1 : 0) + (p.cfg.level ? 1 : 0), in = base + A;
+        for (int e = threadIdx.x; e < 32 * A; e += 256) {
+            const int j = e / A, i = e % A;
+            p.g.W1k[j * in + base + i] = db[j] * p.app[i];
+        }
+        if (threadIdx.x < A) {
+            float s = 0.0f;
+            for (int j = 0; j < 32; j++) s = fmaf(p.W1k[j * in + base + threadIdx.x], db[j], s);
+            p.g.app[threadIdx.x] = s;
+        }
+        return;
+    }
     if (nbsel > p.nb[pi]) return;                       // nbsel == nb  -> the bias vector
     const int head = p.head[pi], layer = p.layer[pi];
     const int k = p.cfg.k, lv = p.cfg.level ? 1 : 0;
@@ -499,6 +759,7 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(WgOut p)
     if (nbsel == p.nb[pi]) {
         if (threadIdx.x < 16) {
             float s = 0.0f;
+#pragma unroll 8
             for (int w = 0; w < p.n_waves; w++) s += p.bias_part[((size_t)pi * WG_WAVES + w) * 16 + threadIdx.x];
             const int row = p.row0[pi] + threadIdx.x;
             if (row < out_dim) B[row] = s;
@@ -507,6 +768,7 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(WgOut p)
     }
     const int m = threadIdx.x >> 4, n = threadIdx.x & 15;
     float s = 0.0f;
+#pragma unroll 8
     for (int w = 0; w < p.n_waves; w++) s += p.part[(((size_t)pi * WG_WAVES + w) * 3 + nbsel) * 256 + threadIdx.x];
     const int row = p.row0[pi] + m, col = 16 * nbsel + n;
     if (row >= out_dim) return;
@@ -517,22 +779,6 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(WgOut p)
     else if (col == 35) dst = dist ? 35 : -1;
     else if (col == 36) dst = lv ? 35 + (dist ? 1 : 0) : -1;
     if (dst >= 0) W[row * in1 + dst] = s;
-}
-
-// appearance: dW1k[:, app cols] = db1k (x) app;  dapp = W1k[:, app cols]^T db1k
-struct AppArgs { gsd_cfg cfg; const float* W1k; const float* app; float* gW1k; const float* gb1k; float* gapp; };
-__global__ void __launch_bounds__(64) k_app_grads(AppArgs p)
-{
-    const int A = p.cfg.A, lv = p.cfg.level ? 1 : 0, base = 35 + (p.cfg.dist_k ? 1 : 0) + lv, in = base + A;
-    const int i = threadIdx.x;
-    if (i >= A) return;
-    float s = 0.0f;
-    for (int j = 0; j < 32; j++) {
-        const float g = p.gb1k[j];
-        p.gW1k[j * in + base + i] = g * p.app[i];
-        s = fmaf(p.W1k[j * in + base + i], g, s);
-    }
-    p.gapp[i] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -554,24 +800,32 @@ static int check_cfg(const gsd_cfg* c, const gsd_inputs* in, const gsd_params* p
     return 0;
 }
 
-static DecArgs make_args(const gsd_cfg* c, const gsd_inputs* in, const gsd_params* p, const float* W1p)
+static DecArgs make_args(const gsd_cfg* c, const gsd_inputs* in)
 {
     DecArgs a;
-    a.cfg = *c; a.in = *in; a.W1p = W1p;
-    a.W2o = p->W2o; a.b2o = p->b2o; a.W2c = p->W2c; a.b2c = p->b2c; a.W2k = p->W2k; a.b2k = p->b2k;
+    a.cfg = *c; a.in = *in;
     return a;
 }
 
-static void launch_pack(const gsd_cfg* c, const gsd_params* p, float* W1p, hipStream_t s)
+static void launch_pack(const gsd_cfg* c, const gsd_params* p, float* img, uint32_t* ticket, hipStream_t s)
 {
     PackArgs pa;
-    pa.cfg = *c; pa.W1o = p->W1o; pa.b1o = p->b1o; pa.W1c = p->W1c; pa.b1c = p->b1c; pa.W1k = p->W1k; pa.b1k = p->b1k; pa.app = p->app;
-    pa.W1p = W1p;
-    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, s, pa);
+    pa.ticket = ticket;
+    pa.cfg = *c;
+    pa.W1o = p->W1o; pa.b1o = p->b1o; pa.W2o = p->W2o; pa.b2o = p->b2o;
+    pa.W1c = p->W1c; pa.b1c = p->b1c; pa.W2c = p->W2c; pa.b2c = p->b2c;
+    pa.W1k = p->W1k; pa.b1k = p->b1k; pa.W2k = p->W2k; pa.b2k = p->b2k;
+    pa.app = p->app; pa.img = img;
+    hipLaunchKernelGGL(k_pack_img, dim3(gsr_div_up(IMG_FLOATS, 256)), dim3(256), 0, s, pa);
+}
+static int tile_grid(int n_tiles, int waves_per_block, int max_blocks)
+{
+    const int b = (n_tiles + waves_per_block - 1) / waves_per_block;
+    return b < max_blocks ? (b > 0 ? b : 1) : max_blocks;
 }
 
-// forward scratch: [W1p][total word (256 B)][scan block sums]
-static size_t fwd_sums_off() { return gsr_align(GSD_W1P_FLOATS * sizeof(float)) + 256; }
+// forward scratch: [weight image][total word (256 B)][scan block sums]
+static size_t fwd_sums_off() { return gsr_align(IMG_FLOATS * sizeof(float)) + 256; }
 extern "C" size_t gsd_forward_scratch_bytes(int32_t Nv)
 {
     return fwd_sums_off() + gsr_align(((size_t)gsr_div_up((uint32_t)(Nv > 0 ? Nv : 1), 1024u) + 1) * sizeof(uint32_t));
@@ -603,24 +857,57 @@ extern "C" int gsd_compact_visible(const uint8_t* mask, int32_t Na, int32_t* vis
     return gsr_check_launch("gsd_compact_visible", s, false);
 }
 
+static int fwd_checks(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, void* scratch, size_t scratch_bytes, const char* who)
+{
+    if (check_cfg(cfg, in, p)) return 1;
+    if (!scratch || scratch_bytes < gsd_forward_scratch_bytes(cfg->Nv)) { gsr_set_error("%s: scratch too small", who); return 1; }
+    return 0;
+}
+static uint32_t* fwd_total(void* scratch) { return (uint32_t*)((char*)scratch + gsr_align(IMG_FLOATS * sizeof(float))); }
+
+// image + opacity head + scan: row_offset final, device total in fwd_total(scratch)[0]
+static void enqueue_stage1(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask,
+                           uint32_t* row_offset, void* scratch, hipStream_t s)
+{
+    float* img = (float*)scratch;
+    uint32_t* total = fwd_total(scratch);
+    uint32_t* sums = (uint32_t*)((char*)scratch + fwd_sums_off());
+    launch_pack(cfg, p, img, total + 1, s);
+    if (cfg->Nv == 0) return;
+    DecArgs a = make_args(cfg, in);
+    const int n_tiles = (cfg->Nv + 15) / 16;
+    hipLaunchKernelGGL(k_dec_opacity, dim3(tile_grid(n_tiles, GSD_BLOCK / 64, 2048)), dim3(GSD_BLOCK), 0, s, a, (const float*)img,
+                       neural_opacity, mask, row_offset, n_tiles);
+    const uint32_t nblk = gsr_div_up((uint32_t)cfg->Nv, 1024u);
+    hipLaunchKernelGGL(k_scan_block_last, dim3(nblk), dim3(1024), 0, s, row_offset, (uint32_t)cfg->Nv, sums, total);
+    if (nblk > 1) hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(1024), 0, s, row_offset, (uint32_t)cfg->Nv, sums);
+}
+static void enqueue_stage2(const gsd_cfg* cfg, const gsd_inputs* in, const float* neural_opacity, const uint32_t* row_offset,
+                           const gsd_outputs* out, const void* scratch, hipStream_t s)
+{
+    DecArgs a = make_args(cfg, in);
+    const int n_tiles = (cfg->Nv + 15) / 16;
+    hipLaunchKernelGGL(k_dec_emit, dim3(tile_grid(n_tiles, GSD_BLOCK / 64, 1024), 2), dim3(GSD_BLOCK), 0, s, a, (const float*)scratch,
+                       neural_opacity, row_offset, *out, n_tiles);
+}
+static int check_outputs(const gsd_outputs* out, const char* who)
+{
+    if (!out || !out->xyz || !out->color || !out->opacity || !out->scaling || !out->rot) { gsr_set_error("%s: null output", who); return 1; }
+    if ((uintptr_t)out->rot & 15) { gsr_set_error("%s: rot must be 16-byte aligned", who); return 1; }
+    return 0;
+}
+
 extern "C" int gsd_forward_stage1(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask,
                                   uint32_t* row_offset, uint32_t* P_host, void* scratch, size_t scratch_bytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    if (check_cfg(cfg, in, p)) return 1;
+    if (fwd_checks(cfg, in, p, scratch, scratch_bytes, "gsd_forward_stage1")) return 1;
     if (!P_host) { gsr_set_error("gsd_forward_stage1: P_host is NULL"); return 1; }
     *P_host = 0;
-    if (!scratch || scratch_bytes < gsd_forward_scratch_bytes(cfg->Nv)) { gsr_set_error("gsd_forward_stage1: scratch too small"); return 1; }
-    float* W1p = (float*)scratch;
-    launch_pack(cfg, p, W1p, s);
+    if (cfg->Nv && (!neural_opacity || !mask || !row_offset)) { gsr_set_error("gsd_forward_stage1: null output"); return 1; }
+    enqueue_stage1(cfg, in, p, neural_opacity, mask, row_offset, scratch, s);
     if (cfg->Nv == 0) return gsr_check_launch("gsd_forward_stage1", s, false);
-    if (!neural_opacity || !mask || !row_offset) { gsr_set_error("gsd_forward_stage1: null output"); return 1; }
-    uint32_t* total = (uint32_t*)((char*)scratch + gsr_align(GSD_W1P_FLOATS * sizeof(float)));
-    uint32_t* sums = (uint32_t*)((char*)scratch + fwd_sums_off());
-    DecArgs a = make_args(cfg, in, p, W1p);
-    hipLaunchKernelGGL(k_decode_opacity, dim3(gsr_div_up(cfg->Nv, GSD_BLOCK)), dim3(GSD_BLOCK), 0, s, a, neural_opacity, mask, row_offset);
-    launch_scan(row_offset, (uint32_t)cfg->Nv, sums, total, s);
-    GSR_CHECK(hipMemcpyAsync(P_host, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "gsd_forward_stage1: copy");
+    GSR_CHECK(hipMemcpyAsync(P_host, fwd_total(scratch), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "gsd_forward_stage1: copy");
     GSR_CHECK(hipStreamSynchronize(s), "gsd_forward_stage1: sync");
     return gsr_check_launch("gsd_forward_stage1", s, false);
 }
@@ -630,30 +917,43 @@ extern "C" int gsd_forward_stage2(const gsd_cfg* cfg, const gsd_inputs* in, cons
                                   void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    if (check_cfg(cfg, in, p)) return 1;
+    if (fwd_checks(cfg, in, p, scratch, scratch_bytes, "gsd_forward_stage2")) return 1;
     if (cfg->Nv == 0 || P == 0) return 0;
-    if (!scratch || scratch_bytes < gsd_forward_scratch_bytes(cfg->Nv)) { gsr_set_error("gsd_forward_stage2: scratch too small"); return 1; }
-    if (!out || !out->xyz || !out->color || !out->opacity || !out->scaling || !out->rot || !neural_opacity || !row_offset) {
-        gsr_set_error("gsd_forward_stage2: null output/input"); return 1;
-    }
-    if ((uintptr_t)out->rot & 15) { gsr_set_error("gsd_forward_stage2: rot must be 16-byte aligned"); return 1; }
-    DecArgs a = make_args(cfg, in, p, (const float*)scratch);       // W1p packed by stage 1 into the same scratch
-    hipLaunchKernelGGL(k_decode_emit, dim3(gsr_div_up(cfg->Nv, GSD_BLOCK)), dim3(GSD_BLOCK), 0, s, a, neural_opacity, row_offset, *out);
+    if (check_outputs(out, "gsd_forward_stage2")) return 1;
+    if (!neural_opacity || !row_offset) { gsr_set_error("gsd_forward_stage2: null input"); return 1; }
+    enqueue_stage2(cfg, in, neural_opacity, row_offset, out, scratch, s);      // the weight image was written by stage 1 into `scratch`
     return gsr_check_launch("gsd_forward_stage2", s, false);
 }
 
-// backward scratch: [W1p][feature-major columns SC_COLS x ld][tile partials][bias partials]
+extern "C" int gsd_forward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask,
+                           uint32_t* row_offset, const gsd_outputs* out, uint32_t* P_host, void* scratch, size_t scratch_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (fwd_checks(cfg, in, p, scratch, scratch_bytes, "gsd_forward")) return 1;
+    if (!P_host) { gsr_set_error("gsd_forward: P_host is NULL"); return 1; }
+    *P_host = 0;
+    if (cfg->Nv && (!neural_opacity || !mask || !row_offset)) { gsr_set_error("gsd_forward: null output"); return 1; }
+    if (cfg->Nv && check_outputs(out, "gsd_forward")) return 1;
+    enqueue_stage1(cfg, in, p, neural_opacity, mask, row_offset, scratch, s);
+    if (cfg->Nv == 0) return gsr_check_launch("gsd_forward", s, false);
+    enqueue_stage2(cfg, in, neural_opacity, row_offset, out, scratch, s);       // outputs sized for the worst case: no host round trip
+    GSR_CHECK(hipMemcpyAsync(P_host, fwd_total(scratch), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "gsd_forward: copy");
+    GSR_CHECK(hipStreamSynchronize(s), "gsd_forward: sync");
+    return gsr_check_launch("gsd_forward", s, false);
+}
+
+// backward scratch: [weight image][feature-major columns SC_COLS x ld][tile partials][bias partials]
 static size_t bwd_ld(const gsd_cfg* c) { return (size_t)gsr_div_up((uint32_t)(c->Nv > 0 ? c->Nv : 1), GSD_BLOCK) * GSD_BLOCK; }
 extern "C" size_t gsd_backward_scratch_bytes(const gsd_cfg* cfg)
 {
     if (!cfg) return 0;
-    return gsr_align(GSD_W1P_FLOATS * sizeof(float)) + gsr_align((size_t)SC_COLS * bwd_ld(cfg) * sizeof(float)) +
+    return gsr_align(IMG_FLOATS * sizeof(float)) + gsr_align((size_t)SC_COLS * bwd_ld(cfg) * sizeof(float)) +
            gsr_align((size_t)WG_MAXPROB * WG_WAVES * 3 * 256 * sizeof(float)) + gsr_align((size_t)WG_MAXPROB * WG_WAVES * 16 * sizeof(float));
 }
 
 extern "C" int gsd_backward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, const float* neural_opacity,
-                            const uint32_t* row_offset, uint32_t P, const gsd_out_grads* og, const gsd_in_grads* ig, void* scratch,
-                            size_t scratch_bytes, void* stream)
+                            const uint32_t* row_offset, uint32_t P, const gsd_out_grads* og, const gsd_in_grads* ig,
+                            const void* fwd_scratch, void* scratch, size_t scratch_bytes, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (check_cfg(cfg, in, p)) return 1;
@@ -680,21 +980,31 @@ extern "C" int gsd_backward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_
     if (((uintptr_t)og->rot | (uintptr_t)ig->feat) & 15) { gsr_set_error("gsd_backward: dL_drot / d_feat must be 16-byte aligned"); return 1; }
     (void)P;
     const size_t ld = bwd_ld(cfg);
-    float* W1p = (float*)scratch;
-    float* sc = (float*)((char*)scratch + gsr_align(GSD_W1P_FLOATS * sizeof(float)));
+    const float* img = fwd_scratch ? (const float*)fwd_scratch : (const float*)scratch;
+    float* sc = (float*)((char*)scratch + gsr_align(IMG_FLOATS * sizeof(float)));
     float* part = (float*)((char*)sc + gsr_align((size_t)SC_COLS * ld * sizeof(float)));
     float* bias_part = (float*)((char*)part + gsr_align((size_t)WG_MAXPROB * WG_WAVES * 3 * 256 * sizeof(float)));
-    launch_pack(cfg, p, W1p, s);
-    DecArgs a = make_args(cfg, in, p, W1p);
-    hipLaunchKernelGGL(k_decode_bwd, dim3(ld / GSD_BLOCK), dim3(GSD_BLOCK), 0, s, a, neural_opacity, row_offset, *og, ig->anchor, ig->feat,
-                       ig->offset, ig->scaling, sc, ld);
+    if (!fwd_scratch) launch_pack(cfg, p, (float*)scratch, nullptr, s);
+    DecArgs a = make_args(cfg, in);
+    {
+        const int n_tiles = (int)(ld / 16);
+        BwdArgs ba;
+        ba.d = a; ba.img = img; ba.neural_opacity = neural_opacity; ba.row_offset = row_offset; ba.og = *og; ba.d_offset = ig->offset;
+        ba.sc = sc; ba.n_tiles = n_tiles;
+        hipLaunchKernelGGL(k_dec_bwd_heads, dim3(tile_grid(n_tiles, GSD_BLOCK / 64, 512), 3), dim3(GSD_BLOCK),
+                           (size_t)BWD_LDS_SLOTS * 64 * sizeof(float), s, ba);
+        hipLaunchKernelGGL(k_dec_bwd_dx, dim3(tile_grid(n_tiles, GSD_BLOCK / 64, 1024)), dim3(GSD_BLOCK), 0, s, a, img,
+                           (const float*)sc, ig->anchor, ig->feat, ig->scaling, n_tiles);
+    }
 
     // weight-gradient problems
     WgArgs wa; WgOut wo;
     wa.sc = sc; wa.ld = ld; wa.n_chunks = (int)(ld / 64); wa.part = part; wa.bias_part = bias_part;
     wo.cfg = *cfg; wo.g = g; wo.part = part; wo.bias_part = bias_part;
     int np = 0;
+    wo.W1k = p->W1k; wo.app = p->app; wo.app_prob[0] = wo.app_prob[1] = 0;
     auto add = [&](int a_col, int b_col, int nb, int head, int layer, int row0) {
+        if (head == 2 && layer == 1) wo.app_prob[row0 / 16] = np;
         wa.prob[np] = {a_col, b_col, nb}; wo.head[np] = head; wo.layer[np] = layer; wo.row0[np] = row0; wo.nb[np] = nb; np++;
     };
     const int p2col[3] = {SC_P2O, SC_P2C, SC_P2K};
@@ -703,14 +1013,10 @@ extern "C" int gsd_backward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_
         for (int r0 = 0; r0 < outd[head]; r0 += 16) add(p2col[head] + r0, SC_H + 32 * head, 2, head, 2, r0);
         for (int r0 = 0; r0 < 32; r0 += 16) add(SC_P1 + 32 * head + r0, SC_X, 3, head, 1, r0);
     }
-    wa.n_prob = np;
+    wa.n_prob = np; wo.n_prob = np;
     const int waves = wa.n_chunks < WG_WAVES ? wa.n_chunks : WG_WAVES;
     wo.n_waves = waves;
     hipLaunchKernelGGL(k_wgrad, dim3(waves, np), dim3(64), 0, s, wa);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(np, 4), dim3(256), 0, s, wo);
-    if (cfg->A) {
-        AppArgs aa; aa.cfg = *cfg; aa.W1k = p->W1k; aa.app = p->app; aa.gW1k = g.W1k; aa.gb1k = g.b1k; aa.gapp = g.app;
-        hipLaunchKernelGGL(k_app_grads, dim3(1), dim3(64), 0, s, aa);
-    }
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(np + 1, 4), dim3(256), 0, s, wo);
     return gsr_check_launch("gsd_backward", s, false);
 }

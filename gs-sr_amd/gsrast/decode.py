@@ -14,7 +14,7 @@ from . import check, dev_f32, lib, ptr, stream_ptr
 _vp = C.c_void_p
 PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app")
 EXPORTS = ["gsd_compact_scratch_bytes", "gsd_compact_visible", "gsd_forward_scratch_bytes", "gsd_forward_stage1", "gsd_forward_stage2",
-           "gsd_backward_scratch_bytes", "gsd_backward"]
+           "gsd_forward", "gsd_backward_scratch_bytes", "gsd_backward"]
 
 
 class Cfg(C.Structure):
@@ -57,10 +57,13 @@ def _lib():
         L.gsd_forward_stage1.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, _vp, C.POINTER(C.c_uint32), _vp, sz, _vp]
         L.gsd_forward_stage2.restype = C.c_int
         L.gsd_forward_stage2.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, C.c_uint32, C.POINTER(Outputs), _vp, sz, _vp]
+        L.gsd_forward.restype = C.c_int
+        L.gsd_forward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, _vp, C.POINTER(Outputs),
+                                  C.POINTER(C.c_uint32), _vp, sz, _vp]
         L.gsd_backward_scratch_bytes.restype = sz; L.gsd_backward_scratch_bytes.argtypes = [C.POINTER(Cfg)]
         L.gsd_backward.restype = C.c_int
         L.gsd_backward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, C.c_uint32, C.POINTER(OutGrads),
-                                   C.POINTER(InGrads), _vp, sz, _vp]
+                                   C.POINTER(InGrads), _vp, _vp, sz, _vp]
         _bound = True
     return L
 
@@ -107,19 +110,18 @@ class _NeuralDecode(torch.autograd.Function):
         row_offset = torch.empty(max(Nv, 1), dtype=torch.int32, device=dev)
         scratch = torch.empty(L.gsd_forward_scratch_bytes(Nv), dtype=torch.uint8, device=dev)
         P = C.c_uint32(0)
-        s = stream_ptr(dev)
-        check(L.gsd_forward_stage1(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(mask), ptr(row_offset), C.byref(P), ptr(scratch),
-                                   scratch.numel(), s), "decode stage1")
-        n = P.value
-        xyz = torch.empty(n, 3, dtype=torch.float32, device=dev); color = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        opacity = torch.empty(n, 1, dtype=torch.float32, device=dev); scl = torch.empty(n, 3, dtype=torch.float32, device=dev)
-        rot = torch.empty(n, 4, dtype=torch.float32, device=dev)
+        cap = Nv * k          # worst case: every offset emitted -> stage 2 is enqueued without waiting for the host to learn P
+        xyz = torch.empty(cap, 3, dtype=torch.float32, device=dev); color = torch.empty(cap, 3, dtype=torch.float32, device=dev)
+        opacity = torch.empty(cap, 1, dtype=torch.float32, device=dev); scl = torch.empty(cap, 3, dtype=torch.float32, device=dev)
+        rot = torch.empty(cap, 4, dtype=torch.float32, device=dev)
         out = Outputs(ptr(xyz), ptr(color), ptr(opacity), ptr(scl), ptr(rot))
-        check(L.gsd_forward_stage2(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(row_offset), n, C.byref(out), ptr(scratch),
-                                   scratch.numel(), s), "decode stage2")
+        check(L.gsd_forward(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(mask), ptr(row_offset), C.byref(out), C.byref(P),
+                            ptr(scratch), scratch.numel(), stream_ptr(dev)), "decode forward")
+        n = P.value
+        xyz, color, opacity, scl, rot = xyz[:n], color[:n], opacity[:n], scl[:n], rot[:n]
         ctx.flags, ctx.n = flags, n
         ctx.save_for_backward(t["anchor"], t["feat"], t["offset"], t["scaling"], t["level"], t["opacity_scale"], t["vis_idx"], t["campos"],
-                              nop, row_offset, *[prm[nm] for nm in PARAM_NAMES])
+                              nop, row_offset, scratch, *[prm[nm] for nm in PARAM_NAMES])
         mask_b = mask.view(torch.bool)
         ctx.mark_non_differentiable(nop, mask_b)
         return xyz, color, opacity, scl, rot, nop, mask_b
@@ -130,8 +132,8 @@ class _NeuralDecode(torch.autograd.Function):
         sv = ctx.saved_tensors
         names = ("anchor", "feat", "offset", "scaling", "level", "opacity_scale", "vis_idx", "campos")
         t = dict(zip(names, sv[:8]))
-        nop, row_offset = sv[8], sv[9]
-        prm = dict(zip(PARAM_NAMES, sv[10:]))
+        nop, row_offset, fwd_scratch = sv[8], sv[9], sv[10]
+        prm = dict(zip(PARAM_NAMES, sv[11:]))
         dev = t["anchor"].device
         Na, Nv, n = t["anchor"].shape[0], t["vis_idx"].numel(), ctx.n
         cfg, inp, cp = _structs(ctx.flags, Na, Nv, t, prm)
@@ -145,8 +147,9 @@ class _NeuralDecode(torch.autograd.Function):
         gp = {nm: (None if prm[nm] is None else torch.empty_like(prm[nm])) for nm in PARAM_NAMES}
         ig = InGrads(ptr(d_anchor), ptr(d_feat), ptr(d_offset), ptr(d_scaling), Params(*[ptr(gp[nm]) for nm in PARAM_NAMES]))
         scratch = torch.empty(L.gsd_backward_scratch_bytes(C.byref(cfg)), dtype=torch.uint8, device=dev)
-        check(L.gsd_backward(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(row_offset), n, C.byref(ogr), C.byref(ig), ptr(scratch),
-                             scratch.numel(), stream_ptr(dev)), "decode backward")
+        # parameters are unchanged between forward and backward of one graph, so the forward's repacked weights are reused
+        check(L.gsd_backward(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(row_offset), n, C.byref(ogr), C.byref(ig),
+                             ptr(fwd_scratch), ptr(scratch), scratch.numel(), stream_ptr(dev)), "decode backward")
         return (None, None, None, None, None, d_anchor, d_feat, d_offset, d_scaling, *[gp[nm] for nm in PARAM_NAMES])
 
 

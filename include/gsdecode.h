@@ -98,11 +98,18 @@ int gsd_forward_stage1(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_param
 int gsd_forward_stage2(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, const float* neural_opacity,
                        const uint32_t* row_offset, uint32_t P, const gsd_outputs* out, void* scratch, size_t scratch_bytes, void* stream);
 
+/* single call: stage 1 and stage 2 enqueued back to back, no host round trip in between.  `out` must have room for the worst case
+   Nv*k rows; the first *P_host rows are valid on return (one stream synchronisation at the end).  scratch as for stage 1. */
+int gsd_forward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask, uint32_t* row_offset,
+                const gsd_outputs* out, uint32_t* P_host, void* scratch, size_t scratch_bytes, void* stream);
+
 /* backward: recomputes the heads, writes the per-anchor gradients, and contracts the weight gradients over the anchors with MFMA.
-   scratch >= gsd_backward_scratch_bytes(cfg). */
+   scratch >= gsd_backward_scratch_bytes(cfg).  fwd_scratch: the forward's scratch buffer if the caller kept it and the parameters are
+   unchanged since (its repacked weights are reused), else NULL. */
 size_t gsd_backward_scratch_bytes(const gsd_cfg* cfg);
 int gsd_backward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, const float* neural_opacity, const uint32_t* row_offset,
-                 uint32_t P, const gsd_out_grads* og, const gsd_in_grads* ig, void* scratch, size_t scratch_bytes, void* stream);
+                 uint32_t P, const gsd_out_grads* og, const gsd_in_grads* ig, const void* fwd_scratch, void* scratch, size_t scratch_bytes,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,20 +5,14 @@ import torch
 import torch.nn.functional as Fn
 
 
-def decode(case, dtype=torch.float64, mask_override=None, device="cpu"):
-    """-> (outputs dict, leaves dict).  Leaves require grad; outputs are torch tensors (compacted like the reference)."""
-    t = lambda a: None if a is None else torch.tensor(a, dtype=dtype, device=device)
+def _chain(case, leaves, par, vis, campos, lvl_t, osc_t, mask_override=None):
     k = case["k"]
-    leaves = {n: t(case[n]).requires_grad_(True) for n in ("anchor", "feat", "offset", "scaling")}
-    par = {n: t(v).requires_grad_(True) for n, v in case["params"].items() if v is not None}
-    vis = torch.tensor(case["vis_idx"], dtype=torch.long, device=device)
-    campos = t(case["campos"])
     anchor = leaves["anchor"][vis]; feat = leaves["feat"][vis]
     grid_offsets = leaves["offset"][vis]; grid_scaling = leaves["scaling"][vis]
     ob_view = anchor - campos
     ob_dist = ob_view.norm(dim=1, keepdim=True)
     ob_view = ob_view / ob_dist
-    lvl = [] if case["level"] is None else [t(case["level"])[vis].unsqueeze(1)]
+    lvl = [] if lvl_t is None else [lvl_t[vis].unsqueeze(1)]
     with_dist = torch.cat([feat, ob_view, ob_dist] + lvl, dim=1)
     wo_dist = torch.cat([feat, ob_view] + lvl, dim=1)
     pick = lambda flag: with_dist if flag else wo_dist
@@ -26,13 +20,13 @@ def decode(case, dtype=torch.float64, mask_override=None, device="cpu"):
     def head(x, W1, b1, W2, b2):
         return Fn.linear(torch.relu(Fn.linear(x, par[W1], par[b1])), par[W2], par[b2])
     neural_opacity = torch.tanh(head(pick(case["dist_o"]), "W1o", "b1o", "W2o", "b2o"))
-    if case["opacity_scale"] is not None:
-        neural_opacity = neural_opacity * t(case["opacity_scale"])[vis].unsqueeze(1)
+    if osc_t is not None:
+        neural_opacity = neural_opacity * osc_t[vis].unsqueeze(1)
     neural_opacity = neural_opacity.reshape([-1, 1])
-    mask = (neural_opacity > 0.0).view(-1) if mask_override is None else torch.tensor(mask_override, dtype=torch.bool, device=device)
+    mask = (neural_opacity > 0.0).view(-1) if mask_override is None else mask_override
     opacity = neural_opacity[mask]
     xk = pick(case["dist_k"])
-    if "app" in par:
+    if par.get("app") is not None:
         xk = torch.cat([xk, par["app"].unsqueeze(0).expand(xk.shape[0], -1)], dim=1)
     color = torch.sigmoid(head(xk, "W1k", "b1k", "W2k", "b2k")).reshape([anchor.shape[0] * k, 3])
     scale_rot = head(pick(case["dist_c"]), "W1c", "b1c", "W2c", "b2c").reshape([anchor.shape[0] * k, 7])
@@ -44,8 +38,23 @@ def decode(case, dtype=torch.float64, mask_override=None, device="cpu"):
     scaling = scaling_repeat[:, 3:] * torch.sigmoid(scale_rot[:, :3])
     rot = Fn.normalize(scale_rot[:, 3:7])
     xyz = repeat_anchor + offsets * scaling_repeat[:, :3]
-    out = {"xyz": xyz, "color": color, "opacity": opacity.view(-1), "scaling": scaling, "rot": rot,
-           "neural_opacity": neural_opacity.view(-1), "mask": mask}
+    return {"xyz": xyz, "color": color, "opacity": opacity.view(-1), "scaling": scaling, "rot": rot,
+            "neural_opacity": neural_opacity.view(-1), "mask": mask}
+
+
+def decode_live(case, leaves, par, vis, campos):
+    """the chain on caller-owned device tensors (benchmark use)"""
+    return _chain(case, leaves, par, vis, campos, None, None), leaves
+
+
+def decode(case, dtype=torch.float64, mask_override=None, device="cpu"):
+    """-> (outputs dict, leaves dict).  Leaves require grad; outputs are torch tensors (compacted like the reference)."""
+    t = lambda a: None if a is None else torch.tensor(a, dtype=dtype, device=device)
+    leaves = {n: t(case[n]).requires_grad_(True) for n in ("anchor", "feat", "offset", "scaling")}
+    par = {n: t(v).requires_grad_(True) for n, v in case["params"].items() if v is not None}
+    vis = torch.tensor(case["vis_idx"], dtype=torch.long, device=device)
+    mo = None if mask_override is None else torch.tensor(mask_override, dtype=torch.bool, device=device)
+    out = _chain(case, leaves, par, vis, t(case["campos"]), t(case["level"]), t(case["opacity_scale"]), mo)
     leaves.update(par)
     return out, leaves
 
