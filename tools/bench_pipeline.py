@@ -1,0 +1,98 @@
+"""End-to-end scaffold-2dgs iteration on synthetic anchors (BASELINE.json configs[1] with its neural-Gaussian decode in front):
+    prefilter (scaffold_filter.visible_filter) -> neural-Gaussian decode -> diff_surfel_rasterization fwd -> loss -> backward -> fused Adam.
+--decode hip   : gsrast.decode (fused HIP, include/gsdecode.h)
+--decode torch : the reference's torch op chain for the decode (tests/ref_decode_torch.py transcription), same rasterizer
+Na anchors x k=10 offsets sized so that ~300k Gaussians reach the rasterizer at 1920x1080.  One JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gs-sr_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hiprun                          # noqa: E402
+import ref_decode_torch                # noqa: E402
+import scenes                          # noqa: E402
+import diff_surfel_rasterization as dsr   # noqa: E402
+import scaffold_filter as sf           # noqa: E402
+from gsrast import decode              # noqa: E402
+from gsrast.losses import l1_plus_linear  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--decode", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--Na", type=int, default=72000)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    W, H, k, A = 1920, 1080, 10, 32
+    sc = scenes.make_scene("surfel", a.Na, W, H, seed=0, color_mode="precomp")
+    t = hiprun.to_dev(sc, dev)
+    rs = hiprun.settings("surfel", t)
+    fs = sf.GaussianRasterizationSettings(**rs._asdict())
+    g = torch.Generator(device="cpu").manual_seed(7)
+    anchor = t["means3D"].clone().requires_grad_(True)
+    s2 = t["scales"]                                         # (Na,2) world-space sigma of the synthetic scene
+    ext = s2.mean(dim=1, keepdim=True)
+    scaling_log = torch.log(torch.cat([3.0 * ext.expand(-1, 3), 2.0 * s2, 2.0 * s2[:, :1]], dim=1)).requires_grad_(True)
+    feat = torch.randn(a.Na, 32, generator=g).to(dev).requires_grad_(True)
+    offset = (0.5 * torch.randn(a.Na, k, 3, generator=g)).to(dev).requires_grad_(True)
+    rot_anchor = torch.nn.functional.normalize(torch.randn(a.Na, 4, generator=g), dim=1).to(dev)
+    mlp = lambda i, o, act: torch.nn.Sequential(torch.nn.Linear(i, 32), torch.nn.ReLU(True), torch.nn.Linear(32, o), act).to(dev)
+    torch.manual_seed(3)
+    mlp_o, mlp_c, mlp_k = mlp(35, k, torch.nn.Tanh()), mlp(35, 7 * k, torch.nn.Identity()), mlp(35 + A, 3 * k, torch.nn.Sigmoid())
+    emb = torch.nn.Embedding(4, A).to(dev)
+    params = [anchor, scaling_log, feat, offset, emb.weight] + [p for m in (mlp_o, mlp_c, mlp_k) for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15, fused=True)
+    gt = torch.rand((3, H, W), generator=g).to(dev)
+    N = float(W * H)
+    gtn = torch.nn.functional.normalize(torch.randn((3, H, W), generator=g), dim=0)
+    wmap = torch.zeros((11, H, W))
+    wmap[0] = 0.01 / N; wmap[1] = 0.01 / N; wmap[2:5] = -0.05 * gtn / N; wmap[5] = 0.01 / N; wmap[6] = 100.0 / N
+    wmap = wmap.to(dev)
+    campos = t["campos"]
+    case = {"k": k, "dist_o": False, "dist_c": False, "dist_k": False}
+    st = {}
+
+    def step():
+        scaling = torch.exp(scaling_log)
+        with torch.no_grad():                                 # prefilter_voxel (scaffold_scene.py:122-155)
+            radii = sf.GaussianRasterizer(fs).visible_filter(means3D=anchor, scales=scaling[:, :3], rotations=rot_anchor, cov3D_precomp=None)
+            vmask = radii > 0
+        app = emb.weight[1]
+        if a.decode == "hip":
+            xyz, color, opacity, scl, rot, nop, mask = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos,
+                                                                              visible_mask=vmask, appearance=app)
+        else:
+            vis = torch.nonzero(vmask).view(-1)
+            leaves = {"anchor": anchor, "feat": feat, "offset": offset, "scaling": scaling}
+            par = {"W1o": mlp_o[0].weight, "b1o": mlp_o[0].bias, "W2o": mlp_o[2].weight, "b2o": mlp_o[2].bias,
+                   "W1c": mlp_c[0].weight, "b1c": mlp_c[0].bias, "W2c": mlp_c[2].weight, "b2c": mlp_c[2].bias,
+                   "W1k": mlp_k[0].weight, "b1k": mlp_k[0].bias, "W2k": mlp_k[2].weight, "b2k": mlp_k[2].bias, "app": app}
+            o, _ = ref_decode_torch.decode_live(case, leaves, par, vis, campos)
+            xyz, color, opacity, scl, rot = o["xyz"], o["color"], o["opacity"].view(-1, 1), o["scaling"], o["rot"]
+        means2D = torch.zeros_like(xyz, requires_grad=True)
+        img, rad, allmap = dsr.GaussianRasterizer(rs)(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color,
+                                                      scales=scl[:, :2].contiguous(), rotations=rot)
+        loss = l1_plus_linear(img, gt, allmap, wmap) + 0.01 * scl[:, :2].prod(dim=1).mean()     # + scaling_loss (scaffold_2dgs_scene.py:26)
+        loss.backward()
+        opt.step(); opt.zero_grad(set_to_none=True)
+        st["P"] = xyz.shape[0]; st["Nv"] = int(vmask.sum()) if "Nv" not in st else st["Nv"]
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"pipeline": "scaffold-2dgs", "decode": a.decode, "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps,
+                      "ms_per_iter": 1e3 * dt / a.steps, "iters_per_s": a.steps / dt}))
+
+
+if __name__ == "__main__":
+    main()
