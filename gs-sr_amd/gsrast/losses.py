@@ -32,3 +32,36 @@ def l1_plus_linear(color, gt, aux=None, waux=None):
     """mean|color - gt| + sum(aux * waux), forward value and dL/dcolor in ONE streaming HIP kernel.
     Equivalent torch: (color - gt).abs().mean() + (aux * waux).sum()."""
     return _L1PlusLinear.apply(color, gt, aux, waux)
+
+
+class _L1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        x = dev_f32(image, "image", allow_empty=False)
+        y = dev_f32(gt, "gt", allow_empty=False)
+        if x.dim() != 3 or x.shape != y.shape:
+            raise RuntimeError("image and gt must both be (C, H, W)")
+        Cc, H, W = x.shape
+        L = lib()
+        out = torch.empty(3, dtype=torch.float32, device=x.device)
+        dimg = torch.empty_like(x)
+        scratch = torch.empty(L.gsr_loss_l1_ssim_scratch_bytes(Cc, H, W), dtype=torch.uint8, device=x.device)
+        check(L.gsr_loss_l1_ssim(Cc, H, W, ptr(x), ptr(y), float(lambda_dssim), ptr(out), ptr(dimg), ptr(scratch), scratch.numel(),
+                                 stream_ptr(x.device)), "loss_l1_ssim")
+        ctx.save_for_backward(dimg)
+        parts = out[:2].detach()
+        ctx.mark_non_differentiable(parts)
+        return out[2], parts
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        (dimg,) = ctx.saved_tensors
+        return dimg * g, None, None
+
+
+def l1_ssim(image, gt, lambda_dssim=0.2, return_parts=False):
+    """(1 - lambda) * |image - gt|.mean() + lambda * (1 - ssim(image, gt)) -- the sum of the reference's `L1_loss` and `ssim_loss`
+    entries (gssr/scene/vanilla_scene.py:63-69) -- with value and dL/dimage from two fused HIP kernels.  `return_parts=True` also returns
+    the (non-differentiable) tensor [mean|image-gt|, mean SSIM] for logging."""
+    loss, parts = _L1SSIM.apply(image, gt, lambda_dssim)
+    return (loss, parts) if return_parts else loss

@@ -170,6 +170,13 @@ int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* or
  * dL/daux is waux itself, so nothing is written for it. */
 int gsr_loss_l1_linear(int64_t n_color, const float* color, const float* gt, float* dL_dcolor,
                        int64_t n_aux, const float* aux, const float* waux, float* loss_out, void* stream);
+/* Fused photometric loss (gssr/scene/vanilla_scene.py:29-69, used by every method's get_loss_dict):
+ *   loss = (1-lambda)*mean|img-gt| + lambda*(1 - SSIM(img,gt)), SSIM with the 11x11 sigma-1.5 window, zero padding, C1=0.01^2, C2=0.03^2.
+ * loss_out (device, 3 floats, overwritten): {mean|img-gt|, mean SSIM, loss}.  dL_dimg [C,H,W] = d loss / d img.
+ * scratch >= gsr_loss_l1_ssim_scratch_bytes (three derivative maps). */
+size_t gsr_loss_l1_ssim_scratch_bytes(int32_t C, int32_t H, int32_t W);
+int gsr_loss_l1_ssim(int32_t C, int32_t H, int32_t W, const float* img /*[C,H,W]*/, const float* gt, float lambda_dssim,
+                     float* loss_out /*[3]*/, float* dL_dimg, void* scratch, size_t scratch_bytes, void* stream);
 size_t gsr_dist2_scratch_bytes(int32_t P);
 int gsr_dist2(int32_t P, const float* points /*[P,3]*/, float* out /*[P]*/, void* scratch, size_t scratch_bytes,
               void* stream);

@@ -247,3 +247,14 @@ def dist2(points):
 
 def omp_threads():
     return int(lib().ref_omp_threads())
+
+
+def loss_l1_ssim(img, gt, lam):
+    """-> (loss[3] = {l1, ssim, loss}, dL_dimg) of the photometric loss (oracle/gsl_oracle.c)."""
+    L = lib()
+    L.ref_loss_l1_ssim.restype = None
+    img = _f32(img); gt = _f32(gt)
+    Cc, H, W = img.shape
+    out = np.zeros(3, np.float32); d = np.zeros_like(img)
+    L.ref_loss_l1_ssim(C.c_int32(Cc), C.c_int32(H), C.c_int32(W), _p(img), _p(gt), C.c_float(lam), _p(out), _p(d))
+    return out, d
