@@ -46,4 +46,16 @@ rs = scaffold_filter.GaussianRasterizationSettings(image_height=H, image_width=W
 rr = scaffold_filter.GaussianRasterizer(rs)
 t = timeit(lambda: rr.visible_filter(td["means3D"], td["scales"], td["rotations"]), n=50)
 out["visible_filter_300k"] = {"ms": round(t * 1e3, 4), "algorithmic_GBps": round(300000 * 44 / t / 1e9, 1)}
+# fused L1+SSIM photometric loss (value + dL/dimg) vs the reference's torch formula, 3x1080x1920
+from gsrast.losses import l1_ssim
+import ref_loss_torch
+img = torch.rand(3, H, W, device="cuda").requires_grad_(True); gt = torch.rand(3, H, W, device="cuda")
+def hip_loss():
+    img.grad = None; l1_ssim(img, gt, 0.2).backward()
+def torch_loss():
+    img.grad = None; ref_loss_torch.loss(img.unsqueeze(0), gt.unsqueeze(0), 0.2)[0].backward()
+th, tt = timeit(hip_loss, n=30), timeit(torch_loss, n=10)
+npx = 3 * H * W
+out["l1_ssim_1080p"] = {"hip_fwd_bwd_ms": round(th * 1e3, 3), "torch_fwd_bwd_ms": round(tt * 1e3, 3), "speedup": round(tt / th, 1),
+                        "algorithmic_GBps": round(npx * 44 / th / 1e9, 1)}
 print(json.dumps(out))
