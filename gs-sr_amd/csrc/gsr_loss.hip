@@ -168,3 +168,166 @@ extern "C" int gsr_loss_l1_ssim(int32_t C, int32_t H, int32_t W, const float* im
     hipLaunchKernelGGL(k_ssim_finish, dim3(1), dim3(1024), 0, s, (const float2*)partial, (int)ssim_blocks(C, H, W), loss_out, inv_n, lambda_dssim);
     return gsr_check_launch("loss_l1_ssim", s, false);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 2DGS geometric regularisers in ONE kernel (forward values, loss, and dL/dallmap):
+//   TwoDGSScene.render post-processing (gssr/scene/twodgs_scene.py:88-115), depth_to_normal (gssr/utils/point_utils.py:9-37),
+//   normal + distortion losses (twodgs_scene.py:25-35).  ~35 N-sized torch ops (+ autograd) in the reference.
+// 16x16 pixel tile per block; the 3x3 normal stencil and its adjoint (a 13-point diamond in depth) are staged through LDS:
+//   P   (20x20) = depth * ray                      halo 2
+//   g   (18x18) = d loss / d (dx, dy) per pixel    halo 1     (zero for non-interior pixels)
+// then every pixel gathers  dP = g_dx(y-1,x) - g_dx(y+1,x) + g_dy(y,x-1) - g_dy(y,x+1)  and chains it into allmap channels 0, 1, 5.
+// Algorithmic bytes: 7 channels read + 11 written (+ optional outputs) = 72 B per pixel.
+#define GEO_T 16
+#define GEO_P (GEO_T + 4)      // 20
+#define GEO_G (GEO_T + 2)      // 18
+
+struct GeoArgs {
+    int H, W;
+    const float* allmap; const float* ray_mat; const float* normal_rot;
+    float depth_ratio, wn, wd;
+    float2* partial; float* dL; float* o_depth; float* o_nw; float* o_sn;
+};
+
+__device__ __forceinline__ float nan0(float v) { return (isnan(v) || isinf(v)) ? 0.0f : v; }
+
+__global__ void __launch_bounds__(256) k_surfel_geo(GeoArgs p)
+{
+    __shared__ float sP[3][GEO_P][GEO_P + 1];
+    __shared__ float sG[6][GEO_G][GEO_G + 1];
+    __shared__ float sDot[GEO_G][GEO_G + 1];
+    __shared__ float sN[3][GEO_G][GEO_G + 1];
+    __shared__ float red[4];
+    typedef const float __attribute__((address_space(4))) * cfp;
+    float rm[9], nr[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { rm[i] = ((cfp)p.ray_mat)[i]; nr[i] = ((cfp)p.normal_rot)[i]; }
+    const int H = p.H, W = p.W, x0 = blockIdx.x * GEO_T, y0 = blockIdx.y * GEO_T;
+    const size_t N = (size_t)H * W;
+    for (int e = threadIdx.x; e < GEO_P * GEO_P; e += 256) {
+        const int ly = e / GEO_P, lx = e % GEO_P, gy = y0 + ly - 2, gx = x0 + lx - 2;
+        float P0 = 0.f, P1 = 0.f, P2 = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t o = (size_t)gy * W + gx;
+            const float a = p.allmap[N + o];
+            const float d = nan0(p.allmap[o] / a) * (1.0f - p.depth_ratio) + p.depth_ratio * nan0(p.allmap[5 * N + o]);
+            const float fx = (float)gx, fy = (float)gy;
+            P0 = d * (fx * rm[0] + fy * rm[3] + rm[6]); P1 = d * (fx * rm[1] + fy * rm[4] + rm[7]); P2 = d * (fx * rm[2] + fy * rm[5] + rm[8]);
+        }
+        sP[0][ly][lx] = P0; sP[1][ly][lx] = P1; sP[2][ly][lx] = P2;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < GEO_G * GEO_G; e += 256) {
+        const int ly = e / GEO_G, lx = e % GEO_G, gy = y0 + ly - 1, gx = x0 + lx - 1;
+        float g[6] = {0, 0, 0, 0, 0, 0}, n[3] = {0, 0, 0}, dot = 0.f;
+        if (gy >= 1 && gy <= H - 2 && gx >= 1 && gx <= W - 2) {
+            const size_t o = (size_t)gy * W + gx;
+            const float a = p.allmap[N + o];
+            const float nv0 = p.allmap[2 * N + o], nv1 = p.allmap[3 * N + o], nv2 = p.allmap[4 * N + o];
+            float nw[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) nw[c] = nv0 * nr[c] + nv1 * nr[3 + c] + nv2 * nr[6 + c];
+            const int py = ly + 1, px = lx + 1;                 // position in the P tile
+            float dx[3], dy[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { dx[c] = sP[c][py + 1][px] - sP[c][py - 1][px]; dy[c] = sP[c][py][px + 1] - sP[c][py][px - 1]; }
+            const float c0 = dx[1] * dy[2] - dx[2] * dy[1], c1 = dx[2] * dy[0] - dx[0] * dy[2], c2 = dx[0] * dy[1] - dx[1] * dy[0];
+            const float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+            const float inv = 1.0f / fmaxf(len, 1e-12f);
+            n[0] = c0 * inv; n[1] = c1 * inv; n[2] = c2 * inv;
+            dot = a * (nw[0] * n[0] + nw[1] * n[1] + nw[2] * n[2]);
+            float dn[3], dc[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) dn[c] = -p.wn * a * nw[c];
+            const float nd = len > 1e-12f ? n[0] * dn[0] + n[1] * dn[1] + n[2] * dn[2] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) dc[c] = (dn[c] - n[c] * nd) * inv;
+            g[0] = dy[1] * dc[2] - dy[2] * dc[1]; g[1] = dy[2] * dc[0] - dy[0] * dc[2]; g[2] = dy[0] * dc[1] - dy[1] * dc[0];
+            g[3] = dc[1] * dx[2] - dc[2] * dx[1]; g[4] = dc[2] * dx[0] - dc[0] * dx[2]; g[5] = dc[0] * dx[1] - dc[1] * dx[0];
+            n[0] *= a; n[1] *= a; n[2] *= a;                   // surf_normal = n * alpha
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) sG[c][ly][lx] = g[c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) sN[c][ly][lx] = n[c];
+        sDot[ly][lx] = dot;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, gx = x0 + lx, gy = y0 + ly;
+    float err = 0.f, dist = 0.f;
+    if (gx < W && gy < H) {
+        const size_t o = (size_t)gy * W + gx;
+        const int qy = ly + 1, qx = lx + 1;                    // position in the g tile
+        float dP[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) dP[c] = sG[c][qy - 1][qx] - sG[c][qy + 1][qx] + sG[3 + c][qy][qx - 1] - sG[3 + c][qy][qx + 1];
+        const float fx = (float)gx, fy = (float)gy;
+        const float dd = dP[0] * (fx * rm[0] + fy * rm[3] + rm[6]) + dP[1] * (fx * rm[1] + fy * rm[4] + rm[7]) + dP[2] * (fx * rm[2] + fy * rm[5] + rm[8]);
+        const float a0 = p.allmap[o], a = p.allmap[N + o], m = p.allmap[5 * N + o], q = a0 / a;
+        const bool okq = !(isnan(q) || isinf(q)), okm = !(isnan(m) || isinf(m));
+        p.dL[o] = okq ? dd * (1.0f - p.depth_ratio) / a : 0.0f;
+        p.dL[N + o] = okq ? -dd * (1.0f - p.depth_ratio) * a0 / (a * a) : 0.0f;
+        p.dL[5 * N + o] = okm ? dd * p.depth_ratio : 0.0f;
+        const float s0 = sN[0][qy][qx], s1 = sN[1][qy][qx], s2 = sN[2][qy][qx];
+#pragma unroll
+        for (int i = 0; i < 3; i++) p.dL[(2 + i) * N + o] = -p.wn * (nr[3 * i] * s0 + nr[3 * i + 1] * s1 + nr[3 * i + 2] * s2);
+        p.dL[6 * N + o] = p.wd;
+#pragma unroll
+        for (int c = 7; c < 11; c++) p.dL[c * N + o] = 0.0f;
+        err = 1.0f - sDot[qy][qx];
+        dist = p.allmap[6 * N + o];
+        if (p.o_depth) p.o_depth[o] = (okq ? q : 0.0f) * (1.0f - p.depth_ratio) + p.depth_ratio * (okm ? m : 0.0f);
+        if (p.o_sn) { p.o_sn[o] = s0; p.o_sn[N + o] = s1; p.o_sn[2 * N + o] = s2; }
+        if (p.o_nw) {
+            const float nv0 = p.allmap[2 * N + o], nv1 = p.allmap[3 * N + o], nv2 = p.allmap[4 * N + o];
+#pragma unroll
+            for (int c = 0; c < 3; c++) p.o_nw[c * N + o] = nv0 * nr[c] + nv1 * nr[3 + c] + nv2 * nr[6 + c];
+        }
+    }
+    const float te = block_sum256(err, red);
+    __syncthreads();
+    const float td = block_sum256(dist, red);
+    if (threadIdx.x == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = make_float2(te, td);
+}
+
+__global__ void __launch_bounds__(1024) k_geo_finish(const float2* __restrict__ partial, int n, float* loss, float inv_n, float ln, float ld)
+{
+    __shared__ float r1[16], r2[16];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) { const float2 q = partial[i]; a += q.x; b += q.y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = a; r2[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sa = 0.f, sb = 0.f;
+        for (int w = 0; w < 16; w++) { sa += r1[w]; sb += r2[w]; }
+        loss[0] = sa * inv_n; loss[1] = sb * inv_n; loss[2] = ln * loss[0] + ld * loss[1];
+    }
+}
+
+extern "C" size_t gsr_loss_surfel_geo_scratch_bytes(int32_t H, int32_t W)
+{
+    return (H > 0 && W > 0) ? (size_t)gsr_div_up(W, GEO_T) * gsr_div_up(H, GEO_T) * sizeof(float2) : 0;
+}
+
+extern "C" int gsr_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, const float* ray_mat, const float* normal_rot, float depth_ratio,
+                                   float lambda_normal, float lambda_dist, float* loss_out, float* dL_dallmap, float* out_surf_depth,
+                                   float* out_normal_world, float* out_surf_normal, void* scratch, size_t scratch_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (H <= 0 || W <= 0) { gsr_set_error("loss_surfel_geo: bad sizes H=%d W=%d", H, W); return 1; }
+    if (!allmap || !ray_mat || !normal_rot || !loss_out || !dL_dallmap || !scratch || scratch_bytes < gsr_loss_surfel_geo_scratch_bytes(H, W)) {
+        gsr_set_error("loss_surfel_geo: null pointer or scratch too small"); return 1;
+    }
+    GeoArgs a;
+    const float inv_n = 1.0f / ((float)H * (float)W);
+    a.H = H; a.W = W; a.allmap = allmap; a.ray_mat = ray_mat; a.normal_rot = normal_rot; a.depth_ratio = depth_ratio;
+    a.wn = lambda_normal * inv_n; a.wd = lambda_dist * inv_n; a.partial = (float2*)scratch; a.dL = dL_dallmap;
+    a.o_depth = out_surf_depth; a.o_nw = out_normal_world; a.o_sn = out_surf_normal;
+    const dim3 grid(gsr_div_up(W, GEO_T), gsr_div_up(H, GEO_T));
+    hipLaunchKernelGGL(k_surfel_geo, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_geo_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, (int)(grid.x * grid.y), loss_out, inv_n, lambda_normal,
+                       lambda_dist);
+    return gsr_check_launch("loss_surfel_geo", s, false);
+}

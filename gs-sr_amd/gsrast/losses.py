@@ -65,3 +65,50 @@ def l1_ssim(image, gt, lambda_dssim=0.2, return_parts=False):
     the (non-differentiable) tensor [mean|image-gt|, mean SSIM] for logging."""
     loss, parts = _L1SSIM.apply(image, gt, lambda_dssim)
     return (loss, parts) if return_parts else loss
+
+
+def camera_ray_matrices(world_view_transform, full_proj_transform, W, H):
+    """-> (ray_mat, normal_rot), 3x3 each, built with the reference's own op sequence (gssr/utils/point_utils.py:9-22,
+    gssr/scene/twodgs_scene.py:93): rays_d = [x y 1] @ ray_mat, normal_world = normal_view @ normal_rot.  Per camera, cacheable."""
+    wvt, fpt = world_view_transform, full_proj_transform
+    c2w = (wvt.T).inverse()
+    ndc2pix = torch.tensor([[W / 2, 0, 0, (W) / 2], [0, H / 2, 0, (H) / 2], [0, 0, 0, 1]], dtype=wvt.dtype, device=wvt.device).T
+    intrins = ((c2w.T @ fpt) @ ndc2pix)[:3, :3].T
+    return (intrins.inverse().T @ c2w[:3, :3].T).contiguous(), wvt[:3, :3].T.contiguous()
+
+
+class _SurfelGeo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist, want_maps):
+        am = dev_f32(allmap, "allmap", allow_empty=False)
+        if am.dim() != 3 or am.shape[0] != 11:
+            raise RuntimeError("allmap must be (11, H, W)")
+        rm = dev_f32(ray_mat, "ray_mat", allow_empty=False); nr = dev_f32(normal_rot, "normal_rot", allow_empty=False)
+        _, H, W = am.shape
+        L = lib()
+        dev = am.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        dL = torch.empty_like(am)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev) if want_maps else None
+        nw = torch.empty(3, H, W, dtype=torch.float32, device=dev) if want_maps else None
+        sn = torch.empty(3, H, W, dtype=torch.float32, device=dev) if want_maps else None
+        scratch = torch.empty(max(L.gsr_loss_surfel_geo_scratch_bytes(H, W), 8), dtype=torch.uint8, device=dev)
+        check(L.gsr_loss_surfel_geo(H, W, ptr(am), ptr(rm), ptr(nr), float(depth_ratio), float(lambda_normal), float(lambda_dist), ptr(out),
+                                    ptr(dL), ptr(depth), ptr(nw), ptr(sn), ptr(scratch), scratch.numel(), stream_ptr(dev)), "loss_surfel_geo")
+        ctx.save_for_backward(dL)
+        parts = out[:2].detach()
+        extras = [parts] + ([depth, nw, sn] if want_maps else [])
+        ctx.mark_non_differentiable(*extras)
+        return (out[2], *extras)
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        (dL,) = ctx.saved_tensors
+        return dL * g, None, None, None, None, None, None
+
+
+def surfel_geo_loss(allmap, ray_mat, normal_rot, depth_ratio=0.0, lambda_normal=0.05, lambda_dist=0.0, return_maps=False):
+    """lambda_normal * normal_loss + lambda_dist * dist_loss of TwoDGSScene.get_loss_dict (gssr/scene/twodgs_scene.py:25-35) computed
+    straight from the rasterizer's allmap, fused with the render() post-processing (:88-115) and depth_to_normal.
+    -> loss, parts=[mean normal error, mean distortion]  (+ depth (1,H,W), normal (3,H,W), surf_normal (3,H,W) when return_maps)."""
+    return _SurfelGeo.apply(allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist, bool(return_maps))

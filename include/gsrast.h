@@ -177,6 +177,18 @@ int gsr_loss_l1_linear(int64_t n_color, const float* color, const float* gt, flo
 size_t gsr_loss_l1_ssim_scratch_bytes(int32_t C, int32_t H, int32_t W);
 int gsr_loss_l1_ssim(int32_t C, int32_t H, int32_t W, const float* img /*[C,H,W]*/, const float* gt, float lambda_dssim,
                      float* loss_out /*[3]*/, float* dL_dimg, void* scratch, size_t scratch_bytes, void* stream);
+/* 2DGS geometric regularisers fused with the render() post-processing (gssr/scene/twodgs_scene.py:25-35,88-115;
+ * gssr/utils/point_utils.py:9-37 depths_to_points / depth_to_normal):
+ *   depth = nan_to_num(allmap[0]/allmap[1])*(1-depth_ratio) + depth_ratio*nan_to_num(allmap[5]);  P = depth * ([x y 1] * ray_mat)
+ *   surf_normal = normalize(cross(P(y+1,x)-P(y-1,x), P(y,x+1)-P(y,x-1))) * allmap[1] (alpha detached), 0 on the image border
+ *   normal = allmap[2:5] * normal_rot;  loss = lambda_normal*mean(1 - <normal, surf_normal>) + lambda_dist*mean(allmap[6])
+ * ray_mat, normal_rot: DEVICE [9] row-major, row-vector convention (gsrast.losses.camera_ray_matrices builds them as the reference does).
+ * loss_out (device [3]): {mean normal error, mean distortion, loss}; dL_dallmap [11,H,W] overwritten (0 where the reference's autograd
+ * yields NaN: channels 0/1 at pixels with allmap[1] == 0).  out_* may be NULL ('depth' [H,W], 'normal' [3,H,W], 'surf_normal' [3,H,W]). */
+size_t gsr_loss_surfel_geo_scratch_bytes(int32_t H, int32_t W);
+int gsr_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, const float* ray_mat, const float* normal_rot, float depth_ratio,
+                        float lambda_normal, float lambda_dist, float* loss_out, float* dL_dallmap, float* out_surf_depth,
+                        float* out_normal_world, float* out_surf_normal, void* scratch, size_t scratch_bytes, void* stream);
 size_t gsr_dist2_scratch_bytes(int32_t P);
 int gsr_dist2(int32_t P, const float* points /*[P,3]*/, float* out /*[P]*/, void* scratch, size_t scratch_bytes,
               void* stream);

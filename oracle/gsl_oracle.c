@@ -80,3 +80,101 @@ void ref_loss_l1_ssim(int32_t C, int32_t H, int32_t W, const float* img, const f
             }
     free(dmu); free(d11); free(d12);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * 2DGS geometric regularisers: the post-processing of TwoDGSScene.render (gssr/scene/twodgs_scene.py:88-115), depth_to_normal /
+ * depths_to_points (gssr/utils/point_utils.py:9-37) and the normal / distortion losses (twodgs_scene.py:25-35).
+ *   alpha = allmap[1]; d_exp = nan_to_num(allmap[0]/alpha, 0, 0); d_med = nan_to_num(allmap[5], 0, 0); depth = d_exp (1-r) + r d_med
+ *   P(y,x) = depth * ([x y 1] * ray_mat)          (+ rays_o, which cancels in the differences)
+ *   interior: n = normalize(cross(P(y+1,x)-P(y-1,x), P(y,x+1)-P(y,x-1))), border: 0;  surf_normal = n * alpha (alpha detached)
+ *   normal_world = allmap[2:5] * normal_rot (row vector);  normal_error = 1 - <normal_world, surf_normal>
+ *   loss = lambda_normal * mean(normal_error) + lambda_dist * mean(allmap[6])
+ * loss_out[3] = {mean normal_error, mean allmap[6], loss}.  dL_dallmap [11,H,W].  Optional outputs may be NULL.
+ */
+static float nan0(float v) { return (isnan(v) || isinf(v)) ? 0.f : v; }
+
+void ref_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, const float* ray_mat, const float* normal_rot, float depth_ratio,
+                         float lambda_normal, float lambda_dist, float* loss_out, float* dL_dallmap, float* out_surf_depth,
+                         float* out_normal_world, float* out_surf_normal)
+{
+    const size_t N = (size_t)H * W;
+    float* P = malloc(3 * N * sizeof(float));
+    float* dP = calloc(3 * N, sizeof(float));
+    float* depth = malloc(N * sizeof(float));
+    memset(dL_dallmap, 0, 11 * N * sizeof(float));
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t o = (size_t)y * W + x;
+            const float a = allmap[N + o];
+            const float de = nan0(allmap[o] / a), dm = nan0(allmap[5 * N + o]);
+            const float d = de * (1.f - depth_ratio) + depth_ratio * dm;
+            depth[o] = d;
+            for (int c = 0; c < 3; c++) P[3 * o + c] = d * ((float)x * ray_mat[c] + (float)y * ray_mat[3 + c] + ray_mat[6 + c]);
+            if (out_surf_depth) out_surf_depth[o] = d;
+        }
+    double s_err = 0.0, s_dist = 0.0;
+    const float wn = lambda_normal / (float)N, wd = lambda_dist / (float)N;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t o = (size_t)y * W + x;
+            const float a = allmap[N + o];
+            float nv[3] = {allmap[2 * N + o], allmap[3 * N + o], allmap[4 * N + o]}, nw[3], n[3] = {0, 0, 0};
+            for (int c = 0; c < 3; c++) nw[c] = nv[0] * normal_rot[c] + nv[1] * normal_rot[3 + c] + nv[2] * normal_rot[6 + c];
+            const int interior = y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2;
+            float dx[3], dy[3], cr[3], len = 0.f;
+            if (interior) {
+                for (int c = 0; c < 3; c++) {
+                    dx[c] = P[3 * (o + W) + c] - P[3 * (o - W) + c];
+                    dy[c] = P[3 * (o + 1) + c] - P[3 * (o - 1) + c];
+                }
+                cr[0] = dx[1] * dy[2] - dx[2] * dy[1]; cr[1] = dx[2] * dy[0] - dx[0] * dy[2]; cr[2] = dx[0] * dy[1] - dx[1] * dy[0];
+                len = sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+                const float den = len > 1e-12f ? len : 1e-12f;
+                for (int c = 0; c < 3; c++) n[c] = cr[c] / den;
+            }
+            float dot = 0.f;
+            for (int c = 0; c < 3; c++) dot += nw[c] * n[c] * a;
+            s_err += 1.0 - (double)dot;
+            s_dist += allmap[6 * N + o];
+            dL_dallmap[6 * N + o] = wd;
+            /* d/d normal (view space): -wn * surf_normal rotated back */
+            for (int i = 0; i < 3; i++) {
+                float g = 0.f;
+                for (int c = 0; c < 3; c++) g += normal_rot[3 * i + c] * (-wn * n[c] * a);
+                dL_dallmap[(2 + i) * N + o] = g;
+            }
+            for (int c = 0; c < 3; c++) {
+                if (out_normal_world) out_normal_world[c * N + o] = nw[c];
+                if (out_surf_normal) out_surf_normal[c * N + o] = n[c] * a;
+            }
+            if (interior) {
+                float dn[3], dc[3], nd = 0.f;
+                for (int c = 0; c < 3; c++) { dn[c] = -wn * a * nw[c]; nd += n[c] * dn[c]; }
+                if (len > 1e-12f) for (int c = 0; c < 3; c++) dc[c] = (dn[c] - n[c] * nd) / len;
+                else for (int c = 0; c < 3; c++) dc[c] = dn[c] / 1e-12f;
+                /* c = dx x dy: d dx = dy x dc, d dy = dc x dx */
+                const float gdx[3] = {dy[1] * dc[2] - dy[2] * dc[1], dy[2] * dc[0] - dy[0] * dc[2], dy[0] * dc[1] - dy[1] * dc[0]};
+                const float gdy[3] = {dc[1] * dx[2] - dc[2] * dx[1], dc[2] * dx[0] - dc[0] * dx[2], dc[0] * dx[1] - dc[1] * dx[0]};
+                for (int c = 0; c < 3; c++) {
+                    dP[3 * (o + W) + c] += gdx[c]; dP[3 * (o - W) + c] -= gdx[c];
+                    dP[3 * (o + 1) + c] += gdy[c]; dP[3 * (o - 1) + c] -= gdy[c];
+                }
+            }
+        }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t o = (size_t)y * W + x;
+            float dd = 0.f;
+            for (int c = 0; c < 3; c++) dd += dP[3 * o + c] * ((float)x * ray_mat[c] + (float)y * ray_mat[3 + c] + ray_mat[6 + c]);
+            const float a = allmap[N + o], q = allmap[o] / a;
+            if (!(isnan(q) || isinf(q))) {
+                dL_dallmap[o] += dd * (1.f - depth_ratio) / a;
+                dL_dallmap[N + o] += -dd * (1.f - depth_ratio) * allmap[o] / (a * a);
+            }
+            const float m = allmap[5 * N + o];
+            if (!(isnan(m) || isinf(m))) dL_dallmap[5 * N + o] += dd * depth_ratio;
+        }
+    loss_out[0] = (float)(s_err / (double)N); loss_out[1] = (float)(s_dist / (double)N);
+    loss_out[2] = lambda_normal * loss_out[0] + lambda_dist * loss_out[1];
+    free(P); free(dP); free(depth);
+}

@@ -258,3 +258,17 @@ def loss_l1_ssim(img, gt, lam):
     out = np.zeros(3, np.float32); d = np.zeros_like(img)
     L.ref_loss_l1_ssim(C.c_int32(Cc), C.c_int32(H), C.c_int32(W), _p(img), _p(gt), C.c_float(lam), _p(out), _p(d))
     return out, d
+
+
+def loss_surfel_geo(allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist):
+    """-> dict(loss[3], dL_dallmap, surf_depth, normal_world, surf_normal) (oracle/gsl_oracle.c ref_loss_surfel_geo)."""
+    L = lib()
+    L.ref_loss_surfel_geo.restype = None
+    am = _f32(allmap); rm = _f32(ray_mat).reshape(-1); nr = _f32(normal_rot).reshape(-1)
+    _, H, W = am.shape
+    out = {"loss": np.zeros(3, np.float32), "dL_dallmap": np.zeros_like(am), "surf_depth": np.zeros((1, H, W), np.float32),
+           "normal_world": np.zeros((3, H, W), np.float32), "surf_normal": np.zeros((3, H, W), np.float32)}
+    L.ref_loss_surfel_geo(C.c_int32(H), C.c_int32(W), _p(am), _p(rm), _p(nr), C.c_float(depth_ratio), C.c_float(lambda_normal),
+                          C.c_float(lambda_dist), _p(out["loss"]), _p(out["dL_dallmap"]), _p(out["surf_depth"]), _p(out["normal_world"]),
+                          _p(out["surf_normal"]))
+    return out

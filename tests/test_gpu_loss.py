@@ -47,3 +47,49 @@ def test_l1_ssim_full_hd_vs_torch_chain():
     # identical images: SSIM = 1, loss = 0
     l0, parts = l1_ssim(y, y, 0.2, return_parts=True)
     assert abs(parts[1].item() - 1.0) < 1e-6 and abs(l0.item()) < 1e-6
+
+
+def _geo_inputs(H, W, seed):
+    import test_loss_cpu
+    import ref_geo_torch
+    am, cam = test_loss_cpu._geo_case(H, W, seed)
+    wvt = torch.tensor(cam["viewmatrix"]); fpt = torch.tensor(cam["projmatrix"])
+    return am, wvt, fpt
+
+
+@pytest.mark.parametrize("H,W,ratio,seed", [(23, 31, 0.0, 0), (17, 40, 1.0, 1), (30, 22, 0.3, 2), (3, 3, 0.0, 3), (2, 5, 0.0, 4), (16, 16, 0.0, 5),
+                                            (33, 49, 0.0, 6), (200, 333, 0.0, 7)])
+def test_surfel_geo_matches_oracle(H, W, ratio, seed):
+    from gsrast.losses import camera_ray_matrices, surfel_geo_loss
+    am, wvt, fpt = _geo_inputs(H, W, seed)
+    rm, nr = camera_ray_matrices(wvt.to(DEV), fpt.to(DEV), W, H)
+    o = oracle.loss_surfel_geo(am, rm.cpu().numpy(), nr.cpu().numpy(), ratio, 0.05, 100.0)
+    x = torch.tensor(am, device=DEV, requires_grad=True)
+    loss, parts, depth, nw, sn = surfel_geo_loss(x, rm, nr, ratio, 0.05, 100.0, return_maps=True)
+    (2.0 * loss).backward()
+    np.testing.assert_allclose([parts[0].item(), parts[1].item(), loss.item()], o["loss"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(depth.cpu().numpy(), o["surf_depth"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(nw.cpu().numpy(), o["normal_world"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(sn.cpu().numpy(), o["surf_normal"], rtol=0, atol=2e-4)     # normalize of a near-degenerate cross product
+    g = x.grad.cpu().numpy() / 2.0
+    r = o["dL_dallmap"]
+    assert np.abs(g - r).max() <= 2e-3 * np.abs(r).max() + 1e-12
+    assert np.linalg.norm((g - r).ravel()) / (np.linalg.norm(r.ravel()) + 1e-30) < 1e-4
+
+
+def test_surfel_geo_full_hd_vs_torch_chain():
+    import ref_geo_torch
+    from gsrast.losses import camera_ray_matrices, surfel_geo_loss
+    H, W = 1080, 1920
+    am, wvt, fpt = _geo_inputs(H, W, 9)
+    wvt, fpt = wvt.to(DEV), fpt.to(DEV)
+    rm, nr = camera_ray_matrices(wvt, fpt, W, H)
+    x = torch.tensor(am, device=DEV, requires_grad=True)
+    loss, parts = surfel_geo_loss(x, rm, nr, 0.0, 0.05, 100.0)
+    loss.backward()
+    xr = torch.tensor(am, device=DEV, requires_grad=True)
+    Lr, ne, dm, post = ref_geo_torch.geo_loss(xr, wvt, fpt, 0.0, 0.05, 100.0)
+    Lr.backward()
+    assert abs(loss.item() - Lr.item()) < 2e-5 * abs(Lr.item()) + 1e-6
+    g, gr = x.grad, torch.nan_to_num(xr.grad, 0.0, 0.0, 0.0)
+    assert ((g - gr).norm() / gr.norm()).item() < 2e-3        # fp32 chain vs fp32 fused: cancellation in the cross products

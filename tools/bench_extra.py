@@ -58,4 +58,18 @@ th, tt = timeit(hip_loss, n=30), timeit(torch_loss, n=10)
 npx = 3 * H * W
 out["l1_ssim_1080p"] = {"hip_fwd_bwd_ms": round(th * 1e3, 3), "torch_fwd_bwd_ms": round(tt * 1e3, 3), "speedup": round(tt / th, 1),
                         "algorithmic_GBps": round(npx * 44 / th / 1e9, 1)}
+# fused 2DGS geometric regularisers (render() post-processing + depth_to_normal + normal/dist losses) vs the torch chain
+from gsrast.losses import camera_ray_matrices, surfel_geo_loss
+import ref_geo_torch, test_loss_cpu
+am, camg = test_loss_cpu._geo_case(H, W, 9)
+wvt = torch.tensor(camg["viewmatrix"]).cuda(); fpt = torch.tensor(camg["projmatrix"]).cuda()
+rm, nr = camera_ray_matrices(wvt, fpt, W, H)
+xa = torch.tensor(am).cuda().requires_grad_(True)
+def hip_geo():
+    xa.grad = None; surfel_geo_loss(xa, rm, nr, 0.0, 0.05, 100.0)[0].backward()
+def torch_geo():
+    xa.grad = None; ref_geo_torch.geo_loss(xa, wvt, fpt, 0.0, 0.05, 100.0)[0].backward()
+th, tt = timeit(hip_geo, n=30), timeit(torch_geo, n=10)
+out["surfel_geo_loss_1080p"] = {"hip_fwd_bwd_ms": round(th * 1e3, 3), "torch_fwd_bwd_ms": round(tt * 1e3, 3), "speedup": round(tt / th, 1),
+                                "algorithmic_GBps": round(H * W * 72 / th / 1e9, 1)}
 print(json.dumps(out))
