@@ -19,12 +19,17 @@ import scenes                          # noqa: E402
 import diff_surfel_rasterization as dsr   # noqa: E402
 import scaffold_filter as sf           # noqa: E402
 from gsrast import decode              # noqa: E402
-from gsrast.losses import l1_plus_linear  # noqa: E402
+from gsrast.losses import camera_ray_matrices, l1_plus_linear, l1_ssim, surfel_geo_loss  # noqa: E402
+import ref_geo_torch                   # noqa: E402
+import ref_loss_torch                  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--decode", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--loss", default="bench", choices=["bench", "full-hip", "full-torch"],
+                    help="bench: L1 + linear aux (bench.py's loss); full-*: the reference's L1+SSIM + normal/dist regularisers + scaling loss, "
+                         "fused HIP kernels or the reference's torch formulas")
     ap.add_argument("--Na", type=int, default=72000)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
@@ -56,6 +61,8 @@ def main():
     wmap[0] = 0.01 / N; wmap[1] = 0.01 / N; wmap[2:5] = -0.05 * gtn / N; wmap[5] = 0.01 / N; wmap[6] = 100.0 / N
     wmap = wmap.to(dev)
     campos = t["campos"]
+    wvt, fpt = t["viewmatrix"], t["projmatrix"]
+    rm, nr = camera_ray_matrices(wvt, fpt, W, H)
     case = {"k": k, "dist_o": False, "dist_c": False, "dist_k": False}
     st = {}
 
@@ -79,7 +86,13 @@ def main():
         means2D = torch.zeros_like(xyz, requires_grad=True)
         img, rad, allmap = dsr.GaussianRasterizer(rs)(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color,
                                                       scales=scl[:, :2].contiguous(), rotations=rot)
-        loss = l1_plus_linear(img, gt, allmap, wmap) + 0.01 * scl[:, :2].prod(dim=1).mean()     # + scaling_loss (scaffold_2dgs_scene.py:26)
+        reg = 0.01 * scl[:, :2].prod(dim=1).mean()                                              # scaling_loss (scaffold_2dgs_scene.py:26)
+        if a.loss == "bench":
+            loss = l1_plus_linear(img, gt, allmap, wmap) + reg
+        elif a.loss == "full-hip":
+            loss = l1_ssim(img, gt, 0.2) + surfel_geo_loss(allmap, rm, nr, 0.0, 0.05, 100.0)[0] + reg
+        else:
+            loss = ref_loss_torch.loss(img.unsqueeze(0), gt.unsqueeze(0), 0.2)[0] + ref_geo_torch.geo_loss(allmap, wvt, fpt, 0.0, 0.05, 100.0)[0] + reg
         loss.backward()
         opt.step(); opt.zero_grad(set_to_none=True)
         st["P"] = xyz.shape[0]; st["Nv"] = int(vmask.sum()) if "Nv" not in st else st["Nv"]
@@ -90,7 +103,7 @@ def main():
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"pipeline": "scaffold-2dgs", "decode": a.decode, "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps,
+    print(json.dumps({"pipeline": "scaffold-2dgs", "decode": a.decode, "loss": a.loss, "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps,
                       "ms_per_iter": 1e3 * dt / a.steps, "iters_per_s": a.steps / dt}))
 
 
