@@ -73,12 +73,21 @@ __device__ __forceinline__ float merge_quad(float a, float b, bool sel)
     const float keep = sel ? b : a, give = sel ? a : b;
     return keep + dpp_f<QP, 0xF>(give);
 }
-template <int SHL, int SHR, int BM_LO, int BM_HI>
+// xor 4 / xor 8 level: lanes with the level bit clear keep a and add a[l + S], the others keep b and add b[l - S].  The DPP bank
+// mask does the lane selection, so each half is ONE v_add_f32_dpp accumulating into w.  The compiler cannot form this itself (it
+// materialises update_dpp(0, x) with a zero-fill and a separate add: 7 VALU instead of 3 per merge), hence the inline assembly; the
+// leading s_nop covers the "VALU write -> DPP read" hazard the assembler does not see inside an asm block.
+template <int S>
 __device__ __forceinline__ float merge_row(float a, float b, bool sel)
 {
-    const float t1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), SHL, 0xF, BM_LO, false));
-    const float t2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), SHR, 0xF, BM_HI, false));
-    return (sel ? b : a) + t1 + t2;
+    float w = sel ? b : a;
+    if (S == 4)
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %0, %2, %0 row_shr:4 row_mask:0xf bank_mask:0xa"
+            : "+v"(w) : "v"(a), "v"(b));
+    else
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %0, %2, %0 row_shr:8 row_mask:0xf bank_mask:0xc"
+            : "+v"(w) : "v"(a), "v"(b));
+    return w;
 }
 // lane-wise sum across the four 16-lane rows (every row ends up with the totals).  row_bcast cannot be used here:
 // the lanes of a row hold DIFFERENT components, so the exchange must be lane l <-> l^16, l^32.  gfx950 has VALU-only
@@ -102,8 +111,8 @@ __device__ __forceinline__ float reduce16(const float* v, int lane)
 #pragma unroll
     for (int i = 0; i < 4; i++) q[i] = merge_quad<0x4E>(r[2 * i], r[2 * i + 1], b1);
 #pragma unroll
-    for (int i = 0; i < 2; i++) p[i] = merge_row<0x104, 0x114, 0x5, 0xA>(q[2 * i], q[2 * i + 1], b2);   // row_shl:4 / row_shr:4
-    const float w = merge_row<0x108, 0x118, 0x3, 0xC>(p[0], p[1], b3);                                   // row_shl:8 / row_shr:8
+    for (int i = 0; i < 2; i++) p[i] = merge_row<4>(q[2 * i], q[2 * i + 1], b2);   // row_shl:4 / row_shr:4
+    const float w = merge_row<8>(p[0], p[1], b3);                                   // row_shl:8 / row_shr:8
     return rows_to_row3(w);
 }
 // lane 56+c (and 48+c) <- total of v[c], c in [0,8)
@@ -115,7 +124,7 @@ __device__ __forceinline__ float reduce8(const float* v, int lane)
     for (int i = 0; i < 4; i++) r[i] = merge_quad<0xB1>(v[2 * i], v[2 * i + 1], b0);
 #pragma unroll
     for (int i = 0; i < 2; i++) q[i] = merge_quad<0x4E>(r[2 * i], r[2 * i + 1], b1);
-    float w = merge_row<0x104, 0x114, 0x5, 0xA>(q[0], q[1], b2);
+    float w = merge_row<4>(q[0], q[1], b2);
     w += dpp_f<0x128, 0xF>(w);   // row_ror:8 -> sum over the row, component = lane & 7
     return rows_to_row3(w);
 }
@@ -378,12 +387,12 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
     float dLp0 = 0, dLp1 = 0, dLp2 = 0;
     if (inside && p.dL_dcolor) { dLp0 = p.dL_dcolor[pix_id]; dLp1 = p.dL_dcolor[HW + pix_id]; dLp2 = p.dL_dcolor[2 * HW + pix_id]; }
     const float bg_dot_dpixel = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
-    float ar0 = 0, ar1 = 0, ar2 = 0, lc0 = 0, lc1 = 0, lc2 = 0, last_alpha = 0;
+    float ar0 = 0, ar1 = 0, ar2 = 0;
     const float ddelx_dx = 0.5f * p.W, ddely_dy = 0.5f * p.H;
 
     // PLANE (backward.cu:433,460-490)
     const bool geo = (V == GSR_PLANE) && p.render_geo;
-    float dA[5] = { 0, 0, 0, 0, 0 }, accA[5] = { 0, 0, 0, 0, 0 }, lastA[5] = { 0, 0, 0, 0, 0 };
+    float dA[5] = { 0, 0, 0, 0, 0 }, accA[5] = { 0, 0, 0, 0, 0 };
     if (geo && inside) {
         const float rayx = (float)((pxf - p.W * 0.5) / p.fx), rayy = (float)((pyf - p.H * 0.5) / p.fy);
         if (p.dL_dout_all_map)
@@ -401,7 +410,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
     float dL_dreg = 0, dL_ddepth = 0, dL_daccum = 0, dN0 = 0, dN1 = 0, dN2 = 0, dL_dmedian_depth = 0;
     float dMN0 = 0, dMN1 = 0, dMN2 = 0;
     uint32_t median_contributor = 0;
-    float last_depth = 0, ln0 = 0, ln1 = 0, ln2 = 0, accum_depth_rec = 0, accum_alpha_rec = 0, an0 = 0, an1 = 0, an2 = 0;
+    float accum_depth_rec = 0, accum_alpha_rec = 0, an0 = 0, an1 = 0, an2 = 0;
     float final_D = 0, final_D2 = 0, final_A = 0, last_dL_dT = 0;
     if (V == GSR_SURFEL && inside) {
         median_contributor = p.n_contrib[pix_id + HW];
@@ -440,42 +449,42 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                 const float alpha = fminf(0.99f, q1.y * G);
                 const bool ok = active && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(ok) == 0) continue;
-                float g_c0 = 0, g_c1 = 0, g_c2 = 0, g_op = 0, g_mx = 0, g_my = 0, g_ca = 0, g_cb = 0, g_cc = 0;
-                float g_ax = 0, g_ay = 0, g_am[5] = { 0, 0, 0, 0, 0 };
-                if (ok) {
-                    const float r1a = rcp_(1.f - alpha);
-                    T = T * r1a;
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dalpha = 0.0f;
-                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q1.z; dL_dalpha += (q1.z - ar0) * dLp0; g_c0 = dchannel_dcolor * dLp0;
-                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q1.w; dL_dalpha += (q1.w - ar1) * dLp1; g_c1 = dchannel_dcolor * dLp1;
-                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q2.x; dL_dalpha += (q2.x - ar2) * dLp2; g_c2 = dchannel_dcolor * dLp2;
-                    if (geo) {
-                        const float4 q3 = ldc(r, 3);
-                        const float am[5] = { q2.y, q2.z, q2.w, q3.x, q3.y };
+                // Branch-free: a lane that does not contribute runs the same instructions with alpha = 0 (its recurrences become the
+                // identity) and dL_dalpha = 0 (all its gradient terms vanish), so no per-value zero initialisation and no divergent
+                // region is needed; G is sanitised because exp(power > 0) may overflow and inf * 0 would poison the sums.
+                const float al = ok ? alpha : 0.0f, Gm = ok ? G : 0.0f;
+                const float r1a = rcp_(1.f - al);
+                T = T * r1a;
+                const float dchannel_dcolor = al * T;
+                float dL_dalpha = (q1.z - ar0) * dLp0 + (q1.w - ar1) * dLp1 + (q2.x - ar2) * dLp2;
+                const float g_c0 = dchannel_dcolor * dLp0, g_c1 = dchannel_dcolor * dLp1, g_c2 = dchannel_dcolor * dLp2;
+                // accum_rec of the NEXT (nearer) contributor: folded now instead of carrying last_alpha / last_color per lane
+                ar0 = al * q1.z + (1.f - al) * ar0; ar1 = al * q1.w + (1.f - al) * ar1; ar2 = al * q2.x + (1.f - al) * ar2;
+                float g_am[5] = { 0, 0, 0, 0, 0 };
+                if (geo) {
+                    const float4 q3 = ldc(r, 3);
+                    const float am[5] = { q2.y, q2.z, q2.w, q3.x, q3.y };
 #pragma unroll
-                        for (int c = 0; c < 5; c++) {
-                            accA[c] = last_alpha * lastA[c] + (1.f - last_alpha) * accA[c];
-                            lastA[c] = am[c];
-                            dL_dalpha += (am[c] - accA[c]) * dA[c];
-                            g_am[c] = dchannel_dcolor * dA[c];
-                        }
+                    for (int c = 0; c < 5; c++) {
+                        dL_dalpha += (am[c] - accA[c]) * dA[c];
+                        g_am[c] = dchannel_dcolor * dA[c];
+                        accA[c] = al * am[c] + (1.f - al) * accA[c];
                     }
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * r1a) * bg_dot_dpixel;
-                    const float dL_dG = q1.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-                    const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-                    g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                    g_my = dL_dG * dG_ddely * ddely_dy;
-                    g_ax = fabsf(g_mx); g_ay = fabsf(g_my);
-                    g_ca = -0.5f * gdx * dx * dL_dG;
-                    g_cb = -0.5f * gdx * dy * dL_dG;
-                    g_cc = -0.5f * gdy * dy * dL_dG;
-                    g_op = G * dL_dalpha;
                 }
+                dL_dalpha *= T;
+                dL_dalpha += (-T_final * r1a) * bg_dot_dpixel;
+                dL_dalpha = ok ? dL_dalpha : 0.0f;
+                const float dL_dG = q1.y * dL_dalpha;
+                const float gdx = Gm * dx, gdy = Gm * dy;
+                const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+                const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+                const float g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                const float g_my = dL_dG * dG_ddely * ddely_dy;
+                const float g_ax = fabsf(g_mx), g_ay = fabsf(g_my);
+                const float g_ca = -0.5f * gdx * dx * dL_dG;
+                const float g_cb = -0.5f * gdx * dy * dL_dG;
+                const float g_cc = -0.5f * gdy * dy * dL_dG;
+                const float g_op = Gm * dL_dalpha;
                 if (V == GSR_EWA) {
                     if (MFMA_RED) {
                         const float v9[9] = { g_c0, g_c1, g_c2, g_op, g_mx, g_my, g_ca, g_cb, g_cc };
@@ -514,67 +523,60 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                 const float alpha = fminf(0.99f, opa * G);
                 const bool ok = active && !(ppz == 0.0f) && !(c_d < NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(ok) == 0) continue;
-                float g_c0 = 0, g_c1 = 0, g_c2 = 0, g_op = 0, g_mx = 0, g_my = 0, g_n0 = 0, g_n1 = 0, g_n2 = 0;
-                float g_T[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-                if (ok) {
-                    const float r1a = rcp_(1.f - alpha);
-                    T = T * r1a;
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dalpha = 0.0f;
-                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q3.w; dL_dalpha += (q3.w - ar0) * dLp0; g_c0 = dchannel_dcolor * dLp0;
-                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q4.x; dL_dalpha += (q4.x - ar1) * dLp1; g_c1 = dchannel_dcolor * dLp1;
-                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q4.y; dL_dalpha += (q4.y - ar2) * dLp2; g_c2 = dchannel_dcolor * dLp2;
-                    float dL_dz = 0.0f, dL_dweight = 0;
-                    const float rcd = rcp_(c_d);
-                    const float m_d = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcd);
-                    const float dmd_dd = ((FAR_N * NEAR_N) / (FAR_N - NEAR_N)) * rcd * rcd;
-                    if (idx0 + 1u == median_contributor) dL_dz += dL_dmedian_depth;      // contributor == median_contributor-1
-                    dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-                    dL_dalpha += dL_dweight - last_dL_dT;
-                    last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
-                    const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                    dL_dz += dL_dmd * dmd_dd;
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                    last_depth = c_d;
-                    dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-                    accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                    dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
-                    an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = q3.x; dL_dalpha += (q3.x - an0) * dN0;
-                    an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = q3.y; dL_dalpha += (q3.y - an1) * dN1;
-                    an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = q3.z; dL_dalpha += (q3.z - an2) * dN2;
-                    // fork quirk (backward.cu:381): median-normal gradient is added for every contributing splat
-                    g_n0 = alpha * T * dN0 + dMN0; g_n1 = alpha * T * dN1 + dMN1; g_n2 = alpha * T * dN2 + dMN2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * r1a) * bg_dot_dpixel;
-                    const float dL_dG = opa * dL_dalpha;
-                    dL_dz += alpha * T * dL_ddepth;
-                    if (rho3d <= rho2d) {
-                        const float dL_dsx = dL_dG * -G * sx + dL_dz * Tw0;
-                        const float dL_dsy = dL_dG * -G * sy + dL_dz * Tw1;
-                        const float dsx_pz = dL_dsx * rpz, dsy_pz = dL_dsy * rpz;
-                        const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * sx + dsy_pz * sy);
-                        // dL_dTu = -cross(l, dL_dp) = cross(dL_dp, l); dL_dTv = -cross(dL_dp, k) = cross(k, dL_dp)  (no sign flips)
-                        const float tux = dpy * lz - dpz * ly, tuy = dpz * lx - dpx * lz, tuz = dpx * ly - dpy * lx;
-                        const float tvx = ky * dpz - kz * dpy, tvy = kz * dpx - kx * dpz, tvz = kx * dpy - ky * dpx;
-                        g_T[0] = tux; g_T[1] = tuy; g_T[2] = tuz;
-                        g_T[3] = tvx; g_T[4] = tvy; g_T[5] = tvz;
-                        g_T[6] = dL_dz * sx - (pxf * tux + pyf * tvx);
-                        g_T[7] = dL_dz * sy - (pxf * tuy + pyf * tvy);
-                        g_T[8] = dL_dz - (pxf * tuz + pyf * tvz);
-                    } else {
-                        g_mx = dL_dG * (-G * FILTER_INV_SQ * dx);
-                        g_my = dL_dG * (-G * FILTER_INV_SQ * dy);
-                        g_T[8] = dL_dz;
-                    }
-                    g_op = G * dL_dalpha;
-                }
+                // Branch-free (see the EWA path): non-contributing lanes run with alpha = 0, dL_dalpha = 0 and sanitised G, s, depth
+                // (p.z == 0 or depth ~ 0 would give inf/NaN that 0 cannot cancel).  The rho3d <= rho2d fork is a pair of selects on
+                // dL_dG / dL_dz instead of a divergent branch: with dL_dG3 = dL_dz3 = 0 the ray-splat terms vanish identically and
+                // g_T[8] reduces to dL_dz, exactly the screen-space-filter branch of backward.cu:434-441.
+                const bool b3 = rho3d <= rho2d;
+                const float al = ok ? alpha : 0.0f, Gm = ok ? G : 0.0f, cd = ok ? c_d : 1.0f;
+                const float sxm = ok ? sx : 0.0f, sym = ok ? sy : 0.0f, okf = ok ? 1.0f : 0.0f;
+                const float r1a = rcp_(1.f - al);
+                T = T * r1a;
+                const float w = al * T;
+                float dL_dalpha = (q3.w - ar0) * dLp0 + (q4.x - ar1) * dLp1 + (q4.y - ar2) * dLp2;
+                const float g_c0 = w * dLp0, g_c1 = w * dLp1, g_c2 = w * dLp2;
+                ar0 = al * q3.w + (1.f - al) * ar0; ar1 = al * q4.x + (1.f - al) * ar1; ar2 = al * q4.y + (1.f - al) * ar2;
+                const float rcd = rcp_(cd);
+                const float m_d = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcd);
+                const float dmd_dd = ((FAR_N * NEAR_N) / (FAR_N - NEAR_N)) * rcd * rcd;
+                float dL_dz = (ok && idx0 + 1u == median_contributor) ? dL_dmedian_depth : 0.0f;      // contributor == median_contributor-1
+                const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
+                dL_dalpha += dL_dweight - last_dL_dT;
+                last_dL_dT = dL_dweight * al + (1 - al) * last_dL_dT;
+                const float dL_dmd = 2.0f * w * (m_d * final_A - final_D) * dL_dreg;
+                dL_dz += dL_dmd * dmd_dd;
+                dL_dalpha += (cd - accum_depth_rec) * dL_ddepth;
+                accum_depth_rec = al * cd + (1.f - al) * accum_depth_rec;
+                dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
+                accum_alpha_rec = al + (1.f - al) * accum_alpha_rec;
+                dL_dalpha += (q3.x - an0) * dN0 + (q3.y - an1) * dN1 + (q3.z - an2) * dN2;
+                an0 = al * q3.x + (1.f - al) * an0; an1 = al * q3.y + (1.f - al) * an1; an2 = al * q3.z + (1.f - al) * an2;
+                // fork quirk (backward.cu:381): median-normal gradient is added for every contributing splat
+                const float g_n0 = w * dN0 + okf * dMN0, g_n1 = w * dN1 + okf * dMN1, g_n2 = w * dN2 + okf * dMN2;
+                dL_dalpha *= T;
+                dL_dalpha += (-T_final * r1a) * bg_dot_dpixel;
+                dL_dalpha = ok ? dL_dalpha : 0.0f;
+                const float dL_dG = opa * dL_dalpha;
+                dL_dz += w * dL_ddepth;
+                const float dL_dG3 = b3 ? dL_dG : 0.0f, dL_dG2 = b3 ? 0.0f : dL_dG, dL_dz3 = b3 ? dL_dz : 0.0f;
+                const float dL_dsx = dL_dG3 * -Gm * sxm + dL_dz3 * Tw0;
+                const float dL_dsy = dL_dG3 * -Gm * sym + dL_dz3 * Tw1;
+                const float rpzm = ok ? rpz : 0.0f;
+                const float dpx = dL_dsx * rpzm, dpy = dL_dsy * rpzm, dpz = -(dpx * sxm + dpy * sym);
+                // dL_dTu = -cross(l, dL_dp) = cross(dL_dp, l); dL_dTv = -cross(dL_dp, k) = cross(k, dL_dp)  (no sign flips)
+                const float tux = dpy * lz - dpz * ly, tuy = dpz * lx - dpx * lz, tuz = dpx * ly - dpy * lx;
+                const float tvx = ky * dpz - kz * dpy, tvy = kz * dpx - kx * dpz, tvz = kx * dpy - ky * dpx;
+                const float g_T[9] = { tux, tuy, tuz, tvx, tvy, tvz, dL_dz3 * sxm - (pxf * tux + pyf * tvx), dL_dz3 * sym - (pxf * tuy + pyf * tvy),
+                                       dL_dz - (pxf * tuz + pyf * tvz) };
+                const float g_mx = dL_dG2 * (-Gm * FILTER_INV_SQ * dx);
+                const float g_my = dL_dG2 * (-Gm * FILTER_INV_SQ * dy);
+                const float g_op = Gm * dL_dalpha;
                 // accumulator layout (SURFEL): 0-2 colour, 3 opacity, 4-6 normal, 7-15 transMat, 16-17 mean2D
                 const float v16[16] = { g_c0, g_c1, g_c2, g_op, g_n0, g_n1, g_n2, g_T[0], g_T[1], g_T[2], g_T[3], g_T[4],
                                         g_T[5], g_T[6], g_T[7], g_T[8] };
                 const float w16 = MFMA_RED ? reduce_mfma<16>(v16, lane) : reduce16(v16, lane);
                 if (lane >= 48 && w16 != 0.f) atomic_addf(accg + (lane - 48), w16);
-                if (__ballot(ok && !(rho3d <= rho2d)) != 0) {      // wave-uniform: any pair on the screen-space filter branch
+                if (__ballot(ok && !b3) != 0) {      // wave-uniform: any pair on the screen-space filter branch
                     const float w2 = reduce2(g_mx, g_my, lane);
                     if (lane >= 62 && w2 != 0.f) atomic_addf(accg + 16 + (lane - 62), w2);
                 }
