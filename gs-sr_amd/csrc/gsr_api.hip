@@ -96,7 +96,7 @@ GeomView gsr_carve_geom(int variant, int P, void* base)
     g.depth_key = take<uint32_t>(p, n);
     g.tiles_touched = take<uint32_t>(p, n);
     g.rect = take<ushort4>(p, n);
-    g.cull = take<float4>(p, n * (variant == GSR_SURFEL ? 1 : 2));
+    g.cull = take<float4>(p, n * 2);
     g.rec = take<float4>(p, n * gsr_rec_stride(variant));
     g.clamped = take<uint32_t>(p, n);
     g.sorted_idx = take<uint32_t>(p, n);     // == vals_a of the depth sort

@@ -188,30 +188,40 @@ __device__ __forceinline__ float4 ldc(const float4* p, int k)
 // test only has to be conservative.  SURFEL: bounding box of the contribution region.  EWA/PLANE: exact minimum of
 // the conic form q(d) = A dx^2 + 2B dx dy + C dy^2 over the block rectangle (centre inside -> 0, else the best of the
 // four edges, each a clamped 1-D parabola) against 2*ln(255*opacity) (with the safety margin added in preprocess).
+// minimum of q(d) = A dx^2 + 2B dx dy + C dy^2 over the rectangle [X0, X0+7] x [Y0, Y0+7] (d relative to the conic centre):
+// 0 when the centre is inside, else the best of the four edges, each a clamped 1-D parabola.
+__device__ __forceinline__ float conic_min_over_block(float A, float B, float C, float X0, float Y0)
+{
+    const float X1 = X0 + 7.f, Y1 = Y0 + 7.f;
+    if (X0 <= 0.f && X1 >= 0.f && Y0 <= 0.f && Y1 >= 0.f) return 0.f;
+    const float rC = __builtin_amdgcn_rcpf(C), rA = __builtin_amdgcn_rcpf(A);
+    float dy = fminf(fmaxf(-B * X0 * rC, Y0), Y1);
+    float qmin = A * X0 * X0 + 2.f * B * X0 * dy + C * dy * dy;
+    dy = fminf(fmaxf(-B * X1 * rC, Y0), Y1);
+    qmin = fminf(qmin, A * X1 * X1 + 2.f * B * X1 * dy + C * dy * dy);
+    float dx = fminf(fmaxf(-B * Y0 * rA, X0), X1);
+    qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * Y0 + C * Y0 * Y0);
+    dx = fminf(fmaxf(-B * Y1 * rA, X0), X1);
+    qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * Y1 + C * Y1 * Y1);
+    return qmin;
+}
 template <int V>
 __device__ __forceinline__ bool cull_hit(const float4* __restrict__ cull, uint32_t id, float ox, float oy)
 {
     if (V == GSR_SURFEL) {
-        const float4 cb = cull[id];
-        return (cb.z >= 0.f) && !(fabsf(cb.x - (ox + 3.5f)) > cb.z + 3.5f) && !(fabsf(cb.y - (oy + 3.5f)) > cb.w + 3.5f);
+        // union of the projected ellipse {A dx^2 + 2B dx dy + C dy^2 <= 1} about (a.x, a.y) and the low-pass disc of radius^2 b.y about
+        // (b.z, b.w); b.y < 0: no pixel can reach alpha >= 1/255; A = B = C = 0: culling disabled for this splat
+        const float4 a = cull[2 * (size_t)id], b = cull[2 * (size_t)id + 1];
+        if (!(b.y >= 0.f)) return false;
+        const float ex0 = ox - b.z, ey0 = oy - b.w;
+        const float ddx = fmaxf(fmaxf(ex0, -(ex0 + 7.f)), 0.f), ddy = fmaxf(fmaxf(ey0, -(ey0 + 7.f)), 0.f);
+        if (ddx * ddx + ddy * ddy <= b.y) return true;
+        return !(conic_min_over_block(a.z, a.w, b.x, ox - a.x, oy - a.y) > 1.0f);      // NaN -> keep
     } else {
         const float4 a = cull[2 * (size_t)id], b = cull[2 * (size_t)id + 1];
         const float A = a.z, B = a.w, C = b.x, tt = b.y;
         if (!(tt > 0.f)) return false;
-        const float X0 = ox - a.x, X1 = X0 + 7.f, Y0 = oy - a.y, Y1 = Y0 + 7.f;
-        if (X0 <= 0.f && X1 >= 0.f && Y0 <= 0.f && Y1 >= 0.f) return true;
-        const float rC = __builtin_amdgcn_rcpf(C), rA = __builtin_amdgcn_rcpf(A);
-        float qmin;
-        {
-            float dy = fminf(fmaxf(-B * X0 * rC, Y0), Y1);
-            qmin = A * X0 * X0 + 2.f * B * X0 * dy + C * dy * dy;
-            dy = fminf(fmaxf(-B * X1 * rC, Y0), Y1);
-            qmin = fminf(qmin, A * X1 * X1 + 2.f * B * X1 * dy + C * dy * dy);
-            float dx = fminf(fmaxf(-B * Y0 * rA, X0), X1);
-            qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * Y0 + C * Y0 * Y0);
-            dx = fminf(fmaxf(-B * Y1 * rA, X0), X1);
-            qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * Y1 + C * Y1 * Y1);
-        }
+        const float qmin = conic_min_over_block(A, B, C, ox - a.x, oy - a.y);
         return !(qmin > tt);      // NaN -> keep
     }
 }

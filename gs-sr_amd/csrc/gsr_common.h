@@ -41,7 +41,7 @@ struct GeomView {
     uint32_t* depth_key;      // [P]  bit pattern of view-space depth; 0xFFFFFFFF for culled gaussians
     uint32_t* tiles_touched;  // [P]
     ushort4* rect;            // [P]  tile rect {x0,y0,x1,y1}
-    float4* cull;             // SURFEL [P] {cx,cy,hx,hy} conservative box of alpha >= 1/255 (hx<0: none); EWA/PLANE [2P] {x,y,A,B},{C,2tau,-,-}
+    float4* cull;             // [2P] region of alpha >= 1/255.  EWA/PLANE {x,y,A,B},{C,2tau,-,-}; SURFEL {cx,cy,A,B},{C,r2,pix,piy}: ellipse form <= 1 or disc
     float4* rec;              // [P * stride] packed blend record
     uint32_t* clamped;        // [P]  3 bits: SH colour clamped to 0 per channel
     uint32_t* sorted_idx;     // [P]  gaussian ids in (depth, id) order

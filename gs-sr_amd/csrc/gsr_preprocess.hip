@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
     float T[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     float3 normal = make_float3(0, 0, 0), rgb = make_float3(0, 0, 0);
     float pix = 0, piy = 0, o = 0;
-    float4 cull = make_float4(0, 0, -1, -1);
+    float4 cull0 = make_float4(0, 0, 0, 0), cull1 = make_float4(0, -1.f, 0, 0);     // culled gaussians never hit (r2 < 0)
 
     const float3 p_orig = make_float3(p.means3D[3 * idx], p.means3D[3 * idx + 1], p.means3D[3 * idx + 2]);
     const float3 p_view = xform_point4x3(p_orig, view);
@@ -152,25 +152,39 @@ __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
         o = p.opac[idx];
         key = __float_as_uint(p_view.z);
         tiles = (uint32_t)((y1 - y0) * (x1 - x0));
-        // conservative box of {min(rho3d, rho2d) <= 2 tau}: union of the projected sqrt(2 tau)-sigma ellipse
-        // (valid only while that ellipse stays in front of the camera: d < 0 and Tw.z > 0) and the screen-space
-        // low-pass disc |xy - pix| <= sqrt(tau).  Anything doubtful disables culling for this splat (hx = huge).
+        // Sub-tile cull record: the region where alpha >= 1/255, i.e. {min(rho3d, rho2d) <= tt}, is the union of
+        //   (i) the projected ellipse of the sqrt(tt)-sigma contour, d^T Sigma'^-1 d <= 1 about its centre c, with
+        //       Sigma' = c c^T - S/w from the dual conic Q* = sum_i t_i T_i T_i^T, t = (tt, tt, -1)  (the same quantities compute_aabb,
+        //       SURFEL forward.cu:119-145, takes its centre and extents from), valid while the contour stays in front of the camera, and
+        //   (ii) the screen-space low-pass disc |xy - pix|^2 <= tt / 2.
+        // The blend kernels test both exactly against the 8x8 block (gsr_blend.hip cull_hit); a box of the union let 21 % of the
+        // (splat, block) pairs through that touch no pixel.  Inflation: +2 % on the form, +0.25 px^2 and the fp32 cancellation bound
+        // 1e-6 c^2 on the diagonal.  Anything doubtful disables culling for this splat (A = B = C = 0 always hits).
         float tt = two_tau(o);
         if (tt > 0) {
-            float bx, by, hx, hy, d;
-            bool ok = surfel_aabb(T, tt, bx, by, hx, hy, &d);
+            cull0 = make_float4(pix, piy, 0.f, 0.f);
+            cull1 = make_float4(0.f, 0.5f * tt * 1.001f + 0.01f, pix, piy);
+            const float* Tu = T; const float* Tv = T + 3; const float* Tw = T + 6;
+            const float t3[3] = { tt, tt, -1.0f };
+            auto qd = [&](const float* X, const float* Y) { return t3[0] * X[0] * Y[0] + t3[1] * X[1] * Y[1] + t3[2] * X[2] * Y[2]; };
+            const float w = qd(Tw, Tw);
             const float tw2 = T[8] * T[8];
-            if (ok && d < -1e-4f * tw2 && T[8] > 0 && isfinite(bx) && isfinite(by) && isfinite(hx) && isfinite(hy)) {
-                float rd = sqrtf(0.5f * tt);
-                float lox = fminf(bx - hx, pix - rd), hix = fmaxf(bx + hx, pix + rd);
-                float loy = fminf(by - hy, piy - rd), hiy = fmaxf(by + hy, piy + rd);
-                cull = make_float4(0.5f * (lox + hix), 0.5f * (loy + hiy),
-                                   0.5f * (hix - lox) * 1.001f + 0.01f, 0.5f * (hiy - loy) * 1.001f + 0.01f);
-            } else {
-                cull = make_float4(pix, piy, 1e30f, 1e30f);
+            if (w < -1e-4f * tw2 && T[8] > 0) {
+                const float iw = 1.0f / w;
+                const float cx = qd(Tu, Tw) * iw, cy = qd(Tv, Tw) * iw;
+                float sxx = cx * cx - qd(Tu, Tu) * iw, syy = cy * cy - qd(Tv, Tv) * iw;
+                const float sxy = cx * cy - qd(Tu, Tv) * iw;
+                sxx += 0.25f + 1e-6f * cx * cx; syy += 0.25f + 1e-6f * cy * cy;
+                const float det = sxx * syy - sxy * sxy;
+                if (sxx > 0 && syy > 0 && det > 1e-6f * sxx * syy && isfinite(cx) && isfinite(cy) && isfinite(det)) {
+                    const float k = 1.0f / (1.02f * det);
+                    cull0 = make_float4(cx, cy, syy * k, -sxy * k);
+                    cull1.x = sxx * k;
+                }
             }
         } else {
-            cull = make_float4(pix, piy, -1.f, -1.f);
+            cull0 = make_float4(pix, piy, 0.f, 0.f);
+            cull1 = make_float4(0.f, -1.f, pix, piy);      // r2 < 0: never hits
         }
     } while (0);
 
@@ -178,7 +192,8 @@ __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
     p.g.depth_key[idx] = key;
     p.g.tiles_touched[idx] = tiles;
     p.g.rect[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
-    p.g.cull[idx] = cull;
+    p.g.cull[2 * (size_t)idx] = cull0;
+    p.g.cull[2 * (size_t)idx + 1] = cull1;
     p.g.clamped[idx] = clamped;
     float4* rec = p.g.rec + (size_t)idx * GSR_REC_SURFEL;
     rec[0] = make_float4(T[0], T[1], T[2], T[3]);
