@@ -58,8 +58,8 @@ def stage_bytes(variant, color_mode, P, R, N, T):
 
 
 def make_step(variant, sc, device):
-    """One training iteration.  All gaussian parameters live in ONE flat leaf z[P,13+] (views: means 3, scales 2|3,
-    rotations 4, opacity 1, colour 3); params = z * lr_scale (per column), optimised by a single fused-Adam group with
+    """One training iteration.  All gaussian parameters live in ONE flat leaf z (contiguous blocks: means 3P, scales 2P|3P,
+    rotations 4P, opacity P, colour 3P|48P); params = z * lr_scale (per block), optimised by a single fused-Adam group with
     lr=1: Adam's step is invariant to gradient scale, so the effective per-column learning rates are exactly lr_scale --
     the per-group rates of gssr/gaussian/*.setup_optimizers -- with one optimizer kernel instead of one per group.
     The auxiliary-map loss is linear in the 11 (5) channels so autograd hands the rasterizer a dense dL_dothers without
@@ -76,8 +76,11 @@ def make_step(variant, sc, device):
     use_sh = t.get("shs") is not None
     cols = [("means3D", 3, 1.6e-5), ("scales", ns, 5e-4), ("rotations", 4, 1e-4), ("opacities", 1, 1e-3)]
     cols.append(("shs", 48, 2.5e-3) if use_sh else ("colors_precomp", 3, 2.5e-3))
-    lr_scale = torch.cat([torch.full((n,), lr, device=device) for _, n, lr in cols])
-    z = (torch.cat([t[k].reshape(P, -1) for k, _, _ in cols], dim=1) / lr_scale).clone().requires_grad_(True)
+    # structure-of-arrays inside the flat leaf: [means 3P | scales nsP | rotations 4P | opacity P | colour cP], so every parameter view
+    # handed to the rasterizer is contiguous (an [P,13] array-of-structs layout costs one strided copy per parameter per iteration)
+    sizes = [P * n for _, n, _ in cols]
+    lr_scale = torch.cat([torch.full((P * n,), lr, device=device) for _, n, lr in cols])
+    z = (torch.cat([t[k].reshape(-1) for k, _, _ in cols]) / lr_scale).clone().requires_grad_(True)
     opt = torch.optim.Adam([z], lr=1.0, eps=1e-15, fused=True)
     g = torch.Generator(device="cpu").manual_seed(1234)
     gt = torch.rand((3, H, W), generator=g).to(device)
@@ -94,14 +97,11 @@ def make_step(variant, sc, device):
         wpd = torch.full((1, H, W), 0.01 / N, device=device)
     all_map = t.get("all_map")
     state = {}
-    offs = [0]
-    for _, n, _ in cols:
-        offs.append(offs[-1] + n)
 
     def step():
         prm = z * lr_scale
-        parts = torch.split(prm, [n for _, n, _ in cols], dim=1)       # backward = one cat, not one zero-pad per slice
-        v = {k: parts[i] for i, (k, _, _) in enumerate(cols)}
+        parts = torch.split(prm, sizes)                                 # backward = one cat, not one zero-pad per slice
+        v = {k: parts[i].view(P, n) for i, (k, n, _) in enumerate(cols)}
         means2D = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
         kw = dict(means3D=v["means3D"], means2D=means2D, opacities=v["opacities"], scales=v["scales"], rotations=v["rotations"])
         if use_sh:
