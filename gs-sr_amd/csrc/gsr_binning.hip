@@ -236,24 +236,53 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
 
 // ------------------------------------------------------------------------------------------------ duplicate + ranges
 // duplicateWithKeys (3DGS rasterizer_impl.cu:70-111) over gaussians in depth order; key = tile id only.
+// Wave-cooperative: a wave owns 64 consecutive gaussians of the depth order and emits their instances 64 at a time, lane = instance
+// (binary search over the wave's 64 prefix values with shuffles), so the work per lane is even -- one thread per gaussian left a few
+// lanes looping over hundreds of tiles -- and the key/value stores are fully coalesced.  Order within a gaussian is (y outer, x inner),
+// as in the reference's nested loop.
 __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ tiles_touched, const ushort4* __restrict__ rect, int gx,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t g = sorted_idx[i];
-    if (tiles_touched[g] == 0) return;
-    uint32_t off = (i == 0) ? 0 : offsets[i - 1];
-    const ushort4 r = rect[g];
-    for (uint32_t y = r.y; y < r.w; y++)
-        for (uint32_t x = r.x; x < r.z; x++) {
-            if (off < cap) {                     // cap == R normally; smaller only when a speculative forward overflowed
-                keys[off] = y * (uint32_t)gx + x;
-                vals[off] = g;
-            }
-            off++;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x);          // position in depth order
+    const bool v = i < P;
+    const uint32_t g = v ? sorted_idx[i] : 0u;
+    const uint32_t cnt = v ? tiles_touched[g] : 0u;
+    const uint32_t incl = v ? offsets[i] : 0u;                            // inclusive prefix of tiles_touched in depth order
+    ushort4 r = make_ushort4(0, 0, 1, 1);
+    if (cnt) r = rect[g];
+    const uint32_t wave_base = __shfl(incl - cnt, 0, 64);
+    // lanes past P carry incl = 0: give them the wave's running total so the prefix stays monotone
+    uint32_t last = __shfl(incl, 63, 64);
+    {
+        const uint64_t vm = __ballot(v);
+        if (vm != ~0ull) last = vm ? __shfl(incl, 63 - __builtin_clzll(vm), 64) : wave_base;
+    }
+    const uint32_t total = last - wave_base;
+    const uint32_t excl = v ? (incl - cnt) - wave_base : total;
+    const uint32_t w = (uint32_t)r.z - (uint32_t)r.x;
+    const float rw = 1.0f / (float)(w ? w : 1u);
+    for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        uint32_t s = 0;
+#pragma unroll
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+            const uint32_t t = s + step;
+            const uint32_t e = __shfl(excl, t & 63u, 64);
+            if (t < 64u && e <= k) s = t;
         }
+        const uint32_t j = k - __shfl(excl, s, 64);
+        const uint32_t sw = __shfl(w, s, 64), sx0 = __shfl((uint32_t)r.x, s, 64), sy0 = __shfl((uint32_t)r.y, s, 64), sg = __shfl(g, s, 64);
+        const float srw = __shfl(rw, s, 64);
+        const uint32_t q = (uint32_t)(((float)j + 0.5f) * srw);           // j / sw: exact for j < 2^20 (margin 0.5/sw >> fp32 error)
+        const uint32_t tx = sx0 + (j - q * sw), ty = sy0 + q;
+        const uint32_t off = wave_base + k;
+        if (k < total && off < cap) {                    // cap == R normally; smaller only when a speculative forward overflowed
+            keys[off] = ty * (uint32_t)gx + tx;
+            vals[off] = sg;
+        }
+    }
 }
 
 // identifyTileRanges (3DGS rasterizer_impl.cu:116-138)
