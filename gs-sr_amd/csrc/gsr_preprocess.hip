@@ -4,6 +4,7 @@
 //   helpers : visible_filter (scaffold-filter), mark_visible
 // Built with -ffp-contract=off (see gsr_math.h).  Reference behaviour cited per kernel.
 #include "gsr_common.h"
+#include <stdlib.h>
 #include "gsr_math.h"
 
 using namespace gsr;
@@ -14,6 +15,7 @@ struct PreParams {
     const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3D_pre, *all_map, *view, *proj, *campos;
     int32_t* radii;
     GeomView g;
+    int no_cull;           // GSR_NO_CULL=1 (diagnostic): every visible gaussian passes the sub-tile cull -> outputs must not change
 };
 
 __device__ __forceinline__ void load16(const float* p, float* m)
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
         // cull record for the blend kernels: conic form + 2*tau (the pair contributes iff dT Q d <= 2 tau)
         cull0 = make_float4(pix, piy, conA, conB);
         cull1 = make_float4(conC, two_tau(o), 0.f, 0.f);
+        if (p.no_cull) { cull0 = make_float4(pix, piy, 0.f, 0.f); cull1 = make_float4(0.f, 1.0f, 0.f, 0.f); }
     } while (0);
 
     p.radii[idx] = radius_out;
@@ -186,6 +189,7 @@ __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
             cull0 = make_float4(pix, piy, 0.f, 0.f);
             cull1 = make_float4(0.f, -1.f, pix, piy);      // r2 < 0: never hits
         }
+        if (p.no_cull) { cull0 = make_float4(pix, piy, 0.f, 0.f); cull1 = make_float4(0.f, 1e30f, pix, piy); }
     } while (0);
 
     p.radii[idx] = radius_out;
@@ -226,6 +230,7 @@ static PreParams make_params(const gsr_cfg* cfg, const gsr_inputs* in, GeomView 
     p.means3D = in->means3D; p.shs = in->shs; p.colors = in->colors_precomp; p.opac = in->opacities;
     p.scales = in->scales; p.rots = in->rotations; p.cov3D_pre = in->cov3D_precomp; p.all_map = in->all_map;
     p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
+    { const char* e = getenv("GSR_NO_CULL"); p.no_cull = (e && atoi(e) != 0) ? 1 : 0; }
     p.radii = radii; p.g = g;
     return p;
 }

@@ -87,3 +87,22 @@ def test_backward_is_repeatable_within_float_noise():
     b = hr.run("surfel", sc, og)["grads"]
     for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations"):
         assert np.abs(a[k] - b[k]).max() <= 2e-5 * np.abs(a[k]).max()
+
+
+@pytest.mark.parametrize("variant,seed,kw", [("surfel", 21, {}), ("surfel", 22, dict(sigma_px=12.0)), ("surfel", 23, dict(sigma_px=1.2)),
+                                             ("surfel", 24, dict(pose=1, scale_modifier=1.7)), ("ewa", 25, dict(sigma_px=9.0)),
+                                             ("plane", 26, dict(pose=1)), ("surfel", 27, dict(sigma_px=30.0))])
+def test_subtile_cull_is_result_neutral(variant, seed, kw, monkeypatch):
+    """Skipping a (splat, 8x8 block) pair is only allowed when no pixel of the block can reach alpha >= 1/255, so the forward outputs with
+    the cull disabled (GSR_NO_CULL=1: every visible gaussian passes) must be BIT-identical to the culled run."""
+    import hiprun
+    import scenes
+    W, H, P = 640, 368, 20000
+    sc = scenes.make_scene(variant, P, W, H, seed=seed, **kw)
+    a = hiprun.run(variant, sc, None, device="cuda:0")
+    monkeypatch.setenv("GSR_NO_CULL", "1")
+    b = hiprun.run(variant, sc, None, device="cuda:0")
+    monkeypatch.delenv("GSR_NO_CULL")
+    for k in ("color", "others", "out_all_map", "plane_depth", "radii"):
+        if k in a and a[k] is not None:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
