@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
                 const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
                 const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
-                const float rpz = rcp_(ppz);
+                const float rpz = (ppz == 0.0f) ? 0.0f : rcp_(ppz);      // keeps s (hence rho, G <= 1) finite on lanes that will not contribute
                 const float sx = ppx * rpz, sy = ppy * rpz;
                 const float rho3d = sx * sx + sy * sy;
                 const float dx = q2.y - pxf, dy = q2.z - pyf;
@@ -534,12 +534,12 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                 const bool ok = active && !(ppz == 0.0f) && !(c_d < NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(ok) == 0) continue;
                 // Branch-free (see the EWA path): non-contributing lanes run with alpha = 0, dL_dalpha = 0 and sanitised G, s, depth
-                // (p.z == 0 or depth ~ 0 would give inf/NaN that 0 cannot cancel).  The rho3d <= rho2d fork is a pair of selects on
+                // (depth ~ 0 would give inf/NaN that 0 cannot cancel; p.z == 0 is handled where s is formed).  The rho3d <= rho2d fork is a pair of selects on
                 // dL_dG / dL_dz instead of a divergent branch: with dL_dG3 = dL_dz3 = 0 the ray-splat terms vanish identically and
                 // g_T[8] reduces to dL_dz, exactly the screen-space-filter branch of backward.cu:434-441.
                 const bool b3 = rho3d <= rho2d;
-                const float al = ok ? alpha : 0.0f, Gm = ok ? G : 0.0f, cd = ok ? c_d : 1.0f;
-                const float sxm = ok ? sx : 0.0f, sym = ok ? sy : 0.0f, okf = ok ? 1.0f : 0.0f;
+                const float al = ok ? alpha : 0.0f, cd = ok ? c_d : 1.0f, okf = ok ? 1.0f : 0.0f;
+                const float Gm = G, sxm = sx, sym = sy;      // finite on every lane (rpz sanitised above, rho >= 0)
                 const float r1a = rcp_(1.f - al);
                 T = T * r1a;
                 const float w = al * T;
@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
                 const float dL_dG3 = b3 ? dL_dG : 0.0f, dL_dG2 = b3 ? 0.0f : dL_dG, dL_dz3 = b3 ? dL_dz : 0.0f;
                 const float dL_dsx = dL_dG3 * -Gm * sxm + dL_dz3 * Tw0;
                 const float dL_dsy = dL_dG3 * -Gm * sym + dL_dz3 * Tw1;
-                const float rpzm = ok ? rpz : 0.0f;
+                const float rpzm = rpz;
                 const float dpx = dL_dsx * rpzm, dpy = dL_dsy * rpzm, dpz = -(dpx * sxm + dpy * sym);
                 // dL_dTu = -cross(l, dL_dp) = cross(dL_dp, l); dL_dTv = -cross(dL_dp, k) = cross(k, dL_dp)  (no sign flips)
                 const float tux = dpy * lz - dpz * ly, tuy = dpz * lx - dpx * lz, tuz = dpx * ly - dpy * lx;
