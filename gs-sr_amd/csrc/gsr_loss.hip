@@ -331,3 +331,115 @@ extern "C" int gsr_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, co
                        lambda_dist);
     return gsr_check_launch("loss_surfel_geo", s, false);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// PGSR single-view normal regulariser (gssr/scene/pgsr_scene.py:105-112,227-238,320; gssr/utils/graphics_utils.py:80-146):
+//   P = plane_depth * ([x y 1] * ray_mat)  (camera space, ray_mat = inverse(K^T));  depth_normal = normalize(cross(right - left, top -
+//   bottom)) * alpha (alpha detached, zero on the border) -- the same vector as the 2DGS stencil above;
+//   loss = lambda * mean(weight * sum_c |depth_normal_c - normal_c|).
+// Same tiling as k_surfel_geo: value, dL/dplane_depth and dL/dnormal in one kernel.
+struct PlaneGeoArgs {
+    int H, W;
+    const float* depth; const float* alpha; const float* normal; const float* weight; const float* ray_mat;
+    float wl;
+    float2* partial; float* dDepth; float* dNormal; float* o_dn;
+};
+__device__ __forceinline__ float sgn_(float v) { return v > 0.f ? 1.0f : (v < 0.f ? -1.0f : 0.0f); }
+
+__global__ void __launch_bounds__(256) k_plane_geo(PlaneGeoArgs p)
+{
+    __shared__ float sP[3][GEO_P][GEO_P + 1];
+    __shared__ float sG[6][GEO_G][GEO_G + 1];
+    __shared__ float sN[3][GEO_G][GEO_G + 1];
+    __shared__ float red[4];
+    typedef const float __attribute__((address_space(4))) * cfp;
+    float rm[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) rm[i] = ((cfp)p.ray_mat)[i];
+    const int H = p.H, W = p.W, x0 = blockIdx.x * GEO_T, y0 = blockIdx.y * GEO_T;
+    const size_t N = (size_t)H * W;
+    for (int e = threadIdx.x; e < GEO_P * GEO_P; e += 256) {
+        const int ly = e / GEO_P, lx = e % GEO_P, gy = y0 + ly - 2, gx = x0 + lx - 2;
+        float P0 = 0.f, P1 = 0.f, P2 = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const float d = p.depth[(size_t)gy * W + gx];
+            const float fx = (float)gx, fy = (float)gy;
+            P0 = d * (fx * rm[0] + fy * rm[3] + rm[6]); P1 = d * (fx * rm[1] + fy * rm[4] + rm[7]); P2 = d * (fx * rm[2] + fy * rm[5] + rm[8]);
+        }
+        sP[0][ly][lx] = P0; sP[1][ly][lx] = P1; sP[2][ly][lx] = P2;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < GEO_G * GEO_G; e += 256) {
+        const int ly = e / GEO_G, lx = e % GEO_G, gy = y0 + ly - 1, gx = x0 + lx - 1;
+        float g[6] = {0, 0, 0, 0, 0, 0}, n[3] = {0, 0, 0};
+        if (gy >= 1 && gy <= H - 2 && gx >= 1 && gx <= W - 2) {
+            const size_t o = (size_t)gy * W + gx;
+            const float a = p.alpha[o], wl = p.wl * (p.weight ? p.weight[o] : 1.0f);
+            const int py = ly + 1, px = lx + 1;
+            float dx[3], dy[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { dx[c] = sP[c][py + 1][px] - sP[c][py - 1][px]; dy[c] = sP[c][py][px + 1] - sP[c][py][px - 1]; }
+            const float c0 = dx[1] * dy[2] - dx[2] * dy[1], c1 = dx[2] * dy[0] - dx[0] * dy[2], c2 = dx[0] * dy[1] - dx[1] * dy[0];
+            const float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+            const float inv = 1.0f / fmaxf(len, 1e-12f);
+            n[0] = c0 * inv; n[1] = c1 * inv; n[2] = c2 * inv;
+            float dn[3], dc[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) dn[c] = wl * a * sgn_(a * n[c] - p.normal[c * N + o]);
+            const float nd = len > 1e-12f ? n[0] * dn[0] + n[1] * dn[1] + n[2] * dn[2] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) dc[c] = (dn[c] - n[c] * nd) * inv;
+            g[0] = dy[1] * dc[2] - dy[2] * dc[1]; g[1] = dy[2] * dc[0] - dy[0] * dc[2]; g[2] = dy[0] * dc[1] - dy[1] * dc[0];
+            g[3] = dc[1] * dx[2] - dc[2] * dx[1]; g[4] = dc[2] * dx[0] - dc[0] * dx[2]; g[5] = dc[0] * dx[1] - dc[1] * dx[0];
+            n[0] *= a; n[1] *= a; n[2] *= a;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) sG[c][ly][lx] = g[c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) sN[c][ly][lx] = n[c];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, gx = x0 + lx, gy = y0 + ly;
+    float err = 0.f;
+    if (gx < W && gy < H) {
+        const size_t o = (size_t)gy * W + gx;
+        const int qy = ly + 1, qx = lx + 1;
+        float dP[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) dP[c] = sG[c][qy - 1][qx] - sG[c][qy + 1][qx] + sG[3 + c][qy][qx - 1] - sG[3 + c][qy][qx + 1];
+        const float fx = (float)gx, fy = (float)gy;
+        p.dDepth[o] = dP[0] * (fx * rm[0] + fy * rm[3] + rm[6]) + dP[1] * (fx * rm[1] + fy * rm[4] + rm[7]) + dP[2] * (fx * rm[2] + fy * rm[5] + rm[8]);
+        const float w = p.weight ? p.weight[o] : 1.0f, wl = p.wl * w;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float dn = sN[c][qy][qx] - p.normal[c * N + o];
+            err += fabsf(dn);
+            p.dNormal[c * N + o] = -wl * sgn_(dn);
+            if (p.o_dn) p.o_dn[c * N + o] = sN[c][qy][qx];
+        }
+        err *= w;
+    }
+    const float te = block_sum256(err, red);
+    if (threadIdx.x == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = make_float2(te, 0.f);
+}
+
+extern "C" int gsr_loss_plane_geo(int32_t H, int32_t W, const float* plane_depth, const float* alpha, const float* normal, const float* weight,
+                                  const float* ray_mat, float lambda_normal, float* loss_out, float* dL_ddepth, float* dL_dnormal,
+                                  float* out_depth_normal, void* scratch, size_t scratch_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (H <= 0 || W <= 0) { gsr_set_error("loss_plane_geo: bad sizes H=%d W=%d", H, W); return 1; }
+    if (!plane_depth || !alpha || !normal || !ray_mat || !loss_out || !dL_ddepth || !dL_dnormal || !scratch ||
+        scratch_bytes < gsr_loss_surfel_geo_scratch_bytes(H, W)) {
+        gsr_set_error("loss_plane_geo: null pointer or scratch too small"); return 1;
+    }
+    PlaneGeoArgs a;
+    const float inv_n = 1.0f / ((float)H * (float)W);
+    a.H = H; a.W = W; a.depth = plane_depth; a.alpha = alpha; a.normal = normal; a.weight = weight; a.ray_mat = ray_mat;
+    a.wl = lambda_normal * inv_n; a.partial = (float2*)scratch; a.dDepth = dL_ddepth; a.dNormal = dL_dnormal; a.o_dn = out_depth_normal;
+    const dim3 grid(gsr_div_up(W, GEO_T), gsr_div_up(H, GEO_T));
+    hipLaunchKernelGGL(k_plane_geo, grid, dim3(256), 0, s, a);
+    // loss_out = {mean weighted L1, 0, lambda * mean}
+    hipLaunchKernelGGL(k_geo_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, (int)(grid.x * grid.y), loss_out, inv_n, lambda_normal, 0.0f);
+    return gsr_check_launch("loss_plane_geo", s, false);
+}

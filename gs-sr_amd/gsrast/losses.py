@@ -112,3 +112,42 @@ def surfel_geo_loss(allmap, ray_mat, normal_rot, depth_ratio=0.0, lambda_normal=
     straight from the rasterizer's allmap, fused with the render() post-processing (:88-115) and depth_to_normal.
     -> loss, parts=[mean normal error, mean distortion]  (+ depth (1,H,W), normal (3,H,W), surf_normal (3,H,W) when return_maps)."""
     return _SurfelGeo.apply(allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist, bool(return_maps))
+
+
+class _PlaneGeo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plane_depth, out_all_map, weight, ray_mat, lambda_normal, want_map):
+        d = dev_f32(plane_depth, "plane_depth", allow_empty=False)
+        am = dev_f32(out_all_map, "out_all_map", allow_empty=False)
+        if am.dim() != 3 or am.shape[0] != 5 or d.numel() != am.shape[1] * am.shape[2]:
+            raise RuntimeError("out_all_map must be (5, H, W) and plane_depth (1, H, W) / (H, W)")
+        w = dev_f32(weight, "weight") if weight is not None else None
+        rm = dev_f32(ray_mat, "ray_mat", allow_empty=False)
+        _, H, W = am.shape
+        L = lib()
+        dev = am.device
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        dD = torch.empty_like(d)
+        dA = torch.zeros_like(am)                       # channels 3 (alpha, detached) and 4 (distance) get no gradient here
+        dn = torch.empty(3, H, W, dtype=torch.float32, device=dev) if want_map else None
+        scratch = torch.empty(max(L.gsr_loss_surfel_geo_scratch_bytes(H, W), 8), dtype=torch.uint8, device=dev)
+        alpha = am[3]
+        check(L.gsr_loss_plane_geo(H, W, ptr(d), ptr(alpha), ptr(am), ptr(w), ptr(rm), float(lambda_normal), ptr(out), ptr(dD), ptr(dA), ptr(dn),
+                                   ptr(scratch), scratch.numel(), stream_ptr(dev)), "loss_plane_geo")
+        ctx.save_for_backward(dD, dA)
+        extras = [out[:1].detach()] + ([dn] if want_map else [])
+        ctx.mark_non_differentiable(*extras)
+        return (out[2], *extras)
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        dD, dA = ctx.saved_tensors
+        return dD * g, dA * g, None, None, None, None
+
+
+def plane_geo_loss(plane_depth, out_all_map, ray_mat, weight=None, lambda_normal=0.015, return_map=False):
+    """PGSR single-view normal loss (gssr/scene/pgsr_scene.py:105-112): lambda * mean(weight * |depth_normal - rendered_normal|.sum(0)) with
+    depth_normal = normal_from_depth_image(plane_depth) * alpha.detach(), straight from the rasterizer outputs.  ray_mat = inverse(K^T) of
+    `get_calib_matrix_nerf`; weight = the detached image-gradient weight map (per camera, cacheable) or None.
+    -> loss, [mean weighted L1]  (+ depth_normal (3,H,W) when return_map)."""
+    return _PlaneGeo.apply(plane_depth, out_all_map, weight, ray_mat, lambda_normal, bool(return_map))

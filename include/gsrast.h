@@ -189,6 +189,14 @@ size_t gsr_loss_surfel_geo_scratch_bytes(int32_t H, int32_t W);
 int gsr_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, const float* ray_mat, const float* normal_rot, float depth_ratio,
                         float lambda_normal, float lambda_dist, float* loss_out, float* dL_dallmap, float* out_surf_depth,
                         float* out_normal_world, float* out_surf_normal, void* scratch, size_t scratch_bytes, void* stream);
+/* PGSR single-view normal regulariser (gssr/scene/pgsr_scene.py:105-112,320; normal_from_depth_image, gssr/utils/graphics_utils.py:80-146):
+ *   P = plane_depth * ([x y 1] * ray_mat), ray_mat = inverse(K^T) (DEVICE [9]);  depth_normal = normalize(cross(P(y,x+1)-P(y,x-1),
+ *   P(y-1,x)-P(y+1,x))) * alpha (alpha detached), 0 on the border;  loss = lambda * mean(weight * sum_c |depth_normal_c - normal_c|).
+ * weight [H,W] or NULL (= 1): the detached image-gradient weight.  loss_out (device [3]) = {mean weighted L1, 0, loss};
+ * dL_ddepth [H,W], dL_dnormal [3,H,W] overwritten; out_depth_normal [3,H,W] or NULL.  scratch as for gsr_loss_surfel_geo. */
+int gsr_loss_plane_geo(int32_t H, int32_t W, const float* plane_depth, const float* alpha, const float* normal, const float* weight,
+                       const float* ray_mat, float lambda_normal, float* loss_out, float* dL_ddepth, float* dL_dnormal,
+                       float* out_depth_normal, void* scratch, size_t scratch_bytes, void* stream);
 size_t gsr_dist2_scratch_bytes(int32_t P);
 int gsr_dist2(int32_t P, const float* points /*[P,3]*/, float* out /*[P]*/, void* scratch, size_t scratch_bytes,
               void* stream);

@@ -178,3 +178,73 @@ void ref_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, const float*
     loss_out[2] = lambda_normal * loss_out[0] + lambda_dist * loss_out[1];
     free(P); free(dP); free(depth);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * PGSR single-view normal regulariser: normal_from_depth_image / depth_pcd2normal / depth2point_cam / ndc_2_cam
+ * (gssr/utils/graphics_utils.py:80-146), PGSRScene.render (gssr/scene/pgsr_scene.py:320) and get_loss_dict (:105-112).
+ *   P = depth * ([x y 1] * ray_mat), ray_mat = inverse(K^T);  n = normalize(cross(P(y,x+1)-P(y,x-1), P(y-1,x)-P(y+1,x))), 0 on the border
+ *   depth_normal = n * alpha (detached);  loss = lambda * mean(weight * sum_c |depth_normal_c - normal_c|)
+ * loss_out[3] = {mean weighted L1, 0, loss}.
+ */
+void ref_loss_plane_geo(int32_t H, int32_t W, const float* depth, const float* alpha, const float* normal, const float* weight,
+                        const float* ray_mat, float lambda, float* loss_out, float* dL_ddepth, float* dL_dnormal, float* out_dn)
+{
+    const size_t N = (size_t)H * W;
+    float* P = malloc(3 * N * sizeof(float));
+    float* dP = calloc(3 * N, sizeof(float));
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t o = (size_t)y * W + x;
+            for (int c = 0; c < 3; c++) P[3 * o + c] = depth[o] * ((float)x * ray_mat[c] + (float)y * ray_mat[3 + c] + ray_mat[6 + c]);
+        }
+    double s_err = 0.0;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t o = (size_t)y * W + x;
+            const float a = alpha[o], w = weight ? weight[o] : 1.f, wl = lambda * w / (float)N;
+            const int interior = y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2;
+            float lr[3], bt[3], cr[3], n[3] = {0, 0, 0}, len = 0.f;
+            if (interior) {
+                for (int c = 0; c < 3; c++) {
+                    lr[c] = P[3 * (o + 1) + c] - P[3 * (o - 1) + c];             /* left_to_right */
+                    bt[c] = P[3 * (o - W) + c] - P[3 * (o + W) + c];             /* bottom_to_top */
+                }
+                cr[0] = lr[1] * bt[2] - lr[2] * bt[1]; cr[1] = lr[2] * bt[0] - lr[0] * bt[2]; cr[2] = lr[0] * bt[1] - lr[1] * bt[0];
+                len = sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+                const float den = len > 1e-12f ? len : 1e-12f;
+                for (int c = 0; c < 3; c++) n[c] = cr[c] / den;
+            }
+            float dn[3], e = 0.f;
+            for (int c = 0; c < 3; c++) {
+                const float df = n[c] * a - normal[c * N + o];
+                const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+                e += fabsf(df);
+                dL_dnormal[c * N + o] = -wl * sg;
+                dn[c] = wl * a * sg;
+                if (out_dn) out_dn[c * N + o] = n[c] * a;
+            }
+            s_err += (double)(w * e);
+            if (interior) {
+                float dc[3], nd = 0.f;
+                for (int c = 0; c < 3; c++) nd += n[c] * dn[c];
+                if (len > 1e-12f) for (int c = 0; c < 3; c++) dc[c] = (dn[c] - n[c] * nd) / len;
+                else for (int c = 0; c < 3; c++) dc[c] = dn[c] / 1e-12f;
+                /* c = lr x bt: d lr = bt x dc, d bt = dc x lr */
+                const float glr[3] = {bt[1] * dc[2] - bt[2] * dc[1], bt[2] * dc[0] - bt[0] * dc[2], bt[0] * dc[1] - bt[1] * dc[0]};
+                const float gbt[3] = {dc[1] * lr[2] - dc[2] * lr[1], dc[2] * lr[0] - dc[0] * lr[2], dc[0] * lr[1] - dc[1] * lr[0]};
+                for (int c = 0; c < 3; c++) {
+                    dP[3 * (o + 1) + c] += glr[c]; dP[3 * (o - 1) + c] -= glr[c];
+                    dP[3 * (o - W) + c] += gbt[c]; dP[3 * (o + W) + c] -= gbt[c];
+                }
+            }
+        }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t o = (size_t)y * W + x;
+            float dd = 0.f;
+            for (int c = 0; c < 3; c++) dd += dP[3 * o + c] * ((float)x * ray_mat[c] + (float)y * ray_mat[3 + c] + ray_mat[6 + c]);
+            dL_ddepth[o] = dd;
+        }
+    loss_out[0] = (float)(s_err / (double)N); loss_out[1] = 0.f; loss_out[2] = lambda * loss_out[0];
+    free(P); free(dP);
+}

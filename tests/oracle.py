@@ -272,3 +272,16 @@ def loss_surfel_geo(allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lam
                           C.c_float(lambda_dist), _p(out["loss"]), _p(out["dL_dallmap"]), _p(out["surf_depth"]), _p(out["normal_world"]),
                           _p(out["surf_normal"]))
     return out
+
+
+def loss_plane_geo(depth, alpha, normal, weight, ray_mat, lam):
+    """-> dict(loss[3], dL_ddepth, dL_dnormal, depth_normal) (oracle/gsl_oracle.c ref_loss_plane_geo)."""
+    L = lib()
+    L.ref_loss_plane_geo.restype = None
+    d = _f32(depth); a = _f32(alpha); n = _f32(normal); w = None if weight is None else _f32(weight); rm = _f32(ray_mat).reshape(-1)
+    H, W = d.shape[-2], d.shape[-1]
+    out = {"loss": np.zeros(3, np.float32), "dL_ddepth": np.zeros((H, W), np.float32), "dL_dnormal": np.zeros((3, H, W), np.float32),
+           "depth_normal": np.zeros((3, H, W), np.float32)}
+    L.ref_loss_plane_geo(C.c_int32(H), C.c_int32(W), _p(d), _p(a), _p(n), _p(w), _p(rm), C.c_float(lam), _p(out["loss"]), _p(out["dL_ddepth"]),
+                         _p(out["dL_dnormal"]), _p(out["depth_normal"]))
+    return out

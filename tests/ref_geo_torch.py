@@ -52,3 +52,51 @@ def geo_loss(allmap, wvt, fpt, depth_ratio, lambda_normal, lambda_dist):
     o = render_post(allmap, wvt, fpt, depth_ratio)
     normal_error = (1 - (o["normal"] * o["surf_normal"]).sum(dim=0))[None]
     return lambda_normal * normal_error.mean() + lambda_dist * o["rend_dist"].mean(), normal_error.mean(), o["rend_dist"].mean(), o
+
+
+# ---- PGSR: normal_from_depth_image chain (gssr/utils/graphics_utils.py:80-146) and the single-view normal loss (pgsr_scene.py:105-112,320)
+def ndc_2_cam(ndc_xyz, intrinsic, W, H):
+    inv_scale = torch.tensor([[W - 1, H - 1]], device=ndc_xyz.device, dtype=ndc_xyz.dtype)
+    cam_z = ndc_xyz[..., 2:3]
+    cam_xy = ndc_xyz[..., :2] * inv_scale * cam_z
+    cam_xyz = torch.cat([cam_xy, cam_z], dim=-1)
+    return cam_xyz @ torch.inverse(intrinsic[0, ...].t())
+
+
+def depth2point_cam(sampled_depth, ref_intrinsic):
+    B, N, C, H, W = sampled_depth.shape
+    valid_z = sampled_depth
+    valid_x = torch.arange(W, dtype=sampled_depth.dtype, device=sampled_depth.device) / (W - 1)
+    valid_y = torch.arange(H, dtype=sampled_depth.dtype, device=sampled_depth.device) / (H - 1)
+    valid_y, valid_x = torch.meshgrid(valid_y, valid_x, indexing="ij")
+    valid_x = valid_x[None, None, None, ...].expand(B, N, C, -1, -1)
+    valid_y = valid_y[None, None, None, ...].expand(B, N, C, -1, -1)
+    ndc_xyz = torch.stack([valid_x, valid_y, valid_z], dim=-1).view(B, N, C, H, W, 3)
+    return ndc_xyz, ndc_2_cam(ndc_xyz, ref_intrinsic, W, H)
+
+
+def depth_pcd2normal(xyz):
+    hd, wd, _ = xyz.shape
+    bottom_point = xyz[..., 2:hd, 1:wd - 1, :]
+    top_point = xyz[..., 0:hd - 2, 1:wd - 1, :]
+    right_point = xyz[..., 1:hd - 1, 2:wd, :]
+    left_point = xyz[..., 1:hd - 1, 0:wd - 2, :]
+    left_to_right = right_point - left_point
+    bottom_to_top = top_point - bottom_point
+    xyz_normal = torch.cross(left_to_right, bottom_to_top, dim=-1)
+    xyz_normal = torch.nn.functional.normalize(xyz_normal, p=2, dim=-1)
+    return torch.nn.functional.pad(xyz_normal.permute(2, 0, 1), (1, 1, 1, 1), mode='constant').permute(1, 2, 0)
+
+
+def normal_from_depth_image(depth, intrinsic_matrix):
+    _, xyz_cam = depth2point_cam(depth[None, None, None, ...], intrinsic_matrix[None, ...])
+    return depth_pcd2normal(xyz_cam.reshape(*depth.shape, 3))
+
+
+def plane_geo_loss(plane_depth, out_all_map, K, weight, lambda_normal):
+    """plane_depth (H,W); out_all_map (5,H,W); K (3,3).  -> loss, mean weighted L1, depth_normal (3,H,W)"""
+    rendered_normal, rendered_alpha = out_all_map[0:3], out_all_map[3:4]
+    depth_normal = normal_from_depth_image(plane_depth, K).permute(2, 0, 1) * rendered_alpha.detach()
+    w = torch.ones_like(plane_depth) if weight is None else weight
+    m = (w * ((depth_normal - rendered_normal).abs().sum(0))).mean()
+    return lambda_normal * m, m, depth_normal

@@ -93,3 +93,44 @@ def test_surfel_geo_full_hd_vs_torch_chain():
     assert abs(loss.item() - Lr.item()) < 2e-5 * abs(Lr.item()) + 1e-6
     g, gr = x.grad, torch.nan_to_num(xr.grad, 0.0, 0.0, 0.0)
     assert ((g - gr).norm() / gr.norm()).item() < 2e-3        # fp32 chain vs fp32 fused: cancellation in the cross products
+
+
+@pytest.mark.parametrize("H,W,seed,use_w", [(23, 31, 0, True), (17, 40, 1, False), (3, 3, 2, True), (2, 6, 3, True), (100, 161, 4, True)])
+def test_plane_geo_matches_oracle(H, W, seed, use_w):
+    import test_loss_cpu
+    from gsrast.losses import plane_geo_loss
+    depth, am, K, weight = test_loss_cpu._plane_case(H, W, seed)
+    w = weight if use_w else None
+    rm = torch.inverse(torch.tensor(K, dtype=torch.float64).t()).float()
+    o = oracle.loss_plane_geo(depth, am[3], am[0:3], w, rm.numpy(), 0.015)
+    d = torch.tensor(depth, device=DEV).unsqueeze(0).requires_grad_(True)
+    a = torch.tensor(am, device=DEV, requires_grad=True)
+    loss, part, dn = plane_geo_loss(d, a, rm.to(DEV), None if w is None else torch.tensor(w, device=DEV), 0.015, return_map=True)
+    (3.0 * loss).backward()
+    np.testing.assert_allclose([part[0].item(), loss.item()], o["loss"][[0, 2]], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(dn.cpu().numpy(), o["depth_normal"], rtol=0, atol=2e-4)
+    gd = d.grad.cpu().numpy()[0] / 3.0
+    assert np.abs(gd - o["dL_ddepth"]).max() <= 2e-3 * np.abs(o["dL_ddepth"]).max() + 1e-12
+    ga = a.grad.cpu().numpy() / 3.0
+    flips = np.sign(ga[0:3]) != np.sign(o["dL_dnormal"])           # sign(depth_normal - normal) can flip where the difference is ~0
+    assert flips.mean() < 1e-3 and not ga[3:].any()
+    assert np.abs(np.abs(ga[0:3]) - np.abs(o["dL_dnormal"])).max() <= 1e-6 * np.abs(o["dL_dnormal"]).max() + 1e-12
+
+
+def test_plane_geo_full_hd_vs_torch_chain():
+    import ref_geo_torch
+    import test_loss_cpu
+    from gsrast.losses import plane_geo_loss
+    H, W = 1080, 1920
+    depth, am, K, weight = test_loss_cpu._plane_case(H, W, 8)
+    Kt = torch.tensor(K, device=DEV)
+    rm = torch.inverse(Kt.double().t()).float()
+    d = torch.tensor(depth, device=DEV).requires_grad_(True); a = torch.tensor(am, device=DEV, requires_grad=True)
+    wt = torch.tensor(weight, device=DEV)
+    loss, part = plane_geo_loss(d, a, rm, wt, 0.015)
+    loss.backward()
+    dr = torch.tensor(depth, device=DEV).requires_grad_(True); ar = torch.tensor(am, device=DEV, requires_grad=True)
+    Lr, m, dn = ref_geo_torch.plane_geo_loss(dr, ar, Kt, wt, 0.015)
+    Lr.backward()
+    assert abs(loss.item() - Lr.item()) < 2e-5 * abs(Lr.item()) + 1e-7
+    assert ((d.grad - dr.grad).norm() / dr.grad.norm()).item() < 5e-3

@@ -70,3 +70,35 @@ def test_surfel_geo_oracle_matches_autograd(H, W, ratio, seed):
     assert np.abs(o["dL_dallmap"] - g).max() <= 2e-3 * np.abs(g).max() + 1e-12
     rel = np.linalg.norm((o["dL_dallmap"] - g).ravel()) / (np.linalg.norm(g.ravel()) + 1e-30)
     assert rel < 2e-4, rel
+
+
+def _plane_case(H, W, seed):
+    r = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    depth = (3.0 + 0.5 * np.sin(xx / 7.0) + 0.3 * np.cos(yy / 5.0) + r.normal(0, 0.02, (H, W))).astype(np.float32)
+    am = np.zeros((5, H, W), np.float32)
+    alpha = r.uniform(0.2, 1.0, (H, W)); n = r.normal(0, 1, (3, H, W)); n /= np.linalg.norm(n, axis=0, keepdims=True)
+    am[0:3] = n * alpha; am[3] = alpha; am[4] = r.uniform(1, 3, (H, W))
+    K = np.array([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]], np.float32)
+    weight = r.uniform(0, 1, (H, W)).astype(np.float32)
+    return depth, am, K, weight
+
+
+@pytest.mark.parametrize("H,W,seed,use_w", [(23, 31, 0, True), (17, 40, 1, False), (3, 3, 2, True), (2, 6, 3, True)])
+def test_plane_geo_oracle_matches_autograd(H, W, seed, use_w):
+    import ref_geo_torch
+    depth, am, K, weight = _plane_case(H, W, seed)
+    w = weight if use_w else None
+    K64 = torch.tensor(K, dtype=torch.float64)
+    rm = torch.inverse(K64.t())
+    o = oracle.loss_plane_geo(depth, am[3], am[0:3], w, rm.numpy(), 0.015)
+    d = torch.tensor(depth, dtype=torch.float64, requires_grad=True)
+    a = torch.tensor(am, dtype=torch.float64, requires_grad=True)
+    L, m, dn = ref_geo_torch.plane_geo_loss(d, a, K64, None if w is None else torch.tensor(w, dtype=torch.float64), 0.015)
+    L.backward()
+    np.testing.assert_allclose(o["loss"][[0, 2]], [m.item(), L.item()], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(o["depth_normal"], dn.detach().numpy(), rtol=0, atol=2e-4)
+    gd, ga = d.grad.numpy(), a.grad.numpy()
+    assert np.abs(o["dL_ddepth"] - gd).max() <= 2e-3 * np.abs(gd).max() + 1e-12
+    assert np.array_equal(np.sign(o["dL_dnormal"]), np.sign(ga[0:3])) or np.abs(o["dL_dnormal"] - ga[0:3]).max() <= 1e-6 * np.abs(ga).max() + 1e-12
+    assert not ga[3:].any()
