@@ -15,6 +15,8 @@ struct PreParams {
     const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3D_pre, *all_map, *view, *proj, *campos;
     int32_t* radii;
     GeomView g;
+    const uint8_t* in_mask;   // FILTER only: optional per-gaussian pre-mask (Octree LOD); masked-out entries get radii 0 without any work
+    int scale_stride;         // floats between consecutive scale triples (3, or 6 when fed get_scaling directly)
     int no_cull;           // GSR_NO_CULL=1 (diagnostic): every visible gaussian passes the sub-tile cull -> outputs must not change
 };
 
@@ -40,6 +42,7 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.P) return;
+    if (FILTER_ONLY && p.in_mask && !p.in_mask[idx]) { p.radii[idx] = 0; return; }
     float view[16], proj[16];
     load16(p.view, view); load16(p.proj, proj);
 
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
 #pragma unroll
             for (int i = 0; i < 6; i++) cov3D[i] = p.cov3D_pre[6 * idx + i];
         } else {
-            cov3d_from_scale_rot(p.scales + 3 * idx, p.mod, p.rots + 4 * idx, cov3D);
+            cov3d_from_scale_rot(p.scales + (size_t)p.scale_stride * idx, p.mod, p.rots + 4 * idx, cov3D);
         }
         Cov2D cv = cov2d_project(p_orig, p.fx, p.fy, p.tanfovx, p.tanfovy, cov3D, view);
         float det = (cv.a * cv.c - cv.b * cv.b);
@@ -231,6 +234,7 @@ static PreParams make_params(const gsr_cfg* cfg, const gsr_inputs* in, GeomView 
     p.scales = in->scales; p.rots = in->rotations; p.cov3D_pre = in->cov3D_precomp; p.all_map = in->all_map;
     p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
     { const char* e = getenv("GSR_NO_CULL"); p.no_cull = (e && atoi(e) != 0) ? 1 : 0; }
+    p.in_mask = nullptr; p.scale_stride = 3;
     p.radii = radii; p.g = g;
     return p;
 }
@@ -255,6 +259,64 @@ extern "C" int gsr_visible_filter(const gsr_cfg* cfg, const float* means3D, cons
     PreParams p = make_params(&c, &in, g, radii);
     hipLaunchKernelGGL(k_preprocess_ewa<true>, dim3(gsr_div_up(cfg->P, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return gsr_check_launch("visible_filter", (hipStream_t)stream, cfg->debug);
+}
+
+// ---- Octree-GS level-of-detail mask (OctreeGaussianModel.set_anchor_mask + map_to_int_level, gssr/gaussian/octree_gaussian.py:184-203,
+// 255-267) fused with the frustum/extent prefilter (OctreeScene.prefilter_voxel, gssr/scene/octree_scene.py:136-172): ~20 torch ops, three
+// boolean-index gathers (each a host sync) and a masked scatter in the reference; two launches and no sync here.
+struct LodArgs {
+    int Na; const float* anchor; const int32_t* level; const float* extra_level; const float* campos;
+    gsr_lod_cfg c;
+    uint8_t* anchor_mask; float* prog_ratio; uint8_t* transition_mask;
+};
+__global__ void __launch_bounds__(256) k_lod_mask(LodArgs p)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.Na) return;
+    const int lvl = p.level[i];
+    const float half = (p.c.voxel_size / 2) / powf(p.c.fork, (float)lvl);                   // :256
+    const float dx = (p.anchor[3 * i] + half) - p.campos[0], dy = (p.anchor[3 * i + 1] + half) - p.campos[1],
+                dz = (p.anchor[3 * i + 2] + half) - p.campos[2];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz) * p.c.resolution_scale;           // :257
+    float pred = log2f(p.c.standard_dist / dist) / log2f(p.c.fork) + (p.extra_level ? p.extra_level[i] : 0.0f);      // :258
+    const int cur = p.c.coarse_index - 1;
+    int il;
+    if (p.c.mode == 3) {                                                                      // 'progressive' :194-198
+        pred = fminf(fmaxf(pred + 1.0f, 0.9999f), (float)cur + 0.9999f);
+        il = (int)floorf(pred);
+        if (p.prog_ratio) p.prog_ratio[i] = pred - truncf(pred);
+        if (p.transition_mask) p.transition_mask[i] = (lvl == il) ? 1 : 0;
+    } else {
+        const float r = p.c.mode == 0 ? floorf(pred) : (p.c.mode == 1 ? rintf(pred) : ceilf(pred));     // torch.round = half to even
+        il = (int)r;
+        il = il < 0 ? 0 : (il > cur ? cur : il);
+    }
+    p.anchor_mask[i] = (lvl <= il) ? 1 : 0;                                                   // :267
+}
+
+extern "C" int gsr_octree_visible(const gsr_cfg* cfg, const gsr_lod_cfg* lod, const float* anchor, const int32_t* level,
+                                  const float* extra_level, const float* scales, int32_t scale_stride, const float* rotations,
+                                  uint8_t* anchor_mask, int32_t* radii, float* prog_ratio, uint8_t* transition_mask, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!cfg || !lod) { gsr_set_error("octree_visible: null cfg"); return 1; }
+    if (cfg->P == 0) return 0;
+    if (!anchor || !level || !scales || !rotations || !anchor_mask || !radii || scale_stride < 3) {
+        gsr_set_error("octree_visible: anchor/level/scales/rotations/anchor_mask/radii must be provided (scale_stride >= 3)"); return 1;
+    }
+    if (lod->mode < 0 || lod->mode > 3) { gsr_set_error("Unknown dist2level: %d", lod->mode); return 1; }
+    LodArgs la;
+    la.Na = cfg->P; la.anchor = anchor; la.level = level; la.extra_level = extra_level; la.campos = cfg->campos; la.c = *lod;
+    la.anchor_mask = anchor_mask; la.prog_ratio = prog_ratio; la.transition_mask = transition_mask;
+    hipLaunchKernelGGL(k_lod_mask, dim3(gsr_div_up(cfg->P, 256)), dim3(256), 0, s, la);
+    gsr_inputs in = {};
+    in.means3D = anchor; in.scales = scales; in.rotations = rotations;
+    GeomView g = {};
+    gsr_cfg c = *cfg; c.variant = GSR_EWA;
+    PreParams p = make_params(&c, &in, g, radii);
+    p.in_mask = anchor_mask; p.scale_stride = scale_stride;
+    hipLaunchKernelGGL(k_preprocess_ewa<true>, dim3(gsr_div_up(cfg->P, 256)), dim3(256), 0, s, p);
+    return gsr_check_launch("octree_visible", s, cfg->debug);
 }
 
 extern "C" int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -170,6 +170,23 @@ int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* or
  * dL/daux is waux itself, so nothing is written for it. */
 int gsr_loss_l1_linear(int64_t n_color, const float* color, const float* gt, float* dL_dcolor,
                        int64_t n_aux, const float* aux, const float* waux, float* loss_out, void* stream);
+/* Octree-GS level-of-detail mask fused with the prefilter (OctreeGaussianModel.set_anchor_mask / map_to_int_level,
+ * gssr/gaussian/octree_gaussian.py:184-203,255-267; OctreeScene.prefilter_voxel, gssr/scene/octree_scene.py:136-172):
+ *   dist = |anchor + (voxel_size/2)/fork^level - campos| * resolution_scale;  pred = log2(standard_dist/dist)/log2(fork) + extra_level
+ *   int_level = clamp(floor|round|ceil(pred), 0, coarse_index-1)   ('progressive': floor(clamp(pred+1, .9999, coarse_index-1+.9999)),
+ *                                                                  prog_ratio = frac(.), transition_mask = (level == int_level))
+ *   anchor_mask = level <= int_level;  radii = anchor_mask ? visible_filter radius : 0     (visible_mask == radii > 0)
+ * cfg: camera/settings as for gsr_visible_filter with P = number of anchors.  scales: first three of every `scale_stride` floats
+ * (6 for get_scaling).  prog_ratio / transition_mask may be NULL.  No host synchronisation. */
+typedef struct gsr_lod_cfg {
+    float voxel_size, fork, standard_dist, resolution_scale;
+    int32_t coarse_index;     /* levels in use (the reference passes coarse_index - 1 as cur_level) */
+    int32_t mode;             /* dist2level: 0 floor, 1 round, 2 ceil, 3 progressive */
+} gsr_lod_cfg;
+int gsr_octree_visible(const gsr_cfg* cfg, const gsr_lod_cfg* lod, const float* anchor /*[Na,3]*/, const int32_t* level /*[Na]*/,
+                       const float* extra_level /*[Na] or NULL*/, const float* scales, int32_t scale_stride, const float* rotations /*[Na,4]*/,
+                       uint8_t* anchor_mask /*[Na]*/, int32_t* radii /*[Na]*/, float* prog_ratio /*[Na] or NULL*/,
+                       uint8_t* transition_mask /*[Na] or NULL*/, void* stream);
 /* Fused photometric loss (gssr/scene/vanilla_scene.py:29-69, used by every method's get_loss_dict):
  *   loss = (1-lambda)*mean|img-gt| + lambda*(1 - SSIM(img,gt)), SSIM with the 11x11 sigma-1.5 window, zero padding, C1=0.01^2, C2=0.03^2.
  * loss_out (device, 3 floats, overwritten): {mean|img-gt|, mean SSIM, loss}.  dL_dimg [C,H,W] = d loss / d img.

@@ -222,3 +222,33 @@ void refd_backward(const refd_cfg* c, const refd_inputs* in, const refd_params* 
     acc_store_free(&ak, &mk, g->W1k, g->b1k, g->W2k, g->b2k);
     if (c->A && g->app) for (int i = 0; i < c->A; i++) g->app[i] = (float)dapp[i];
 }
+
+/* Octree-GS level-of-detail mask: OctreeGaussianModel.set_anchor_mask + map_to_int_level (gssr/gaussian/octree_gaussian.py:184-203,255-267).
+ * mode: 0 floor, 1 round (half to even, torch.round), 2 ceil, 3 progressive.  prog_ratio / transition may be NULL. */
+void refd_lod_mask(int32_t Na, const float* anchor, const int32_t* level, const float* extra_level, const float* campos, float voxel_size,
+                   float fork, float standard_dist, float resolution_scale, int32_t coarse_index, int32_t mode, uint8_t* anchor_mask,
+                   float* prog_ratio, uint8_t* transition)
+{
+    const int cur = coarse_index - 1;
+    for (int i = 0; i < Na; i++) {
+        const float half = (voxel_size / 2) / powf(fork, (float)level[i]);
+        float d2 = 0.f;
+        for (int c = 0; c < 3; c++) { const float d = (anchor[3 * i + c] + half) - campos[c]; d2 += d * d; }
+        const float dist = sqrtf(d2) * resolution_scale;
+        float pred = log2f(standard_dist / dist) / log2f(fork) + (extra_level ? extra_level[i] : 0.f);
+        int il;
+        if (mode == 3) {
+            pred = pred + 1.0f;
+            if (pred < 0.9999f) pred = 0.9999f;
+            if (pred > (float)cur + 0.9999f) pred = (float)cur + 0.9999f;
+            il = (int)floorf(pred);
+            if (prog_ratio) prog_ratio[i] = pred - truncf(pred);
+            if (transition) transition[i] = level[i] == il;
+        } else {
+            const float r = mode == 0 ? floorf(pred) : (mode == 1 ? rintf(pred) : ceilf(pred));
+            il = (int)r;
+            il = il < 0 ? 0 : (il > cur ? cur : il);
+        }
+        anchor_mask[i] = level[i] <= il;
+    }
+}

