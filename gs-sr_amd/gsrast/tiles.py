@@ -47,3 +47,33 @@ def reduce_job(elapsed_s, iters_done, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     return float(t.item()), int(n.item())
+
+
+def allreduce_shared_(grads, shared_rows=None, average=True):
+    """OPTIONAL build extension (no reference counterpart: the reference never synchronises tiles) -- OFF unless called.
+
+    Sums (or averages) the gradients of parameters that several tile workers share -- the overlap-band anchors of neighbouring
+    VastGaussian tiles (`shared_rows`: one LongTensor of local row indices per tensor, same length and order on every rank) or whole
+    tensors such as the three decode MLPs / the appearance embedding (`shared_rows[i] is None`).  Everything is packed into ONE flat fp32
+    bucket and reduced with a single all-reduce: over xGMI the payload (a few MB) is latency-bound, so one collective per iteration is the
+    right shape (RCCL picks its direct/tree path for small messages; a per-tensor loop would pay the launch latency a dozen times).
+    In place; returns the number of floats communicated."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    if shared_rows is None:
+        shared_rows = [None] * len(grads)
+    parts = [(g if r is None else g.index_select(0, r)).reshape(-1).float() for g, r in zip(grads, shared_rows)]
+    flat = torch.cat(parts)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    off = 0
+    for g, r, p in zip(grads, shared_rows, parts):
+        n = p.numel()
+        red = flat[off:off + n].to(g.dtype)
+        if r is None:
+            g.copy_(red.view_as(g))
+        else:
+            g.index_copy_(0, r, red.view(r.numel(), *g.shape[1:]))
+        off += n
+    return int(flat.numel())

@@ -106,3 +106,31 @@ def test_launch_tiles_two_workers_gloo():
             assert txt[0] == src and int(txt[1]) == k and txt[2] == "cpu"
             ranks.add(txt[3])
         assert ranks == {"rank0", "rank1"}
+
+
+def _shared_worker(rank, world, port):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "gs-sr_amd"))
+    from gsrast import tiles
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    feat = torch.randn(50, 32, generator=g); W = torch.randn(32, 35, generator=g); b = torch.randn(32, generator=g)
+    keep = [feat.clone(), W.clone(), b.clone()]
+    # each rank shares 10 anchor rows (different local indices, same logical anchors, same order) + the whole MLP layer
+    rows = torch.arange(5, 15) if rank == 0 else torch.arange(30, 40)
+    n = tiles.allreduce_shared_([feat, W, b], [rows, None, None], average=True)
+    assert n == 10 * 32 + 32 * 35 + 32
+    other = torch.Generator().manual_seed(100 + (1 - rank))
+    ofeat = torch.randn(50, 32, generator=other); oW = torch.randn(32, 35, generator=other); ob = torch.randn(32, generator=other)
+    orows = torch.arange(30, 40) if rank == 0 else torch.arange(5, 15)
+    assert torch.allclose(feat[rows], 0.5 * (keep[0][rows] + ofeat[orows]))
+    mask = torch.ones(50, dtype=torch.bool); mask[rows] = False
+    assert torch.equal(feat[mask], keep[0][mask])                      # private rows untouched
+    assert torch.allclose(W, 0.5 * (keep[1] + oW)) and torch.allclose(b, 0.5 * (keep[2] + ob))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_allreduce_shared_anchor_grads_world2_gloo():
+    mp.spawn(_shared_worker, args=(2, _free_port()), nprocs=2, join=True)
