@@ -110,14 +110,14 @@ def make_step(variant, sc, device):
             kw["colors_precomp"] = v["colors_precomp"]
         if variant == "surfel":
             color, radii, allmap = dsr.GaussianRasterizer(rs)(**kw)
-            loss = l1_plus_linear(color, gt, allmap, wmap)
+            loss = l1_plus_linear(color, gt, allmap, wmap, root=True)
         elif variant == "plane":
             m2a = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
             color, radii, observe, oam, pd = dpr.GaussianRasterizer(rs)(means2D_abs=m2a, all_map=all_map, **kw)
-            loss = l1_plus_linear(color, gt, oam, wmap) + (pd * wpd).sum()
+            loss = l1_plus_linear(color, gt, oam, wmap, root=True) + (pd * wpd).sum()
         else:
             color, radii = dgr.GaussianRasterizer(rs)(**kw)
-            loss = l1_plus_linear(color, gt)
+            loss = l1_plus_linear(color, gt, root=True)
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)

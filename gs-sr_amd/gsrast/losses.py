@@ -6,7 +6,7 @@ from . import lib, check, ptr, stream_ptr, dev_f32
 
 class _L1PlusLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, color, gt, aux, waux):
+    def forward(ctx, color, gt, aux, waux, root=False):
         c = dev_f32(color, "color", allow_empty=False)
         g = dev_f32(gt, "gt", allow_empty=False)
         a = dev_f32(aux, "aux") if aux is not None else None
@@ -19,19 +19,25 @@ class _L1PlusLinear(torch.autograd.Function):
                                        ptr(loss), stream_ptr(c.device)), "loss_l1_linear")
         ctx.save_for_backward(dcol, w if w is not None else torch.empty(0, device=c.device))
         ctx.has_aux = a is not None
+        ctx.root = bool(root)
         ctx.aux_shape = aux.shape if aux is not None else None
         return loss
 
     @staticmethod
     def backward(ctx, g):
         dcol, w = ctx.saved_tensors
-        return dcol * g, None, (w.reshape(ctx.aux_shape) * g) if ctx.has_aux else None, None
+        if ctx.root:       # the caller declared this value the root of the backward pass: its upstream gradient is exactly 1
+            return dcol, None, w.reshape(ctx.aux_shape) if ctx.has_aux else None, None, None
+        return dcol * g, None, (w.reshape(ctx.aux_shape) * g) if ctx.has_aux else None, None, None
 
 
-def l1_plus_linear(color, gt, aux=None, waux=None):
+def l1_plus_linear(color, gt, aux=None, waux=None, root=False):
     """mean|color - gt| + sum(aux * waux), forward value and dL/dcolor in ONE streaming HIP kernel.
-    Equivalent torch: (color - gt).abs().mean() + (aux * waux).sum()."""
-    return _L1PlusLinear.apply(color, gt, aux, waux)
+    Equivalent torch: (color - gt).abs().mean() + (aux * waux).sum().
+    root=True: the returned value is (a plain summand of) the scalar `.backward()` is called on, so its upstream gradient is exactly 1 and
+    the stored gradients are handed to autograd as they are -- saves two N-sized multiplies by one per iteration.  Do not set it if the
+    loss is rescaled afterwards."""
+    return _L1PlusLinear.apply(color, gt, aux, waux, root)
 
 
 class _L1SSIM(torch.autograd.Function):

@@ -62,7 +62,7 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
     empty_call = (P == 0)
     mk = torch.zeros if empty_call else torch.empty
     outs["color"] = mk((3, H, W), **f32)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    radii = mk((P,), dtype=torch.int32, device=dev)          # the preprocess kernel writes every entry
     if variant == SURFEL:
         outs["others"] = mk((11, H, W), **f32)
     if variant == PLANE:

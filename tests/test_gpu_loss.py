@@ -134,3 +134,19 @@ def test_plane_geo_full_hd_vs_torch_chain():
     Lr.backward()
     assert abs(loss.item() - Lr.item()) < 2e-5 * abs(Lr.item()) + 1e-7
     assert ((d.grad - dr.grad).norm() / dr.grad.norm()).item() < 5e-3
+
+
+def test_l1_plus_linear_root_flag_same_gradients():
+    from gsrast.losses import l1_plus_linear
+    g = torch.Generator().manual_seed(0)
+    c = torch.rand(3, 40, 56, generator=g).to(DEV); gt = torch.rand(3, 40, 56, generator=g).to(DEV)
+    a = torch.rand(11, 40, 56, generator=g).to(DEV); w = torch.randn(11, 40, 56, generator=g).to(DEV)
+    grads = []
+    for root in (False, True):
+        cc = c.clone().requires_grad_(True); aa = a.clone().requires_grad_(True)
+        loss = l1_plus_linear(cc, gt, aa, w, root=root)
+        loss.backward()
+        grads.append((loss.item(), cc.grad.clone(), aa.grad.clone()))
+    assert grads[0][0] == grads[1][0] and torch.equal(grads[0][1], grads[1][1]) and torch.equal(grads[0][2], grads[1][2])
+    ref = (c - gt).abs().mean() + (a * w).sum()
+    assert abs(grads[0][0] - ref.item()) < 1e-3 * abs(ref.item()) + 1e-5
