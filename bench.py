@@ -97,12 +97,14 @@ def make_step(variant, sc, device):
         wpd = torch.full((1, H, W), 0.01 / N, device=device)
     all_map = t.get("all_map")
     state = {}
+    # screen-space gradient carriers: the rasterizer only uses their .grad slot, so the leaves persist across iterations
+    means2D = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
+    m2a = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True) if variant == "plane" else None
 
     def step():
         prm = z * lr_scale
         parts = torch.split(prm, sizes)                                 # backward = one cat, not one zero-pad per slice
         v = {k: parts[i].view(P, n) for i, (k, n, _) in enumerate(cols)}
-        means2D = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
         kw = dict(means3D=v["means3D"], means2D=means2D, opacities=v["opacities"], scales=v["scales"], rotations=v["rotations"])
         if use_sh:
             kw["shs"] = v["shs"].reshape(P, 16, 3)
@@ -112,7 +114,6 @@ def make_step(variant, sc, device):
             color, radii, allmap = dsr.GaussianRasterizer(rs)(**kw)
             loss = l1_plus_linear(color, gt, allmap, wmap, root=True)
         elif variant == "plane":
-            m2a = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True)
             color, radii, observe, oam, pd = dpr.GaussianRasterizer(rs)(means2D_abs=m2a, all_map=all_map, **kw)
             loss = l1_plus_linear(color, gt, oam, wmap, root=True) + (pd * wpd).sum()
         else:
@@ -121,6 +122,10 @@ def make_step(variant, sc, device):
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
+        state["viewspace_grad"] = means2D.grad          # what densification reads (viewspace_points.grad[:, :2])
+        means2D.grad = None
+        if m2a is not None:
+            m2a.grad = None
         state["loss"] = loss
         state["vis"] = radii
     return step, state
