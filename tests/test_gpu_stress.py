@@ -106,3 +106,19 @@ def test_subtile_cull_is_result_neutral(variant, seed, kw, monkeypatch):
     for k in ("color", "others", "out_all_map", "plane_depth", "radii"):
         if k in a and a[k] is not None:
             assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_heavy_tiles_with_depth_ties():
+    """6000 splats all covering every tile of a 64x48 image: every tile holds 6000 instances; many equal depths (z quantised), so the
+    order inside a tile depends on the tie-break by gaussian id, exactly as the reference's stable 64-bit sort resolves it."""
+    hr = _hr()
+    W, H, P = 64, 48, 6000
+    sc = scenes.make_scene("ewa", P, W, H, seed=41, sigma_px=200.0)
+    sc["means3D"][:, 2] = np.round(sc["means3D"][:, 2] * 4.0) / 4.0          # many equal depths
+    sc["opacities"][:] = 0.01
+    st = hr.run_raw("ewa", sc)
+    with oracle.Forward(sc, "ewa") as f:
+        assert st["R"] == f.R and f.R > 4096 * 12
+        assert np.array_equal(st["ranges"], f.ranges())
+        assert np.array_equal(st["point_list"], f.point_list())
+        assert np.abs(st["color"] - f.color).max() < 1e-4
