@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
     } while (0)
 
 template <int V, bool MFMA_RED>
-__global__ void __launch_bounds__(256) k_blend_bwd(BlendParams p)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_blend_bwd(BlendParams p)
 {
     constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
     constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
