@@ -124,3 +124,30 @@ def test_no_cpu_fallback():
                 txt = open(os.path.join(dp, f)).read()
                 for pat in ("import oracle", "from oracle", "gsr_oracle", "libgsr_oracle", "oracle/"):
                     assert pat not in txt, (os.path.join(dp, f), pat)
+
+
+def test_decode_argument_errors_without_a_device():
+    """gsd_* validate their arguments before touching the device: messages are checkable on a CPU-only box."""
+    import ctypes as C
+    import gsrast
+    from gsrast import decode
+    L = decode._lib()
+    buf = (C.c_float * 64)()
+    addr = C.addressof(buf)
+    prm = decode.Params(*[addr] * 13)
+    inp = decode.Inputs(*[addr] * 8)
+    P = C.c_uint32(0)
+
+    def stage1(cfg):
+        return L.gsd_forward_stage1(C.byref(cfg), C.byref(inp), C.byref(prm), addr, addr, addr, C.byref(P), addr, 1 << 20, None)
+    assert stage1(decode.Cfg(10, 5, 17, 0, 0, 0, 0, 0)) != 0 and "n_offsets" in gsrast.last_error()
+    assert stage1(decode.Cfg(10, 5, 10, 65, 0, 0, 0, 0)) != 0 and "appearance_dim" in gsrast.last_error()
+    assert stage1(decode.Cfg(10, 11, 10, 0, 0, 0, 0, 0)) != 0 and "bad sizes" in gsrast.last_error()
+    bad = decode.Inputs(addr, addr + 4, addr, addr, None, None, addr, addr)              # feat not 16-byte aligned
+    assert L.gsd_forward_stage1(C.byref(decode.Cfg(10, 5, 10, 0, 0, 0, 0, 0)), C.byref(bad), C.byref(prm), addr, addr, addr, C.byref(P), addr,
+                                1 << 20, None) != 0 and "aligned" in gsrast.last_error()
+    lvl = decode.Inputs(addr, addr, addr, addr, None, None, addr, addr)
+    assert L.gsd_forward_stage1(C.byref(decode.Cfg(10, 5, 10, 0, 0, 0, 0, 1)), C.byref(lvl), C.byref(prm), addr, addr, addr, C.byref(P), addr,
+                                1 << 20, None) != 0 and "level" in gsrast.last_error()
+    assert L.gsd_forward_stage1(C.byref(decode.Cfg(10, 5, 10, 0, 0, 0, 0, 0)), C.byref(inp), C.byref(prm), addr, addr, addr, C.byref(P), addr,
+                                16, None) != 0 and "scratch" in gsrast.last_error()
