@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
 {
     if (n_dev) n = min(n, *n_dev);
     __shared__ uint32_t cnt[4][256];
-    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t gbase[256], lbase[256];
+    __shared__ uint32_t skey[GSR_SORT_BLOCK], sval[GSR_SORT_BLOCK];
     __shared__ uint32_t lds[17];
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,21 +146,38 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
         rank[it] = old + before;
     }
     __syncthreads();
+    // per-digit totals of the block -> exclusive prefix over the digits = position of the digit's run inside the block
+    uint32_t tot_d = 0;
     if (threadIdx.x <= mask) {
-        uint32_t run = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { uint32_t t = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = run; run += t; }
+        for (int w = 0; w < 4; w++) { uint32_t t = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = tot_d; tot_d += t; }
+    }
+    {
+        uint32_t tot;
+        const uint32_t incl = block_incl_scan(tot_d, lds, &tot);
+        if (threadIdx.x <= mask) lbase[threadIdx.x] = incl - tot_d;
     }
     __syncthreads();
+    // stage the block's keys/values in LDS in digit order, then write each digit's run with consecutive lanes on consecutive
+    // addresses (a direct scatter puts the 64 lanes of a store on 64 different cache lines)
 #pragma unroll
     for (int it = 0; it < GSR_SORT_ITEMS; it++) {
         const uint32_t i = base + it * GSR_WAVE + lane;
         if (i < n) {
             const uint32_t d = (key[it] >> shift) & mask;
-            const uint32_t pos = gbase[d] + cnt[wave][d] + rank[it];
-            keys_out[pos] = key[it];
-            vals_out[pos] = vals_in ? vals_in[i] : i;
+            const uint32_t lp = lbase[d] + cnt[wave][d] + rank[it];
+            skey[lp] = key[it];
+            sval[lp] = vals_in ? vals_in[i] : i;
         }
+    }
+    __syncthreads();
+    const uint32_t nb = min((uint32_t)GSR_SORT_BLOCK, n - min(n, blockIdx.x * GSR_SORT_BLOCK));
+    for (uint32_t q = threadIdx.x; q < nb; q += GSR_SORT_THREADS) {
+        const uint32_t k = skey[q];
+        const uint32_t d = (k >> shift) & mask;
+        const uint32_t pos = gbase[d] + (q - lbase[d]);
+        keys_out[pos] = k;
+        vals_out[pos] = sval[q];
     }
 }
 
