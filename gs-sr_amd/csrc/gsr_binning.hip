@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256) k_scan_rows(uint32_t* __restrict__ data, 
 
 // ------------------------------------------------------------------------------------------------ radix sort
 // per-block digit histogram, hist[d * nblk + blk]
+template <int ITEMS>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev,
                                                                  int shift, uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk)
 {
@@ -89,9 +90,9 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t*
     if (n_dev) n = min(n, *n_dev);       // device-side element count (speculative forward): n is then the capacity
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * GSR_SORT_BLOCK;
+    const uint32_t base = blockIdx.x * (GSR_SORT_THREADS * ITEMS);
 #pragma unroll 4
-    for (int it = 0; it < GSR_SORT_ITEMS; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         uint32_t i = base + it * GSR_SORT_THREADS + threadIdx.x;
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
@@ -99,7 +100,8 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t*
     if (threadIdx.x <= mask) hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-// stable scatter.  Order inside a block is (wave, item, lane): wave w owns keys [w*1024, w*1024+1024).
+// stable scatter.  Order inside a block is (wave, item, lane): wave w owns 64*ITEMS consecutive keys.
+template <int ITEMS>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                     uint32_t n, const uint32_t* __restrict__ n_dev, int shift, int bits,
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     if (n_dev) n = min(n, *n_dev);
     __shared__ uint32_t cnt[4][256];
     __shared__ uint32_t gbase[256], lbase[256];
-    __shared__ uint32_t skey[GSR_SORT_BLOCK], sval[GSR_SORT_BLOCK];
+    __shared__ uint32_t skey[(GSR_SORT_THREADS * ITEMS)], sval[(GSR_SORT_THREADS * ITEMS)];
     __shared__ uint32_t lds[17];
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -121,11 +123,11 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     }
     __syncthreads();
 
-    const uint32_t base = blockIdx.x * GSR_SORT_BLOCK + wave * (GSR_WAVE * GSR_SORT_ITEMS);
-    uint32_t key[GSR_SORT_ITEMS], rank[GSR_SORT_ITEMS];
+    const uint32_t base = blockIdx.x * (GSR_SORT_THREADS * ITEMS) + wave * (GSR_WAVE * ITEMS);
+    uint32_t key[ITEMS], rank[ITEMS];
     const uint64_t lt = lanemask_lt();
 #pragma unroll
-    for (int it = 0; it < GSR_SORT_ITEMS; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * GSR_WAVE + lane;
         const bool valid = i < n;
         key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     // stage the block's keys/values in LDS in digit order, then write each digit's run with consecutive lanes on consecutive
     // addresses (a direct scatter puts the 64 lanes of a store on 64 different cache lines)
 #pragma unroll
-    for (int it = 0; it < GSR_SORT_ITEMS; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * GSR_WAVE + lane;
         if (i < n) {
             const uint32_t d = (key[it] >> shift) & mask;
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
         }
     }
     __syncthreads();
-    const uint32_t nb = min((uint32_t)GSR_SORT_BLOCK, n - min(n, blockIdx.x * GSR_SORT_BLOCK));
+    const uint32_t nb = min((uint32_t)(GSR_SORT_THREADS * ITEMS), n - min(n, blockIdx.x * (GSR_SORT_THREADS * ITEMS)));
     for (uint32_t q = threadIdx.x; q < nb; q += GSR_SORT_THREADS) {
         const uint32_t k = skey[q];
         const uint32_t d = (k >> shift) & mask;
@@ -183,9 +185,11 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
 
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
-                         bool* result_in_b, hipStream_t s)
+                         bool* result_in_b, hipStream_t s, bool big_blocks)
 {
-    const uint32_t nblk = gsr_div_up(n, GSR_SORT_BLOCK);
+    // keys per block: 1024 (many blocks: small inputs are latency-bound) or 4096 (longer digit runs -> full-line writes on big inputs).
+    // The histogram area is always sized for the 1024-key geometry, the larger upper bound.
+    const uint32_t nblk = gsr_div_up(n, GSR_SORT_THREADS * (big_blocks ? 16u : (uint32_t)GSR_SORT_ITEMS));
     uint32_t* digit_tot = hist + (size_t)256 * nblk;      // 256 words behind the histogram matrix
     // identity_vals: the first pass generates value i for element i instead of reading vals_a
     uint32_t *kin = keys_a, *vin = identity_vals ? nullptr : vals_a, *kout = keys_b, *vout = vals_b;
@@ -196,9 +200,11 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         int passes_left = (remaining + bits_per_pass - 1) / bits_per_pass;
         int bits = (remaining + passes_left - 1) / passes_left;
         uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, n_dev, shift, mask, hist, nblk);
+        if (big_blocks) hipLaunchKernelGGL(k_radix_hist<16>, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, n_dev, shift, mask, hist, nblk);
+        else hipLaunchKernelGGL(k_radix_hist<GSR_SORT_ITEMS>, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, n_dev, shift, mask, hist, nblk);
         hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, hist, nblk, digit_tot);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
+        if (big_blocks) hipLaunchKernelGGL(k_radix_scatter<16>, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
+        else hipLaunchKernelGGL(k_radix_scatter<GSR_SORT_ITEMS>, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         if (vin == nullptr) { vin = vout; vout = vals_a; }     // first pass generated identity values into vals_b
@@ -242,7 +248,7 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
     const uint32_t P = (uint32_t)cfg->P;
     bool in_b = false;
     // keys: depth_key (A) <-> keys_b; values: identity -> vals_b <-> vals_a
-    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, 8, true, g.hist, &in_b, s);
+    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, 8, true, g.hist, &in_b, s, false);
     // 4 passes: keys end in depth_key (A).  values: pass1 -> vals_b, pass2 -> vals_a, pass3 -> vals_b, pass4 -> vals_a
     // (gsr_radix_sort_pairs alternates vout between vals_b and vals_a), so the ids end in vals_a == sorted_idx.
     const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
@@ -341,7 +347,7 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up(cfg->P, 256)), dim3(256), 0, s, (uint32_t)cfg->P, g.sorted_idx, g.offsets,
                        g.tiles_touched, g.rect, gx, k0, v0, R);
     bool in_b = false;
-    gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s);
+    gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19));
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
     return gsr_check_launch("binning", s, cfg->debug);
 }

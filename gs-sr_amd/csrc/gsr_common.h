@@ -21,7 +21,7 @@
 // radix sort geometry
 #define GSR_SORT_THREADS 256
 #define GSR_SORT_ITEMS 4
-#define GSR_SORT_BLOCK (GSR_SORT_THREADS * GSR_SORT_ITEMS)   // 1024 keys per block: short rank chains, many blocks
+#define GSR_SORT_BLOCK (GSR_SORT_THREADS * GSR_SORT_ITEMS)
 #define GSR_SCAN_BLOCK 1024
 
 static inline __host__ __device__ int gsr_rec_stride(int variant)
@@ -97,4 +97,4 @@ int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const in
 // generic device-wide primitives (gsr_binning.hip)
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
-                         bool* result_in_b, hipStream_t s);
+                         bool* result_in_b, hipStream_t s, bool big_blocks = false);
