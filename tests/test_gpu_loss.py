@@ -147,6 +147,7 @@ def test_l1_plus_linear_root_flag_same_gradients():
         loss = l1_plus_linear(cc, gt, aa, w, root=root)
         loss.backward()
         grads.append((loss.item(), cc.grad.clone(), aa.grad.clone()))
-    assert grads[0][0] == grads[1][0] and torch.equal(grads[0][1], grads[1][1]) and torch.equal(grads[0][2], grads[1][2])
+    assert abs(grads[0][0] - grads[1][0]) < 1e-4 * abs(grads[0][0])          # the value is summed with float atomics: order-dependent
+    assert torch.equal(grads[0][1], grads[1][1]) and torch.equal(grads[0][2], grads[1][2])
     ref = (c - gt).abs().mean() + (a * w).sum()
     assert abs(grads[0][0] - ref.item()) < 1e-3 * abs(ref.item()) + 1e-5
