@@ -142,8 +142,11 @@ class _NeuralDecode(torch.autograd.Function):
             return torch.zeros(n, cols, dtype=torch.float32, device=dev) if g is None else g.contiguous().float()
         gx, gc, go, gs, gr = og(g_xyz, 3), og(g_color, 3), og(g_opacity, 1), og(g_scaling, 3), og(g_rot, 4)
         ogr = OutGrads(ptr(gx), ptr(gc), ptr(go), ptr(gs), ptr(gr))
-        d_anchor = torch.zeros_like(t["anchor"]); d_feat = torch.zeros_like(t["feat"])
-        d_offset = torch.zeros_like(t["offset"]); d_scaling = torch.zeros_like(t["scaling"])
+        # rows of invisible anchors must read as zero: ONE zero-filled flat buffer, sliced into the four gradient tensors
+        shapes = [t["feat"].shape, t["anchor"].shape, t["offset"].shape, t["scaling"].shape]      # feat first: it must be 16-B aligned
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        d_feat, d_anchor, d_offset, d_scaling = [p_.view(sh) for p_, sh in zip(torch.split(flat, sizes), shapes)]
         gp = {nm: (None if prm[nm] is None else torch.empty_like(prm[nm])) for nm in PARAM_NAMES}
         ig = InGrads(ptr(d_anchor), ptr(d_feat), ptr(d_offset), ptr(d_scaling), Params(*[ptr(gp[nm]) for nm in PARAM_NAMES]))
         scratch = torch.empty(L.gsd_backward_scratch_bytes(C.byref(cfg)), dtype=torch.uint8, device=dev)
