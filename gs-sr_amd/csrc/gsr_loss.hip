@@ -4,7 +4,8 @@
 //   SSIM: 11x11 Gaussian window (sigma 1.5), zero padding 5, per channel, C1 = 0.01^2, C2 = 0.03^2, mean over C*H*W.
 //
 // The reference builds it from five grouped conv2d calls and ~20 elementwise ops (and autograd replays all of them).  Here: two
-// HBM-bound streaming kernels over 16x16 pixel tiles with a 5-pixel halo staged in LDS and a separable 11+11 tap filter:
+// HBM-bound streaming kernels over 32x32 pixel tiles with a 5-pixel halo staged in LDS and a separable 11+11 tap filter
+// (4 outputs per thread in each pass: 27 LDS reads per pixel instead of 91):
 //   k_ssim_fwd : mu1, mu2, E[x^2], E[y^2], E[xy] -> SSIM map value (block-reduced into the loss) and the three partial-derivative
 //                maps dS/dmu1, dS/dE[x^2], dS/dE[xy]
 //   k_ssim_bwd : dL/dimg = w * dS/dmu1 + 2 img (w * dS/dE[x^2]) + gt (w * dS/dE[xy])  (the window is symmetric, so the adjoint of the
@@ -12,10 +13,11 @@
 // Algorithmic bytes per pixel-channel: fwd 8 read + 12 written, bwd 12 + 8 read + 4 written = 44 B.
 #include "gsr_common.h"
 
-#define SS_T 16
+#define SS_T 32                         // output tile edge
 #define SS_R 5
-#define SS_P (SS_T + 2 * SS_R)        // 26
+#define SS_P (SS_T + 2 * SS_R)        // 42: staged patch edge
 #define SS_LD (SS_P + 1)
+#define SS_B 4                          // outputs per thread in each filter pass (sliding window: 14 LDS reads feed 4 outputs, not 44)
 
 __constant__ float c_win[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f, 2.130055279e-01f, 2.660117149e-01f,
                                 2.130055279e-01f, 1.093606874e-01f, 3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f};
@@ -29,6 +31,8 @@ __device__ __forceinline__ float block_sum256(float v, float* red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// 32x32 outputs per 256-thread block.  Horizontal pass: a work item = one patch row x 4 adjacent output columns (42 rows x 8 groups);
+// vertical pass: one output column x 4 adjacent output rows (32 x 8 = 256 items, one per thread).
 __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
                                                   float* __restrict__ maps /*[3][C][H][W]*/, size_t plane_all, float2* __restrict__ partial)
 {
@@ -45,45 +49,73 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, const float* __r
         sy[ly][lx] = in ? gp[(size_t)gy * W + gx] : 0.0f;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < SS_P * SS_T; e += 256) {        // horizontal pass: 26 rows x 16 columns
-        const int ly = e / SS_T, lx = e % SS_T;
-        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+    for (int e = threadIdx.x; e < SS_P * (SS_T / SS_B); e += 256) {
+        const int ly = e / (SS_T / SS_B), lx = (e % (SS_T / SS_B)) * SS_B;
+        float a[SS_B], b[SS_B], aa[SS_B], bb[SS_B], ab[SS_B];
 #pragma unroll
-        for (int t = 0; t < 11; t++) {
-            const float w = c_win[t], u = sx[ly][lx + t], v = sy[ly][lx + t];
-            a = fmaf(w, u, a); b = fmaf(w, v, b); aa = fmaf(w, u * u, aa); bb = fmaf(w, v * v, bb); ab = fmaf(w, u * v, ab);
+        for (int o = 0; o < SS_B; o++) a[o] = b[o] = aa[o] = bb[o] = ab[o] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11 + SS_B - 1; t++) {
+            const float u = sx[ly][lx + t], v = sy[ly][lx + t];
+            const float uu = u * u, vv = v * v, uv = u * v;
+#pragma unroll
+            for (int o = 0; o < SS_B; o++) {
+                if (t - o >= 0 && t - o < 11) {
+                    const float w = c_win[t - o];
+                    a[o] = fmaf(w, u, a[o]); b[o] = fmaf(w, v, b[o]); aa[o] = fmaf(w, uu, aa[o]); bb[o] = fmaf(w, vv, bb[o]); ab[o] = fmaf(w, uv, ab[o]);
+                }
+            }
         }
-        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = aa; h[3][ly][lx] = bb; h[4][ly][lx] = ab;
+#pragma unroll
+        for (int o = 0; o < SS_B; o++) { h[0][ly][lx + o] = a[o]; h[1][ly][lx + o] = b[o]; h[2][ly][lx + o] = aa[o]; h[3][ly][lx + o] = bb[o]; h[4][ly][lx + o] = ab[o]; }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, gx = x0 + lx, gy = y0 + ly;
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SS_B, gx = x0 + lx;
+    float q[5][SS_B];
 #pragma unroll
-    for (int t = 0; t < 11; t++) {
-        const float w = c_win[t];
-        mu1 = fmaf(w, h[0][ly + t][lx], mu1); mu2 = fmaf(w, h[1][ly + t][lx], mu2);
-        e11 = fmaf(w, h[2][ly + t][lx], e11); e22 = fmaf(w, h[3][ly + t][lx], e22); e12 = fmaf(w, h[4][ly + t][lx], e12);
+    for (int k = 0; k < 5; k++)
+#pragma unroll
+        for (int o = 0; o < SS_B; o++) q[k][o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 11 + SS_B - 1; t++) {
+        float hv[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) hv[k] = h[k][ly0 + t][lx];
+#pragma unroll
+        for (int o = 0; o < SS_B; o++) {
+            if (t - o >= 0 && t - o < 11) {
+                const float w = c_win[t - o];
+#pragma unroll
+                for (int k = 0; k < 5; k++) q[k][o] = fmaf(w, hv[k], q[k][o]);
+            }
+        }
     }
     float ssim = 0.f, l1 = 0.f;
-    if (gx < W && gy < H) {
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
-        const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1s + mu2s + C1, B2 = s1 + s2 + C2;
-        const float inv = 1.0f / (B1 * B2);
-        ssim = A1 * A2 * inv;
-        // S as a function of (mu1, E[x^2], E[xy]) with mu2, E[y^2] fixed
-        const float dmu = 2.f * mu2 * (A2 - A1) * inv - ssim * 2.f * mu1 * (1.0f / B1 - 1.0f / B2);
-        const float d11 = -ssim / B2;
-        const float d12 = 2.f * A1 * inv;
-        const size_t o = ((size_t)c * H + gy) * W + gx;
-        maps[o] = dmu; maps[plane_all + o] = d11; maps[2 * plane_all + o] = d12;
-        l1 = fabsf(sx[ly + SS_R][lx + SS_R] - sy[ly + SS_R][lx + SS_R]);
+#pragma unroll
+    for (int o = 0; o < SS_B; o++) {
+        const int gy = y0 + ly0 + o;
+        if (gx < W && gy < H) {
+            const float mu1 = q[0][o], mu2 = q[1][o], e11 = q[2][o], e22 = q[3][o], e12 = q[4][o];
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
+            const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1s + mu2s + C1, B2 = s1 + s2 + C2;
+            const float inv = 1.0f / (B1 * B2);
+            const float sv = A1 * A2 * inv;
+            ssim += sv;
+            // S as a function of (mu1, E[x^2], E[xy]) with mu2, E[y^2] fixed
+            const float dmu = 2.f * mu2 * (A2 - A1) * inv - sv * 2.f * mu1 * (1.0f / B1 - 1.0f / B2);
+            const float d11 = -sv / B2;
+            const float d12 = 2.f * A1 * inv;
+            const size_t oo = ((size_t)c * H + gy) * W + gx;
+            maps[oo] = dmu; maps[plane_all + oo] = d11; maps[2 * plane_all + oo] = d12;
+            l1 += fabsf(sx[ly0 + o + SS_R][lx + SS_R] - sy[ly0 + o + SS_R][lx + SS_R]);
+        }
     }
     const float ts = block_sum256(ssim, red);
     __syncthreads();
     const float tl = block_sum256(l1, red);
-    // one partial per block, summed by k_ssim_finish: 24k same-address atomics serialise (measured 0.5 ms) and are order-dependent
+    // one partial per block, summed by k_ssim_finish: same-address atomics from thousands of blocks serialise (measured 0.5 ms)
     if (threadIdx.x == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float2(tl, ts);
 }
 
@@ -102,29 +134,58 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
         for (int m = 0; m < 3; m++) sm[m][ly][lx] = in ? maps[m * plane_all + o] : 0.0f;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < SS_P * SS_T; e += 256) {
-        const int ly = e / SS_T, lx = e % SS_T;
-        float a = 0.f, b = 0.f, d = 0.f;
+    for (int e = threadIdx.x; e < SS_P * (SS_T / SS_B); e += 256) {
+        const int ly = e / (SS_T / SS_B), lx = (e % (SS_T / SS_B)) * SS_B;
+        float a[3][SS_B];
 #pragma unroll
-        for (int t = 0; t < 11; t++) {
-            const float w = c_win[t];
-            a = fmaf(w, sm[0][ly][lx + t], a); b = fmaf(w, sm[1][ly][lx + t], b); d = fmaf(w, sm[2][ly][lx + t], d);
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int o = 0; o < SS_B; o++) a[m][o] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11 + SS_B - 1; t++) {
+            const float v0 = sm[0][ly][lx + t], v1 = sm[1][ly][lx + t], v2 = sm[2][ly][lx + t];
+#pragma unroll
+            for (int o = 0; o < SS_B; o++) {
+                if (t - o >= 0 && t - o < 11) {
+                    const float w = c_win[t - o];
+                    a[0][o] = fmaf(w, v0, a[0][o]); a[1][o] = fmaf(w, v1, a[1][o]); a[2][o] = fmaf(w, v2, a[2][o]);
+                }
+            }
         }
-        h[0][ly][lx] = a; h[1][ly][lx] = b; h[2][ly][lx] = d;
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int o = 0; o < SS_B; o++) h[m][ly][lx + o] = a[m][o];
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, gx = x0 + lx, gy = y0 + ly;
-    if (gx >= W || gy >= H) return;
-    float a = 0.f, b = 0.f, d = 0.f;
+    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SS_B, gx = x0 + lx;
+    float q[3][SS_B];
 #pragma unroll
-    for (int t = 0; t < 11; t++) {
-        const float w = c_win[t];
-        a = fmaf(w, h[0][ly + t][lx], a); b = fmaf(w, h[1][ly + t][lx], b); d = fmaf(w, h[2][ly + t][lx], d);
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int o = 0; o < SS_B; o++) q[m][o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 11 + SS_B - 1; t++) {
+        const float v0 = h[0][ly0 + t][lx], v1 = h[1][ly0 + t][lx], v2 = h[2][ly0 + t][lx];
+#pragma unroll
+        for (int o = 0; o < SS_B; o++) {
+            if (t - o >= 0 && t - o < 11) {
+                const float w = c_win[t - o];
+                q[0][o] = fmaf(w, v0, q[0][o]); q[1][o] = fmaf(w, v1, q[1][o]); q[2][o] = fmaf(w, v2, q[2][o]);
+            }
+        }
     }
-    const size_t o = ((size_t)c * H + gy) * W + gx;
-    const float x = img[o], y = gt[o], df = x - y;
-    const float sgn = df > 0.f ? 1.0f : (df < 0.f ? -1.0f : 0.0f);
-    dimg[o] = w_l1 * sgn - w_ssim * (a + 2.f * x * b + y * d);
+    if (gx >= W) return;
+#pragma unroll
+    for (int o = 0; o < SS_B; o++) {
+        const int gy = y0 + ly0 + o;
+        if (gy < H) {
+            const size_t oo = ((size_t)c * H + gy) * W + gx;
+            const float x = img[oo], y = gt[oo], df = x - y;
+            const float sgn = df > 0.f ? 1.0f : (df < 0.f ? -1.0f : 0.0f);
+            dimg[oo] = w_l1 * sgn - w_ssim * (q[0][o] + 2.f * x * q[1][o] + y * q[2][o]);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(1024) k_ssim_finish(const float2* __restrict__ partial, int n, float* loss, float inv_n, float lambda)
