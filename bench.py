@@ -171,15 +171,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # one GPU per rank on the 8-GPU node; wraps only in single-GPU dry runs
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or "RANK" in os.environ:      # under torch.distributed.run: RCCL for the barrier / max-reduction only
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")        # "gloo": dry run of the N-rank path on a box with fewer GPUs
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import gsrast
     import scenes
@@ -204,7 +209,8 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = gsrast.profile_read()
     gsrast.profile_enable(False)
-    elapsed, total_iters = tiles.reduce_job(elapsed, args.steps, device)
+    reduce_dev = device if os.environ.get("GSR_BENCH_BACKEND", "nccl") == "nccl" else None
+    elapsed, total_iters = tiles.reduce_job(elapsed, args.steps, reduce_dev)
 
     if rank == 0:
         import hiprun
