@@ -2,9 +2,11 @@
  * gsd_oracle.h -- CPU restatement of the neural-Gaussian decode that feeds the rasterizer in the Scaffold/Octree methods
  * (gssr/scene/scaffold_scene.py:27-120, gssr/scene/octree_scene.py:26-133).  TEST INFRASTRUCTURE ONLY (see gsr_oracle.h).
  *
- * PARITY STATUS: "parity unpinned by the reference" -- the reference defines this step as a chain of torch ops inside scene classes that
- * cannot be imported here (they import the CUDA rasterizers); it ships no fixtures for it.  The restatement is pinned by a float64
- * torch-autograd transcription of those lines (tests/ref_decode_torch.py), forward and backward.
+ * PARITY STATUS: PINNED against the reference itself run in the authoring container -- tests/golden/make_golden_ref.py instantiates the
+ * reference's ScaffoldGaussian / OctreeGaussian (CPU torch; the CUDA-extension imports of those modules satisfied by inert stand-ins)
+ * and calls ScaffoldScene / OctreeScene.generate_neural_gaussians and OctreeGaussian.set_anchor_mask; outputs and autograd gradients are
+ * committed as tests/golden/ref_decode_*.npz, ref_lod_*.npz and checked by tests/test_golden_ref_cpu.py (oracle) and
+ * tests/test_gpu_golden_ref.py (HIP).  A float64 transcription (tests/ref_decode_torch.py) adds randomized cases beyond the fixtures.
  *
  * Per visible anchor a (feat_dim = hidden = 32, k = n_offsets):
  *   view = anchor - campos; dist = |view|; view /= dist

@@ -3,7 +3,9 @@
  *   loss = (1-lambda)*mean|img-gt| + lambda*(1-SSIM)      gssr/scene/vanilla_scene.py:29-69 (l1_loss, _ssim, _gaussian, ssim, get_loss_dict)
  * Direct (non-separable) 11x11 correlation with zero padding, like F.conv2d(padding=5, groups=C) with the outer-product window; the
  * gradient is the chain rule of those ops, checked against torch autograd of the reference's formula in tests/.
- * PARITY STATUS: the reference ships no fixture for it -- "parity unpinned by the reference"; pinned by tests/test_loss_cpu.py.
+ * PARITY STATUS: PINNED against the reference itself run in the authoring container (tests/golden/make_golden_ref.py calls
+ * VanillaScene.get_loss_dict, TwoDGSScene.render post-processing + get_loss_dict, PGSRScene.render_normal/_get_img_grad_weight/erode on CPU
+ * torch; vectors in tests/golden/ref_loss_*.npz, checked by tests/test_golden_ref_cpu.py); randomized cases in tests/test_loss_cpu.py.
  */
 #include <math.h>
 #include <stdint.h>

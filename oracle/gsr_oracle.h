@@ -9,6 +9,8 @@
  * pinned instead by (1) golden vectors generated from the importable reference Python helpers
  * (tests/golden/make_golden.py: camera matrices, SH evaluation), (2) a float64 torch-autograd restatement of the
  * forward maths that checks every analytic backward (tests/ref_torch.py), (3) closed-form cases and invariants.
+ * Exception: ref_tsdf_integrate restates PYTHON (gssr/utils/mesh_utils.py:195-246) and IS pinned by a reference run
+ * (tests/golden/ref_tsdf_unbounded.npz, tests/test_golden_ref_cpu.py).
  *
  * Variants: 0 = EWA   (submodules/diff-gaussian-rasterization)
  *           1 = SURFEL(submodules/diff-surfel-rasterization)

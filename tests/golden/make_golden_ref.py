@@ -1,0 +1,321 @@
+"""Golden vectors produced by RUNNING the reference's own Python (torch, CPU) in the authoring container.
+
+    python tests/golden/make_golden_ref.py          # needs /root/reference; writes tests/golden/ref_*.npz
+
+The reference's scene / gaussian classes import CUDA extension modules and a few packages this image lacks (cv2, plyfile, tyro ...);
+those imports are satisfied with inert MagicMock stand-ins so that the pure-torch methods below can be called.  Nothing here builds or
+replaces the CUDA rasterizers: wherever the reference would call one, the generator hands it a seeded synthetic raster output (the
+"allmap"), and what is pinned is the reference's *Python* math around it.  The committed .npz files are data only (inputs + expected
+outputs and gradients); no reference source travels.
+
+Pinned (reference file:line -> fixture):
+  ref_decode_{scaffold,scaffold_dist,octree}.npz
+        gssr/scene/scaffold_scene.py:27-122, gssr/scene/octree_scene.py:26-128  generate_neural_gaussians(is_training=True) on the
+        reference's own ScaffoldGaussian / OctreeGaussian MLP stacks (gssr/gaussian/scaffold_gaussian.py:141-159) + autograd of
+        sum(out * dL) back to anchors / features / offsets / scaling / every MLP weight / the appearance row.
+  ref_lod_{floor,round,ceil,progressive}.npz
+        gssr/gaussian/octree_gaussian.py:184-203,255-267 set_anchor_mask + map_to_int_level.
+  ref_loss_l1_ssim.npz
+        gssr/scene/vanilla_scene.py:29-69 get_loss_dict (l1_loss, ssim) + autograd to the image.
+  ref_loss_surfel_geo_r{0,1}.npz
+        gssr/scene/twodgs_scene.py:25-35 get_loss_dict(step=8000) over gssr/scene/twodgs_scene.py:83-128 render() post-processing
+        (depth_to_normal: gssr/utils/point_utils.py:9-36) with the rasterizer call returning the fixture's allmap; autograd to allmap.
+  ref_tsdf_unbounded.npz
+        gssr/utils/mesh_utils.py:195-246 compute_sdf_perframe / compute_unbounded_tsdf, driven through extract_mesh_unbounded (:182-277)
+        with marching_cubes_with_contraction replaced by a probe that evaluates the sdf callable on the fixture's samples: the
+        contracted pass (adaptive truncation) gives `tsdf`, the texturing pass (scalar truncation) gives `rgb`.
+  ref_loss_plane_geo.npz
+        gssr/scene/pgsr_scene.py:227-238 render_normal (normal_from_depth_image, gssr/utils/graphics_utils.py:139-146),
+        pgsr_scene.py:32-58 _get_img_grad_weight / erode, combined exactly as pgsr_scene.py:108-112 (the single-view normal loss);
+        autograd to plane_depth and out_all_map.
+"""
+import importlib
+import math
+import os
+import sys
+import types
+import warnings
+from unittest import mock
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))          # tests/ : decode_cases, scenes
+STUBBED = []
+
+
+def ref_import(name):
+    while True:
+        try:
+            return importlib.import_module(name)
+        except ModuleNotFoundError as e:
+            if e.name.startswith("gssr"):
+                raise
+            STUBBED.append(e.name)
+            sys.modules[e.name] = mock.MagicMock()
+            for k in [k for k in sys.modules if k.startswith("gssr")]:
+                del sys.modules[k]
+
+
+ref_import("gssr.configs.method_config")           # the entry the reference's own train.py imports first (resolves its import cycle)
+
+# the reference hard-codes device="cuda" / .cuda() in its torch helpers; run them on the CPU
+torch.Tensor.cuda = lambda self, *a, **k: self
+_arange = torch.arange
+torch.arange = lambda *a, **k: _arange(*a, **{**k, "device": "cpu"}) if "device" in k else _arange(*a, **k)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: v for k, v in arrays.items() if v is not None})
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+# ----------------------------------------------------------------------------------------------------------------- decode
+def _fill_linear(lin, W, b):
+    with torch.no_grad():
+        lin.weight.copy_(torch.tensor(W)); lin.bias.copy_(torch.tensor(b))
+
+
+def decode_fixture(name, octree, **kw):
+    import decode_cases
+    case = decode_cases.make_case(Na=160, **kw)
+    p = case["params"]
+    A = 0 if p["app"] is None else p["app"].size
+    if octree:
+        mod = ref_import("gssr.gaussian.octree_gaussian"); scn = ref_import("gssr.scene.octree_scene")
+        cfg = mod.OctreeGaussianConfig(); Gauss, Scene = mod.OctreeGaussian, scn.OctreeScene
+        cfg.add_level = case["level"] is not None
+        cfg.dist2level = "progressive" if case["opacity_scale"] is not None else "round"
+    else:
+        mod = ref_import("gssr.gaussian.scaffold_gaussian"); scn = ref_import("gssr.scene.scaffold_scene")
+        cfg = mod.ScaffoldGaussianConfig(); Gauss, Scene = mod.ScaffoldGaussian, scn.ScaffoldScene
+    cfg.n_offsets = case["k"]; cfg.appearance_dim = A; cfg.use_feat_bank = False
+    cfg.add_opacity_dist, cfg.add_cov_dist, cfg.add_color_dist = case["dist_o"], case["dist_c"], case["dist_k"]
+    g = Gauss(cfg, device="cpu")
+    uid = 2
+    if A:
+        g.set_appearance(5)
+        emb = [q for q in g.embedding_appearance.parameters()][0]
+        with torch.no_grad():
+            emb[uid].copy_(torch.tensor(p["app"]))
+    _fill_linear(g.mlp_opacity[0], p["W1o"], p["b1o"]); _fill_linear(g.mlp_opacity[2], p["W2o"], p["b2o"])
+    _fill_linear(g.mlp_cov[0], p["W1c"], p["b1c"]); _fill_linear(g.mlp_cov[2], p["W2c"], p["b2c"])
+    _fill_linear(g.mlp_color[0], p["W1k"], p["b1k"]); _fill_linear(g.mlp_color[2], p["W2k"], p["b2k"])
+    leaf = lambda a: torch.tensor(a).requires_grad_(True)
+    g._anchor = leaf(case["anchor"]); g._anchor_feat = leaf(case["feat"]); g._offset = leaf(case["offset"])
+    g._scaling = leaf(np.log(case["scaling"]))                     # get_scaling = exp(_scaling)
+    Na = case["anchor"].shape[0]
+    if octree:
+        g._level = torch.tensor(case["level"]).reshape(Na, 1)
+        if case["opacity_scale"] is not None:
+            r = np.random.default_rng(77)
+            trans = r.uniform(size=Na) < 0.5
+            prog = np.where(trans, case["opacity_scale"], r.uniform(0.1, 0.9, Na)).astype(np.float32)   # ignored where ~trans
+            g._prog_ratio = torch.tensor(prog).reshape(Na, 1); g.transition_mask = torch.tensor(trans)
+            case["opacity_scale"] = np.where(trans, prog, 1.0).astype(np.float32)
+    vmask = torch.zeros(Na, dtype=torch.bool); vmask[torch.tensor(case["vis_idx"], dtype=torch.long)] = True
+    cam = types.SimpleNamespace(camera_center=torch.tensor(case["campos"]), uid=uid)
+    fake = types.SimpleNamespace(_gaussians=g)
+    xyz, color, opacity, scaling, rot, nop, mask = Scene.generate_neural_gaussians(fake, cam, visible_mask=vmask, is_training=True)
+    P = xyz.shape[0]
+    dL = decode_cases.make_out_grads(P, seed=kw.get("seed", 0))
+    loss = ((xyz * torch.tensor(dL["xyz"])).sum() + (color * torch.tensor(dL["color"])).sum() +
+            (opacity.reshape(-1) * torch.tensor(dL["opacity"])).sum() + (scaling * torch.tensor(dL["scaling"])).sum() +
+            (rot * torch.tensor(dL["rot"])).sum())
+    loss.backward()
+    gr = {"g_anchor": g._anchor.grad, "g_feat": g._anchor_feat.grad, "g_offset": g._offset.grad,
+          "g_scaling": g._scaling.grad / torch.tensor(case["scaling"])}      # d/d get_scaling = d/d _scaling / exp(_scaling)
+    for head, m in (("o", g.mlp_opacity), ("c", g.mlp_cov), ("k", g.mlp_color)):
+        gr[f"g_W1{head}"], gr[f"g_b1{head}"], gr[f"g_W2{head}"], gr[f"g_b2{head}"] = m[0].weight.grad, m[0].bias.grad, m[2].weight.grad, m[2].bias.grad
+    if A:
+        gr["g_app"] = emb.grad[uid]
+        assert not emb.grad[[0, 1, 3, 4]].any()
+    margin = float(nop.detach().abs().min())
+    assert margin > 1e-4, f"{name}: opacity gate too close to 0 ({margin}); pick another seed"
+    flat = {f"in_{n}": case[n] for n in ("anchor", "feat", "offset", "scaling", "level", "opacity_scale", "campos", "vis_idx")}
+    flat.update({f"p_{n}": v for n, v in p.items()})
+    flat.update({f"dL_{n}": v for n, v in dL.items()})
+    flat.update({n: v.detach().numpy() for n, v in gr.items()})
+    save(name, k=case["k"], dist_o=case["dist_o"], dist_c=case["dist_c"], dist_k=case["dist_k"], gate_margin=margin,
+         xyz=xyz.detach().numpy(), color=color.detach().numpy(), opacity=opacity.detach().numpy(), scaling=scaling.detach().numpy(),
+         rot=rot.detach().numpy(), neural_opacity=nop.detach().numpy().reshape(-1), mask=mask.numpy(), **flat)
+
+
+def lod_fixture(mode):
+    mod = ref_import("gssr.gaussian.octree_gaussian")
+    cfg = mod.OctreeGaussianConfig(); cfg.dist2level = mode; cfg.progressive = False
+    g = mod.OctreeGaussian(cfg, device="cpu")
+    r = np.random.default_rng(3)
+    Na, levels, fork, vs, sd, rs = 3000, 6, 2, 0.4, 12.0, 1.0
+    anchor = r.uniform(-8, 8, (Na, 3)).astype(np.float32); level = r.integers(0, levels, Na).astype(np.int32)
+    extra = r.uniform(-0.3, 0.3, Na).astype(np.float32); campos = np.array([0.5, -1.0, 3.0], np.float32)
+    g._anchor = torch.tensor(anchor); g._level = torch.tensor(level).unsqueeze(1); g._extra_level = torch.tensor(extra)
+    g.voxel_size, g.fork, g.standard_dist, g.levels = vs, fork, sd, levels
+    g.set_anchor_mask(torch.tensor(campos), 0, rs)
+    out = {"anchor_mask": g._anchor_mask.numpy()}
+    if mode == "progressive":
+        out["prog_ratio"] = g._prog_ratio.numpy().reshape(-1); out["transition_mask"] = g.transition_mask.numpy()
+    save(f"ref_lod_{mode}.npz", anchor=anchor, level=level, extra_level=extra, campos=campos, voxel_size=vs, fork=fork, standard_dist=sd,
+         resolution_scale=rs, levels=levels, **out)
+
+
+# ----------------------------------------------------------------------------------------------------------------- losses
+def _bare(cls, **attrs):
+    o = object.__new__(cls)
+    for k, v in attrs.items():
+        object.__setattr__(o, k, v)
+    return o
+
+
+def l1_ssim_fixture():
+    scn = ref_import("gssr.scene.vanilla_scene")
+    r = np.random.default_rng(21)
+    shape = (3, 45, 61)
+    gt = r.uniform(0, 1, shape).astype(np.float32)
+    img = np.clip(gt + r.normal(0, 0.12, shape), 0, 1).astype(np.float32)
+    scene = _bare(scn.VanillaScene, config=types.SimpleNamespace(lambda_dssim=0.2), device="cpu")
+    x = torch.tensor(img, requires_grad=True)
+    cam = types.SimpleNamespace(original_image=torch.tensor(gt))
+    d = scene.get_loss_dict({"render": x}, cam, step=1)
+    total = d["L1_loss"] + d["ssim_loss"]
+    total.backward()
+    save("ref_loss_l1_ssim.npz", image=img, gt=gt, lambda_dssim=0.2, L1_loss=d["L1_loss"].item(), ssim_loss=d["ssim_loss"].item(),
+         total=total.item(), d_image=x.grad.numpy())
+
+
+def _camera(W, H):
+    import scenes
+    cam = scenes.make_camera(W, H, 0.8 * W, 0.8 * W, yaw_deg=20.0, t=(0.5, 0.2, 0.0))
+    wvt = torch.tensor(cam["viewmatrix"]); fpt = torch.tensor(cam["projmatrix"])
+    return cam, types.SimpleNamespace(world_view_transform=wvt, full_proj_transform=fpt, image_width=W, image_height=H,
+                                      FoVx=2 * math.atan(cam["tanfovx"]), FoVy=2 * math.atan(cam["tanfovy"]),
+                                      camera_center=wvt.inverse()[3, :3])
+
+
+def _allmap(H, W, seed):
+    r = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    depth = 3.0 + 0.5 * np.sin(xx / 7.0) + 0.3 * np.cos(yy / 5.0) + r.normal(0, 0.02, (H, W))
+    alpha = r.uniform(0.3, 1.0, (H, W))
+    alpha[r.uniform(size=(H, W)) < 0.04] = 0.0                     # empty pixels: the reference's 0/0 -> nan_to_num path
+    am = np.zeros((7, H, W), np.float32)
+    n = r.normal(0, 1, (3, H, W)); n /= np.linalg.norm(n, axis=0, keepdims=True)
+    am[0] = depth * alpha; am[1] = alpha; am[2:5] = n * alpha; am[5] = depth + r.normal(0, 0.05, (H, W)); am[6] = r.uniform(0, 0.1, (H, W))
+    return am.astype(np.float32)
+
+
+def surfel_geo_fixture(depth_ratio):
+    scn = ref_import("gssr.scene.twodgs_scene")
+    H, W = 37, 52
+    am = _allmap(H, W, 5 + int(depth_ratio))
+    camd, cam = _camera(W, H)
+    x = torch.tensor(am, requires_grad=True)
+    img = torch.zeros(3, H, W)
+    # the one non-Python step of render(): the rasterizer call returns the fixture's raster output
+    scn.GaussianRasterizationSettings = lambda **kw: None
+    scn.GaussianRasterizer = lambda raster_settings: (lambda **kw: (img, torch.ones(4), x))
+    lam_n, lam_d = 0.05, 100.0
+    scene = _bare(scn.TwoDGSScene, device="cpu", background=torch.zeros(3),
+                  config=types.SimpleNamespace(lambda_dssim=0.2, lambda_normal=lam_n, lambda_dist=lam_d, depth_ratio=depth_ratio,
+                                               scaling_modifier=1.0, debug=False),
+                  _gaussians=types.SimpleNamespace(active_sh_degree=0))
+    out = scene.render(cam, torch.zeros(4, 3), None, None, None, None, None, None)
+    cam.original_image = torch.zeros(3, H, W)
+    d = scene.get_loss_dict(out, cam, step=8000)
+    total = d["normal_loss"] + d["dist_loss"]
+    total.backward()
+    g = x.grad.numpy()
+    bad = ~np.isfinite(g)                                          # autograd of x/0 -> nan_to_num: NaN on ch 0/1 at alpha == 0 only
+    assert not bad[2:].any() and (am[1] == 0)[bad[0] | bad[1]].all()
+    save(f"ref_loss_surfel_geo_r{int(depth_ratio)}.npz", allmap=am, viewmatrix=camd["viewmatrix"], projmatrix=camd["projmatrix"], W=W, H=H,
+         depth_ratio=depth_ratio, lambda_normal=lam_n, lambda_dist=lam_d, normal_loss=d["normal_loss"].item(), dist_loss=d["dist_loss"].item(),
+         surf_depth=out["depth"].detach().numpy(), surf_normal=out["surf_normal"].detach().numpy(), normal=out["normal"].detach().numpy(),
+         d_allmap=np.where(bad, 0.0, g).astype(np.float32), d_allmap_nan=bad)
+
+
+def plane_geo_fixture():
+    scn = ref_import("gssr.scene.pgsr_scene")
+    H, W = 41, 47
+    r = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    depth = (3.0 + 0.5 * np.sin(xx / 7.0) + 0.3 * np.cos(yy / 5.0) + r.normal(0, 0.02, (H, W))).astype(np.float32)
+    alpha = r.uniform(0.2, 1.0, (H, W)); n = r.normal(0, 1, (3, H, W)); n /= np.linalg.norm(n, axis=0, keepdims=True)
+    oam = np.zeros((5, H, W), np.float32); oam[0:3] = n * alpha; oam[3] = alpha; oam[4] = r.uniform(0, 1, (H, W))
+    gt = r.uniform(0, 1, (3, H, W)).astype(np.float32)
+    gt[:, :, : W // 2] = gt[:, :, : W // 2] * 0.05 + 0.4          # a flat half: non-trivial image-gradient weights after erosion
+    fx = fy = 0.8 * W; cx, cy = W / 2.0, H / 2.0
+    camd, cam = _camera(W, H)
+    cam.Fx, cam.Fy, cam.Cx, cam.Cy = fx, fy, cx, cy
+    Camera = ref_import("gssr.cameras").Camera
+    cam.get_calib_matrix_nerf = types.MethodType(Camera.get_calib_matrix_nerf, cam)
+    scene = _bare(scn.PGSRScene, device="cpu", config=types.SimpleNamespace(lambda_normal=0.015))
+    pd = torch.tensor(depth[None], requires_grad=True); om = torch.tensor(oam, requires_grad=True)
+    # pgsr_scene.py:316-320
+    rendered_normal = om[0:3]; rendered_alpha = om[3:4]
+    depth_normal = scene.render_normal(cam, pd.squeeze()) * rendered_alpha.detach()
+    # pgsr_scene.py:108-112
+    image_weight = 1.0 - scene._get_img_grad_weight(torch.tensor(gt))
+    image_weight = image_weight.clamp(0, 1).detach() ** 5
+    image_weight = scene.erode(image_weight[None, None]).squeeze()
+    normal_loss = scene.config.lambda_normal * (image_weight * ((depth_normal - rendered_normal).abs().sum(0))).mean()
+    normal_loss.backward()
+    save("ref_loss_plane_geo.npz", plane_depth=depth[None], out_all_map=oam, gt_image=gt, fx=fx, fy=fy, cx=cx, cy=cy, W=W, H=H,
+         viewmatrix=camd["viewmatrix"], projmatrix=camd["projmatrix"], lambda_normal=0.015, image_weight=image_weight.numpy(),
+         depth_normal=depth_normal.detach().numpy(), normal_loss=normal_loss.item(), d_plane_depth=pd.grad.numpy(), d_out_all_map=om.grad.numpy())
+
+
+def tsdf_fixture():
+    import scenes
+    mu = ref_import("gssr.utils.mesh_utils")
+    r = np.random.default_rng(31)
+    W, H, nf = 64, 48, 3
+    stack, depths, rgbs = [], [], []
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    for i in range(nf):
+        cam = scenes.make_camera(W, H, 0.9 * W, 0.9 * W, yaw_deg=-15.0 + 15.0 * i, t=(0.2 * i - 0.2, 0.05 * i, 0.1 * i))
+        stack.append(types.SimpleNamespace(full_proj_transform=torch.tensor(cam["projmatrix"])))
+        depths.append((2.5 + 0.4 * np.sin(xx / 9.0 + i) + 0.3 * np.cos(yy / 6.0) + r.normal(0, 0.01, (H, W))).astype(np.float32)[None])
+        rgbs.append(r.uniform(0, 1, (3, H, W)).astype(np.float32))
+    center = np.array([0.1, -0.05, 2.6], np.float32); radius = 1.7; N = 64
+    ex = _bare(mu.GaussianExtractor, viewpoint_stack=stack, depthmaps=[torch.tensor(d) for d in depths], rgbmaps=[torch.tensor(c) for c in rgbs],
+               radius=radius, center=torch.tensor(center), gaussians=types.SimpleNamespace(get_xyz=torch.tensor(r.normal(0, 1, (50, 3)).astype(np.float32)) + torch.tensor(center)))
+    samples = r.uniform(-1.6, 1.6, (6000, 3)).astype(np.float32)          # contracted coordinates, inside and outside the unit ball
+    samples = samples[np.linalg.norm(samples, axis=1) < 1.95][:2500]
+    near = np.stack([r.uniform(-0.8, 0.8, 3500), r.uniform(-0.6, 0.6, 3500), r.uniform(-0.35, 0.25, 3500)], 1)   # around the depth surfaces
+    samples = np.concatenate([samples, near]).astype(np.float32)
+    verts = (center + r.uniform(-1.2, 1.2, (3000, 3)) * np.array([1.0, 0.8, 0.25])).astype(np.float32)   # world points for the texturing pass
+    got = {}
+
+    def probe(sdf, bounding_box_min, bounding_box_max, level, resolution, inv_contraction):
+        got["tsdf"] = sdf(torch.tensor(samples)).numpy()
+        got["points"] = inv_contraction(torch.tensor(samples)).numpy()
+        return types.SimpleNamespace(as_open3d=types.SimpleNamespace(vertices=verts))
+    mu.marching_cubes_with_contraction = probe
+    mu.tqdm = lambda it, **kw: it
+    mu.o3d.utility.Vector3dVector = lambda a: a
+    mesh = ex.extract_mesh_unbounded(resolution=N)
+    voxel = radius * 2 / N
+    nrm = np.linalg.norm(samples, axis=1)
+    trunc = (5 * voxel * np.where(nrm > 1, 1.0 / (2.0 - np.minimum(nrm, 1.9)), 1.0)).astype(np.float32)   # mesh_utils.py:213-216 (an INPUT of our op)
+    save("ref_tsdf_unbounded.npz", W=W, H=H, full_proj=np.stack([c.full_proj_transform.numpy() for c in stack]), depth=np.stack(depths),
+         rgb=np.stack(rgbs), points=got["points"], sdf_trunc=trunc, tsdf=got["tsdf"], verts=verts, voxel_size=voxel, vert_rgb=np.asarray(mesh.vertex_colors))
+
+
+if __name__ == "__main__":
+    tsdf_fixture()
+    torch.manual_seed(0)
+    decode_fixture("ref_decode_scaffold.npz", octree=False)
+    decode_fixture("ref_decode_scaffold_dist.npz", octree=False, A=0, k=5, dist_o=True, dist_c=True, dist_k=True, seed=1)
+    decode_fixture("ref_decode_octree.npz", octree=True, level=True, progressive=True, A=16, k=12, dist_k=True, seed=2)
+    for m in ("floor", "round", "ceil", "progressive"):
+        lod_fixture(m)
+    l1_ssim_fixture()
+    surfel_geo_fixture(0.0)
+    surfel_geo_fixture(1.0)
+    plane_geo_fixture()
+    print("stubbed imports:", sorted(set(STUBBED)))
