@@ -1,0 +1,202 @@
+/*
+ * gsm_oracle.c -- CPU restatement of PGSR's multi-view regularisers.  TEST INFRASTRUCTURE ONLY (see gsr_oracle.h).
+ *   gssr/scene/pgsr_scene.py:113-204 (get_loss_dict, "multi-view loss"), :60-95 (lncc)
+ *   gssr/utils/point_utils.py:38-75 (get_points_from_depth, get_points_depth_in_depth_map)
+ *   gssr/utils/graphics_utils.py:185-198 (patch_offsets, patch_warp);  gssr/cameras/__init__.py:96-121 (get_rays, get_k, get_inv_k)
+ * PARITY STATUS: PINNED against the reference itself run in the authoring container (tests/golden/make_golden_ref.py ->
+ * tests/golden/ref_loss_plane_multiview.npz, checked by tests/test_golden_ref_cpu.py).
+ *
+ * The two rigid transforms are handed in composed (row-vector convention, X' = X A + b, A row-major then b):
+ *   v2n: view camera -> near camera  (A = Rv^T Rn, b = Tn - Tv A);  n2v its inverse.  The reference walks through world coordinates.
+ * Part 1 (geometric consistency), per pixel (x,y):
+ *   pc = ((x-cx)/fx, (y-cy)/fy, 1) * depth;  q = pc v2n;  (u,v) = (q.x nfx/q.z + ncx, q.y nfy/q.z + ncy)
+ *   mask = 0<u<Wn & 0<v<Hn & q.z>0.1;  mz = bilinear(near_depth, u, v) with border clamp (grid_sample align_corners, padding 'border')
+ *   r = (q/q.z * mz) n2v;  e = (r.x fx/r.z + cx - x, r.y fy/r.z + cy - y);  noise = |e|;  d_mask = mask & noise < th
+ *   weight = exp(-noise) (detached), 0 outside d_mask;  stats = {sum_{d_mask} weight*noise, |d_mask|}
+ *   g_depth / g_near = d stats[0] / d depth, d near_depth (weight held constant) -- the caller scales by lambda_geo / stats[1].
+ * Part 2 (patch NCC), per sampled pixel p = idx[i]:
+ *   ref_j  = bilinear0(gray, x/s + ox, y/s + oy), (ox,oy) in [-h,h]^2      (grid_sample zeros padding, no gradient)
+ *   Hm = A^T - b n^T / dist;  Hk = K_near(s) Hm Kinv_view(s);  g = Hk (u_j, v_j, 1);  nea_j = bilinear0(near_gray, g.x/(g.z+1e-10), g.y/(g.z+1e-10))
+ *   cc = cross^2 / (ref_var nea_var + 1e-8) from the patch sums (lncc);  ncc = clamp(1-cc, 0, 2);  mask = ncc < 0.9
+ *   stats = {sum_{mask} ncc*weight[p], |mask|};  g_normal[:,p], g_dist[p] = d stats[0] / d normal, dist.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+typedef struct {
+    int32_t W, H, Wn, Hn, Wg, Hg;
+    float fx, fy, cx, cy, nfx, nfy, ncx, ncy;
+    float v2n[12], n2v[12];
+    float ncc_scale, noise_th;
+    int32_t patch;
+} refm_cfg;
+
+static void xform(const float* M, const float* p, float* o) {
+    for (int j = 0; j < 3; ++j) o[j] = p[0] * M[0 * 3 + j] + p[1] * M[1 * 3 + j] + p[2] * M[2 * 3 + j] + M[9 + j];
+}
+
+/* grid_sample(align_corners=True, padding_mode='border') at pixel coordinates (u,v): value, d/du, d/dv, taps */
+static float bilerp_border(const float* img, int W, int H, float u, float v, float* du, float* dv, int* idx, float* wt) {
+    float mu = 1.f, mv = 1.f;
+    if (u < 0.f) { u = 0.f; mu = 0.f; } else if (u > (float)(W - 1)) { u = (float)(W - 1); mu = 0.f; }
+    if (v < 0.f) { v = 0.f; mv = 0.f; } else if (v > (float)(H - 1)) { v = (float)(H - 1); mv = 0.f; }
+    int x0 = (int)floorf(u), y0 = (int)floorf(v);
+    float ax = u - (float)x0, ay = v - (float)y0;
+    int xs[2] = {x0, x0 + 1}, ys[2] = {y0, y0 + 1};
+    float wx[2] = {1.f - ax, ax}, wy[2] = {1.f - ay, ay};
+    float val = 0.f, gx = 0.f, gy = 0.f;
+    for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+            int k = b * 2 + a;
+            int in = xs[a] >= 0 && xs[a] < W && ys[b] >= 0 && ys[b] < H;
+            idx[k] = in ? ys[b] * W + xs[a] : -1;
+            wt[k] = in ? wx[a] * wy[b] : 0.f;
+            float t = in ? img[idx[k]] : 0.f;
+            val += t * wx[a] * wy[b];
+            gx += t * (a ? 1.f : -1.f) * wy[b];
+            gy += t * (b ? 1.f : -1.f) * wx[a];
+        }
+    *du = gx * mu; *dv = gy * mv;
+    return val;
+}
+
+/* grid_sample(align_corners=True, padding_mode='zeros') */
+static float bilerp_zeros(const float* img, int W, int H, float u, float v, float* du, float* dv) {
+    int x0 = (int)floorf(u), y0 = (int)floorf(v);
+    float ax = u - (float)x0, ay = v - (float)y0;
+    float val = 0.f, gx = 0.f, gy = 0.f;
+    for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a) {
+            int xx = x0 + a, yy = y0 + b;
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            float t = img[yy * W + xx], wx = a ? ax : 1.f - ax, wy = b ? ay : 1.f - ay;
+            val += t * wx * wy;
+            gx += t * (a ? 1.f : -1.f) * wy;
+            gy += t * (b ? 1.f : -1.f) * wx;
+        }
+    if (du) { *du = gx; *dv = gy; }
+    return val;
+}
+
+void refm_multiview_geo(const refm_cfg* c, const float* depth, const float* near_depth, float* noise_out, uint8_t* dmask_out, float* weight_out,
+                        double* stats, float* g_depth, float* g_near) {
+    const int W = c->W, H = c->H, Wn = c->Wn, Hn = c->Hn;
+    memset(g_near, 0, sizeof(float) * (size_t)Wn * Hn);
+    double sum = 0.0; int64_t cnt = 0;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int p = y * W + x;
+            const float d = depth[p];
+            const float rx = ((float)x - c->cx) / c->fx, ry = ((float)y - c->cy) / c->fy;
+            float pc[3] = {rx * d, ry * d, d}, q[3];
+            xform(c->v2n, pc, q);
+            const float u = q[0] * c->nfx / q[2] + c->ncx, v = q[1] * c->nfy / q[2] + c->ncy;
+            const int mask = u > 0.f && u < (float)Wn && v > 0.f && v < (float)Hn && q[2] > 0.1f;
+            float du, dv, wt[4]; int idx[4];
+            const float mz = bilerp_border(near_depth, Wn, Hn, u, v, &du, &dv, idx, wt);
+            float qp[3] = {q[0] / q[2] * mz, q[1] / q[2] * mz, mz}, r[3];
+            xform(c->n2v, qp, r);
+            const float ex = r[0] * c->fx / r[2] + c->cx - (float)x, ey = r[1] * c->fy / r[2] + c->cy - (float)y;
+            const float noise = sqrtf(ex * ex + ey * ey);
+            const int dm = mask && noise < c->noise_th;
+            const float w = dm ? 1.0f / expf(noise) : 0.f;
+            noise_out[p] = noise; dmask_out[p] = (uint8_t)dm; weight_out[p] = w;
+            g_depth[p] = 0.f;
+            if (!dm) continue;
+            sum += (double)(w * noise); ++cnt;
+            if (noise == 0.f) continue;
+            const float dex = w * ex / noise, dey = w * ey / noise;
+            float dr[3] = {dex * c->fx / r[2], dey * c->fy / r[2], -(dex * r[0] * c->fx + dey * r[1] * c->fy) / (r[2] * r[2])};
+            float dqp[3];
+            for (int i = 0; i < 3; ++i) dqp[i] = dr[0] * c->n2v[i * 3 + 0] + dr[1] * c->n2v[i * 3 + 1] + dr[2] * c->n2v[i * 3 + 2];
+            const float dmz = dqp[0] * q[0] / q[2] + dqp[1] * q[1] / q[2] + dqp[2];
+            float dq[3] = {dqp[0] * mz / q[2], dqp[1] * mz / q[2], -(dqp[0] * q[0] + dqp[1] * q[1]) * mz / (q[2] * q[2])};
+            for (int k = 0; k < 4; ++k)
+                if (idx[k] >= 0) g_near[idx[k]] += dmz * wt[k];
+            const float gu = dmz * du, gv = dmz * dv;
+            dq[0] += gu * c->nfx / q[2]; dq[1] += gv * c->nfy / q[2];
+            dq[2] += -(gu * q[0] * c->nfx + gv * q[1] * c->nfy) / (q[2] * q[2]);
+            float dpc[3];
+            for (int i = 0; i < 3; ++i) dpc[i] = dq[0] * c->v2n[i * 3 + 0] + dq[1] * c->v2n[i * 3 + 1] + dq[2] * c->v2n[i * 3 + 2];
+            g_depth[p] = dpc[0] * rx + dpc[1] * ry + dpc[2];
+        }
+    stats[0] = sum; stats[1] = (double)cnt;
+}
+
+void refm_multiview_ncc(const refm_cfg* c, int32_t N, const int32_t* idx, const float* weight, const float* normal, const float* dist,
+                        const float* gray, const float* near_gray, float* ncc_out, uint8_t* mask_out, double* stats, float* g_normal, float* g_dist) {
+    const int W = c->W, H = c->H, Wg = c->Wg, Hg = c->Hg, h = c->patch;
+    const size_t HW = (size_t)W * H;
+    const float s = c->ncc_scale, tps = (float)((2 * h + 1) * (2 * h + 1));
+    memset(g_normal, 0, sizeof(float) * 3 * HW); memset(g_dist, 0, sizeof(float) * HW);
+    const float Kn[9] = {c->nfx / s, 0, c->ncx / s, 0, c->nfy / s, c->ncy / s, 0, 0, 1};
+    const float Kvi[9] = {s / c->fx, 0, -c->cx / c->fx, 0, s / c->fy, -c->cy / c->fy, 0, 0, 1};
+    double sum = 0.0; int64_t cnt = 0;
+    for (int i = 0; i < N; ++i) {
+        const int p = idx[i];
+        if (p < 0) { ncc_out[i] = 0.f; mask_out[i] = 0; continue; }
+        const int x = p % W, y = p / W;
+        const float n[3] = {normal[p], normal[HW + p], normal[2 * HW + p]}, dd = dist[p];
+        float Hm[9], T1[9], Hk[9];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) Hm[a * 3 + b] = c->v2n[b * 3 + a] - c->v2n[9 + a] * n[b] / dd;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) T1[a * 3 + b] = Kn[a * 3 + 0] * Hm[0 * 3 + b] + Kn[a * 3 + 1] * Hm[1 * 3 + b] + Kn[a * 3 + 2] * Hm[2 * 3 + b];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) Hk[a * 3 + b] = T1[a * 3 + 0] * Kvi[0 * 3 + b] + T1[a * 3 + 1] * Kvi[1 * 3 + b] + T1[a * 3 + 2] * Kvi[2 * 3 + b];
+        const float px = (float)x / s, py = (float)y / s;
+        float Sr = 0, Sn = 0, Srr = 0, Snn = 0, Srn = 0;
+        for (int oy = -h; oy <= h; ++oy)
+            for (int ox = -h; ox <= h; ++ox) {
+                const float uu = px + (float)ox, vv = py + (float)oy;
+                const float rj = bilerp_zeros(gray, Wg, Hg, uu, vv, 0, 0);
+                const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+                const float nj = bilerp_zeros(near_gray, Wg, Hg, g0 / g2, g1 / g2, 0, 0);
+                Sr += rj; Sn += nj; Srr += rj * rj; Snn += nj * nj; Srn += rj * nj;
+            }
+        const float ravg = Sr / tps, navg = Sn / tps;
+        const float cross = Srn - navg * Sr, rvar = Srr - ravg * Sr, nvar = Snn - navg * Sn;
+        const float den = rvar * nvar + 1e-8f;
+        const float cc = cross * cross / den;
+        float ncc = 1.f - cc;
+        const int clamped = ncc < 0.f || ncc > 2.f;
+        ncc = ncc < 0.f ? 0.f : (ncc > 2.f ? 2.f : ncc);
+        const int m = ncc < 0.9f;
+        ncc_out[i] = ncc; mask_out[i] = (uint8_t)m;
+        if (!m) continue;
+        const float w = weight[p];
+        sum += (double)(ncc * w); ++cnt;
+        if (clamped || w == 0.f) continue;
+        const float dcc = -w;                                       /* d(ncc w)/dcc */
+        const float dcross = dcc * 2.f * cross / den, dnvar = -dcc * cross * cross * rvar / (den * den);
+        float dH[9] = {0};
+        for (int oy = -h; oy <= h; ++oy)
+            for (int ox = -h; ox <= h; ++ox) {
+                const float uu = px + (float)ox, vv = py + (float)oy;
+                const float rj = bilerp_zeros(gray, Wg, Hg, uu, vv, 0, 0);
+                const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+                float du, dv;
+                const float nj = bilerp_zeros(near_gray, Wg, Hg, g0 / g2, g1 / g2, &du, &dv);
+                const float dn = dcross * (rj - Sr / tps) + dnvar * (2.f * nj - 2.f * navg);
+                const float dgx = dn * du, dgy = dn * dv;
+                const float dg[3] = {dgx / g2, dgy / g2, -(dgx * g0 + dgy * g1) / (g2 * g2)};
+                const float uv1[3] = {uu, vv, 1.f};
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) dH[a * 3 + b] += dg[a] * uv1[b];
+            }
+        float T2[9], dHm[9];                                        /* dHm = Kn^T dH Kvi^T */
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) T2[a * 3 + b] = Kn[0 * 3 + a] * dH[0 * 3 + b] + Kn[1 * 3 + a] * dH[1 * 3 + b] + Kn[2 * 3 + a] * dH[2 * 3 + b];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) dHm[a * 3 + b] = T2[a * 3 + 0] * Kvi[b * 3 + 0] + T2[a * 3 + 1] * Kvi[b * 3 + 1] + T2[a * 3 + 2] * Kvi[b * 3 + 2];
+        float gd = 0.f;
+        for (int b = 0; b < 3; ++b) {
+            float gn = 0.f;
+            for (int a = 0; a < 3; ++a) { gn -= dHm[a * 3 + b] * c->v2n[9 + a] / dd; gd += dHm[a * 3 + b] * c->v2n[9 + a] * n[b] / (dd * dd); }
+            g_normal[(size_t)b * HW + p] = gn;
+        }
+        g_dist[p] = gd;
+    }
+    stats[0] = sum; stats[1] = (double)cnt;
+}

@@ -24,6 +24,12 @@ Pinned (reference file:line -> fixture):
         gssr/utils/mesh_utils.py:195-246 compute_sdf_perframe / compute_unbounded_tsdf, driven through extract_mesh_unbounded (:182-277)
         with marching_cubes_with_contraction replaced by a probe that evaluates the sdf callable on the fixture's samples: the
         contracted pass (adaptive truncation) gives `tsdf`, the texturing pass (scalar truncation) gives `rgb`.
+  ref_loss_plane_multiview.npz
+        gssr/scene/pgsr_scene.py:97-204 get_loss_dict(step=8000, near_cam=..., nearest_render_pkg=...): the multi-view geometric
+        consistency loss and the patch NCC loss (get_points_from_depth / get_points_depth_in_depth_map, gssr/utils/point_utils.py:38-75;
+        patch_offsets / patch_warp, gssr/utils/graphics_utils.py:185-198; lncc :60-95) on a two-camera view of a textured plane, all
+        valid pixels sampled (fewer than nunm_sample, so np.random.choice is not reached); autograd to both plane-depth maps, the
+        rendered normal and the rendered distance.
   ref_loss_plane_geo.npz
         gssr/scene/pgsr_scene.py:227-238 render_normal (normal_from_depth_image, gssr/utils/graphics_utils.py:139-146),
         pgsr_scene.py:32-58 _get_img_grad_weight / erode, combined exactly as pgsr_scene.py:108-112 (the single-view normal loss);
@@ -65,6 +71,8 @@ ref_import("gssr.configs.method_config")           # the entry the reference's o
 
 # the reference hard-codes device="cuda" / .cuda() in its torch helpers; run them on the CPU
 torch.Tensor.cuda = lambda self, *a, **k: self
+_to = torch.Tensor.to
+torch.Tensor.to = lambda self, *a, **k: _to(self, *[("cpu" if isinstance(x, str) and x.startswith("cuda") else x) for x in a], **k)
 _arange = torch.arange
 torch.arange = lambda *a, **k: _arange(*a, **{**k, "device": "cpu"}) if "device" in k else _arange(*a, **k)
 
@@ -269,6 +277,59 @@ def plane_geo_fixture():
          depth_normal=depth_normal.detach().numpy(), normal_loss=normal_loss.item(), d_plane_depth=pd.grad.numpy(), d_out_all_map=om.grad.numpy())
 
 
+def _plane_view(Camera, W, H, yaw, t, n_w, c_w, phase):
+    """A reference-Camera-shaped object looking at the world plane n_w . X = c_w, with its analytic depth / normal / distance / texture."""
+    import scenes
+    cam = scenes.make_camera(W, H, 0.9 * W, 0.9 * W, yaw_deg=yaw, t=t)
+    wvt = cam["viewmatrix"].astype(np.float64)
+    R, T = wvt[:3, :3].copy(), wvt[3, :3].copy()                   # cameras/__init__.py:85 with trans = 0, scale = 1
+    o = types.SimpleNamespace(R=R, T=T, world_view_transform=torch.tensor(wvt, dtype=torch.float32), image_width=W, image_height=H,
+                              Fx=0.9 * W, Fy=0.9 * W, Cx=0.5 * W, Cy=0.5 * H, ncc_scale=1.0)
+    for m in ("get_rays", "get_k", "get_inv_k"):
+        setattr(o, m, types.MethodType(getattr(Camera, m), o))
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    ray = np.stack([(xx - o.Cx) / o.Fx, (yy - o.Cy) / o.Fy, np.ones_like(xx)], -1)
+    n_c = n_w @ R; c_c = c_w + n_c @ T
+    d0 = c_c / (ray @ n_c)
+    Xw = (ray * d0[..., None] - T) @ R.T
+    a, b = Xw[..., 0], Xw[..., 1]
+    gray = 0.5 + 0.2 * np.sin(5 * a) + 0.2 * np.cos(7 * b) + 0.1 * np.sin(11 * (a + b))
+    depth = d0 * (1 + 0.12 * np.sin(xx / 5.0 + phase) * np.cos(yy / 4.0))
+    sgn = -1.0 if (ray[H // 2, W // 2] @ n_c) > 0 else 1.0      # rendered normals face the camera
+    return o, depth.astype(np.float32), (sgn * n_c).astype(np.float32), float(abs(c_c)), gray.astype(np.float32)
+
+
+def plane_multiview_fixture():
+    scn = ref_import("gssr.scene.pgsr_scene")
+    Camera = ref_import("gssr.cameras").Camera
+    r = np.random.default_rng(41)
+    W, H = 72, 54
+    n_w = np.array([0.12, -0.2, -1.0]); n_w /= np.linalg.norm(n_w); c_w = float(n_w @ np.array([0.0, 0.0, 3.0]))
+    vc, dv, nv, distv, gv = _plane_view(Camera, W, H, 4.0, (0.05, 0.0, 0.0), n_w, c_w, 0.0)
+    nc, dn, _, _, gn = _plane_view(Camera, W, H, -5.0, (-0.25, 0.04, 0.03), n_w, c_w, 1.3)
+    normal = (nv[:, None, None] + r.normal(0, 0.01, (3, H, W))).astype(np.float32)
+    dist = (distv * (1 + r.normal(0, 0.002, (H, W)))).astype(np.float32)
+    gt = np.repeat(gv[None], 3, 0)
+    vc.original_image = torch.tensor(gt); vc.gray_image = torch.tensor(gv[None])
+    nc.gray_image = torch.tensor(gn[None])
+    cfg = scn.PGSRSceneConfig()
+    scene = _bare(scn.PGSRScene, device="cpu", config=types.SimpleNamespace(
+        lambda_dssim=0.2, lambda_normal=cfg.lambda_normal, lambda_ncc=cfg.lambda_ncc, lambda_geo=cfg.lambda_geo, patch_size=cfg.patch_size,
+        nunm_sample=cfg.nunm_sample, pixel_noise_threshold=cfg.pixel_noise_threshold))
+    pd = torch.tensor(dv[None], requires_grad=True); npd = torch.tensor(dn[None], requires_grad=True)
+    nm = torch.tensor(normal, requires_grad=True); ds = torch.tensor(dist[None], requires_grad=True)
+    outputs = {"render": torch.tensor(gt), "rendered_normal": nm, "depth_normal": nm.detach(), "plane_depth": pd, "rendered_distance": ds}
+    d = scene.get_loss_dict(outputs, vc, step=8000, near_cam=nc, nearest_render_pkg={"plane_depth": npd})
+    assert float(d["normal_loss"]) == 0.0 and float(d["geo_loss"]) > 0 and float(d["ncc_loss"]) > 0
+    (d["geo_loss"] + d["ncc_loss"]).backward()
+    camd = lambda o: dict(R=o.R, T=o.T, Fx=o.Fx, Fy=o.Fy, Cx=o.Cx, Cy=o.Cy)
+    save("ref_loss_plane_multiview.npz", W=W, H=H, plane_depth=dv[None], near_plane_depth=dn[None], rendered_normal=normal, rendered_distance=dist[None],
+         gray=gv[None], near_gray=gn[None], **{f"v_{k}": v for k, v in camd(vc).items()}, **{f"n_{k}": v for k, v in camd(nc).items()},
+         lambda_geo=cfg.lambda_geo, lambda_ncc=cfg.lambda_ncc, patch_size=cfg.patch_size, pixel_noise_threshold=cfg.pixel_noise_threshold,
+         geo_loss=d["geo_loss"].item(), ncc_loss=d["ncc_loss"].item(), d_plane_depth=pd.grad.numpy(), d_near_plane_depth=npd.grad.numpy(),
+         d_rendered_normal=nm.grad.numpy(), d_rendered_distance=ds.grad.numpy())
+
+
 def tsdf_fixture():
     import scenes
     mu = ref_import("gssr.utils.mesh_utils")
@@ -307,6 +368,7 @@ def tsdf_fixture():
 
 
 if __name__ == "__main__":
+    plane_multiview_fixture()
     tsdf_fixture()
     torch.manual_seed(0)
     decode_fixture("ref_decode_scaffold.npz", octree=False)

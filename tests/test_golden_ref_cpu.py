@@ -112,3 +112,27 @@ def test_tsdf_oracle_matches_reference_run():
     for F, d, c in zip(z["full_proj"], z["depth"], z["rgb"]):
         oracle.tsdf_integrate(z["verts"], F, d, c, 5 * float(z["voxel_size"]), tsdf, w, rgb)
     assert np.abs(rgb - z["vert_rgb"]).max() < 2e-4 and (rgb != 0).mean() > 0.2
+
+
+def test_plane_multiview_oracle_matches_reference_run():
+    """oracle/gsm_oracle.c vs PGSRScene.get_loss_dict's multi-view branch (geo consistency + patch NCC) on two views of a textured plane."""
+    import oracle_multiview as om
+    z = golden_ref.load("ref_loss_plane_multiview")
+    cfg = om.fixture_cfg(z)
+    g = om.geo(cfg, z["plane_depth"], z["near_plane_depth"])
+    cnt = g["stats"][1]
+    assert 0.5 * cfg.W * cfg.H < cnt < 0.9 * cfg.W * cfg.H                       # the noise threshold and the frustum both cut
+    lam = float(z["lambda_geo"])
+    np.testing.assert_allclose(lam * g["stats"][0] / cnt, float(z["geo_loss"]), rtol=2e-4)
+    idx = np.nonzero(g["dmask"])[0].astype(np.int32)                             # fewer than nunm_sample: the reference takes every valid pixel
+    n = om.ncc(cfg, idx, g["weight"], z["rendered_normal"], z["rendered_distance"], z["gray"], z["near_gray"])
+    lam_n = float(z["lambda_ncc"])
+    assert n["stats"][1] > 0.5 * idx.size
+    np.testing.assert_allclose(lam_n * n["stats"][0] / n["stats"][1], float(z["ncc_loss"]), rtol=5e-4)
+    H, W = int(z["H"]), int(z["W"])
+    for got, exp, name in ((lam / cnt * g["g_depth"], z["d_plane_depth"], "depth"), (lam / cnt * g["g_near"], z["d_near_plane_depth"], "near"),
+                           (lam_n / n["stats"][1] * n["g_normal"], z["d_rendered_normal"], "normal"),
+                           (lam_n / n["stats"][1] * n["g_dist"], z["d_rendered_distance"], "dist")):
+        exp = exp.reshape(got.shape)
+        rel = np.linalg.norm(got - exp) / np.linalg.norm(exp)
+        assert rel < 2e-3, (name, rel, np.abs(got - exp).max(), np.abs(exp).max())
