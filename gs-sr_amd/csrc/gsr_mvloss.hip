@@ -1,0 +1,269 @@
+// gsr_mvloss.hip -- PGSR multi-view regularisers (geometric consistency + patch NCC), gfx950 only.
+//
+//   gssr/scene/pgsr_scene.py:113-204 (multi-view branch of get_loss_dict), :60-95 (lncc)
+//   gssr/utils/point_utils.py:38-75, gssr/utils/graphics_utils.py:185-198, gssr/cameras/__init__.py:96-121
+//
+// The reference evaluates this as ~120 torch ops over (H*W,3) and (N,49,2) temporaries with two grid_samples, two host
+// synchronisations (d_mask.sum() > 0, np.random.choice on the CPU) and autograd replay.  Here:
+//   k_mv_geo : one thread per pixel.  Reprojects the pixel into the neighbour view through its plane depth, samples the neighbour's
+//              plane depth (bilinear, border clamp), reprojects back, writes noise / d_mask / weight and the UNSCALED analytic
+//              gradients of sum(weight * noise) to both depth maps (4 float atomics per valid pixel into the neighbour map), and
+//              block-reduces {sum, count}.
+//   k_mv_ncc : one thread per sampled pixel.  Builds the plane-induced homography from the rendered normal / distance, walks the
+//              (2h+1)^2 patch twice (sums, then the chain rule back to the homography), writes ncc / mask and the UNSCALED gradients
+//              of sum(ncc * weight) to normal and distance at that pixel (each pixel is sampled at most once: plain stores).
+//   k_mv_finish : {sum, count, sum/count (0 if count == 0)}.
+// The means' 1/count and the lambdas are applied by the caller (gsrast.losses) as one device-scalar multiply in backward, so no
+// host synchronisation is needed anywhere.  Both kernels are gather-latency bound (random bilinear taps), not HBM-bound.
+#include "gsr_common.h"
+
+__device__ __forceinline__ float3 mv_xform(const float* M, float3 p)
+{
+    return make_float3(p.x * M[0] + p.y * M[3] + p.z * M[6] + M[9], p.x * M[1] + p.y * M[4] + p.z * M[7] + M[10],
+                       p.x * M[2] + p.y * M[5] + p.z * M[8] + M[11]);
+}
+__device__ __forceinline__ float3 mv_xform_t(const float* M, float3 d)      // d @ A^T
+{
+    return make_float3(d.x * M[0] + d.y * M[1] + d.z * M[2], d.x * M[3] + d.y * M[4] + d.z * M[5], d.x * M[6] + d.y * M[7] + d.z * M[8]);
+}
+
+__device__ __forceinline__ float2 mv_block_sum2(float a, float b, float* red)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[4 + (threadIdx.x >> 6)] = b; }
+    __syncthreads();
+    return make_float2((red[0] + red[1]) + (red[2] + red[3]), (red[4] + red[5]) + (red[6] + red[7]));
+}
+
+__global__ void __launch_bounds__(256) k_mv_geo(gsr_mv_cfg c, const float* __restrict__ depth, const float* __restrict__ near_depth,
+                                                float* __restrict__ noise_out, uint8_t* __restrict__ dmask_out, float* __restrict__ weight_out,
+                                                float* __restrict__ g_depth, float* __restrict__ g_near, float2* __restrict__ partial)
+{
+    __shared__ float red[8];
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    float s_w = 0.f, s_c = 0.f;
+    if (x < c.W && y < c.H) {
+        const int p = y * c.W + x;
+        const float d = depth[p];
+        const float rx = ((float)x - c.cx) / c.fx, ry = ((float)y - c.cy) / c.fy;
+        const float3 q = mv_xform(c.v2n, make_float3(rx * d, ry * d, d));
+        const float u = q.x * c.nfx / q.z + c.ncx, v = q.y * c.nfy / q.z + c.ncy;
+        const bool mask = u > 0.f && u < (float)c.Wn && v > 0.f && v < (float)c.Hn && q.z > 0.1f;
+        // grid_sample(align_corners=True, padding_mode='border'): clamp the coordinate (zero coordinate-gradient where clamped)
+        const float uc = fminf(fmaxf(u, 0.f), (float)(c.Wn - 1)), vc = fminf(fmaxf(v, 0.f), (float)(c.Hn - 1));
+        const float mu = (u < 0.f || u > (float)(c.Wn - 1)) ? 0.f : 1.f, mv = (v < 0.f || v > (float)(c.Hn - 1)) ? 0.f : 1.f;
+        const int x0 = (int)floorf(uc), y0 = (int)floorf(vc);
+        const float ax = uc - (float)x0, ay = vc - (float)y0;
+        const bool xr = x0 + 1 < c.Wn, yb = y0 + 1 < c.Hn;                       // ax (ay) is 0 whenever the right (bottom) tap is out of range
+        const float wx0 = 1.f - ax, wy0 = 1.f - ay;
+        float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f;
+        if (isfinite(u) && isfinite(v)) {
+            t00 = near_depth[y0 * c.Wn + x0];
+            if (xr) t01 = near_depth[y0 * c.Wn + x0 + 1];
+            if (yb) t10 = near_depth[(y0 + 1) * c.Wn + x0];
+            if (xr && yb) t11 = near_depth[(y0 + 1) * c.Wn + x0 + 1];
+        }
+        const float mz = t00 * wx0 * wy0 + t01 * ax * wy0 + t10 * wx0 * ay + t11 * ax * ay;
+        const float dmz_du = (-t00 * wy0 + t01 * wy0 - t10 * ay + t11 * ay) * mu, dmz_dv = (-t00 * wx0 - t01 * ax + t10 * wx0 + t11 * ax) * mv;
+        const float3 qp = make_float3(q.x / q.z * mz, q.y / q.z * mz, mz);
+        const float3 r = mv_xform(c.n2v, qp);
+        const float ex = r.x * c.fx / r.z + c.cx - (float)x, ey = r.y * c.fy / r.z + c.cy - (float)y;
+        const float noise = sqrtf(ex * ex + ey * ey);
+        const bool dm = mask && noise < c.noise_th;
+        const float w = dm ? 1.0f / expf(noise) : 0.f;
+        noise_out[p] = noise; dmask_out[p] = dm ? 1 : 0; weight_out[p] = w;
+        float gd = 0.f;
+        if (dm) {
+            s_w = w * noise; s_c = 1.f;
+            if (noise > 0.f) {
+                const float dex = w * ex / noise, dey = w * ey / noise;
+                const float3 dr = make_float3(dex * c.fx / r.z, dey * c.fy / r.z, -(dex * r.x * c.fx + dey * r.y * c.fy) / (r.z * r.z));
+                const float3 dqp = mv_xform_t(c.n2v, dr);
+                const float dmz = dqp.x * q.x / q.z + dqp.y * q.y / q.z + dqp.z;
+                float3 dq = make_float3(dqp.x * mz / q.z, dqp.y * mz / q.z, -(dqp.x * q.x + dqp.y * q.y) * mz / (q.z * q.z));
+                atomicAdd(&g_near[y0 * c.Wn + x0], dmz * (wx0 * wy0));
+                if (xr) atomicAdd(&g_near[y0 * c.Wn + x0 + 1], dmz * (ax * wy0));
+                if (yb) atomicAdd(&g_near[(y0 + 1) * c.Wn + x0], dmz * (wx0 * ay));
+                if (xr && yb) atomicAdd(&g_near[(y0 + 1) * c.Wn + x0 + 1], dmz * (ax * ay));
+                const float gu = dmz * dmz_du, gv = dmz * dmz_dv;
+                dq.x += gu * c.nfx / q.z; dq.y += gv * c.nfy / q.z; dq.z += -(gu * q.x * c.nfx + gv * q.y * c.nfy) / (q.z * q.z);
+                const float3 dpc = mv_xform_t(c.v2n, dq);
+                gd = dpc.x * rx + dpc.y * ry + dpc.z;
+            }
+        }
+        g_depth[p] = gd;
+    }
+    const float2 t = mv_block_sum2(s_w, s_c, red);
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = t;
+}
+
+// grid_sample(align_corners=True, padding_mode='zeros') at pixel coordinates; optionally the coordinate gradient
+template <bool GRAD>
+__device__ __forceinline__ float mv_bilerp0(const float* __restrict__ img, int W, int H, float u, float v, float& du, float& dv)
+{
+    const float fu = floorf(u), fv = floorf(v);
+    if (!(fu >= -1.f && fu < (float)W && fv >= -1.f && fv < (float)H)) { if (GRAD) { du = 0.f; dv = 0.f; } return 0.f; }   // also NaN/inf
+    const int x0 = (int)fu, y0 = (int)fv;
+    const float ax = u - fu, ay = v - fv;
+    const bool xl = x0 >= 0, xr = x0 + 1 < W, yt = y0 >= 0, yb = y0 + 1 < H;
+    const float t00 = (xl && yt) ? img[y0 * W + x0] : 0.f, t01 = (xr && yt) ? img[y0 * W + x0 + 1] : 0.f;
+    const float t10 = (xl && yb) ? img[(y0 + 1) * W + x0] : 0.f, t11 = (xr && yb) ? img[(y0 + 1) * W + x0 + 1] : 0.f;
+    const float wx0 = 1.f - ax, wy0 = 1.f - ay;
+    if (GRAD) { du = -t00 * wy0 + t01 * wy0 - t10 * ay + t11 * ay; dv = -t00 * wx0 - t01 * ax + t10 * wx0 + t11 * ax; }
+    return t00 * wx0 * wy0 + t01 * ax * wy0 + t10 * wx0 * ay + t11 * ax * ay;
+}
+
+__global__ void __launch_bounds__(256) k_mv_ncc(gsr_mv_cfg c, int N, const int32_t* __restrict__ idx, const float* __restrict__ weight,
+                                                const float* __restrict__ normal, const float* __restrict__ dist, const float* __restrict__ gray,
+                                                const float* __restrict__ near_gray, float* __restrict__ ncc_out, uint8_t* __restrict__ mask_out,
+                                                float* __restrict__ g_normal, float* __restrict__ g_dist, float2* __restrict__ partial)
+{
+    __shared__ float red[8];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float s_v = 0.f, s_c = 0.f;
+    const int p = i < N ? idx[i] : -1;
+    if (p >= 0) {
+        const int HW = c.W * c.H, h = c.patch;
+        const int x = p % c.W, y = p / c.W;
+        const float s = c.ncc_scale, tps = (float)((2 * h + 1) * (2 * h + 1));
+        const float n0 = normal[p], n1 = normal[HW + p], n2 = normal[2 * HW + p], dd = dist[p];
+        const float* A = c.v2n; const float* b = c.v2n + 9;
+        // Hm = A^T - b n^T / dist;  Hk = K_near(s) Hm Kinv_view(s)
+        float Hm[9], T1[9], Hk[9];
+        const float nn[3] = {n0, n1, n2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) Hm[a * 3 + e] = A[e * 3 + a] - b[a] * nn[e] / dd;
+        const float kfx = c.nfx / s, kfy = c.nfy / s, kcx = c.ncx / s, kcy = c.ncy / s;       // K_near(s)
+        const float ifx = s / c.fx, ify = s / c.fy, icx = -c.cx / c.fx, icy = -c.cy / c.fy;    // Kinv_view(s)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { T1[e] = kfx * Hm[e] + kcx * Hm[6 + e]; T1[3 + e] = kfy * Hm[3 + e] + kcy * Hm[6 + e]; T1[6 + e] = Hm[6 + e]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { Hk[a * 3] = T1[a * 3] * ifx; Hk[a * 3 + 1] = T1[a * 3 + 1] * ify; Hk[a * 3 + 2] = T1[a * 3] * icx + T1[a * 3 + 1] * icy + T1[a * 3 + 2]; }
+        const float px = (float)x / s, py = (float)y / s;
+        float Sr = 0.f, Sn = 0.f, Srr = 0.f, Snn = 0.f, Srn = 0.f, du, dv;
+        for (int oy = -h; oy <= h; ++oy)
+            for (int ox = -h; ox <= h; ++ox) {
+                const float uu = px + (float)ox, vv = py + (float)oy;
+                const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
+                const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+                const float nj = mv_bilerp0<false>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
+                Sr += rj; Sn += nj; Srr += rj * rj; Snn += nj * nj; Srn += rj * nj;
+            }
+        const float ravg = Sr / tps, navg = Sn / tps;
+        const float cross = Srn - navg * Sr, rvar = Srr - ravg * Sr, nvar = Snn - navg * Sn;
+        const float den = rvar * nvar + 1e-8f;
+        const float cc = cross * cross / den;
+        float ncc = 1.f - cc;
+        const bool clamped = !(ncc >= 0.f && ncc <= 2.f);
+        ncc = fminf(fmaxf(ncc, 0.f), 2.f);
+        const bool m = ncc < 0.9f;
+        if (ncc_out) ncc_out[i] = ncc;
+        if (mask_out) mask_out[i] = m ? 1 : 0;
+        const float w = weight[p];
+        if (m) { s_v = ncc * w; s_c = 1.f; }
+        if (m && !clamped && w != 0.f) {
+            const float dcc = -w;
+            const float dcross = dcc * 2.f * cross / den, dnvar = -dcc * cross * cross * rvar / (den * den);
+            float dH[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int oy = -h; oy <= h; ++oy)
+                for (int ox = -h; ox <= h; ++ox) {
+                    const float uu = px + (float)ox, vv = py + (float)oy;
+                    const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
+                    const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+                    const float nj = mv_bilerp0<true>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
+                    const float dn = dcross * (rj - Sr / tps) + dnvar * (2.f * nj - 2.f * navg);
+                    const float dgx = dn * du, dgy = dn * dv;
+                    const float d0 = dgx / g2, d1 = dgy / g2, d2 = -(dgx * g0 + dgy * g1) / (g2 * g2);
+                    dH[0] += d0 * uu; dH[1] += d0 * vv; dH[2] += d0;
+                    dH[3] += d1 * uu; dH[4] += d1 * vv; dH[5] += d1;
+                    dH[6] += d2 * uu; dH[7] += d2 * vv; dH[8] += d2;
+                }
+            // dHm = K_near^T dH Kinv_view^T
+            float T2[9], dHm[9];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { T2[e] = kfx * dH[e]; T2[3 + e] = kfy * dH[3 + e]; T2[6 + e] = kcx * dH[e] + kcy * dH[3 + e] + dH[6 + e]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { dHm[a * 3] = T2[a * 3] * ifx + T2[a * 3 + 2] * icx; dHm[a * 3 + 1] = T2[a * 3 + 1] * ify + T2[a * 3 + 2] * icy; dHm[a * 3 + 2] = T2[a * 3 + 2]; }
+            float gd = 0.f, gn[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const float tb = dHm[e] * b[0] + dHm[3 + e] * b[1] + dHm[6 + e] * b[2];
+                gn[e] = -tb / dd; gd += tb * nn[e] / (dd * dd);
+            }
+            g_normal[p] = gn[0]; g_normal[HW + p] = gn[1]; g_normal[2 * HW + p] = gn[2]; g_dist[p] = gd;
+        }
+    } else if (i < N) {
+        if (ncc_out) ncc_out[i] = 0.f;
+        if (mask_out) mask_out[i] = 0;
+    }
+    const float2 t = mv_block_sum2(s_v, s_c, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(1024) k_mv_finish(const float2* __restrict__ partial, int n, float* stats)
+{
+    __shared__ float r1[16], r2[16];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) { const float2 q = partial[i]; a += q.x; b += q.y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = a; r2[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sa = 0.f, sb = 0.f;
+        for (int w = 0; w < 16; w++) { sa += r1[w]; sb += r2[w]; }
+        stats[0] = sa; stats[1] = sb; stats[2] = sb > 0.f ? sa / sb : 0.f;
+    }
+}
+
+static bool mv_cfg_ok(const gsr_mv_cfg* c)
+{
+    return c && c->W > 0 && c->H > 0 && c->Wn > 0 && c->Hn > 0 && c->Wg > 0 && c->Hg > 0 && c->patch >= 0 && c->patch <= 8 && c->ncc_scale > 0.f &&
+           (int64_t)c->W * c->H < (int64_t)1 << 30;
+}
+
+extern "C" size_t gsr_loss_plane_mv_scratch_bytes(int32_t W, int32_t H, int32_t n_samples)
+{
+    const size_t geo = (size_t)gsr_div_up(W > 0 ? W : 1, 32) * gsr_div_up(H > 0 ? H : 1, 8);
+    const size_t ncc = (size_t)gsr_div_up(n_samples > 0 ? n_samples : 1, 256);
+    return (geo > ncc ? geo : ncc) * sizeof(float2);
+}
+
+extern "C" int gsr_loss_plane_mv_geo(const gsr_mv_cfg* cfg, const float* plane_depth, const float* near_plane_depth, float* noise, uint8_t* d_mask,
+                                     float* weight, float* stats, float* g_depth, float* g_near, void* scratch, size_t scratch_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!mv_cfg_ok(cfg)) { gsr_set_error("loss_plane_mv_geo: bad configuration"); return 1; }
+    if (!plane_depth || !near_plane_depth || !noise || !d_mask || !weight || !stats || !g_depth || !g_near || !scratch ||
+        scratch_bytes < gsr_loss_plane_mv_scratch_bytes(cfg->W, cfg->H, 0)) {
+        gsr_set_error("loss_plane_mv_geo: null pointer or scratch too small"); return 1;
+    }
+    const dim3 grid(gsr_div_up(cfg->W, 32), gsr_div_up(cfg->H, 8));
+    (void)hipMemsetAsync(g_near, 0, sizeof(float) * (size_t)cfg->Wn * cfg->Hn, s);
+    hipLaunchKernelGGL(k_mv_geo, grid, dim3(256), 0, s, *cfg, plane_depth, near_plane_depth, noise, d_mask, weight, g_depth, g_near, (float2*)scratch);
+    hipLaunchKernelGGL(k_mv_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, (int)(grid.x * grid.y), stats);
+    return gsr_check_launch("loss_plane_mv_geo", s, false);
+}
+
+extern "C" int gsr_loss_plane_mv_ncc(const gsr_mv_cfg* cfg, int32_t n_samples, const int32_t* idx, const float* weight, const float* normal,
+                                     const float* distance, const float* gray, const float* near_gray, float* ncc, uint8_t* mask, float* stats,
+                                     float* g_normal, float* g_distance, void* scratch, size_t scratch_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!mv_cfg_ok(cfg) || n_samples < 0) { gsr_set_error("loss_plane_mv_ncc: bad configuration"); return 1; }
+    if (!weight || !normal || !distance || !gray || !near_gray || !stats || !g_normal || !g_distance || !scratch || (n_samples > 0 && !idx) ||
+        scratch_bytes < gsr_loss_plane_mv_scratch_bytes(0, 0, n_samples)) {
+        gsr_set_error("loss_plane_mv_ncc: null pointer or scratch too small"); return 1;
+    }
+    const size_t HW = (size_t)cfg->W * cfg->H;
+    (void)hipMemsetAsync(g_normal, 0, sizeof(float) * 3 * HW, s);
+    (void)hipMemsetAsync(g_distance, 0, sizeof(float) * HW, s);
+    const int blocks = gsr_div_up(n_samples > 0 ? n_samples : 1, 256);
+    hipLaunchKernelGGL(k_mv_ncc, dim3(blocks), dim3(256), 0, s, *cfg, (int)n_samples, idx, weight, normal, distance, gray, near_gray, ncc, mask,
+                       g_normal, g_distance, (float2*)scratch);
+    hipLaunchKernelGGL(k_mv_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, blocks, stats);
+    return gsr_check_launch("loss_plane_mv_ncc", s, false);
+}

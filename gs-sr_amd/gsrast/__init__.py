@@ -45,6 +45,13 @@ class InGrads(C.Structure):
                                    "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dall_map")]
 
 
+class MvCfg(C.Structure):
+    """gsr_mv_cfg (include/gsrast.h)."""
+    _fields_ = ([(n, C.c_int32) for n in ("W", "H", "Wn", "Hn", "Wg", "Hg")] +
+                [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "nfx", "nfy", "ncx", "ncy")] +
+                [("v2n", C.c_float * 12), ("n2v", C.c_float * 12), ("ncc_scale", C.c_float), ("noise_th", C.c_float), ("patch", C.c_int32)])
+
+
 class LodCfg(C.Structure):
     _fields_ = [("voxel_size", C.c_float), ("fork", C.c_float), ("standard_dist", C.c_float), ("resolution_scale", C.c_float),
                 ("coarse_index", C.c_int32), ("mode", C.c_int32)]
@@ -54,7 +61,8 @@ EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward
            "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_visible_filter",
            "gsr_tsdf_integrate", "gsr_tsdf_integrate_dense", "gsr_loss_l1_linear", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
            "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward",
-           "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_octree_visible"]
+           "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_octree_visible",
+           "gsr_loss_plane_mv_scratch_bytes", "gsr_loss_plane_mv_geo", "gsr_loss_plane_mv_ncc"]
 PROF_LABELS = ["preprocess", "depth_order", "binning", "blend_fwd", "bwd_memset", "blend_bwd", "preprocess_bwd", "_"]
 
 _lib = None
@@ -105,6 +113,11 @@ def lib():
     L.gsr_loss_surfel_geo.argtypes = [C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, sz, _vp]
     L.gsr_loss_plane_geo.restype = C.c_int
     L.gsr_loss_plane_geo.argtypes = [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, sz, _vp]
+    L.gsr_loss_plane_mv_scratch_bytes.restype = sz; L.gsr_loss_plane_mv_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.gsr_loss_plane_mv_geo.restype = C.c_int
+    L.gsr_loss_plane_mv_geo.argtypes = [C.POINTER(MvCfg)] + [_vp] * 9 + [sz, _vp]
+    L.gsr_loss_plane_mv_ncc.restype = C.c_int
+    L.gsr_loss_plane_mv_ncc.argtypes = [C.POINTER(MvCfg), C.c_int32] + [_vp] * 12 + [sz, _vp]
     L.gsr_octree_visible.restype = C.c_int
     L.gsr_octree_visible.argtypes = [C.POINTER(Cfg), C.POINTER(LodCfg), _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
     L.gsr_dist2_scratch_bytes.restype = sz; L.gsr_dist2_scratch_bytes.argtypes = [C.c_int32]

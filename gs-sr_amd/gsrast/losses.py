@@ -157,3 +157,114 @@ def plane_geo_loss(plane_depth, out_all_map, ray_mat, weight=None, lambda_normal
     `get_calib_matrix_nerf`; weight = the detached image-gradient weight map (per camera, cacheable) or None.
     -> loss, [mean weighted L1]  (+ depth_normal (3,H,W) when return_map)."""
     return _PlaneGeo.apply(plane_depth, out_all_map, weight, ray_mat, lambda_normal, bool(return_map))
+
+
+def multiview_cfg(view_cam, near_cam, W, H, near_size=None, gray_size=None, patch_size=3, pixel_noise_threshold=1.0):
+    """gsr_mv_cfg from two reference Cameras (attributes R, T, Fx, Fy, Cx, Cy, ncc_scale: gssr/cameras/__init__.py:36-88).
+    The relative pose is composed on the host in float64 (X_near = X_view A + b), once per camera pair."""
+    import numpy as np
+    from . import MvCfg
+    Rv, Tv, Rn, Tn = (np.asarray(a, dtype=np.float64) for a in (view_cam.R, view_cam.T, near_cam.R, near_cam.T))
+    A = Rv.T @ Rn
+    b = Tn - Tv @ A
+    Ai = Rn.T @ Rv
+    bi = Tv - Tn @ Ai
+    Wn, Hn = near_size if near_size is not None else (int(near_cam.image_width), int(near_cam.image_height))
+    Wg, Hg = gray_size if gray_size is not None else (W, H)
+    c = MvCfg(int(W), int(H), int(Wn), int(Hn), int(Wg), int(Hg), float(view_cam.Fx), float(view_cam.Fy), float(view_cam.Cx), float(view_cam.Cy),
+              float(near_cam.Fx), float(near_cam.Fy), float(near_cam.Cx), float(near_cam.Cy))
+    c.v2n[:] = [float(v) for v in np.concatenate([A.reshape(-1), b])]
+    c.n2v[:] = [float(v) for v in np.concatenate([Ai.reshape(-1), bi])]
+    c.ncc_scale = float(getattr(view_cam, "ncc_scale", 1.0))
+    c.noise_th = float(pixel_noise_threshold)
+    c.patch = int(patch_size)
+    return c
+
+
+def sample_valid_pixels(d_mask, num_sample, generator=None):
+    """Uniform sample WITHOUT replacement of at most `num_sample` pixels of d_mask (pgsr_scene.py:147-151 draws it with np.random.choice on
+    the host), without leaving the device: the `num_sample` smallest of per-pixel random keys, invalid pixels keyed out of range.
+    -> int32 [min(num_sample, H*W)] pixel indices, -1 in unused slots (all valid pixels are returned when there are fewer than num_sample)."""
+    m = d_mask.reshape(-1).bool()
+    n = m.numel()
+    if n <= num_sample:
+        ar = torch.arange(n, dtype=torch.int32, device=m.device)
+        return torch.where(m, ar, torch.full_like(ar, -1))
+    keys = torch.rand(n, device=m.device, generator=generator)
+    keys = torch.where(m, keys, torch.full_like(keys, 2.0))
+    val, idx = torch.topk(keys, num_sample, largest=False, sorted=False)
+    return torch.where(val < 1.5, idx.to(torch.int32), torch.full_like(idx, -1, dtype=torch.int32))
+
+
+class _PlaneMultiview(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plane_depth, near_plane_depth, normal, distance, gray, near_gray, cfg, lambda_geo, lambda_ncc, num_sample, indices, generator):
+        import ctypes as C
+        d = dev_f32(plane_depth, "plane_depth", allow_empty=False)
+        nd = dev_f32(near_plane_depth, "near_plane_depth", allow_empty=False)
+        nm = dev_f32(normal, "rendered_normal", allow_empty=False)
+        ds = dev_f32(distance, "rendered_distance", allow_empty=False)
+        g = dev_f32(gray, "gray", allow_empty=False)
+        ng = dev_f32(near_gray, "near_gray", allow_empty=False)
+        W, H = cfg.W, cfg.H
+        if d.numel() != W * H or nd.numel() != cfg.Wn * cfg.Hn or nm.numel() != 3 * W * H or ds.numel() != W * H:
+            raise RuntimeError("plane_multiview_loss: map sizes do not match the configuration")
+        if g.numel() != cfg.Wg * cfg.Hg or ng.numel() != cfg.Wg * cfg.Hg:
+            raise RuntimeError("plane_multiview_loss: both gray images must be (1, Hg, Wg)")
+        L = lib()
+        dev = d.device
+        f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        noise, weight, gD, gN = f(H * W), f(H * W), f(H * W), f(cfg.Hn * cfg.Wn)
+        dmask = torch.empty(H * W, dtype=torch.uint8, device=dev)
+        stats = f(6)
+        nmax = min(int(num_sample), H * W) if indices is None else int(indices.numel())
+        scratch = torch.empty(max(L.gsr_loss_plane_mv_scratch_bytes(W, H, nmax), 8), dtype=torch.uint8, device=dev)
+        check(L.gsr_loss_plane_mv_geo(C.byref(cfg), ptr(d), ptr(nd), ptr(noise), ptr(dmask), ptr(weight), ptr(stats), ptr(gD), ptr(gN), ptr(scratch),
+                                      scratch.numel(), stream_ptr(dev)), "loss_plane_mv_geo")
+        if indices is None:
+            indices = sample_valid_pixels(dmask, num_sample, generator)
+        idx = indices.to(device=dev, dtype=torch.int32).contiguous()
+        gNm, gDs = f(3, H, W), f(H, W)
+        ncc = f(max(idx.numel(), 1))
+        cmask = torch.empty(max(idx.numel(), 1), dtype=torch.uint8, device=dev)
+        check(L.gsr_loss_plane_mv_ncc(C.byref(cfg), int(idx.numel()), ptr(idx), ptr(weight), ptr(nm), ptr(ds), ptr(g), ptr(ng), ptr(ncc), ptr(cmask),
+                                      ptr(stats[3:]), ptr(gNm), ptr(gDs), ptr(scratch), scratch.numel(), stream_ptr(dev)), "loss_plane_mv_ncc")
+        geo = stats[2] * float(lambda_geo)
+        nccl = stats[5] * float(lambda_ncc)
+        # d mean / d x = (d sum / d x) / count; an empty mask leaves zero maps, so the clamp only avoids 0/0
+        sg = float(lambda_geo) / torch.clamp(stats[1], min=1.0)
+        sn = float(lambda_ncc) / torch.clamp(stats[4], min=1.0)
+        ctx.save_for_backward(gD, gN, gNm, gDs, sg, sn)
+        ctx.shapes = (plane_depth.shape, near_plane_depth.shape, normal.shape, distance.shape)
+        aux = {"pixel_noise": noise.view(H, W), "d_mask": dmask.view(H, W).bool(), "weights": weight.view(H, W), "indices": idx,
+               "ncc": ncc[: idx.numel()], "ncc_mask": cmask[: idx.numel()].bool(), "stats": stats}
+        ctx.mark_non_differentiable(*[v for v in aux.values()])
+        return (geo, nccl, *aux.values())
+
+    @staticmethod
+    def backward(ctx, g_geo, g_ncc, *_):
+        gD, gN, gNm, gDs, sg, sn = ctx.saved_tensors
+        s0, s1, s2, s3 = ctx.shapes
+        a = g_geo * sg
+        b = g_ncc * sn
+        return ((gD * a).view(s0), (gN * a).view(s1), (gNm * b).view(s2), (gDs * b).view(s3), None, None, None, None, None, None, None, None)
+
+
+_MV_AUX = ("pixel_noise", "d_mask", "weights", "indices", "ncc", "ncc_mask", "stats")
+
+
+def plane_multiview_loss(plane_depth, near_plane_depth, rendered_normal, rendered_distance, gray, near_gray, cfg, lambda_geo=0.03, lambda_ncc=0.15,
+                         num_sample=102400, indices=None, generator=None, return_aux=False):
+    """PGSR multi-view losses (gssr/scene/pgsr_scene.py:113-204): -> (geo_loss, ncc_loss) [, aux dict].
+
+    plane_depth (1,H,W) / rendered_normal (3,H,W) / rendered_distance (1,H,W): this view's render; near_plane_depth: `nearest_render_pkg
+    ['plane_depth']` (it receives gradient, as in the reference); gray / near_gray: `viewpoint_cam.gray_image`, `near_cam.gray_image`;
+    cfg = multiview_cfg(viewpoint_cam, near_cam, W, H, patch_size=config.patch_size, pixel_noise_threshold=config.pixel_noise_threshold).
+    `indices` (int32 pixel indices, -1 = unused) overrides the random sample of at most `num_sample` (= config.nunm_sample) valid pixels.
+    Both losses are 0 with zero gradients when their mask is empty (the reference's `if d_mask.sum() > 0` / `if mask.sum() > 0`), decided on
+    the device: no host synchronisation."""
+    out = _PlaneMultiview.apply(plane_depth, near_plane_depth, rendered_normal, rendered_distance, gray, near_gray, cfg, lambda_geo, lambda_ncc,
+                                int(num_sample), indices, generator)
+    if return_aux:
+        return out[0], out[1], dict(zip(_MV_AUX, out[2:]))
+    return out[0], out[1]

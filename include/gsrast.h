@@ -214,6 +214,37 @@ int gsr_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, const float* 
 int gsr_loss_plane_geo(int32_t H, int32_t W, const float* plane_depth, const float* alpha, const float* normal, const float* weight,
                        const float* ray_mat, float lambda_normal, float* loss_out, float* dL_ddepth, float* dL_dnormal,
                        float* out_depth_normal, void* scratch, size_t scratch_bytes, void* stream);
+
+/* PGSR multi-view regularisers (gssr/scene/pgsr_scene.py:113-204 -- the "multi-view loss" branch of get_loss_dict; lncc :60-95;
+ * get_points_from_depth / get_points_depth_in_depth_map gssr/utils/point_utils.py:38-75; patch_offsets / patch_warp
+ * gssr/utils/graphics_utils.py:185-198; get_rays / get_k / get_inv_k gssr/cameras/__init__.py:96-121).
+ * Cameras are row-vector (X_cam = X_world R + T, world_view_transform[:3,:3] = R, [3,:3] = T); the two rigid maps are handed in composed:
+ *   v2n = {A row-major [9], b [3]} with X_near = X_view A + b  (A = Rv^T Rn, b = Tn - Tv A);  n2v = its inverse.
+ * (fx,fy,cx,cy) / (nfx,..) are Camera.Fx.. of the view / the neighbour; (W,H) the view's maps, (Wn,Hn) the neighbour's plane depth,
+ * (Wg,Hg) both gray images (the reference assumes they agree); patch = config.patch_size (half width), noise_th = pixel_noise_threshold. */
+typedef struct gsr_mv_cfg {
+    int32_t W, H, Wn, Hn, Wg, Hg;
+    float fx, fy, cx, cy, nfx, nfy, ncx, ncy;
+    float v2n[12], n2v[12];
+    float ncc_scale, noise_th;
+    int32_t patch;
+} gsr_mv_cfg;
+/* scratch for either call below (block partials) */
+size_t gsr_loss_plane_mv_scratch_bytes(int32_t W, int32_t H, int32_t n_samples);
+/* Geometric consistency (pgsr_scene.py:117-143): per pixel, reproject through plane_depth into the neighbour, sample its plane depth
+ * (bilinear, border clamp), reproject back; pixel_noise = reprojection error, d_mask = in-frustum & noise < noise_th,
+ * weight = exp(-noise) (detached; 0 outside d_mask).  Outputs (all DEVICE): noise/d_mask/weight [H*W]; stats[3] = {sum_{d_mask} weight*noise,
+ * |d_mask|, their ratio (0 if empty)};  g_depth [H*W], g_near [Hn*Wn] (overwritten) = d stats[0] / d plane_depth, d near_plane_depth.
+ * geo_loss = lambda_geo * stats[2]; its gradients are lambda_geo / stats[1] times the g_* maps (the caller scales: no host sync). */
+int gsr_loss_plane_mv_geo(const gsr_mv_cfg* cfg, const float* plane_depth, const float* near_plane_depth, float* noise, uint8_t* d_mask,
+                          float* weight, float* stats, float* g_depth, float* g_near, void* scratch, size_t scratch_bytes, void* stream);
+/* Patch NCC (pgsr_scene.py:145-199): idx [n_samples] = sampled pixel indices y*W+x, each at most once, -1 = unused slot.
+ * Per sample: plane-induced homography from normal [3,H,W] / distance [H,W], (2*patch+1)^2 bilinear taps (zeros padding) in both gray
+ * images, lncc; ncc [n] / mask [n] may be NULL.  stats[3] = {sum_{mask} ncc*weight, |mask|, ratio};  g_normal [3,H,W], g_distance [H,W]
+ * (overwritten, zero where unsampled) = d stats[0] / d normal, d distance.  ncc_loss = lambda_ncc * stats[2]. */
+int gsr_loss_plane_mv_ncc(const gsr_mv_cfg* cfg, int32_t n_samples, const int32_t* idx, const float* weight, const float* normal,
+                          const float* distance, const float* gray, const float* near_gray, float* ncc, uint8_t* mask, float* stats,
+                          float* g_normal, float* g_distance, void* scratch, size_t scratch_bytes, void* stream);
 size_t gsr_dist2_scratch_bytes(int32_t P);
 int gsr_dist2(int32_t P, const float* points /*[P,3]*/, float* out /*[P]*/, void* scratch, size_t scratch_bytes,
               void* stream);
