@@ -9,9 +9,9 @@
 //              plane depth (bilinear, border clamp), reprojects back, writes noise / d_mask / weight and the UNSCALED analytic
 //              gradients of sum(weight * noise) to both depth maps (4 float atomics per valid pixel into the neighbour map), and
 //              block-reduces {sum, count}.
-//   k_mv_ncc : one thread per sampled pixel.  Builds the plane-induced homography from the rendered normal / distance, walks the
-//              (2h+1)^2 patch twice (sums, then the chain rule back to the homography), writes ncc / mask and the UNSCALED gradients
-//              of sum(ncc * weight) to normal and distance at that pixel (each pixel is sampled at most once: plain stores).
+//   k_mv_ncc : 16 lanes per sampled pixel.  Builds the plane-induced homography from the rendered normal / distance, walks the
+//              (2h+1)^2 patch twice (sums, then the chain rule back to the homography; 16-lane butterflies), writes ncc / mask and the
+//              UNSCALED gradients of sum(ncc * weight) to normal and distance at that pixel (sampled at most once: plain stores).
 //   k_mv_finish : {sum, count, sum/count (0 if count == 0)}.
 // The means' 1/count and the lambdas are applied by the caller (gsrast.losses) as one device-scalar multiply in backward, so no
 // host synchronisation is needed anywhere.  Both kernels are gather-latency bound (random bilinear taps), not HBM-bound.
@@ -114,19 +114,30 @@ __device__ __forceinline__ float mv_bilerp0(const float* __restrict__ img, int W
     return t00 * wx0 * wy0 + t01 * ax * wy0 + t10 * wx0 * ay + t11 * ax * ay;
 }
 
+// sum over the 16 lanes of a sample group (xor butterflies stay inside a 16-lane row)
+__device__ __forceinline__ float mv_sum16(float v)
+{
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// 16 lanes per sampled pixel (4 samples per wave, 16 per block): a thread-per-sample walk of 2 x 49 dependent gathers leaves only
+// ~1.5 waves per SIMD at 102400 samples and runs at gather latency (measured 0.44 ms); spreading the taps over 16 lanes gives 16x the
+// waves and 4 short iterations per pass (measured below in DESIGN.md).  Pass 2 re-gathers (L1/L2 hits) instead of caching per-tap state.
 __global__ void __launch_bounds__(256) k_mv_ncc(gsr_mv_cfg c, int N, const int32_t* __restrict__ idx, const float* __restrict__ weight,
                                                 const float* __restrict__ normal, const float* __restrict__ dist, const float* __restrict__ gray,
                                                 const float* __restrict__ near_gray, float* __restrict__ ncc_out, uint8_t* __restrict__ mask_out,
                                                 float* __restrict__ g_normal, float* __restrict__ g_dist, float2* __restrict__ partial)
 {
     __shared__ float red[8];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int sub = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
     float s_v = 0.f, s_c = 0.f;
     const int p = i < N ? idx[i] : -1;
     if (p >= 0) {
-        const int HW = c.W * c.H, h = c.patch;
+        const int HW = c.W * c.H, h = c.patch, side = 2 * h + 1, ntap = side * side;
         const int x = p % c.W, y = p / c.W;
-        const float s = c.ncc_scale, tps = (float)((2 * h + 1) * (2 * h + 1));
+        const float s = c.ncc_scale, tps = (float)ntap;
         const float n0 = normal[p], n1 = normal[HW + p], n2 = normal[2 * HW + p], dd = dist[p];
         const float* A = c.v2n; const float* b = c.v2n + 9;
         // Hm = A^T - b n^T / dist;  Hk = K_near(s) Hm Kinv_view(s)
@@ -144,14 +155,14 @@ __global__ void __launch_bounds__(256) k_mv_ncc(gsr_mv_cfg c, int N, const int32
         for (int a = 0; a < 3; ++a) { Hk[a * 3] = T1[a * 3] * ifx; Hk[a * 3 + 1] = T1[a * 3 + 1] * ify; Hk[a * 3 + 2] = T1[a * 3] * icx + T1[a * 3 + 1] * icy + T1[a * 3 + 2]; }
         const float px = (float)x / s, py = (float)y / s;
         float Sr = 0.f, Sn = 0.f, Srr = 0.f, Snn = 0.f, Srn = 0.f, du, dv;
-        for (int oy = -h; oy <= h; ++oy)
-            for (int ox = -h; ox <= h; ++ox) {
-                const float uu = px + (float)ox, vv = py + (float)oy;
-                const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
-                const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
-                const float nj = mv_bilerp0<false>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
-                Sr += rj; Sn += nj; Srr += rj * rj; Snn += nj * nj; Srn += rj * nj;
-            }
+        for (int j = sub; j < ntap; j += 16) {
+            const float uu = px + (float)(j % side - h), vv = py + (float)(j / side - h);
+            const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
+            const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+            const float nj = mv_bilerp0<false>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
+            Sr += rj; Sn += nj; Srr += rj * rj; Snn += nj * nj; Srn += rj * nj;
+        }
+        Sr = mv_sum16(Sr); Sn = mv_sum16(Sn); Srr = mv_sum16(Srr); Snn = mv_sum16(Snn); Srn = mv_sum16(Srn);
         const float ravg = Sr / tps, navg = Sn / tps;
         const float cross = Srn - navg * Sr, rvar = Srr - ravg * Sr, nvar = Snn - navg * Sn;
         const float den = rvar * nvar + 1e-8f;
@@ -160,27 +171,30 @@ __global__ void __launch_bounds__(256) k_mv_ncc(gsr_mv_cfg c, int N, const int32
         const bool clamped = !(ncc >= 0.f && ncc <= 2.f);
         ncc = fminf(fmaxf(ncc, 0.f), 2.f);
         const bool m = ncc < 0.9f;
-        if (ncc_out) ncc_out[i] = ncc;
-        if (mask_out) mask_out[i] = m ? 1 : 0;
         const float w = weight[p];
-        if (m) { s_v = ncc * w; s_c = 1.f; }
-        if (m && !clamped && w != 0.f) {
+        if (sub == 0) {
+            if (ncc_out) ncc_out[i] = ncc;
+            if (mask_out) mask_out[i] = m ? 1 : 0;
+            if (m) { s_v = ncc * w; s_c = 1.f; }
+        }
+        if (m && !clamped && w != 0.f) {                                    // uniform across the 16 lanes of the sample
             const float dcc = -w;
             const float dcross = dcc * 2.f * cross / den, dnvar = -dcc * cross * cross * rvar / (den * den);
             float dH[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int oy = -h; oy <= h; ++oy)
-                for (int ox = -h; ox <= h; ++ox) {
-                    const float uu = px + (float)ox, vv = py + (float)oy;
-                    const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
-                    const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
-                    const float nj = mv_bilerp0<true>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
-                    const float dn = dcross * (rj - Sr / tps) + dnvar * (2.f * nj - 2.f * navg);
-                    const float dgx = dn * du, dgy = dn * dv;
-                    const float d0 = dgx / g2, d1 = dgy / g2, d2 = -(dgx * g0 + dgy * g1) / (g2 * g2);
-                    dH[0] += d0 * uu; dH[1] += d0 * vv; dH[2] += d0;
-                    dH[3] += d1 * uu; dH[4] += d1 * vv; dH[5] += d1;
-                    dH[6] += d2 * uu; dH[7] += d2 * vv; dH[8] += d2;
-                }
+            for (int j = sub; j < ntap; j += 16) {
+                const float uu = px + (float)(j % side - h), vv = py + (float)(j / side - h);
+                const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
+                const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+                const float nj = mv_bilerp0<true>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
+                const float dn = dcross * (rj - ravg) + dnvar * (2.f * nj - 2.f * navg);
+                const float dgx = dn * du, dgy = dn * dv;
+                const float d0 = dgx / g2, d1 = dgy / g2, d2 = -(dgx * g0 + dgy * g1) / (g2 * g2);
+                dH[0] += d0 * uu; dH[1] += d0 * vv; dH[2] += d0;
+                dH[3] += d1 * uu; dH[4] += d1 * vv; dH[5] += d1;
+                dH[6] += d2 * uu; dH[7] += d2 * vv; dH[8] += d2;
+            }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) dH[e] = mv_sum16(dH[e]);
             // dHm = K_near^T dH Kinv_view^T
             float T2[9], dHm[9];
 #pragma unroll
@@ -193,9 +207,10 @@ __global__ void __launch_bounds__(256) k_mv_ncc(gsr_mv_cfg c, int N, const int32
                 const float tb = dHm[e] * b[0] + dHm[3 + e] * b[1] + dHm[6 + e] * b[2];
                 gn[e] = -tb / dd; gd += tb * nn[e] / (dd * dd);
             }
-            g_normal[p] = gn[0]; g_normal[HW + p] = gn[1]; g_normal[2 * HW + p] = gn[2]; g_dist[p] = gd;
+            if (sub < 3) g_normal[sub * HW + p] = sub == 0 ? gn[0] : (sub == 1 ? gn[1] : gn[2]);
+            if (sub == 3) g_dist[p] = gd;
         }
-    } else if (i < N) {
+    } else if (i < N && sub == 0) {
         if (ncc_out) ncc_out[i] = 0.f;
         if (mask_out) mask_out[i] = 0;
     }
@@ -228,7 +243,7 @@ static bool mv_cfg_ok(const gsr_mv_cfg* c)
 extern "C" size_t gsr_loss_plane_mv_scratch_bytes(int32_t W, int32_t H, int32_t n_samples)
 {
     const size_t geo = (size_t)gsr_div_up(W > 0 ? W : 1, 32) * gsr_div_up(H > 0 ? H : 1, 8);
-    const size_t ncc = (size_t)gsr_div_up(n_samples > 0 ? n_samples : 1, 256);
+    const size_t ncc = (size_t)gsr_div_up(n_samples > 0 ? n_samples : 1, 16);
     return (geo > ncc ? geo : ncc) * sizeof(float2);
 }
 
@@ -261,7 +276,7 @@ extern "C" int gsr_loss_plane_mv_ncc(const gsr_mv_cfg* cfg, int32_t n_samples, c
     const size_t HW = (size_t)cfg->W * cfg->H;
     (void)hipMemsetAsync(g_normal, 0, sizeof(float) * 3 * HW, s);
     (void)hipMemsetAsync(g_distance, 0, sizeof(float) * HW, s);
-    const int blocks = gsr_div_up(n_samples > 0 ? n_samples : 1, 256);
+    const int blocks = gsr_div_up(n_samples > 0 ? n_samples : 1, 16);
     hipLaunchKernelGGL(k_mv_ncc, dim3(blocks), dim3(256), 0, s, *cfg, (int)n_samples, idx, weight, normal, distance, gray, near_gray, ncc, mask,
                        g_normal, g_distance, (float2*)scratch);
     hipLaunchKernelGGL(k_mv_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, blocks, stats);

@@ -151,3 +151,25 @@ def test_decode_argument_errors_without_a_device():
                                 1 << 20, None) != 0 and "level" in gsrast.last_error()
     assert L.gsd_forward_stage1(C.byref(decode.Cfg(10, 5, 10, 0, 0, 0, 0, 0)), C.byref(inp), C.byref(prm), addr, addr, addr, C.byref(P), addr,
                                 16, None) != 0 and "scratch" in gsrast.last_error()
+
+
+def test_multiview_loss_argument_errors_without_a_device():
+    """gsr_loss_plane_mv_* reject bad configurations / null pointers / short scratch before launching anything."""
+    import ctypes as C
+    import gsrast
+    L = gsrast.lib()
+    buf = (C.c_float * 64)()
+    a = C.addressof(buf)
+    good = gsrast.MvCfg(8, 4, 8, 4, 8, 4, 10, 10, 4, 2, 10, 10, 4, 2)
+    good.ncc_scale, good.noise_th, good.patch = 1.0, 1.0, 3
+    bad = gsrast.MvCfg(0, 4, 8, 4, 8, 4, 10, 10, 4, 2, 10, 10, 4, 2)
+    bad.ncc_scale, bad.patch = 1.0, 3
+    big = 1 << 16
+    assert L.gsr_loss_plane_mv_geo(C.byref(bad), a, a, a, a, a, a, a, a, a, big, None) != 0 and "configuration" in gsrast.last_error()
+    assert L.gsr_loss_plane_mv_geo(C.byref(good), a, None, a, a, a, a, a, a, a, big, None) != 0 and "null pointer" in gsrast.last_error()
+    assert L.gsr_loss_plane_mv_geo(C.byref(good), a, a, a, a, a, a, a, a, a, 0, None) != 0 and "scratch" in gsrast.last_error()
+    good.patch = 9
+    assert L.gsr_loss_plane_mv_ncc(C.byref(good), 4, a, a, a, a, a, a, None, None, a, a, a, a, big, None) != 0 and "configuration" in gsrast.last_error()
+    good.patch = 3
+    assert L.gsr_loss_plane_mv_ncc(C.byref(good), 4, None, a, a, a, a, a, None, None, a, a, a, a, big, None) != 0 and "null pointer" in gsrast.last_error()
+    assert L.gsr_loss_plane_mv_scratch_bytes(1920, 1080, 102400) >= 8 * max(60 * 135, 6400)

@@ -136,3 +136,19 @@ def test_plane_multiview_oracle_matches_reference_run():
         exp = exp.reshape(got.shape)
         rel = np.linalg.norm(got - exp) / np.linalg.norm(exp)
         assert rel < 2e-3, (name, rel, np.abs(got - exp).max(), np.abs(exp).max())
+
+
+def test_multiview_torch_restatement_matches_reference_run():
+    """tests/ref_mv_torch.py (used for timing and full-size GPU parity) against the same reference-run fixture."""
+    import torch
+    import ref_mv_torch
+    z = golden_ref.load("ref_loss_plane_multiview")
+    cam = lambda pre: {k: (z[f"{pre}_{k}"] if k in ("R", "T") else float(z[f"{pre}_{k}"])) for k in ("R", "T", "Fx", "Fy", "Cx", "Cy")}
+    lv = {k: torch.tensor(z[k], requires_grad=True) for k in ("plane_depth", "near_plane_depth", "rendered_normal", "rendered_distance")}
+    geo, ncc = ref_mv_torch.multiview_loss(lv["plane_depth"], lv["near_plane_depth"], lv["rendered_normal"], lv["rendered_distance"],
+                                           torch.tensor(z["gray"]), torch.tensor(z["near_gray"]), cam("v"), cam("n"))
+    (geo + ncc).backward()
+    np.testing.assert_allclose([geo.item(), ncc.item()], [float(z["geo_loss"]), float(z["ncc_loss"])], rtol=1e-5)
+    for k in lv:
+        e = z["d_" + k]
+        assert np.linalg.norm(lv[k].grad.numpy() - e) / np.linalg.norm(e) < 1e-4, k

@@ -30,7 +30,7 @@ def _rel(a, b):
     return np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(W=200, H=120, seed=1, amp=0.05), dict(W=33, H=17, seed=2), dict(W=96, H=64, seed=3, amp=0.3, near_yaw=-12.0),
+@pytest.mark.parametrize("kw", [dict(), dict(W=200, H=120, seed=1, amp=0.05, tex=3.0), dict(W=33, H=17, seed=2), dict(W=96, H=64, seed=3, amp=0.3, near_yaw=-12.0),
                                 dict(W=64, H=48, seed=4, near_t=(-3.0, 0.0, 0.0))])
 def test_multiview_matches_oracle(kw):
     case = mv_cases.plane_pair(**kw)
@@ -56,17 +56,17 @@ def test_multiview_matches_oracle(kw):
     on = om.ncc(cfg, idx, og["weight"], case["rendered_normal"], case["rendered_distance"], case["gray"], case["near_gray"])
     geo2, ncc2, aux2, g2 = _run_hip(case, indices=idx)
     mflip = aux2["ncc_mask"] != on["mask"].astype(bool)
-    assert mflip.sum() <= 2
-    # The kernel is written with the oracle's operation order (true divisions, same bilinear accumulation, -ffp-contract=off), so the
-    # per-sample values agree to the last bit in practice (measured: 0.0).  The slack covers libm-vs-device expf/sqrtf: ncc is
-    # ill-conditioned on low-contrast patches (variances cancel to ~1e-3 of the float32 sums), where 1 ulp in a tap moves it by ~1e-3.
+    assert mflip.sum() <= max(2, int(1e-3 * idx.size))
+    # Per-tap arithmetic follows the oracle's operation order (true divisions, same bilinear accumulation, -ffp-contract=off); the patch
+    # sums are 16-lane butterflies instead of a sequential walk.  ncc = 1 - cross^2/(var var) is ill-conditioned on low-contrast patches
+    # (the variances cancel to ~1e-3 of the float32 sums), where the summation order alone moves it by ~1e-3: bulk tight, tail loose.
     e = np.abs(aux2["ncc"][~mflip] - on["ncc"][~mflip])
-    assert np.quantile(e, 0.99) < 1e-5 and e.max() < 5e-3, (np.quantile(e, 0.99), e.max())
-    if on["stats"][1] > 0 and not mflip.any() and not flips.any():
-        np.testing.assert_allclose(ncc2, 0.15 * on["stats"][0] / on["stats"][1], rtol=1e-5)
+    assert np.quantile(e, 0.5) < 2e-5 and np.quantile(e, 0.99) < 2e-3 and e.max() < 3e-2, (np.quantile(e, 0.5), np.quantile(e, 0.99), e.max())
+    if on["stats"][1] > 0 and mflip.sum() <= 2 and not flips.any():
+        np.testing.assert_allclose(ncc2, 0.15 * on["stats"][0] / on["stats"][1], rtol=1e-4)
         sc = 0.15 / on["stats"][1]
-        assert _rel(g2["rendered_normal"].reshape(3, -1) / 3.0, sc * on["g_normal"]) < 1e-4
-        assert _rel(g2["rendered_distance"].reshape(-1) / 3.0, sc * on["g_dist"]) < 1e-4
+        assert _rel(g2["rendered_normal"].reshape(3, -1) / 3.0, sc * on["g_normal"]) < 5e-3       # conditioning as above
+        assert _rel(g2["rendered_distance"].reshape(-1) / 3.0, sc * on["g_dist"]) < 5e-3
 
 
 def test_multiview_matches_reference_run():
@@ -103,3 +103,26 @@ def test_multiview_sampling_and_empty_masks():
     geo, ncc, aux, g = _run_hip(far)
     assert geo == 0.0 and ncc == 0.0 and not aux["d_mask"].any()
     assert all(np.isfinite(v).all() and not v.any() for v in g.values())
+
+
+def test_multiview_full_hd_vs_torch_chain():
+    """1920x1080, 102400 sampled patches: fused kernels vs the torch op chain on the same device and the same sample set."""
+    import ref_mv_torch
+    from gsrast.losses import multiview_cfg, plane_multiview_loss
+    case = mv_cases.plane_pair(W=1920, H=1080, seed=11, amp=0.002, tex=25.0)
+    t = lambda a: torch.tensor(a, device=DEV)
+    names = ("plane_depth", "near_plane_depth", "rendered_normal", "rendered_distance")
+    a = {k: t(case[k]).requires_grad_(True) for k in names}
+    b = {k: t(case[k]).requires_grad_(True) for k in names}
+    cfg = multiview_cfg(mv_cases.cam_ns(case["view"]), mv_cases.cam_ns(case["near"]), 1920, 1080, near_size=(1920, 1080))
+    gen = torch.Generator(device=DEV); gen.manual_seed(5)
+    geo, ncc, aux = plane_multiview_loss(*[a[k] for k in names], t(case["gray"]), t(case["near_gray"]), cfg, generator=gen, return_aux=True)
+    (geo + ncc).backward()
+    idx = aux["indices"]
+    assert idx.numel() == 102400 and (idx >= 0).all()
+    rgeo, rncc = ref_mv_torch.multiview_loss(*[b[k] for k in names], t(case["gray"]), t(case["near_gray"]), case["view"], case["near"], indices=idx)
+    (rgeo + rncc).backward()
+    assert abs(geo.item() - rgeo.item()) < 2e-3 * abs(rgeo.item()) and abs(ncc.item() - rncc.item()) < 2e-3 * abs(rncc.item())
+    for k in names:
+        rel = ((a[k].grad - b[k].grad).norm() / b[k].grad.norm()).item()
+        assert rel < 2e-2, (k, rel)          # float32 chain through world coordinates vs composed transforms; NCC conditioning (see above)

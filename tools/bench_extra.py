@@ -72,4 +72,29 @@ def torch_geo():
 th, tt = timeit(hip_geo, n=30), timeit(torch_geo, n=10)
 out["surfel_geo_loss_1080p"] = {"hip_fwd_bwd_ms": round(th * 1e3, 3), "torch_fwd_bwd_ms": round(tt * 1e3, 3), "speedup": round(tt / th, 1),
                                 "algorithmic_GBps": round(H * W * 72 / th / 1e9, 1)}
+# PGSR multi-view losses (geometric consistency + 102400 x 7x7 patch NCC), value + gradients, 1080p, vs the torch op chain
+import mv_cases, ref_mv_torch
+from gsrast.losses import multiview_cfg, plane_multiview_loss
+mc = mv_cases.plane_pair(W=W, H=H, seed=11, amp=0.002, tex=25.0)
+tt_ = lambda a: torch.tensor(a, device="cuda")
+mnames = ("plane_depth", "near_plane_depth", "rendered_normal", "rendered_distance")
+ml = {k: tt_(mc[k]).requires_grad_(True) for k in mnames}
+mg, mng = tt_(mc["gray"]), tt_(mc["near_gray"])
+mcfg = multiview_cfg(mv_cases.cam_ns(mc["view"]), mv_cases.cam_ns(mc["near"]), W, H, near_size=(W, H))
+def hip_mv():
+    for v in ml.values(): v.grad = None
+    a, b = plane_multiview_loss(*[ml[k] for k in mnames], mg, mng, mcfg)
+    (a + b).backward()
+fixed_idx = plane_multiview_loss(*[ml[k] for k in mnames], mg, mng, mcfg, return_aux=True)[2]["indices"]
+def hip_mv_fixed():
+    for v in ml.values(): v.grad = None
+    a, b = plane_multiview_loss(*[ml[k] for k in mnames], mg, mng, mcfg, indices=fixed_idx)
+    (a + b).backward()
+def torch_mv():
+    for v in ml.values(): v.grad = None
+    a, b = ref_mv_torch.multiview_loss(*[ml[k] for k in mnames], mg, mng, mc["view"], mc["near"], indices=fixed_idx)
+    (a + b).backward()
+th, thf, tt = timeit(hip_mv, n=20), timeit(hip_mv_fixed, n=20), timeit(torch_mv, n=5, w=2)
+out["plane_multiview_1080p"] = {"hip_fwd_bwd_ms": round(th * 1e3, 3), "hip_fwd_bwd_ms_given_indices": round(thf * 1e3, 3), "torch_fwd_bwd_ms": round(tt * 1e3, 3),
+                                "speedup": round(tt / th, 1), "samples": 102400, "note": "torch chain timed WITHOUT its host-side np.random.choice / nonzero"}
 print(json.dumps(out))
