@@ -386,3 +386,123 @@ extern "C" int gsr_dist2(int32_t P, const float* points, float* out, void* scrat
     hipLaunchKernelGGL(k_knn_dist, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, points, order, k.boxes, nbox, out);
     return gsr_check_launch("dist2", s, false);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Per-Gaussian `all_map` input of the plane rasterizer (gssr/scene/pgsr_scene.py:241-257 get_smallest_axis / get_normal, :297-304):
+//   R = quaternion_to_matrix(q) (pytorch3d: real part first, two_s = 2/(q.q));  n = R[:, argmin(scale)], flipped towards the camera;
+//   local_normal = n Wv[:3,:3];  local_distance = |local_normal . (xyz Wv[:3,:3] + Wv[3,:3])|;  all_map = {local_normal, 1, local_distance}.
+// The reference spends ~25 torch ops forward and ~40 backward on it every iteration; here one streaming kernel each way (HBM-bound:
+// 40 B read + 20 B written per Gaussian forward, 60 B + 28 B backward).
+struct PlaneAxis { float n[3], ln[3], pc[3], flip; int k; };
+
+__device__ __forceinline__ void plane_q2m(const float4 q, float* R)
+{
+    const float r = q.x, i = q.y, j = q.z, k = q.w;
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    R[0] = 1 - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r); R[4] = 1 - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1 - two_s * (i * i + j * j);
+}
+
+__device__ __forceinline__ PlaneAxis plane_axis(int p, const float* __restrict__ xyz, const float4 q, const float* __restrict__ scale, int ss,
+                                                const float* __restrict__ V, const float* __restrict__ cp)
+{
+    PlaneAxis a;
+    float R[9]; plane_q2m(q, R);
+    const float s0 = scale[(size_t)p * ss], s1 = scale[(size_t)p * ss + 1], s2 = scale[(size_t)p * ss + 2];
+    int k = 0; float sm = s0;
+    if (s1 < sm) { k = 1; sm = s1; }
+    if (s2 < sm) k = 2;                                               // first minimum wins, like torch.min
+    a.k = k;
+    a.n[0] = k == 0 ? R[0] : (k == 1 ? R[1] : R[2]); a.n[1] = k == 0 ? R[3] : (k == 1 ? R[4] : R[5]); a.n[2] = k == 0 ? R[6] : (k == 1 ? R[7] : R[8]);
+    const float x0 = xyz[3 * (size_t)p], x1 = xyz[3 * (size_t)p + 1], x2 = xyz[3 * (size_t)p + 2];
+    const float dot = a.n[0] * (cp[0] - x0) + a.n[1] * (cp[1] - x1) + a.n[2] * (cp[2] - x2);
+    a.flip = dot < 0.f ? -1.f : 1.f;
+    if (dot < 0.f) { a.n[0] = -a.n[0]; a.n[1] = -a.n[1]; a.n[2] = -a.n[2]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.ln[c] = a.n[0] * V[c] + a.n[1] * V[4 + c] + a.n[2] * V[8 + c];
+        a.pc[c] = x0 * V[c] + x1 * V[4 + c] + x2 * V[8 + c] + V[12 + c];
+    }
+    return a;
+}
+
+__global__ void __launch_bounds__(256) k_plane_allmap(int P, const float* __restrict__ xyz, const float4* __restrict__ rot, const float* __restrict__ scale,
+                                                      int ss, const float* __restrict__ V, const float* __restrict__ cp, float* __restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const PlaneAxis a = plane_axis(p, xyz, rot[p], scale, ss, V, cp);
+    float* o = out + 5 * (size_t)p;
+    o[0] = a.ln[0]; o[1] = a.ln[1]; o[2] = a.ln[2]; o[3] = 1.0f;
+    o[4] = fabsf(a.ln[0] * a.pc[0] + a.ln[1] * a.pc[1] + a.ln[2] * a.pc[2]);
+}
+
+__global__ void __launch_bounds__(256) k_plane_allmap_bwd(int P, const float* __restrict__ xyz, const float4* __restrict__ rot,
+                                                          const float* __restrict__ scale, int ss, const float* __restrict__ V,
+                                                          const float* __restrict__ cp, const float* __restrict__ g_all, float* __restrict__ d_xyz,
+                                                          float4* __restrict__ d_rot)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float4 q = rot[p];
+    const PlaneAxis a = plane_axis(p, xyz, q, scale, ss, V, cp);
+    const float* g = g_all + 5 * (size_t)p;
+    const float g4 = g[4];
+    const float sd = a.ln[0] * a.pc[0] + a.ln[1] * a.pc[1] + a.ln[2] * a.pc[2];
+    const float sg = sd > 0.f ? 1.f : (sd < 0.f ? -1.f : 0.f);
+    float dln[3], dpc[3], dn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { dln[c] = g[c] + sg * g4 * a.pc[c]; dpc[c] = sg * g4 * a.ln[c]; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d_xyz[3 * (size_t)p + r] = dpc[0] * V[r * 4] + dpc[1] * V[r * 4 + 1] + dpc[2] * V[r * 4 + 2];
+        dn[r] = a.flip * (dln[0] * V[r * 4] + dln[1] * V[r * 4 + 1] + dln[2] * V[r * 4 + 2]);
+    }
+    const float r = q.x, i = q.y, j = q.z, kk = q.w;
+    const float s2 = r * r + i * i + j * j + kk * kk, two_s = 2.0f / s2;
+    float dR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { dR[c] = a.k == c ? dn[0] : 0.f; dR[3 + c] = a.k == c ? dn[1] : 0.f; dR[6 + c] = a.k == c ? dn[2] : 0.f; }
+    const float M[9] = {-(j * j + kk * kk), i * j - kk * r, i * kk + j * r, i * j + kk * r, -(i * i + kk * kk), j * kk - i * r,
+                        i * kk - j * r, j * kk + i * r, -(i * i + j * j)};
+    float dts = 0.f, dM[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { dts += dR[e] * M[e]; dM[e] = dR[e] * two_s; }
+    float4 dq;
+    dq.x = -kk * dM[1] + j * dM[2] + kk * dM[3] - i * dM[5] - j * dM[6] + i * dM[7];
+    dq.y = j * dM[1] + kk * dM[2] + j * dM[3] - 2 * i * dM[4] - r * dM[5] + kk * dM[6] + r * dM[7] - 2 * i * dM[8];
+    dq.z = -2 * j * dM[0] + i * dM[1] + r * dM[2] + i * dM[3] + kk * dM[5] - r * dM[6] + kk * dM[7] - 2 * j * dM[8];
+    dq.w = -2 * kk * dM[0] - r * dM[1] + i * dM[2] + r * dM[3] - 2 * kk * dM[4] + j * dM[5] + i * dM[6] + j * dM[7];
+    const float sc = dts * (-2.0f / (s2 * s2)) * 2.0f;
+    d_rot[p] = make_float4(dq.x + sc * r, dq.y + sc * i, dq.z + sc * j, dq.w + sc * kk);
+}
+
+extern "C" int gsr_plane_allmap(int32_t P, const float* means3D, const float* rotations, const float* scales, int32_t scale_stride,
+                                const float* viewmatrix, const float* campos, float* all_map, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!means3D || !rotations || !scales || !viewmatrix || !campos || !all_map || scale_stride < 3) {
+        gsr_set_error("plane_allmap: null pointer or scale_stride < 3"); return 1;
+    }
+    if (((uintptr_t)rotations & 15) != 0) { gsr_set_error("plane_allmap: rotations must be 16-byte aligned"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_plane_allmap, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, means3D, (const float4*)rotations, scales, scale_stride,
+                       viewmatrix, campos, all_map);
+    return gsr_check_launch("plane_allmap", s, false);
+}
+
+extern "C" int gsr_plane_allmap_backward(int32_t P, const float* means3D, const float* rotations, const float* scales, int32_t scale_stride,
+                                         const float* viewmatrix, const float* campos, const float* dL_dall_map, float* dL_dmeans3D,
+                                         float* dL_drotations, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!means3D || !rotations || !scales || !viewmatrix || !campos || !dL_dall_map || !dL_dmeans3D || !dL_drotations || scale_stride < 3) {
+        gsr_set_error("plane_allmap_backward: null pointer or scale_stride < 3"); return 1;
+    }
+    if ((((uintptr_t)rotations | (uintptr_t)dL_drotations) & 15) != 0) { gsr_set_error("plane_allmap_backward: rotations must be 16-byte aligned"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_plane_allmap_bwd, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, means3D, (const float4*)rotations, scales, scale_stride,
+                       viewmatrix, campos, dL_dall_map, dL_dmeans3D, (float4*)dL_drotations);
+    return gsr_check_launch("plane_allmap_backward", s, false);
+}

@@ -215,6 +215,21 @@ int gsr_loss_plane_geo(int32_t H, int32_t W, const float* plane_depth, const flo
                        const float* ray_mat, float lambda_normal, float* loss_out, float* dL_ddepth, float* dL_dnormal,
                        float* out_depth_normal, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Per-Gaussian `all_map` input of the plane rasterizer, as PGSRScene.render() builds it (gssr/scene/pgsr_scene.py:241-257
+ * get_rotation_matrix / get_smallest_axis / get_normal and :297-304):  all_map[i] = {local_normal (3), 1, local_distance} with
+ *   n = quaternion_to_matrix(rotations[i])[:, argmin(scales[i])] (pytorch3d convention: real part first, normalised by 2/(q.q); first
+ *   minimum on ties), flipped where n . (campos - means3D[i]) < 0;  local_normal = n Wv[:3,:3];
+ *   local_distance = |local_normal . (means3D[i] Wv[:3,:3] + Wv[3,:3])|.
+ * viewmatrix [16] / campos [3]: DEVICE pointers, the reference's world_view_transform / camera_center (as in gsr_cfg).
+ * scales [P, scale_stride] (scale_stride >= 3: get_scaling may be wider).  rotations / dL_drotations 16-byte aligned.
+ * Backward: dL_dall_map [P,5] (the rasterizer's gsr_in_grads.dL_dall_map) -> dL_dmeans3D [P,3] (through the camera-space centre only),
+ * dL_drotations [P,4] (through R, including the 2/(q.q) term); both overwritten.  scales get no gradient (argmin). */
+int gsr_plane_allmap(int32_t P, const float* means3D, const float* rotations, const float* scales, int32_t scale_stride,
+                     const float* viewmatrix, const float* campos, float* all_map, void* stream);
+int gsr_plane_allmap_backward(int32_t P, const float* means3D, const float* rotations, const float* scales, int32_t scale_stride,
+                              const float* viewmatrix, const float* campos, const float* dL_dall_map, float* dL_dmeans3D,
+                              float* dL_drotations, void* stream);
+
 /* PGSR multi-view regularisers (gssr/scene/pgsr_scene.py:113-204 -- the "multi-view loss" branch of get_loss_dict; lncc :60-95;
  * get_points_from_depth / get_points_depth_in_depth_map gssr/utils/point_utils.py:38-75; patch_offsets / patch_warp
  * gssr/utils/graphics_utils.py:185-198; get_rays / get_k / get_inv_k gssr/cameras/__init__.py:96-121).

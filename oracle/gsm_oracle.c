@@ -200,3 +200,88 @@ void refm_multiview_ncc(const refm_cfg* c, int32_t N, const int32_t* idx, const 
     }
     stats[0] = sum; stats[1] = (double)cnt;
 }
+
+/*
+ * Per-Gaussian input of the plane rasterizer (gssr/scene/pgsr_scene.py:241-257 get_rotation_matrix / get_smallest_axis / get_normal and
+ * :297-304 in render()):  all_map[i] = {local_normal(3), 1, local_distance}.
+ *   R = quaternion_to_matrix(q)   -- pytorch3d.transforms (third-party, absent from /root/reference; requirements.txt names pytorch3d
+ *                                    without a pin).  Published algorithm: (r,i,j,k) = q, two_s = 2/(q.q), R = I + two_s * [...] (below).
+ *   n = R[:, argmin(scale)] (first minimum);  n = -n where n . (campos - xyz) < 0
+ *   ln = n Wv[:3,:3];  pc = xyz Wv[:3,:3] + Wv[3,:3];  dist = |ln . pc|
+ * Backward: dL/dxyz (through pc only: the flip mask is not differentiable), dL/dq (through R incl. the two_s normalisation).
+ * viewmatrix: the reference's world_view_transform, 16 floats row-major.
+ */
+static void q2m(const float* q, float* R) {
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    R[0] = 1 - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r); R[4] = 1 - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1 - two_s * (i * i + j * j);
+}
+
+static int argmin3(const float* s) { int k = 0; if (s[1] < s[k]) k = 1; if (s[2] < s[k]) k = 2; return k; }
+
+void refm_plane_allmap(int32_t P, const float* xyz, const float* rot, const float* scale, const float* V, const float* campos, float* all_map) {
+    for (int p = 0; p < P; ++p) {
+        float R[9]; q2m(rot + 4 * p, R);
+        const int k = argmin3(scale + 3 * p);
+        float n[3] = {R[k], R[3 + k], R[6 + k]};
+        const float* x = xyz + 3 * p;
+        const float dot = n[0] * (campos[0] - x[0]) + n[1] * (campos[1] - x[1]) + n[2] * (campos[2] - x[2]);
+        if (dot < 0.f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        float ln[3], pc[3];
+        for (int c = 0; c < 3; ++c) {
+            ln[c] = n[0] * V[0 * 4 + c] + n[1] * V[1 * 4 + c] + n[2] * V[2 * 4 + c];
+            pc[c] = x[0] * V[0 * 4 + c] + x[1] * V[1 * 4 + c] + x[2] * V[2 * 4 + c] + V[3 * 4 + c];
+        }
+        float* o = all_map + 5 * p;
+        o[0] = ln[0]; o[1] = ln[1]; o[2] = ln[2]; o[3] = 1.0f;
+        o[4] = fabsf(ln[0] * pc[0] + ln[1] * pc[1] + ln[2] * pc[2]);
+    }
+}
+
+void refm_plane_allmap_bwd(int32_t P, const float* xyz, const float* rot, const float* scale, const float* V, const float* campos,
+                           const float* d_all_map, float* d_xyz, float* d_rot) {
+    for (int p = 0; p < P; ++p) {
+        const float* q = rot + 4 * p;
+        float R[9]; q2m(q, R);
+        const int k = argmin3(scale + 3 * p);
+        float n[3] = {R[k], R[3 + k], R[6 + k]};
+        const float* x = xyz + 3 * p;
+        const float dot = n[0] * (campos[0] - x[0]) + n[1] * (campos[1] - x[1]) + n[2] * (campos[2] - x[2]);
+        const float flip = dot < 0.f ? -1.f : 1.f;
+        n[0] *= flip; n[1] *= flip; n[2] *= flip;
+        float ln[3], pc[3];
+        for (int c = 0; c < 3; ++c) {
+            ln[c] = n[0] * V[0 * 4 + c] + n[1] * V[1 * 4 + c] + n[2] * V[2 * 4 + c];
+            pc[c] = x[0] * V[0 * 4 + c] + x[1] * V[1 * 4 + c] + x[2] * V[2 * 4 + c] + V[3 * 4 + c];
+        }
+        const float* g = d_all_map + 5 * p;
+        const float sd = ln[0] * pc[0] + ln[1] * pc[1] + ln[2] * pc[2];
+        const float sg = sd > 0.f ? 1.f : (sd < 0.f ? -1.f : 0.f);                  /* d|x|/dx, 0 at 0 like torch.abs */
+        float dln[3], dpc[3], dn[3];
+        for (int c = 0; c < 3; ++c) { dln[c] = g[c] + sg * g[4] * pc[c]; dpc[c] = sg * g[4] * ln[c]; }
+        for (int a = 0; a < 3; ++a) {
+            d_xyz[3 * p + a] = dpc[0] * V[a * 4 + 0] + dpc[1] * V[a * 4 + 1] + dpc[2] * V[a * 4 + 2];
+            dn[a] = flip * (dln[0] * V[a * 4 + 0] + dln[1] * V[a * 4 + 1] + dln[2] * V[a * 4 + 2]);
+        }
+        /* dR: only column k receives dn.  R = I + two_s * M(q) with M the bracketed terms: dR = dtwo_s * M + two_s * dM */
+        const float r = q[0], i = q[1], j = q[2], kk = q[3];
+        const float s2 = r * r + i * i + j * j + kk * kk, two_s = 2.0f / s2;
+        float dR[9] = {0};
+        dR[k] = dn[0]; dR[3 + k] = dn[1]; dR[6 + k] = dn[2];
+        const float M[9] = {-(j * j + kk * kk), i * j - kk * r, i * kk + j * r, i * j + kk * r, -(i * i + kk * kk), j * kk - i * r,
+                            i * kk - j * r, j * kk + i * r, -(i * i + j * j)};
+        float dts = 0.f;
+        for (int e = 0; e < 9; ++e) dts += dR[e] * M[e];
+        float dM[9];
+        for (int e = 0; e < 9; ++e) dM[e] = dR[e] * two_s;
+        float dq[4];
+        dq[0] = -kk * dM[1] + j * dM[2] + kk * dM[3] - i * dM[5] - j * dM[6] + i * dM[7];
+        dq[1] = j * dM[1] + kk * dM[2] + j * dM[3] - 2 * i * dM[4] - r * dM[5] + kk * dM[6] + r * dM[7] - 2 * i * dM[8];
+        dq[2] = -2 * j * dM[0] + i * dM[1] + r * dM[2] + i * dM[3] + kk * dM[5] - r * dM[6] + kk * dM[7] - 2 * j * dM[8];
+        dq[3] = -2 * kk * dM[0] - r * dM[1] + i * dM[2] + r * dM[3] - 2 * kk * dM[4] + j * dM[5] + i * dM[6] + j * dM[7];
+        const float dtds2 = -2.0f / (s2 * s2);                                     /* d two_s / d (q.q) */
+        for (int e = 0; e < 4; ++e) d_rot[4 * p + e] = dq[e] + dts * dtds2 * 2.0f * q[e];
+    }
+}

@@ -30,6 +30,11 @@ Pinned (reference file:line -> fixture):
         patch_offsets / patch_warp, gssr/utils/graphics_utils.py:185-198; lncc :60-95) on a two-camera view of a textured plane, all
         valid pixels sampled (fewer than nunm_sample, so np.random.choice is not reached); autograd to both plane-depth maps, the
         rendered normal and the rendered distance.
+  ref_plane_allmap.npz
+        gssr/scene/pgsr_scene.py:241-257 (get_smallest_axis / get_normal) and :297-304: the per-Gaussian `all_map` input PGSRScene.render()
+        hands to the plane rasterizer, captured from a stub rasterizer, + autograd of sum(all_map * dL) to means3D / rotations.
+        quaternion_to_matrix comes from pytorch3d (absent third-party dependency, unpinned in requirements.txt): the generator supplies its
+        published formula.
   ref_loss_plane_geo.npz
         gssr/scene/pgsr_scene.py:227-238 render_normal (normal_from_depth_image, gssr/utils/graphics_utils.py:139-146),
         pgsr_scene.py:32-58 _get_img_grad_weight / erode, combined exactly as pgsr_scene.py:108-112 (the single-view normal loss);
@@ -330,6 +335,54 @@ def plane_multiview_fixture():
          d_rendered_normal=nm.grad.numpy(), d_rendered_distance=ds.grad.numpy())
 
 
+def _pytorch3d_quaternion_to_matrix(quaternions):
+    """pytorch3d.transforms.quaternion_to_matrix (real part first), restated from its published definition."""
+    r, i, j, k = torch.unbind(quaternions, -1)
+    two_s = 2.0 / (quaternions * quaternions).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(quaternions.shape[:-1] + (3, 3))
+
+
+def plane_allmap_fixture():
+    scn = ref_import("gssr.scene.pgsr_scene")
+    Camera = ref_import("gssr.cameras").Camera
+    scn.quaternion_to_matrix = _pytorch3d_quaternion_to_matrix
+    r = np.random.default_rng(51)
+    P, W, H = 700, 64, 48
+    camd, cam = _camera(W, H)
+    cam.Fx, cam.Fy, cam.Cx, cam.Cy = 0.8 * W, 0.8 * W, W / 2.0, H / 2.0
+    cam.get_calib_matrix_nerf = types.MethodType(Camera.get_calib_matrix_nerf, cam)
+    xyz = np.concatenate([r.uniform(-3, 3, (P, 2)), r.uniform(-2, 8, (P, 1))], 1).astype(np.float32)     # in front of and behind the camera
+    q = r.normal(0, 1, (P, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[:50] *= r.uniform(0.5, 2.0, (50, 1)).astype(np.float32)          # un-normalised rows exercise the two_s term
+    sc = np.exp(r.normal(-2, 0.7, (P, 3))).astype(np.float32)
+    sc[60:70, 1] = sc[60:70, 0]                                          # ties: first minimum wins
+    got = {}
+
+    def rasterizer_stub(raster_settings):
+        def call(**kw):
+            got["all_map"] = kw["all_map"]
+            return (torch.zeros(3, H, W), torch.ones(P), torch.zeros(P), torch.ones(5, H, W), torch.ones(1, H, W) * 3)
+        return call
+    scn.PlaneGaussianRasterizationSettings = lambda **kw: None
+    scn.PlaneGaussianRasterizer = rasterizer_stub
+    scene = _bare(scn.PGSRScene, device="cpu", background=torch.zeros(3), config=types.SimpleNamespace(scaling_modifier=1.0, debug=False),
+                  _gaussians=types.SimpleNamespace(active_sh_degree=0))
+    _zl = torch.zeros_like
+    torch.zeros_like = lambda t, **kw: _zl(t, **{k: ("cpu" if k == "device" else v) for k, v in kw.items()})
+    m = torch.tensor(xyz, requires_grad=True); rq = torch.tensor(q, requires_grad=True); ss = torch.tensor(sc, requires_grad=True)
+    scene.render(cam, m, torch.ones(P, 1), ss, rq, None, None, torch.zeros(P, 3))
+    torch.zeros_like = _zl
+    am = got["all_map"]
+    dL = r.normal(0, 1, (P, 5)).astype(np.float32)
+    (am * torch.tensor(dL)).sum().backward()
+    assert ss.grad is None or not ss.grad.any()
+    save("ref_plane_allmap.npz", means3D=xyz, rotations=q, scales=sc, viewmatrix=camd["viewmatrix"], campos=cam.camera_center.numpy(),
+         all_map=am.detach().numpy(), dL_dall_map=dL, d_means3D=m.grad.numpy(), d_rotations=rq.grad.numpy())
+
+
 def tsdf_fixture():
     import scenes
     mu = ref_import("gssr.utils.mesh_utils")
@@ -368,6 +421,7 @@ def tsdf_fixture():
 
 
 if __name__ == "__main__":
+    plane_allmap_fixture()
     plane_multiview_fixture()
     tsdf_fixture()
     torch.manual_seed(0)

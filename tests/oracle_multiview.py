@@ -68,3 +68,18 @@ def ncc(cfg, idx, weight, normal, dist, gray, near_gray):
 def fixture_cfg(z):
     cam = lambda pre: {k: (z[f"{pre}_{k}"] if k in ("R", "T") else float(z[f"{pre}_{k}"])) for k in ("R", "T", "Fx", "Fy", "Cx", "Cy")}
     return make_cfg(int(z["W"]), int(z["H"]), cam("v"), cam("n"), noise_th=float(z["pixel_noise_threshold"]), patch=int(z["patch_size"]))
+
+
+def plane_allmap(xyz, rot, scale, viewmatrix, campos, d_all_map=None):
+    """-> all_map [P,5] (and (d_xyz, d_rot) when d_all_map is given): oracle/gsm_oracle.c refm_plane_allmap[_bwd]."""
+    L = oracle.lib()
+    L.refm_plane_allmap.restype = None; L.refm_plane_allmap_bwd.restype = None
+    x, q, s, V, cp = _f(xyz), _f(rot), _f(scale), _f(viewmatrix).reshape(-1), _f(campos)
+    P = x.shape[0]
+    am = np.zeros((P, 5), np.float32)
+    L.refm_plane_allmap(C.c_int32(P), _p(x), _p(q), _p(s), _p(V), _p(cp), _p(am))
+    if d_all_map is None:
+        return am
+    g = _f(d_all_map); dx = np.zeros((P, 3), np.float32); dq = np.zeros((P, 4), np.float32)
+    L.refm_plane_allmap_bwd(C.c_int32(P), _p(x), _p(q), _p(s), _p(V), _p(cp), _p(g), _p(dx), _p(dq))
+    return am, dx, dq

@@ -152,3 +152,14 @@ def test_multiview_torch_restatement_matches_reference_run():
     for k in lv:
         e = z["d_" + k]
         assert np.linalg.norm(lv[k].grad.numpy() - e) / np.linalg.norm(e) < 1e-4, k
+
+
+def test_plane_allmap_oracle_matches_reference_run():
+    """refm_plane_allmap[_bwd] vs PGSRScene.render()'s per-Gaussian all_map (captured from a stub rasterizer) and its autograd."""
+    import oracle_multiview as om
+    z = golden_ref.load("ref_plane_allmap")
+    am, dx, dq = om.plane_allmap(z["means3D"], z["rotations"], z["scales"], z["viewmatrix"], z["campos"], z["dL_dall_map"])
+    np.testing.assert_allclose(am, z["all_map"], rtol=2e-5, atol=2e-6)
+    assert (am[:, 3] == 1).all()
+    assert np.abs(dx - z["d_means3D"]).max() <= 2e-5 * np.abs(z["d_means3D"]).max()
+    assert np.abs(dq - z["d_rotations"]).max() <= 5e-5 * np.abs(z["d_rotations"]).max()

@@ -124,3 +124,30 @@ def test_tsdf_matches_reference_run():
         got = {"tsdf": tsdf, "rgb": rgb}[key].cpu().numpy()
         assert np.abs(got - exp).max() < 1e-4, (key, np.abs(got - exp).max())
         assert (w > 1).float().mean().item() > 0.2
+
+
+def test_plane_allmap_matches_reference_run_and_oracle():
+    """gsr_plane_allmap[_backward] vs PGSRScene.render()'s captured all_map + autograd (fixture), and vs the oracle at 300k Gaussians."""
+    import oracle_multiview as om
+    from gsrast.plane_prep import plane_input_all_map
+    z = golden_ref.load("ref_plane_allmap")
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)
+    x = t(z["means3D"]).requires_grad_(True); q = t(z["rotations"]).requires_grad_(True); s = t(z["scales"]).requires_grad_(True)
+    am = plane_input_all_map(x, q, s, t(z["viewmatrix"]), t(z["campos"]))
+    (am * t(z["dL_dall_map"])).sum().backward()
+    np.testing.assert_allclose(am.detach().cpu().numpy(), z["all_map"], rtol=2e-5, atol=2e-6)
+    assert s.grad is None
+    assert np.abs(x.grad.cpu().numpy() - z["d_means3D"]).max() <= 2e-5 * np.abs(z["d_means3D"]).max()
+    assert np.abs(q.grad.cpu().numpy() - z["d_rotations"]).max() <= 5e-5 * np.abs(z["d_rotations"]).max()
+    # full size, get_scaling-shaped (P,6) scales, against the oracle
+    r = np.random.default_rng(2)
+    P = 300000
+    xyz = r.uniform(-5, 5, (P, 3)).astype(np.float32); qq = r.normal(0, 1, (P, 4)).astype(np.float32)
+    sc = np.exp(r.normal(-2, 0.7, (P, 6))).astype(np.float32); dL = r.normal(0, 1, (P, 5)).astype(np.float32)
+    oam, odx, odq = om.plane_allmap(xyz, qq, sc[:, :3], z["viewmatrix"], z["campos"], dL)
+    x = t(xyz).requires_grad_(True); q = t(qq).requires_grad_(True)
+    am = plane_input_all_map(x, q, t(sc), t(z["viewmatrix"]), t(z["campos"]))
+    (am * t(dL)).sum().backward()
+    np.testing.assert_allclose(am.detach().cpu().numpy(), oam, rtol=1e-5, atol=1e-6)
+    assert np.abs(x.grad.cpu().numpy() - odx).max() <= 1e-5 * np.abs(odx).max()
+    assert np.abs(q.grad.cpu().numpy() - odq).max() <= 1e-5 * np.abs(odq).max()

@@ -97,4 +97,29 @@ def torch_mv():
 th, thf, tt = timeit(hip_mv, n=20), timeit(hip_mv_fixed, n=20), timeit(torch_mv, n=5, w=2)
 out["plane_multiview_1080p"] = {"hip_fwd_bwd_ms": round(th * 1e3, 3), "hip_fwd_bwd_ms_given_indices": round(thf * 1e3, 3), "torch_fwd_bwd_ms": round(tt * 1e3, 3),
                                 "speedup": round(tt / th, 1), "samples": 102400, "note": "torch chain timed WITHOUT its host-side np.random.choice / nonzero"}
+# per-Gaussian all_map input of the plane rasterizer (PGSRScene.render prep) vs its torch op chain, P = 300k
+from gsrast.plane_prep import plane_input_all_map
+Pp = 300000
+px_ = (torch.rand(Pp, 3, device="cuda") * 10 - 5).requires_grad_(True); pq_ = torch.nn.functional.normalize(torch.randn(Pp, 4, device="cuda")).requires_grad_(True)
+ps_ = torch.exp(torch.randn(Pp, 3, device="cuda") - 2); pg_ = torch.randn(Pp, 5, device="cuda")
+Vm = torch.tensor(camg["viewmatrix"]).cuda(); cpos = torch.linalg.inv(Vm)[3, :3].contiguous()
+def q2m(q):
+    r, i, j, k = torch.unbind(q, -1); two_s = 2.0 / (q * q).sum(-1)
+    return torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r), two_s * (i * j + k * r), 1 - two_s * (i * i + k * k),
+                        two_s * (j * k - i * r), two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1).reshape(-1, 3, 3)
+def torch_prep():
+    px_.grad = None; pq_.grad = None
+    R = q2m(pq_); idx = ps_.min(dim=-1)[1][..., None, None].expand(-1, 3, -1)
+    n = R.gather(2, idx).squeeze(2)
+    neg = (n * (cpos - px_)).sum(-1) < 0.0
+    n = torch.where(neg[:, None], -n, n)
+    ln = n @ Vm[:3, :3]; pc = px_ @ Vm[:3, :3] + Vm[3, :3]
+    am = torch.zeros(Pp, 5, device="cuda"); am[:, :3] = ln; am[:, 3] = 1.0; am[:, 4] = (ln * pc).sum(-1).abs()
+    (am * pg_).sum().backward()
+def hip_prep():
+    px_.grad = None; pq_.grad = None
+    (plane_input_all_map(px_, pq_, ps_, Vm, cpos) * pg_).sum().backward()
+th, tt = timeit(hip_prep, n=30), timeit(torch_prep, n=10)
+out["plane_allmap_prep_300k"] = {"hip_fwd_bwd_ms": round(th * 1e3, 3), "torch_fwd_bwd_ms": round(tt * 1e3, 3), "speedup": round(tt / th, 1),
+                                 "note": "both include the (am * g).sum().backward() driver ops"}
 print(json.dumps(out))
