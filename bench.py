@@ -231,6 +231,21 @@ def main():
                 traffic = None
         raster_fwd = ms["preprocess"] + ms["depth_order"] + ms["binning"] + ms["blend_fwd"]
         raster_bwd = ms["bwd_memset"] + ms["blend_bwd"] + ms["preprocess_bwd"]
+        # informational second ceiling for the dominant kernel: VALU issue rate.  Instruction count per launch from the committed PMC pass
+        # (profiles/r01_pmc_summary.json, SQ_INSTS_VALU, same workload); duration measured live.  Peak = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles
+        # per wave64 VALU instruction = 614.4 G wave-instructions/s (MI355X_MICROARCH.md: max clock 2400 MHz).
+        valu = None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        vidx = {"ewa": 0, "surfel": 1, "plane": 2}[args.variant]
+        if os.path.exists(pj) and args.P == 300000 and (args.W, args.H) == (1920, 1080) and args.color_mode == "precomp":
+            try:
+                insts = json.load(open(pj)).get(f"k_blend_{'bwd' if dom == 'blend_bwd' else 'fwd'}<{vidx}>", {}).get("SQ_INSTS_VALU")
+                if insts:
+                    rate = insts / (ms[dom] * 1e-3)
+                    valu = {"wave_insts_per_launch": int(insts), "achieved_Ginst_s": round(rate / 1e9, 1), "peak_Ginst_s": 614.4,
+                            "frac": round(rate / 614.4e9, 4), "source": "profiles/r01_pmc_summary.json SQ_INSTS_VALU / live avg_launch_ms"}
+            except Exception:
+                valu = None
         out = {
             "metric": "train iters/sec @300k Gaussians 1080p (rasterize fwd+bwd ms and HBM GB/s vs roofline alongside)",
             "value": round(total_iters / elapsed, 3), "unit": "iters/s",
@@ -251,7 +266,9 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(ms[dom], 4),
-                         "note": "blend is VALU/atomic-bound by construction (SURVEY §7-5); HBM fraction reported as BASELINE asks"},
+                         "valu_issue": valu,
+                         "note": "blend is VALU/atomic-bound by construction (SURVEY §7-5); HBM fraction reported as BASELINE asks, "
+                                 "VALU issue fraction alongside"},
         }
         if world == 1 and not args.no_cpu_baseline:
             og = scenes.random_out_grads(args.variant, args.W, args.H, seed=0)
