@@ -234,6 +234,182 @@ __global__ void __launch_bounds__(1024) k_mv_finish(const float2* __restrict__ p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Uniform sample WITHOUT replacement of at most `num` set entries of a byte mask, on the device and without a sort
+// (pgsr_scene.py:147-151 draws it with np.random.choice on the host).  Every entry gets a 24-bit hashed key from (seed, index); the `num`
+// smallest keys are taken: two 4096-bin histogram levels locate the exact 24-bit threshold, then a count / scan / write pass emits the
+// selected indices in ascending order (gather locality for k_mv_ncc) followed by the threshold ties needed to fill up, -1 in unused slots.
+#define SM_ITEMS 16
+#define SM_BLOCK (256 * SM_ITEMS)
+struct SmSel { uint32_t bin0, below0, bin1, below1, T24, c_lt, all; };
+
+__device__ __forceinline__ uint32_t sm_key24(uint32_t p, uint32_t s0, uint32_t s1)
+{
+    uint32_t x = p * 0x9E3779B1u + s0;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x += s1; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x >> 8;
+}
+
+template <int LEVEL>
+__global__ void __launch_bounds__(256) k_sm_hist(int64_t n, const uint8_t* __restrict__ mask, uint32_t s0, uint32_t s1, const SmSel* __restrict__ sel,
+                                                 uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t b0 = LEVEL ? sel->bin0 : 0u;
+    if (!(LEVEL && sel->all)) {
+        const int64_t base = (int64_t)blockIdx.x * SM_BLOCK;
+#pragma unroll 4
+        for (int it = 0; it < SM_ITEMS; ++it) {
+            const int64_t p = base + it * 256 + threadIdx.x;
+            if (p < n && mask[p]) {
+                const uint32_t k = sm_key24((uint32_t)p, s0, s1);
+                if (!LEVEL) atomicAdd(&h[k >> 12], 1u);
+                else if ((k >> 12) == b0) atomicAdd(&h[k & 4095u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// one block: boundary bin = first bin whose inclusive prefix exceeds `need`
+template <int LEVEL>
+__global__ void __launch_bounds__(1024) k_sm_pick(const uint32_t* __restrict__ hist, uint32_t num, SmSel* sel)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t found_bin, found_below;
+    if (threadIdx.x == 0) { found_bin = 4096u; found_below = 0u; }
+    const uint32_t need = LEVEL ? num - sel->below0 : num;
+    uint32_t v[4], t = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = hist[threadIdx.x * 4 + e]; t += v[e]; }
+    uint32_t inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((threadIdx.x & 63) >= d) inc += o; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+    uint32_t excl = woff + inc - t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (excl <= need && excl + v[e] > need) { found_bin = threadIdx.x * 4 + e; found_below = excl; }   // unique: prefixes are monotone
+        excl += v[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!LEVEL) { sel->bin0 = found_bin; sel->below0 = found_below; sel->all = found_bin == 4096u; }
+        else {
+            sel->bin1 = found_bin; sel->below1 = found_below;
+            if (sel->all) { sel->T24 = 0x1000000u; sel->c_lt = 0xFFFFFFFFu; }
+            else { sel->T24 = (sel->bin0 << 12) | (found_bin & 4095u); sel->c_lt = sel->below0 + found_below; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sm_count(int64_t n, const uint8_t* __restrict__ mask, uint32_t s0, uint32_t s1, const SmSel* __restrict__ sel,
+                                                  uint2* __restrict__ blockcnt)
+{
+    __shared__ float red[8];
+    const uint32_t T = sel->T24;
+    const int64_t base = (int64_t)blockIdx.x * SM_BLOCK;
+    float lt = 0.f, eq = 0.f;                                        // <= 4096 per block: exact in float
+    for (int it = 0; it < SM_ITEMS; ++it) {
+        const int64_t p = base + it * 256 + threadIdx.x;
+        if (p < n && mask[p]) { const uint32_t k = sm_key24((uint32_t)p, s0, s1); lt += k < T ? 1.f : 0.f; eq += k == T ? 1.f : 0.f; }
+    }
+    const float2 t = mv_block_sum2(lt, eq, red);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = make_uint2((uint32_t)t.x, (uint32_t)t.y);
+}
+
+__global__ void __launch_bounds__(1024) k_sm_scan(uint2* __restrict__ blockcnt, uint32_t nblk)
+{
+    __shared__ uint32_t wa[16], wb[16];
+    __shared__ uint32_t carry_a, carry_b;
+    if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint2 v = i < nblk ? blockcnt[i] : make_uint2(0u, 0u);
+        uint32_t a = v.x, b = v.y;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t oa = __shfl_up(a, d, 64), ob = __shfl_up(b, d, 64);
+            if ((threadIdx.x & 63) >= d) { a += oa; b += ob; }
+        }
+        if ((threadIdx.x & 63) == 63) { wa[threadIdx.x >> 6] = a; wb[threadIdx.x >> 6] = b; }
+        __syncthreads();
+        uint32_t oa = carry_a, ob = carry_b;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) { oa += wa[w]; ob += wb[w]; }
+        if (i < nblk) blockcnt[i] = make_uint2(oa + a - v.x, ob + b - v.y);
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_a = oa + a; carry_b = ob + b; }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sm_write(int64_t n, const uint8_t* __restrict__ mask, uint32_t s0, uint32_t s1, const SmSel* __restrict__ sel,
+                                                  const uint2* __restrict__ blockoff, uint32_t num, int32_t* __restrict__ idx)
+{
+    __shared__ uint32_t wl[4], we[4];
+    const uint32_t T = sel->T24;
+    const uint32_t c_lt = sel->all ? 0xFFFFFFFFu : sel->c_lt;
+    const uint2 off = blockoff[blockIdx.x];
+    uint32_t run_l = off.x, run_e = off.y;
+    const int64_t base = (int64_t)blockIdx.x * SM_BLOCK;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int it = 0; it < SM_ITEMS; ++it) {
+        const int64_t p = base + it * 256 + threadIdx.x;
+        bool l = false, e = false;
+        if (p < n && mask[p]) { const uint32_t k = sm_key24((uint32_t)p, s0, s1); l = k < T; e = k == T; }
+        const uint64_t bl = __ballot(l), be = __ballot(e);
+        const uint64_t lo = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (lane == 0) { wl[wv] = (uint32_t)__popcll(bl); we[wv] = (uint32_t)__popcll(be); }
+        __syncthreads();
+        uint32_t pl = 0, pe = 0, tl = 0, te = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wv) { pl += wl[w]; pe += we[w]; } tl += wl[w]; te += we[w]; }
+        if (l) { const uint32_t slot = run_l + pl + (uint32_t)__popcll(bl & lo); if (slot < num) idx[slot] = (int32_t)p; }
+        if (e && c_lt != 0xFFFFFFFFu) { const uint32_t slot = c_lt + run_e + pe + (uint32_t)__popcll(be & lo); if (slot < num) idx[slot] = (int32_t)p; }
+        run_l += tl; run_e += te;
+        __syncthreads();
+    }
+}
+
+extern "C" size_t gsr_sample_mask_scratch_bytes(int64_t n)
+{
+    const size_t nblk = (size_t)((n > 0 ? n : 1) + SM_BLOCK - 1) / SM_BLOCK;
+    return gsr_align(2 * 4096 * sizeof(uint32_t)) + gsr_align(sizeof(SmSel)) + gsr_align(nblk * sizeof(uint2));
+}
+
+extern "C" int gsr_sample_mask(int64_t n, const uint8_t* mask, int32_t num, uint64_t seed, int32_t* idx_out, void* scratch, size_t scratch_bytes,
+                               void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 0 || num <= 0) return 0;
+    if (n >= ((int64_t)1 << 31)) { gsr_set_error("sample_mask: n must be < 2^31"); return 1; }
+    if (!mask || !idx_out || !scratch || scratch_bytes < gsr_sample_mask_scratch_bytes(n)) { gsr_set_error("sample_mask: null pointer or scratch too small"); return 1; }
+    const uint32_t nblk = (uint32_t)((n + SM_BLOCK - 1) / SM_BLOCK);
+    char* q = (char*)scratch;
+    uint32_t* hist = (uint32_t*)q; q += gsr_align(2 * 4096 * sizeof(uint32_t));
+    SmSel* sel = (SmSel*)q; q += gsr_align(sizeof(SmSel));
+    uint2* blockcnt = (uint2*)q;
+    const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    const int64_t slots = n < (int64_t)num ? n : (int64_t)num;
+    (void)hipMemsetAsync(hist, 0, 2 * 4096 * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(idx_out, 0xFF, sizeof(int32_t) * (size_t)slots, s);
+    hipLaunchKernelGGL(k_sm_hist<0>, dim3(nblk), dim3(256), 0, s, n, mask, s0, s1, (const SmSel*)sel, hist);
+    hipLaunchKernelGGL(k_sm_pick<0>, dim3(1), dim3(1024), 0, s, (const uint32_t*)hist, (uint32_t)num, sel);
+    hipLaunchKernelGGL(k_sm_hist<1>, dim3(nblk), dim3(256), 0, s, n, mask, s0, s1, (const SmSel*)sel, hist + 4096);
+    hipLaunchKernelGGL(k_sm_pick<1>, dim3(1), dim3(1024), 0, s, (const uint32_t*)(hist + 4096), (uint32_t)num, sel);
+    hipLaunchKernelGGL(k_sm_count, dim3(nblk), dim3(256), 0, s, n, mask, s0, s1, (const SmSel*)sel, blockcnt);
+    hipLaunchKernelGGL(k_sm_scan, dim3(1), dim3(1024), 0, s, blockcnt, nblk);
+    hipLaunchKernelGGL(k_sm_write, dim3(nblk), dim3(256), 0, s, n, mask, s0, s1, (const SmSel*)sel, (const uint2*)blockcnt, (uint32_t)slots, idx_out);
+    return gsr_check_launch("sample_mask", s, false);
+}
+
 static bool mv_cfg_ok(const gsr_mv_cfg* c)
 {
     return c && c->W > 0 && c->H > 0 && c->Wn > 0 && c->Hn > 0 && c->Wg > 0 && c->Hg > 0 && c->patch >= 0 && c->patch <= 8 && c->ncc_scale > 0.f &&

@@ -181,19 +181,36 @@ def multiview_cfg(view_cam, near_cam, W, H, near_size=None, gray_size=None, patc
     return c
 
 
-def sample_valid_pixels(d_mask, num_sample, generator=None):
+_sample_calls = 0
+
+
+def sample_valid_pixels(d_mask, num_sample, generator=None, seed=None):
     """Uniform sample WITHOUT replacement of at most `num_sample` pixels of d_mask (pgsr_scene.py:147-151 draws it with np.random.choice on
-    the host), without leaving the device: the `num_sample` smallest of per-pixel random keys, invalid pixels keyed out of range.
-    -> int32 [min(num_sample, H*W)] pixel indices, -1 in unused slots (all valid pixels are returned when there are fewer than num_sample)."""
-    m = d_mask.reshape(-1).bool()
+    the host), without leaving the device and without a sort (gsr_sample_mask: hashed keys + two-level histogram select + scan compaction).
+    -> int32 [min(num_sample, H*W)] pixel indices, ascending, -1 in unused slots (all valid pixels when there are fewer than num_sample).
+    `seed` (int) fixes the draw; otherwise it is taken from `generator` (CPU generators are advanced; for device generators initial_seed() is
+    mixed with a call counter so that no device->host read is needed) or from torch's default CPU generator."""
+    global _sample_calls
+    m = d_mask.reshape(-1)
     n = m.numel()
     if n <= num_sample:
         ar = torch.arange(n, dtype=torch.int32, device=m.device)
-        return torch.where(m, ar, torch.full_like(ar, -1))
-    keys = torch.rand(n, device=m.device, generator=generator)
-    keys = torch.where(m, keys, torch.full_like(keys, 2.0))
-    val, idx = torch.topk(keys, num_sample, largest=False, sorted=False)
-    return torch.where(val < 1.5, idx.to(torch.int32), torch.full_like(idx, -1, dtype=torch.int32))
+        return torch.where(m.bool(), ar, torch.full_like(ar, -1))
+    if not m.is_cuda:
+        raise RuntimeError("sample_valid_pixels: d_mask must be a HIP-device tensor (no CPU path)")
+    if seed is None:
+        if generator is not None and generator.device.type != "cpu":
+            _sample_calls += 1
+            seed = (int(generator.initial_seed()) * 0x9E3779B97F4A7C15 + _sample_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        else:
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())          # CPU tensor: no device sync
+    m8 = m.contiguous() if m.dtype == torch.uint8 else m.to(torch.uint8).contiguous()
+    L = lib()
+    out = torch.empty(num_sample, dtype=torch.int32, device=m.device)
+    scratch = torch.empty(L.gsr_sample_mask_scratch_bytes(n), dtype=torch.uint8, device=m.device)
+    check(L.gsr_sample_mask(n, ptr(m8), int(num_sample), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(out), ptr(scratch), scratch.numel(), stream_ptr(m.device)),
+          "sample_mask")
+    return out
 
 
 class _PlaneMultiview(torch.autograd.Function):

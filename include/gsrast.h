@@ -230,6 +230,13 @@ int gsr_plane_allmap_backward(int32_t P, const float* means3D, const float* rota
                               const float* viewmatrix, const float* campos, const float* dL_dall_map, float* dL_dmeans3D,
                               float* dL_drotations, void* stream);
 
+/* Uniform sample WITHOUT replacement of at most `num` set bytes of mask [n] (pgsr_scene.py:147-151: the reference draws it with
+ * np.random.choice on the host).  Keys = 24-bit hash of (seed, index); the `num` smallest are taken (two histogram levels find the exact
+ * threshold; no sort).  idx_out [min(num, n)] (DEVICE): the selected indices ascending, then the threshold ties that fill up, then -1.
+ * All set entries are returned when there are at most `num` of them.  Deterministic in (mask, num, seed). */
+size_t gsr_sample_mask_scratch_bytes(int64_t n);
+int gsr_sample_mask(int64_t n, const uint8_t* mask, int32_t num, uint64_t seed, int32_t* idx_out, void* scratch, size_t scratch_bytes, void* stream);
+
 /* PGSR multi-view regularisers (gssr/scene/pgsr_scene.py:113-204 -- the "multi-view loss" branch of get_loss_dict; lncc :60-95;
  * get_points_from_depth / get_points_depth_in_depth_map gssr/utils/point_utils.py:38-75; patch_offsets / patch_warp
  * gssr/utils/graphics_utils.py:185-198; get_rays / get_k / get_inv_k gssr/cameras/__init__.py:96-121).

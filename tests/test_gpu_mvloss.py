@@ -91,6 +91,21 @@ def test_multiview_sampling_and_empty_masks():
     geo, ncc, aux, g = _run_hip(case, num_sample=2000, gen=gen)
     idx = aux["indices"]
     assert idx.size == 2000 and (idx >= 0).all() and np.unique(idx).size == 2000 and aux["d_mask"].reshape(-1)[idx].all()
+    # the sampler itself: exact count, no repeats, only valid pixels, ascending, deterministic in the seed, roughly uniform over the mask
+    dm = torch.tensor(aux["d_mask"].reshape(-1), device=DEV)
+    s1 = sample_valid_pixels(dm, 3000, seed=11).cpu().numpy(); s1b = sample_valid_pixels(dm, 3000, seed=11).cpu().numpy()
+    s2 = sample_valid_pixels(dm, 3000, seed=12).cpu().numpy()
+    assert np.array_equal(s1, s1b) and not np.array_equal(s1, s2)
+    for sset in (s1, s2):
+        assert (sset >= 0).all() and np.unique(sset).size == 3000 and aux["d_mask"].reshape(-1)[sset].all()
+    assert (np.diff(s1[:2990]) > 0).all()                                   # ascending (the last few slots may hold threshold ties)
+    valid = np.nonzero(aux["d_mask"].reshape(-1))[0]
+    pooled = np.concatenate([sample_valid_pixels(dm, 3000, seed=100 + k).cpu().numpy() for k in range(20)])
+    rank = np.searchsorted(valid, pooled) / valid.size                      # position of each draw within the valid set: ~U(0,1)
+    hist = np.histogram(rank, bins=10, range=(0, 1))[0]
+    assert np.abs(hist / hist.sum() - 0.1).max() < 0.01, hist
+    counts = np.bincount(np.searchsorted(valid, pooled), minlength=valid.size)
+    assert counts.max() <= 20 and abs(counts.mean() - 20 * 3000 / valid.size) < 1e-9
     assert ncc > 0 and (np.abs(g["rendered_distance"]).reshape(-1) > 0).sum() <= 2000
     # fewer valid pixels than slots: every valid pixel exactly once, the rest -1
     m = torch.zeros(50, dtype=torch.bool, device=DEV); m[[3, 7, 11]] = True
