@@ -123,7 +123,9 @@ __device__ __forceinline__ float mv_sum16(float v)
 
 // 16 lanes per sampled pixel (4 samples per wave, 16 per block): a thread-per-sample walk of 2 x 49 dependent gathers leaves only
 // ~1.5 waves per SIMD at 102400 samples and runs at gather latency (measured 0.44 ms); spreading the taps over 16 lanes gives 16x the
-// waves and 4 short iterations per pass (measured below in DESIGN.md).  Pass 2 re-gathers (L1/L2 hits) instead of caching per-tap state.
+// waves and 4 short iterations per pass.  With at most 4 taps per lane (patch <= 3) pass 1 keeps value and coordinate-gradient of its taps in
+// registers; larger patches re-gather in pass 2.
+template <bool CACHE>      // CACHE: (2h+1)^2 <= 64, i.e. at most 4 taps per lane -- pass 1 keeps its taps in registers and pass 2 does not gather again
 __global__ void __launch_bounds__(256) k_mv_ncc(gsr_mv_cfg c, int N, const int32_t* __restrict__ idx, const float* __restrict__ weight,
                                                 const float* __restrict__ normal, const float* __restrict__ dist, const float* __restrict__ gray,
                                                 const float* __restrict__ near_gray, float* __restrict__ ncc_out, uint8_t* __restrict__ mask_out,
@@ -155,12 +157,28 @@ __global__ void __launch_bounds__(256) k_mv_ncc(gsr_mv_cfg c, int N, const int32
         for (int a = 0; a < 3; ++a) { Hk[a * 3] = T1[a * 3] * ifx; Hk[a * 3 + 1] = T1[a * 3 + 1] * ify; Hk[a * 3 + 2] = T1[a * 3] * icx + T1[a * 3 + 1] * icy + T1[a * 3 + 2]; }
         const float px = (float)x / s, py = (float)y / s;
         float Sr = 0.f, Sn = 0.f, Srr = 0.f, Snn = 0.f, Srn = 0.f, du, dv;
-        for (int j = sub; j < ntap; j += 16) {
-            const float uu = px + (float)(j % side - h), vv = py + (float)(j / side - h);
-            const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
-            const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
-            const float nj = mv_bilerp0<false>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
-            Sr += rj; Sn += nj; Srr += rj * rj; Snn += nj * nj; Srn += rj * nj;
+        float c_r[4] = {0.f, 0.f, 0.f, 0.f}, c_n[4] = {0.f, 0.f, 0.f, 0.f}, c_du[4] = {0.f, 0.f, 0.f, 0.f}, c_dv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (CACHE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = sub + 16 * k;
+                if (j < ntap) {
+                    const float uu = px + (float)(j % side - h), vv = py + (float)(j / side - h);
+                    const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
+                    const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+                    const float nj = mv_bilerp0<true>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
+                    c_r[k] = rj; c_n[k] = nj; c_du[k] = du; c_dv[k] = dv;
+                    Sr += rj; Sn += nj; Srr += rj * rj; Snn += nj * nj; Srn += rj * nj;
+                }
+            }
+        } else {
+            for (int j = sub; j < ntap; j += 16) {
+                const float uu = px + (float)(j % side - h), vv = py + (float)(j / side - h);
+                const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
+                const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+                const float nj = mv_bilerp0<false>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
+                Sr += rj; Sn += nj; Srr += rj * rj; Snn += nj * nj; Srn += rj * nj;
+            }
         }
         Sr = mv_sum16(Sr); Sn = mv_sum16(Sn); Srr = mv_sum16(Srr); Snn = mv_sum16(Snn); Srn = mv_sum16(Srn);
         const float ravg = Sr / tps, navg = Sn / tps;
@@ -181,17 +199,29 @@ __global__ void __launch_bounds__(256) k_mv_ncc(gsr_mv_cfg c, int N, const int32
             const float dcc = -w;
             const float dcross = dcc * 2.f * cross / den, dnvar = -dcc * cross * cross * rvar / (den * den);
             float dH[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int j = sub; j < ntap; j += 16) {
-                const float uu = px + (float)(j % side - h), vv = py + (float)(j / side - h);
-                const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
+            auto tap_grad = [&](float uu, float vv, float rj, float nj, float tdu, float tdv) {
                 const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
-                const float nj = mv_bilerp0<true>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
                 const float dn = dcross * (rj - ravg) + dnvar * (2.f * nj - 2.f * navg);
-                const float dgx = dn * du, dgy = dn * dv;
+                const float dgx = dn * tdu, dgy = dn * tdv;
                 const float d0 = dgx / g2, d1 = dgy / g2, d2 = -(dgx * g0 + dgy * g1) / (g2 * g2);
                 dH[0] += d0 * uu; dH[1] += d0 * vv; dH[2] += d0;
                 dH[3] += d1 * uu; dH[4] += d1 * vv; dH[5] += d1;
                 dH[6] += d2 * uu; dH[7] += d2 * vv; dH[8] += d2;
+            };
+            if (CACHE) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int j = sub + 16 * k;
+                    if (j < ntap) tap_grad(px + (float)(j % side - h), py + (float)(j / side - h), c_r[k], c_n[k], c_du[k], c_dv[k]);
+                }
+            } else {
+                for (int j = sub; j < ntap; j += 16) {
+                    const float uu = px + (float)(j % side - h), vv = py + (float)(j / side - h);
+                    const float rj = mv_bilerp0<false>(gray, c.Wg, c.Hg, uu, vv, du, dv);
+                    const float g0 = Hk[0] * uu + Hk[1] * vv + Hk[2], g1 = Hk[3] * uu + Hk[4] * vv + Hk[5], g2 = Hk[6] * uu + Hk[7] * vv + Hk[8] + 1e-10f;
+                    const float nj = mv_bilerp0<true>(near_gray, c.Wg, c.Hg, g0 / g2, g1 / g2, du, dv);
+                    tap_grad(uu, vv, rj, nj, du, dv);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 9; ++e) dH[e] = mv_sum16(dH[e]);
@@ -453,8 +483,13 @@ extern "C" int gsr_loss_plane_mv_ncc(const gsr_mv_cfg* cfg, int32_t n_samples, c
     (void)hipMemsetAsync(g_normal, 0, sizeof(float) * 3 * HW, s);
     (void)hipMemsetAsync(g_distance, 0, sizeof(float) * HW, s);
     const int blocks = gsr_div_up(n_samples > 0 ? n_samples : 1, 16);
-    hipLaunchKernelGGL(k_mv_ncc, dim3(blocks), dim3(256), 0, s, *cfg, (int)n_samples, idx, weight, normal, distance, gray, near_gray, ncc, mask,
-                       g_normal, g_distance, (float2*)scratch);
+    const int ntap = (2 * cfg->patch + 1) * (2 * cfg->patch + 1);
+    if (ntap <= 64)
+        hipLaunchKernelGGL(k_mv_ncc<true>, dim3(blocks), dim3(256), 0, s, *cfg, (int)n_samples, idx, weight, normal, distance, gray, near_gray, ncc, mask,
+                           g_normal, g_distance, (float2*)scratch);
+    else
+        hipLaunchKernelGGL(k_mv_ncc<false>, dim3(blocks), dim3(256), 0, s, *cfg, (int)n_samples, idx, weight, normal, distance, gray, near_gray, ncc, mask,
+                           g_normal, g_distance, (float2*)scratch);
     hipLaunchKernelGGL(k_mv_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, blocks, stats);
     return gsr_check_launch("loss_plane_mv_ncc", s, false);
 }

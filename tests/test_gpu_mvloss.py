@@ -141,3 +141,22 @@ def test_multiview_full_hd_vs_torch_chain():
     for k in names:
         rel = ((a[k].grad - b[k].grad).norm() / b[k].grad.norm()).item()
         assert rel < 2e-2, (k, rel)          # float32 chain through world coordinates vs composed transforms; NCC conditioning (see above)
+
+
+@pytest.mark.parametrize("patch", [1, 4])
+def test_multiview_other_patch_sizes(patch):
+    """patch = 4 (81 taps) takes the re-gathering kernel variant, patch = 1 the register-cached one with idle lanes."""
+    case = mv_cases.plane_pair(W=96, H=64, seed=9, tex=2.0)
+    cfg = om.make_cfg(96, 64, case["view"], case["near"], patch=patch)
+    og = om.geo(cfg, case["plane_depth"], case["near_plane_depth"])
+    idx = np.nonzero(og["dmask"])[0].astype(np.int32)
+    on = om.ncc(cfg, idx, og["weight"], case["rendered_normal"], case["rendered_distance"], case["gray"], case["near_gray"])
+    _, ncc, aux, g = _run_hip(case, indices=idx, patch=patch)
+    mflip = aux["ncc_mask"] != on["mask"].astype(bool)
+    assert mflip.sum() <= max(2, int(1e-3 * idx.size))
+    e = np.abs(aux["ncc"][~mflip] - on["ncc"][~mflip])
+    assert np.quantile(e, 0.5) < 2e-5 and np.quantile(e, 0.99) < 2e-3, (np.quantile(e, 0.5), np.quantile(e, 0.99))
+    if mflip.sum() <= 2:
+        sc = 0.15 / on["stats"][1]
+        assert _rel(g["rendered_normal"].reshape(3, -1) / 3.0, sc * on["g_normal"]) < 5e-3
+        assert _rel(g["rendered_distance"].reshape(-1) / 3.0, sc * on["g_dist"]) < 5e-3
