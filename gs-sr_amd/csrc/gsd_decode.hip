@@ -1020,3 +1020,105 @@ extern "C" int gsd_backward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(np + 1, 4), dim3(256), 0, s, wo);
     return gsr_check_launch("gsd_backward", s, false);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Per-iteration densification statistics (gssr/gaussian/scaffold_gaussian.py:488-508 training_statis; Octree-GS calls the same method).
+// The reference maps generated Gaussians back to (anchor, offset) slots with three boolean-mask assignments and two masked gathers -- six
+// nonzero() host synchronisations per iteration.  Here the slot -> Gaussian map is the exclusive prefix of the opacity gate, rebuilt by a
+// 3-kernel anchor-level scan (count, scan of block sums, apply): no synchronisation, ~15 us.
+#define ST_BLOCK 256
+__device__ __forceinline__ uint32_t st_count(const uint8_t* __restrict__ mask, int v, int k)
+{
+    uint32_t c = 0;
+    for (int j = 0; j < k; ++j) c += mask[(size_t)v * k + j] ? 1u : 0u;
+    return c;
+}
+
+__global__ void __launch_bounds__(ST_BLOCK) k_stats_count(int Nv, int k, const uint8_t* __restrict__ mask, uint32_t* __restrict__ blocksum)
+{
+    __shared__ uint32_t ws[ST_BLOCK / 64];
+    const int v = blockIdx.x * ST_BLOCK + threadIdx.x;
+    uint32_t c = v < Nv ? st_count(mask, v, k) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void __launch_bounds__(1024) k_stats_scan(uint32_t* __restrict__ blocksum, uint32_t nblk)
+{
+    __shared__ uint32_t wa[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblk ? blocksum[i] : 0u;
+        uint32_t a = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(a, d, 64); if ((threadIdx.x & 63) >= d) a += o; }
+        if ((threadIdx.x & 63) == 63) wa[threadIdx.x >> 6] = a;
+        __syncthreads();
+        uint32_t off = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wa[w];
+        if (i < nblk) blocksum[i] = off + a - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + a;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(ST_BLOCK) k_stats_apply(int Nv, int k, const int32_t* __restrict__ vis_idx, const float* __restrict__ nop,
+                                                          const uint8_t* __restrict__ mask, const uint8_t* __restrict__ upd, const float* __restrict__ grad,
+                                                          int gs, const uint32_t* __restrict__ blockoff, float* __restrict__ opacity_accum,
+                                                          float* __restrict__ anchor_demon, float* __restrict__ off_grad, float* __restrict__ off_den)
+{
+    __shared__ uint32_t ws[ST_BLOCK / 64];
+    const int v = blockIdx.x * ST_BLOCK + threadIdx.x;
+    const uint32_t c = v < Nv ? st_count(mask, v, k) : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((threadIdx.x & 63) >= d) inc += o; }
+    if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t p = blockoff[blockIdx.x] + inc - c;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) p += ws[w];
+    if (v >= Nv) return;
+    const int a = vis_idx[v];
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) { const float o = nop[(size_t)v * k + j]; s += o < 0.f ? 0.f : o; }
+    opacity_accum[a] += s; anchor_demon[a] += 1.f;                    // one thread per visible anchor, anchors distinct: plain read-modify-write
+    for (int j = 0; j < k; ++j) {
+        if (!mask[(size_t)v * k + j]) continue;
+        if (upd[p]) {
+            const float gx = grad[(size_t)p * gs], gy = grad[(size_t)p * gs + 1];
+            off_grad[(size_t)a * k + j] += sqrtf(gx * gx + gy * gy);
+            off_den[(size_t)a * k + j] += 1.f;
+        }
+        ++p;
+    }
+}
+
+extern "C" size_t gsd_training_stats_scratch_bytes(int32_t Nv) { return gsr_align(((size_t)(Nv > 0 ? Nv : 1) + ST_BLOCK - 1) / ST_BLOCK * sizeof(uint32_t)); }
+
+extern "C" int gsd_training_stats(int32_t Nv, int32_t k, const int32_t* vis_idx, const float* neural_opacity, const uint8_t* mask,
+                                  const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride, float* opacity_accum,
+                                  float* anchor_demon, float* offset_gradient_accum, float* offset_denom, void* scratch, size_t scratch_bytes,
+                                  void* stream)
+{
+    if (Nv <= 0) return 0;
+    if (k <= 0 || grad_stride < 2) { gsr_set_error("training_stats: bad sizes k=%d grad_stride=%d", k, grad_stride); return 1; }
+    if (!vis_idx || !neural_opacity || !mask || !update_filter || !viewspace_grad || !opacity_accum || !anchor_demon || !offset_gradient_accum ||
+        !offset_denom || !scratch || scratch_bytes < gsd_training_stats_scratch_bytes(Nv)) {
+        gsr_set_error("training_stats: null pointer or scratch too small"); return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nblk = ((uint32_t)Nv + ST_BLOCK - 1) / ST_BLOCK;
+    uint32_t* bs = (uint32_t*)scratch;
+    hipLaunchKernelGGL(k_stats_count, dim3(nblk), dim3(ST_BLOCK), 0, s, Nv, k, mask, bs);
+    hipLaunchKernelGGL(k_stats_scan, dim3(1), dim3(1024), 0, s, bs, nblk);
+    hipLaunchKernelGGL(k_stats_apply, dim3(nblk), dim3(ST_BLOCK), 0, s, Nv, k, vis_idx, neural_opacity, mask, update_filter, viewspace_grad,
+                       grad_stride, (const uint32_t*)bs, opacity_accum, anchor_demon, offset_gradient_accum, offset_denom);
+    return gsr_check_launch("training_stats", s, false);
+}

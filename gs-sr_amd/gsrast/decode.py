@@ -14,7 +14,7 @@ from . import check, dev_f32, lib, ptr, stream_ptr
 _vp = C.c_void_p
 PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app")
 EXPORTS = ["gsd_compact_scratch_bytes", "gsd_compact_visible", "gsd_forward_scratch_bytes", "gsd_forward_stage1", "gsd_forward_stage2",
-           "gsd_forward", "gsd_backward_scratch_bytes", "gsd_backward"]
+           "gsd_forward", "gsd_backward_scratch_bytes", "gsd_backward", "gsd_training_stats_scratch_bytes", "gsd_training_stats"]
 
 
 class Cfg(C.Structure):
@@ -64,6 +64,9 @@ def _lib():
         L.gsd_backward.restype = C.c_int
         L.gsd_backward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, C.c_uint32, C.POINTER(OutGrads),
                                    C.POINTER(InGrads), _vp, _vp, sz, _vp]
+        L.gsd_training_stats_scratch_bytes.restype = sz; L.gsd_training_stats_scratch_bytes.argtypes = [C.c_int32]
+        L.gsd_training_stats.restype = C.c_int
+        L.gsd_training_stats.argtypes = [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, sz, _vp]
         _bound = True
     return L
 
@@ -185,3 +188,41 @@ def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_co
     flags = (int(k), int(A), bool(add_opacity_dist), bool(add_cov_dist), bool(add_color_dist), lvl is not None)
     app = None if appearance is None else appearance.reshape(-1)
     return _NeuralDecode.apply(flags, vis_idx, campos, lvl, osc, anchor, feat, offset, scaling, *heads, app)
+
+
+def training_stats_(opacity_accum, anchor_demon, offset_gradient_accum, offset_denom, viewspace_grad, neural_opacity, update_filter,
+                    offset_selection_mask, anchor_visible_mask=None, vis_idx=None):
+    """In-place `ScaffoldGaussian.training_statis` (gssr/gaussian/scaffold_gaussian.py:488-508; same argument meaning: `viewspace_grad` =
+    viewspace_point_tensor.grad (P, >=2), `neural_opacity` = the decode's pre-gate opacity (Nv*k), `update_filter` = visibility_filter (P,),
+    `offset_selection_mask` = the decode's mask (Nv*k), `anchor_visible_mask` (Na,) bool -- or the `vis_idx` the decode already computed).
+    The four accumulators are the model's float32 buffers ((Na,1), (Na,1), (Na*k,1), (Na*k,1)); updated without any host synchronisation."""
+    L = _lib()
+    with torch.no_grad():
+        if vis_idx is None:
+            vis_idx = compact_visible(anchor_visible_mask)
+        Nv = int(vis_idx.numel())
+        if Nv == 0:
+            return
+        sel = offset_selection_mask.reshape(-1)
+        k = sel.numel() // Nv
+        if sel.numel() != Nv * k or neural_opacity.numel() != Nv * k:
+            raise RuntimeError("training_stats_: neural_opacity / offset_selection_mask must have Nv * n_offsets entries")
+        g = dev_f32(viewspace_grad, "viewspace_grad")
+        P = g.shape[0]
+        upd = update_filter.reshape(-1)
+        if upd.numel() != P:
+            raise RuntimeError("training_stats_: update_filter must have one entry per generated Gaussian")
+        for t, n, cnt in ((opacity_accum, "opacity_accum", None), (anchor_demon, "anchor_demon", None),
+                          (offset_gradient_accum, "offset_gradient_accum", None), (offset_denom, "offset_denom", None)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise RuntimeError(f"training_stats_: {n} must be a contiguous float32 HIP tensor")
+        if offset_gradient_accum.numel() != opacity_accum.numel() * k or offset_denom.numel() != offset_gradient_accum.numel():
+            raise RuntimeError("training_stats_: accumulator sizes do not match (Na, Na*k)")
+        no = dev_f32(neural_opacity.reshape(-1), "neural_opacity")
+        sel8 = sel.contiguous().view(torch.uint8) if sel.dtype == torch.bool else sel.to(torch.uint8).contiguous()
+        upd8 = upd.contiguous().view(torch.uint8) if upd.dtype == torch.bool else upd.to(torch.uint8).contiguous()
+        vi = vis_idx.to(torch.int32).contiguous()
+        dev = g.device
+        scratch = torch.empty(max(L.gsd_training_stats_scratch_bytes(Nv), 8), dtype=torch.uint8, device=dev)
+        check(L.gsd_training_stats(Nv, k, ptr(vi), ptr(no), ptr(sel8), ptr(upd8), ptr(g), int(g.shape[1]), ptr(opacity_accum), ptr(anchor_demon),
+                                   ptr(offset_gradient_accum), ptr(offset_denom), ptr(scratch), scratch.numel(), stream_ptr(dev)), "training_stats")

@@ -111,6 +111,19 @@ int gsd_backward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, 
                  uint32_t P, const gsd_out_grads* og, const gsd_in_grads* ig, const void* fwd_scratch, void* scratch, size_t scratch_bytes,
                  void* stream);
 
+/* Per-iteration densification statistics of the Scaffold / Octree methods (gssr/gaussian/scaffold_gaussian.py:488-508 training_statis,
+ * called from densify() :707-712 every iteration between start_stat and densify_until_iter):
+ *   for each visible anchor a = vis_idx[v]:  opacity_accum[a] += sum_j max(neural_opacity[v*k+j], 0);  anchor_demon[a] += 1
+ *   for each generated Gaussian p (= the p-th set byte of mask, slot (v,j)) with update_filter[p] != 0:
+ *       offset_gradient_accum[a*k+j] += |viewspace_grad[p, 0:2]|;  offset_denom[a*k+j] += 1
+ * neural_opacity / mask [Nv*k]: the decode's outputs (`neural_opacity`, `selection_mask`); update_filter [P] u8 = `visibility_filter`
+ * (radii > 0); viewspace_grad [P, grad_stride] = `viewspace_points.grad`.  The four accumulators ([Na], [Na], [Na*k], [Na*k] floats) are
+ * updated in place.  No host synchronisation (the reference's boolean-mask indexing has six). */
+size_t gsd_training_stats_scratch_bytes(int32_t Nv);
+int gsd_training_stats(int32_t Nv, int32_t k, const int32_t* vis_idx, const float* neural_opacity, const uint8_t* mask,
+                       const uint8_t* update_filter, const float* viewspace_grad, int32_t grad_stride, float* opacity_accum,
+                       float* anchor_demon, float* offset_gradient_accum, float* offset_denom, void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

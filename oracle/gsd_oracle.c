@@ -252,3 +252,32 @@ void refd_lod_mask(int32_t Na, const float* anchor, const int32_t* level, const 
         anchor_mask[i] = level[i] <= il;
     }
 }
+
+/*
+ * Per-iteration densification statistics of the Scaffold / Octree methods (gssr/gaussian/scaffold_gaussian.py:488-508 training_statis):
+ *   for every visible anchor a = vis_idx[v]:  opacity_accum[a] += sum_j max(neural_opacity[v,j], 0);  anchor_demon[a] += 1
+ *   for every generated Gaussian p (the p-th set entry of mask, i.e. slot (v,j)) with update_filter[p]:
+ *       offset_gradient_accum[a*k+j] += |viewspace_grad[p, 0:2]|;  offset_denom[a*k+j] += 1
+ * (the reference expresses the slot -> Gaussian map through three boolean-mask assignments.)
+ */
+void refd_training_stats(int32_t Nv, int32_t k, const int32_t* vis_idx, const float* neural_opacity, const uint8_t* mask, const uint8_t* update_filter,
+                         const float* grad, int32_t grad_stride, float* opacity_accum, float* anchor_demon, float* offset_gradient_accum,
+                         float* offset_denom)
+{
+    int64_t p = 0;
+    for (int v = 0; v < Nv; ++v) {
+        const int a = vis_idx[v];
+        float s = 0.f;
+        for (int j = 0; j < k; ++j) { const float o = neural_opacity[(size_t)v * k + j]; s += o < 0.f ? 0.f : o; }
+        opacity_accum[a] += s; anchor_demon[a] += 1.f;
+        for (int j = 0; j < k; ++j) {
+            if (!mask[(size_t)v * k + j]) continue;
+            if (update_filter[p]) {
+                const float gx = grad[(size_t)p * grad_stride], gy = grad[(size_t)p * grad_stride + 1];
+                offset_gradient_accum[(size_t)a * k + j] += sqrtf(gx * gx + gy * gy);
+                offset_denom[(size_t)a * k + j] += 1.f;
+            }
+            ++p;
+        }
+    }
+}

@@ -30,6 +30,9 @@ Pinned (reference file:line -> fixture):
         patch_offsets / patch_warp, gssr/utils/graphics_utils.py:185-198; lncc :60-95) on a two-camera view of a textured plane, all
         valid pixels sampled (fewer than nunm_sample, so np.random.choice is not reached); autograd to both plane-depth maps, the
         rendered normal and the rendered distance.
+  ref_training_stats.npz
+        gssr/gaussian/scaffold_gaussian.py:488-508 ScaffoldGaussian.training_statis (the per-iteration densification statistics of the
+        Scaffold / Octree methods) run twice on the reference's own model object: accumulators before / after.
   ref_plane_allmap.npz
         gssr/scene/pgsr_scene.py:241-257 (get_smallest_axis / get_normal) and :297-304: the per-Gaussian `all_map` input PGSRScene.render()
         hands to the plane rasterizer, captured from a stub rasterizer, + autograd of sum(all_map * dL) to means3D / rotations.
@@ -335,6 +338,36 @@ def plane_multiview_fixture():
          d_rendered_normal=nm.grad.numpy(), d_rendered_distance=ds.grad.numpy())
 
 
+def training_stats_fixture():
+    mod = ref_import("gssr.gaussian.scaffold_gaussian")
+    cfg = mod.ScaffoldGaussianConfig(); cfg.n_offsets = 6
+    g = mod.ScaffoldGaussian(cfg, device="cpu")
+    r = np.random.default_rng(61)
+    Na, k = 400, 6
+    g.opacity_accum = torch.tensor(r.uniform(0, 2, (Na, 1)).astype(np.float32))
+    g.anchor_demon = torch.tensor(r.integers(0, 5, (Na, 1)).astype(np.float32))
+    g.offset_gradient_accum = torch.tensor(r.uniform(0, 1, (Na * k, 1)).astype(np.float32))
+    g.offset_denom = torch.tensor(r.integers(0, 4, (Na * k, 1)).astype(np.float32))
+    before = {n: getattr(g, n).numpy().copy() for n in ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom")}
+    calls = []
+    for it in range(2):
+        vis = r.uniform(size=Na) < 0.6
+        Nv = int(vis.sum())
+        nop = np.tanh(r.normal(0, 1, (Nv * k, 1))).astype(np.float32)
+        sel = (nop > 0).reshape(-1)
+        P = int(sel.sum())
+        upd = r.uniform(size=P) < 0.7
+        grad = r.normal(0, 1, (P, 3)).astype(np.float32)
+        vsp = types.SimpleNamespace(grad=torch.tensor(grad))
+        g.training_statis(vsp, torch.tensor(nop), torch.tensor(upd), torch.tensor(sel), torch.tensor(vis))
+        calls.append(dict(visible=vis, neural_opacity=nop.reshape(-1), selection=sel, update_filter=upd, grad=grad))
+    after = {n: getattr(g, n).numpy().copy() for n in before}
+    flat = {}
+    for i, c in enumerate(calls):
+        flat.update({f"c{i}_{n}": v for n, v in c.items()})
+    save("ref_training_stats.npz", Na=Na, k=k, **{f"before_{n}": v for n, v in before.items()}, **{f"after_{n}": v for n, v in after.items()}, **flat)
+
+
 def _pytorch3d_quaternion_to_matrix(quaternions):
     """pytorch3d.transforms.quaternion_to_matrix (real part first), restated from its published definition."""
     r, i, j, k = torch.unbind(quaternions, -1)
@@ -421,6 +454,7 @@ def tsdf_fixture():
 
 
 if __name__ == "__main__":
+    training_stats_fixture()
     plane_allmap_fixture()
     plane_multiview_fixture()
     tsdf_fixture()

@@ -93,3 +93,16 @@ def lod_mask(anchor, level, extra_level, campos, voxel_size, fork, standard_dist
                     C.c_float(standard_dist), C.c_float(resolution_scale), C.c_int32(coarse_index), C.c_int32(mode), m.ctypes.data_as(u8), _p(pr),
                     tr.ctypes.data_as(u8))
     return m.astype(bool), pr, tr.astype(bool)
+
+
+def training_stats(vis_idx, k, neural_opacity, mask, update_filter, grad, opacity_accum, anchor_demon, offset_gradient_accum, offset_denom):
+    """In place on the four float32 accumulators (oracle/gsd_oracle.c refd_training_stats)."""
+    L = oracle.lib()
+    L.refd_training_stats.restype = None
+    vi = np.ascontiguousarray(vis_idx, dtype=np.int32); no = _f(neural_opacity).reshape(-1)
+    m = np.ascontiguousarray(mask, dtype=np.uint8); u = np.ascontiguousarray(update_filter, dtype=np.uint8); g = _f(grad)
+    u8 = C.POINTER(C.c_uint8)
+    for a in (opacity_accum, anchor_demon, offset_gradient_accum, offset_denom):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    L.refd_training_stats(C.c_int32(vi.size), C.c_int32(k), vi.ctypes.data_as(C.POINTER(C.c_int32)), _p(no), m.ctypes.data_as(u8), u.ctypes.data_as(u8),
+                          _p(g), C.c_int32(g.shape[1]), _p(opacity_accum), _p(anchor_demon), _p(offset_gradient_accum), _p(offset_denom))

@@ -64,3 +64,21 @@ def backward(out, leaves, dL, device="cpu"):
     names = list(leaves)
     grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
     return {n: (None if g is None else g.cpu().numpy()) for n, g in zip(names, grads)}
+
+
+def training_statis(acc, n_offsets, viewspace_grad, opacity, update_filter, offset_selection_mask, anchor_visible_mask):
+    """Torch restatement of ScaffoldGaussian.training_statis (gssr/gaussian/scaffold_gaussian.py:488-508) for timing the op chain;
+    acc: dict of the four accumulators, updated in place."""
+    temp = opacity.clone().view(-1).detach()
+    temp[temp < 0] = 0
+    temp = temp.view([-1, n_offsets])
+    acc["opacity_accum"][anchor_visible_mask] += temp.sum(dim=1, keepdim=True)
+    acc["anchor_demon"][anchor_visible_mask] += 1
+    avm = anchor_visible_mask.unsqueeze(dim=1).repeat([1, n_offsets]).view(-1)
+    combined = torch.zeros_like(acc["offset_gradient_accum"], dtype=torch.bool).squeeze(dim=1)
+    combined[avm] = offset_selection_mask
+    tmp = combined.clone()
+    combined[tmp] = update_filter
+    grad_norm = torch.norm(viewspace_grad[update_filter, :2], dim=-1, keepdim=True)
+    acc["offset_gradient_accum"][combined] += grad_norm
+    acc["offset_denom"][combined] += 1

@@ -163,3 +163,22 @@ def test_plane_allmap_oracle_matches_reference_run():
     assert (am[:, 3] == 1).all()
     assert np.abs(dx - z["d_means3D"]).max() <= 2e-5 * np.abs(z["d_means3D"]).max()
     assert np.abs(dq - z["d_rotations"]).max() <= 5e-5 * np.abs(z["d_rotations"]).max()
+
+
+def _stats_fixture():
+    z = golden_ref.load("ref_training_stats")
+    names = ("opacity_accum", "anchor_demon", "offset_gradient_accum", "offset_denom")
+    calls = [{n: z[f"c{i}_{n}"] for n in ("visible", "neural_opacity", "selection", "update_filter", "grad")} for i in range(2)]
+    return z, names, calls
+
+
+def test_training_stats_oracle_matches_reference_run():
+    """refd_training_stats vs ScaffoldGaussian.training_statis run twice on the reference's own model object."""
+    z, names, calls = _stats_fixture()
+    acc = {n: z["before_" + n].reshape(-1).copy() for n in names}
+    for c in calls:
+        oracle_decode.training_stats(np.nonzero(c["visible"])[0], int(z["k"]), c["neural_opacity"], c["selection"], c["update_filter"], c["grad"],
+                                     *[acc[n] for n in names])
+    for n in names:
+        np.testing.assert_allclose(acc[n], z["after_" + n].reshape(-1), rtol=1e-6, atol=1e-6, err_msg=n)
+        assert not np.array_equal(acc[n], z["before_" + n].reshape(-1))

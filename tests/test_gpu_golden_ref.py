@@ -151,3 +151,31 @@ def test_plane_allmap_matches_reference_run_and_oracle():
     np.testing.assert_allclose(am.detach().cpu().numpy(), oam, rtol=1e-5, atol=1e-6)
     assert np.abs(x.grad.cpu().numpy() - odx).max() <= 1e-5 * np.abs(odx).max()
     assert np.abs(q.grad.cpu().numpy() - odq).max() <= 1e-5 * np.abs(odq).max()
+
+
+def test_training_stats_matches_reference_run_and_oracle():
+    """gsd_training_stats vs ScaffoldGaussian.training_statis (fixture: two consecutive calls on the reference's model object) and vs the
+    oracle at 60k anchors x 10 offsets."""
+    import oracle_decode
+    from gsrast.decode import training_stats_
+    from test_golden_ref_cpu import _stats_fixture
+    z, names, calls = _stats_fixture()
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)
+    acc = {n: t(z["before_" + n]) for n in names}
+    for c in calls:
+        training_stats_(acc["opacity_accum"], acc["anchor_demon"], acc["offset_gradient_accum"], acc["offset_denom"], t(c["grad"]),
+                        t(c["neural_opacity"]), t(c["update_filter"]), t(c["selection"]), anchor_visible_mask=t(c["visible"]))
+    for n in names:
+        np.testing.assert_allclose(acc[n].cpu().numpy(), z["after_" + n], rtol=1e-6, atol=1e-6, err_msg=n)
+    r = np.random.default_rng(4)
+    Na, k = 60000, 10
+    vis = r.uniform(size=Na) < 0.55; Nv = int(vis.sum())
+    nop = np.tanh(r.normal(0, 1, Nv * k)).astype(np.float32); sel = nop > 0; P = int(sel.sum())
+    upd = r.uniform(size=P) < 0.8; grad = r.normal(0, 1, (P, 3)).astype(np.float32)
+    host = [r.uniform(0, 1, Na).astype(np.float32), r.integers(0, 9, Na).astype(np.float32), r.uniform(0, 1, Na * k).astype(np.float32),
+            r.integers(0, 9, Na * k).astype(np.float32)]
+    devt = [t(a.reshape(-1, 1)) for a in host]
+    oracle_decode.training_stats(np.nonzero(vis)[0], k, nop, sel, upd, grad, *host)
+    training_stats_(*devt, t(grad), t(nop), t(upd), t(sel), anchor_visible_mask=t(vis))
+    for a, b in zip(host, devt):
+        assert np.array_equal(a, b.cpu().numpy().reshape(-1))                # same float operations in the same order: bit-exact

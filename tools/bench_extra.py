@@ -122,4 +122,20 @@ def hip_prep():
 th, tt = timeit(hip_prep, n=30), timeit(torch_prep, n=10)
 out["plane_allmap_prep_300k"] = {"hip_fwd_bwd_ms": round(th * 1e3, 3), "torch_fwd_bwd_ms": round(tt * 1e3, 3), "speedup": round(tt / th, 1),
                                  "note": "both include the (am * g).sum().backward() driver ops"}
+# per-iteration densification statistics of the Scaffold / Octree methods (training_statis) vs its torch chain: 72k anchors x 10 offsets
+import ref_decode_torch
+from gsrast.decode import training_stats_, compact_visible
+Na_, k_ = 72000, 10
+gen_ = torch.Generator(device="cuda").manual_seed(5)
+vis_ = torch.rand(Na_, device="cuda", generator=gen_) < 0.88; Nv_ = int(vis_.sum())
+nop_ = torch.tanh(torch.randn(Nv_ * k_, device="cuda", generator=gen_)); sel_ = nop_ > 0; P_ = int(sel_.sum())
+upd_ = torch.rand(P_, device="cuda", generator=gen_) < 0.8; vg_ = torch.randn(P_, 3, device="cuda", generator=gen_)
+acc_ = {"opacity_accum": torch.zeros(Na_, 1, device="cuda"), "anchor_demon": torch.zeros(Na_, 1, device="cuda"),
+        "offset_gradient_accum": torch.zeros(Na_ * k_, 1, device="cuda"), "offset_denom": torch.zeros(Na_ * k_, 1, device="cuda")}
+vi_ = compact_visible(vis_)
+th = timeit(lambda: training_stats_(acc_["opacity_accum"], acc_["anchor_demon"], acc_["offset_gradient_accum"], acc_["offset_denom"], vg_, nop_, upd_, sel_,
+                                    vis_idx=vi_), n=50)
+tt = timeit(lambda: ref_decode_torch.training_statis(acc_, k_, vg_, nop_.view(-1, 1), upd_, sel_, vis_), n=20)
+out["scaffold_training_stats_72k_anchors"] = {"hip_ms": round(th * 1e3, 4), "torch_ms": round(tt * 1e3, 3), "speedup": round(tt / th, 1), "P": P_,
+                                              "note": "the torch chain's boolean-mask indexing synchronises with the host six times per call"}
 print(json.dumps(out))

@@ -64,6 +64,8 @@ def main():
     wvt, fpt = t["viewmatrix"], t["projmatrix"]
     rm, nr = camera_ray_matrices(wvt, fpt, W, H)
     case = {"k": k, "dist_o": False, "dist_c": False, "dist_k": False}
+    acc = {"opacity_accum": torch.zeros(a.Na, 1, device=dev), "anchor_demon": torch.zeros(a.Na, 1, device=dev),
+           "offset_gradient_accum": torch.zeros(a.Na * k, 1, device=dev), "offset_denom": torch.zeros(a.Na * k, 1, device=dev)}
     st = {}
 
     def step():
@@ -73,8 +75,9 @@ def main():
             vmask = radii > 0
         app = emb.weight[1]
         if a.decode == "hip":
+            vis_idx = decode.compact_visible(vmask)           # once per iteration, shared by the decode and the statistics
             xyz, color, opacity, scl, rot, nop, mask = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos,
-                                                                              visible_mask=vmask, appearance=app)
+                                                                              vis_idx=vis_idx, appearance=app)
         else:
             vis = torch.nonzero(vmask).view(-1)
             leaves = {"anchor": anchor, "feat": feat, "offset": offset, "scaling": scaling}
@@ -94,6 +97,12 @@ def main():
         else:
             loss = ref_loss_torch.loss(img.unsqueeze(0), gt.unsqueeze(0), 0.2)[0] + ref_geo_torch.geo_loss(allmap, wvt, fpt, 0.0, 0.05, 100.0)[0] + reg
         loss.backward()
+        if a.loss != "bench":                                    # densify(): training_statis every iteration (scaffold_gaussian.py:707-712)
+            if a.decode == "hip":
+                decode.training_stats_(acc["opacity_accum"], acc["anchor_demon"], acc["offset_gradient_accum"], acc["offset_denom"], means2D.grad,
+                                       nop, rad > 0, mask, vis_idx=vis_idx)
+            else:
+                ref_decode_torch.training_statis(acc, k, means2D.grad, o["neural_opacity"].view(-1, 1), rad > 0, o["mask"], vmask)
         opt.step(); opt.zero_grad(set_to_none=True)
         st["P"] = xyz.shape[0]; st["Nv"] = int(vmask.sum()) if "Nv" not in st else st["Nv"]
 
