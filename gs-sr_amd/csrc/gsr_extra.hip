@@ -506,3 +506,38 @@ extern "C" int gsr_plane_allmap_backward(int32_t P, const float* means3D, const 
                        viewmatrix, campos, dL_dall_map, dL_dmeans3D, (float4*)dL_drotations);
     return gsr_check_launch("plane_allmap_backward", s, false);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Per-iteration densification statistics of the explicit-Gaussian methods (vanilla_gaussian.py:467-472,428-430; pgsr_gaussian.py:164-172,
+// 157-161).  The reference writes them as boolean-mask index assignments (a nonzero() host synchronisation each: 3 for 3DGS/2DGS, 5 for
+// PGSR per iteration); one elementwise kernel here.
+__global__ void __launch_bounds__(256) k_densify_stats(int P, const uint8_t* __restrict__ filter, const int32_t* __restrict__ radii,
+                                                       const int32_t* __restrict__ observe, const float* __restrict__ grad, int gs,
+                                                       const float* __restrict__ grad_abs, float* __restrict__ max_radii, float* __restrict__ accum,
+                                                       float* __restrict__ denom, float* __restrict__ accum_abs, float* __restrict__ denom_abs)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P || !filter[p]) return;
+    if (!observe || observe[p] > 0) { const float r = (float)radii[p]; if (r > max_radii[p]) max_radii[p] = r; }
+    const float gx = grad[(size_t)p * gs], gy = grad[(size_t)p * gs + 1];
+    accum[p] += sqrtf(gx * gx + gy * gy); denom[p] += 1.f;
+    if (grad_abs) {
+        const float ax = grad_abs[(size_t)p * gs], ay = grad_abs[(size_t)p * gs + 1];
+        accum_abs[p] += sqrtf(ax * ax + ay * ay); denom_abs[p] += 1.f;
+    }
+}
+
+extern "C" int gsr_densify_stats(int32_t P, const uint8_t* visibility_filter, const int32_t* radii, const int32_t* out_observe,
+                                 const float* viewspace_grad, int32_t grad_stride, const float* viewspace_grad_abs, float* max_radii2D,
+                                 float* xyz_gradient_accum, float* denom, float* xyz_gradient_accum_abs, float* denom_abs, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!visibility_filter || !radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom || grad_stride < 2 ||
+        (viewspace_grad_abs && (!xyz_gradient_accum_abs || !denom_abs))) {
+        gsr_set_error("densify_stats: null pointer or grad_stride < 2"); return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_densify_stats, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, visibility_filter, radii, out_observe, viewspace_grad,
+                       grad_stride, viewspace_grad_abs, max_radii2D, xyz_gradient_accum, denom, xyz_gradient_accum_abs, denom_abs);
+    return gsr_check_launch("densify_stats", s, false);
+}

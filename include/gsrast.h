@@ -215,6 +215,15 @@ int gsr_loss_plane_geo(int32_t H, int32_t W, const float* plane_depth, const flo
                        const float* ray_mat, float lambda_normal, float* loss_out, float* dL_ddepth, float* dL_dnormal,
                        float* out_depth_normal, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Per-iteration densification statistics of the explicit-Gaussian methods (gssr/gaussian/vanilla_gaussian.py:467-472 densify + :428-430
+ * add_densification_stats; gssr/gaussian/pgsr_gaussian.py:164-172 + :157-161).  For every p with visibility_filter[p] != 0:
+ *   max_radii2D[p] = max(max_radii2D[p], radii[p])          (PGSR: only where out_observe[p] > 0; pass NULL for 3DGS / 2DGS)
+ *   xyz_gradient_accum[p] += |viewspace_grad[p,0:2]|; denom[p] += 1;  and the same for the *_abs pair when viewspace_grad_abs != NULL (PGSR).
+ * All accumulators float [P], updated in place; viewspace_grad [P, grad_stride].  One launch, no host synchronisation. */
+int gsr_densify_stats(int32_t P, const uint8_t* visibility_filter, const int32_t* radii, const int32_t* out_observe, const float* viewspace_grad,
+                      int32_t grad_stride, const float* viewspace_grad_abs, float* max_radii2D, float* xyz_gradient_accum, float* denom,
+                      float* xyz_gradient_accum_abs, float* denom_abs, void* stream);
+
 /* Per-Gaussian `all_map` input of the plane rasterizer, as PGSRScene.render() builds it (gssr/scene/pgsr_scene.py:241-257
  * get_rotation_matrix / get_smallest_axis / get_normal and :297-304):  all_map[i] = {local_normal (3), 1, local_distance} with
  *   n = quaternion_to_matrix(rotations[i])[:, argmin(scales[i])] (pytorch3d convention: real part first, normalised by 2/(q.q); first

@@ -285,3 +285,24 @@ void refm_plane_allmap_bwd(int32_t P, const float* xyz, const float* rot, const 
         for (int e = 0; e < 4; ++e) d_rot[4 * p + e] = dq[e] + dts * dtds2 * 2.0f * q[e];
     }
 }
+
+/*
+ * Per-iteration densification statistics of the explicit-Gaussian methods (3DGS / 2DGS / PGSR):
+ *   gssr/gaussian/vanilla_gaussian.py:467-472 (densify: max_radii2D) + :428-430 (add_densification_stats)
+ *   gssr/gaussian/pgsr_gaussian.py:164-172 + :157-161 (mask = (out_observe > 0) & visibility_filter for max_radii2D; abs-gradient accumulators)
+ * out_observe / grad_abs / accum_abs / denom_abs may be NULL (vanilla).
+ */
+void refm_densify_stats(int32_t P, const uint8_t* filter, const int32_t* radii, const int32_t* out_observe, const float* grad, int32_t gs,
+                        const float* grad_abs, float* max_radii2D, float* accum, float* denom, float* accum_abs, float* denom_abs)
+{
+    for (int p = 0; p < P; ++p) {
+        if (!filter[p]) continue;
+        if (!out_observe || out_observe[p] > 0) { const float r = (float)radii[p]; if (r > max_radii2D[p]) max_radii2D[p] = r; }
+        const float gx = grad[(size_t)p * gs], gy = grad[(size_t)p * gs + 1];
+        accum[p] += sqrtf(gx * gx + gy * gy); denom[p] += 1.f;
+        if (grad_abs) {
+            const float ax = grad_abs[(size_t)p * gs], ay = grad_abs[(size_t)p * gs + 1];
+            accum_abs[p] += sqrtf(ax * ax + ay * ay); denom_abs[p] += 1.f;
+        }
+    }
+}

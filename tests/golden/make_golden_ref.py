@@ -30,6 +30,9 @@ Pinned (reference file:line -> fixture):
         patch_offsets / patch_warp, gssr/utils/graphics_utils.py:185-198; lncc :60-95) on a two-camera view of a textured plane, all
         valid pixels sampled (fewer than nunm_sample, so np.random.choice is not reached); autograd to both plane-depth maps, the
         rendered normal and the rendered distance.
+  ref_densify_stats.npz
+        gssr/gaussian/vanilla_gaussian.py:467-472,428-430 and gssr/gaussian/pgsr_gaussian.py:164-172,157-161: VanillaGaussian.densify /
+        PGSRGaussian.densify called at a step that is not a densification / opacity-reset step (statistics only), accumulators before / after.
   ref_training_stats.npz
         gssr/gaussian/scaffold_gaussian.py:488-508 ScaffoldGaussian.training_statis (the per-iteration densification statistics of the
         Scaffold / Octree methods) run twice on the reference's own model object: accumulators before / after.
@@ -338,6 +341,33 @@ def plane_multiview_fixture():
          d_rendered_normal=nm.grad.numpy(), d_rendered_distance=ds.grad.numpy())
 
 
+def densify_stats_fixture():
+    van = ref_import("gssr.gaussian.vanilla_gaussian"); pg = ref_import("gssr.gaussian.pgsr_gaussian")
+    r = np.random.default_rng(71)
+    P = 900
+    cfg = types.SimpleNamespace(densify_until_iter=15000, densify_from_iter=500, densification_interval=100, opacity_reset_interval=3000)
+    filt = r.uniform(size=P) < 0.6
+    radii = np.where(filt, r.integers(1, 60, P), 0).astype(np.int32)
+    obs = r.integers(0, 3, P).astype(np.int32)
+    grad = r.normal(0, 1, (P, 3)).astype(np.float32); grad_abs = np.abs(r.normal(0, 1, (P, 3))).astype(np.float32)
+    init = {"max_radii2D": r.uniform(0, 40, P).astype(np.float32), "xyz_gradient_accum": r.uniform(0, 1, (P, 1)).astype(np.float32),
+            "denom": r.integers(0, 5, (P, 1)).astype(np.float32), "xyz_gradient_accum_abs": r.uniform(0, 1, (P, 1)).astype(np.float32),
+            "denom_abs": r.integers(0, 5, (P, 1)).astype(np.float32)}
+    out = {}
+    for tag, cls, names in (("vanilla", van.VanillaGaussian, ("max_radii2D", "xyz_gradient_accum", "denom")),
+                            ("pgsr", pg.PGSRGaussian, tuple(init))):
+        g = _bare(cls, config=cfg)
+        for n in names:
+            object.__setattr__(g, n, torch.tensor(init[n]))
+        kw = dict(visibility_filter=torch.tensor(filt), radii=torch.tensor(radii), viewspace_points=types.SimpleNamespace(grad=torch.tensor(grad)))
+        if tag == "pgsr":
+            kw.update(out_observe=torch.tensor(obs), viewspace_points_abs=types.SimpleNamespace(grad=torch.tensor(grad_abs)))
+        g.densify(101, **kw)
+        out.update({f"{tag}_{n}": getattr(g, n).numpy() for n in names})
+    save("ref_densify_stats.npz", visibility_filter=filt, radii=radii, out_observe=obs, grad=grad, grad_abs=grad_abs,
+         **{f"init_{n}": v for n, v in init.items()}, **out)
+
+
 def training_stats_fixture():
     mod = ref_import("gssr.gaussian.scaffold_gaussian")
     cfg = mod.ScaffoldGaussianConfig(); cfg.n_offsets = 6
@@ -454,6 +484,7 @@ def tsdf_fixture():
 
 
 if __name__ == "__main__":
+    densify_stats_fixture()
     training_stats_fixture()
     plane_allmap_fixture()
     plane_multiview_fixture()

@@ -83,3 +83,15 @@ def plane_allmap(xyz, rot, scale, viewmatrix, campos, d_all_map=None):
     g = _f(d_all_map); dx = np.zeros((P, 3), np.float32); dq = np.zeros((P, 4), np.float32)
     L.refm_plane_allmap_bwd(C.c_int32(P), _p(x), _p(q), _p(s), _p(V), _p(cp), _p(g), _p(dx), _p(dq))
     return am, dx, dq
+
+
+def densify_stats(filt, radii, grad, max_radii2D, accum, denom, out_observe=None, grad_abs=None, accum_abs=None, denom_abs=None):
+    """In place on the float32 accumulators (oracle/gsm_oracle.c refm_densify_stats)."""
+    L = oracle.lib()
+    L.refm_densify_stats.restype = None
+    f = np.ascontiguousarray(filt, dtype=np.uint8); r = np.ascontiguousarray(radii, dtype=np.int32); g = _f(grad)
+    ob = None if out_observe is None else np.ascontiguousarray(out_observe, dtype=np.int32)
+    ga = None if grad_abs is None else _f(grad_abs)
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    L.refm_densify_stats(C.c_int32(f.size), vp(f), vp(r), vp(ob), _p(g), C.c_int32(g.shape[1]), vp(ga), vp(max_radii2D), vp(accum), vp(denom),
+                         vp(accum_abs), vp(denom_abs))

@@ -182,3 +182,19 @@ def test_training_stats_oracle_matches_reference_run():
     for n in names:
         np.testing.assert_allclose(acc[n], z["after_" + n].reshape(-1), rtol=1e-6, atol=1e-6, err_msg=n)
         assert not np.array_equal(acc[n], z["before_" + n].reshape(-1))
+
+
+def test_densify_stats_oracle_matches_reference_run():
+    """refm_densify_stats vs VanillaGaussian.densify / PGSRGaussian.densify (statistics-only step) on the reference's own classes."""
+    import oracle_multiview as om
+    z = golden_ref.load("ref_densify_stats")
+    for tag, names in (("vanilla", ("max_radii2D", "xyz_gradient_accum", "denom")),
+                       ("pgsr", ("max_radii2D", "xyz_gradient_accum", "denom", "xyz_gradient_accum_abs", "denom_abs"))):
+        a = {n: z["init_" + n].reshape(-1).copy() for n in names}
+        if tag == "vanilla":
+            om.densify_stats(z["visibility_filter"], z["radii"], z["grad"], a["max_radii2D"], a["xyz_gradient_accum"], a["denom"])
+        else:
+            om.densify_stats(z["visibility_filter"], z["radii"], z["grad"], a["max_radii2D"], a["xyz_gradient_accum"], a["denom"], z["out_observe"],
+                             z["grad_abs"], a["xyz_gradient_accum_abs"], a["denom_abs"])
+        for n in names:
+            np.testing.assert_allclose(a[n], z[f"{tag}_{n}"].reshape(-1), rtol=1e-6, atol=1e-6, err_msg=f"{tag}:{n}")

@@ -179,3 +179,20 @@ def test_training_stats_matches_reference_run_and_oracle():
     training_stats_(*devt, t(grad), t(nop), t(upd), t(sel), anchor_visible_mask=t(vis))
     for a, b in zip(host, devt):
         assert np.array_equal(a, b.cpu().numpy().reshape(-1))                # same float operations in the same order: bit-exact
+
+
+def test_densify_stats_matches_reference_run():
+    """gsr_densify_stats vs the reference's VanillaGaussian.densify / PGSRGaussian.densify statistics (fixture)."""
+    from gsrast.stats import densification_stats_
+    z = golden_ref.load("ref_densify_stats")
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)
+    for tag, names in (("vanilla", ("max_radii2D", "xyz_gradient_accum", "denom")),
+                       ("pgsr", ("max_radii2D", "xyz_gradient_accum", "denom", "xyz_gradient_accum_abs", "denom_abs"))):
+        a = {n: t(z["init_" + n]) for n in names}
+        if tag == "vanilla":
+            densification_stats_(a["max_radii2D"], a["xyz_gradient_accum"], a["denom"], t(z["grad"]), t(z["visibility_filter"]), t(z["radii"]))
+        else:
+            densification_stats_(a["max_radii2D"], a["xyz_gradient_accum"], a["denom"], t(z["grad"]), t(z["visibility_filter"]), t(z["radii"]),
+                                 t(z["out_observe"]), t(z["grad_abs"]), a["xyz_gradient_accum_abs"], a["denom_abs"])
+        for n in names:
+            np.testing.assert_allclose(a[n].cpu().numpy(), z[f"{tag}_{n}"], rtol=1e-6, atol=1e-6, err_msg=f"{tag}:{n}")
