@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
             const float4* __restrict__ r = p.rec + (size_t)gid * ST;
             const uint32_t contributor = base - range.x + (uint32_t)j + 1u;
             if (V != GSR_SURFEL) {
-                const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+                const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2);      // scalar loads: the out_observe atomic must not demote them to VMEM
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
                 const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
                 const float alpha = fminf(0.99f, q1.y * __expf(power));
@@ -287,14 +287,14 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                     const float w = alpha * T;
                     C0 += q1.z * w; C1 += q1.w * w; C2 += q2.x * w;
                     if (V == GSR_PLANE && p.render_geo) {
-                        const float4 q3 = r[3];
+                        const float4 q3 = ldc(r, 3);
                         A0 += q2.y * w; A1 += q2.z * w; A2 += q2.w * w; A3 += q3.x * w; A4 += q3.y * w;
                     }
                     T = test_T;
                     last_contributor = contributor;
                 }
             } else {
-                const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
+                const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2), q3 = ldc(r, 3), q4 = ldc(r, 4);
                 const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
                 const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
