@@ -453,6 +453,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 
             if (V != GSR_SURFEL) {
                 const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2);
+                // pins every loop-carried recurrence to one register across both back edges (the early-out below and the loop latch):
+                // without it the register allocator reconciles them with a block of v_mov per pair (ISA: -10 VALU in the surfel loop)
+                if (V == GSR_PLANE) asm volatile("" : "+v"(T), "+v"(ar0), "+v"(ar1), "+v"(ar2), "+v"(accA[0]), "+v"(accA[1]), "+v"(accA[2]), "+v"(accA[3]), "+v"(accA[4]));
+                else asm volatile("" : "+v"(T), "+v"(ar0), "+v"(ar1), "+v"(ar2));
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
                 const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
                 const float G = __expf(power);
@@ -515,6 +519,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 }
             } else {
                 const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2), q3 = ldc(r, 3), q4 = ldc(r, 4);
+                asm volatile("" : "+v"(T), "+v"(ar0), "+v"(ar1), "+v"(ar2), "+v"(last_dL_dT), "+v"(accum_depth_rec), "+v"(accum_alpha_rec), "+v"(an0), "+v"(an1), "+v"(an2));   // see the EWA path
                 const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
                 const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
