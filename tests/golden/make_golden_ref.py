@@ -30,6 +30,11 @@ Pinned (reference file:line -> fixture):
         patch_offsets / patch_warp, gssr/utils/graphics_utils.py:185-198; lncc :60-95) on a two-camera view of a textured plane, all
         valid pixels sampled (fewer than nunm_sample, so np.random.choice is not reached); autograd to both plane-depth maps, the
         rendered normal and the rendered distance.
+  ref_cov3d.npz
+        gssr/utils/general_utils.py:64-110 build_rotation / build_scaling_rotation / strip_symmetric composed as the reference's
+        build_covariance_from_scaling_rotation (vanilla_gaussian.py:53-57): the Python twin of the rasterizers' computeCov3D
+        (3DGS/cuda_rasterizer/forward.cu:116-147), i.e. the `cov3D_precomp` a caller may pass instead of scales + rotations.  Also
+        geom_transform_points (gssr/utils/graphics_utils.py:22-29) on the same cameras as camera_*.npz.
   ref_densify_stats.npz
         gssr/gaussian/vanilla_gaussian.py:467-472,428-430 and gssr/gaussian/pgsr_gaussian.py:164-172,157-161: VanillaGaussian.densify /
         PGSRGaussian.densify called at a step that is not a densification / opacity-reset step (statistics only), accumulators before / after.
@@ -341,6 +346,25 @@ def plane_multiview_fixture():
          d_rendered_normal=nm.grad.numpy(), d_rendered_distance=ds.grad.numpy())
 
 
+def cov3d_fixture():
+    gu = ref_import("gssr.utils.general_utils"); gr = ref_import("gssr.utils.graphics_utils")
+    _z = torch.zeros
+    torch.zeros = lambda *a, **k: _z(*a, **{kk: ("cpu" if kk == "device" else v) for kk, v in k.items()})
+    r = np.random.default_rng(81)
+    P = 256
+    scales = np.exp(r.normal(-2.5, 0.8, (P, 3))).astype(np.float32)
+    q = r.normal(0, 1, (P, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    mod = 1.3
+    L = gu.build_scaling_rotation(mod * torch.tensor(scales), torch.tensor(q))
+    cov6 = gu.strip_symmetric(L @ L.transpose(1, 2))
+    pts = r.uniform(-3, 3, (P, 3)).astype(np.float32)
+    cam = np.load(os.path.join(HERE, "camera_1.npz"))
+    proj = gr.geom_transform_points(torch.tensor(pts), torch.tensor(cam["full_proj_transform"]))
+    torch.zeros = _z
+    save("ref_cov3d.npz", scales=scales, rotations=q, scale_modifier=mod, cov3D=cov6.numpy(), points=pts,
+         full_proj_transform=cam["full_proj_transform"], points_ndc=proj.numpy())
+
+
 def densify_stats_fixture():
     van = ref_import("gssr.gaussian.vanilla_gaussian"); pg = ref_import("gssr.gaussian.pgsr_gaussian")
     r = np.random.default_rng(71)
@@ -484,6 +508,7 @@ def tsdf_fixture():
 
 
 if __name__ == "__main__":
+    cov3d_fixture()
     densify_stats_fixture()
     training_stats_fixture()
     plane_allmap_fixture()

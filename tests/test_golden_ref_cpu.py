@@ -198,3 +198,24 @@ def test_densify_stats_oracle_matches_reference_run():
                              z["grad_abs"], a["xyz_gradient_accum_abs"], a["denom_abs"])
         for n in names:
             np.testing.assert_allclose(a[n], z[f"{tag}_{n}"].reshape(-1), rtol=1e-6, atol=1e-6, err_msg=f"{tag}:{n}")
+
+
+def _cov_scene():
+    import scenes
+    z = golden_ref.load("ref_cov3d")
+    sc = scenes.make_scene("ewa", z["scales"].shape[0], 160, 120, seed=3, color_mode="precomp", scale_modifier=float(z["scale_modifier"]))
+    a = dict(sc); a["scales"] = z["scales"]; a["rotations"] = z["rotations"]; a["cov3D_precomp"] = None
+    b = dict(a); b["scales"] = None; b["rotations"] = None; b["cov3D_precomp"] = z["cov3D"]
+    return z, a, b
+
+
+def test_cov3d_oracle_matches_reference_python_twin():
+    """The oracle's computeCov3D (scales + rotations + scale_modifier) vs the reference's own Python twin of it
+    (build_scaling_rotation / strip_symmetric, general_utils.py:64-110) fed back in as cov3D_precomp: same radii, same image."""
+    z, a, b = _cov_scene()
+    with oracle.Forward(a, "ewa") as fa, oracle.Forward(b, "ewa") as fb:
+        assert np.array_equal(fa.radii, fb.radii) and (fa.radii > 0).sum() > 50
+        np.testing.assert_allclose(fa.color, fb.color, rtol=0, atol=2e-5)
+    # geom_transform_points pins the row-vector projection convention the preprocess uses (p_hom = [x y z 1] @ full_proj, / w)
+    ph = np.concatenate([z["points"], np.ones((z["points"].shape[0], 1), np.float32)], 1) @ z["full_proj_transform"]
+    np.testing.assert_allclose(ph[:, :3] / (ph[:, 3:] + 1e-7), z["points_ndc"], rtol=1e-5, atol=1e-6)
