@@ -152,6 +152,28 @@ def cpu_baseline(variant, sc, og, budget_s=25.0):
                       f"rasterizer forward+backward only (no loss/optimizer)"}
 
 
+def method_iteration(device, steps=40, warmup=8):
+    """Extra, informational: the COMPLETE scaffold-2dgs training iteration of configs[1] around the same rasterizer -- prefilter
+    (scaffold_filter) -> neural-Gaussian decode (72k anchors x 10 offsets -> ~320k Gaussians) -> diff_surfel_rasterization -> the
+    reference's real losses (L1+SSIM, normal + distortion regularisers, scaling loss) -> backward -> per-iteration densification statistics
+    -> fused Adam; every op a HIP kernel of this repo (tools/bench_pipeline.py --decode hip --loss full-hip).  `value` above times the
+    hot path itself (rasterizer + image loss + Adam on explicit Gaussians), which is what the roofline / stage figures refer to."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_pipeline
+    a = types.SimpleNamespace(decode="hip", loss="full-hip", Na=72000)
+    step, st = bench_pipeline.build(a, device)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(device); t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device); dt = time.perf_counter() - t0
+    return {"what": "full scaffold-2dgs iteration: prefilter + decode + surfel raster + L1/SSIM + normal/dist + scaling loss + backward + "
+                    "densification statistics + fused Adam, all HIP", "anchors": a.Na, "gaussians": int(st["P"]), "steps": steps,
+            "ms_per_iter": round(1e3 * dt / steps, 4), "iters_per_s": round(steps / dt, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +186,8 @@ def main():
     ap.add_argument("--color-mode", default="precomp", choices=["precomp", "sh"],
                     help="precomp = scaffold/octree path (configs 2-5, default); sh = vanilla path with degree-3 SH (config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-method-iteration", action="store_true",
+                    help="skip the extra 'method_iteration' measurement (full scaffold-2dgs iteration incl. decode, real losses, statistics)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -270,6 +294,8 @@ def main():
                          "note": "blend is VALU/atomic-bound by construction (SURVEY §7-5); HBM fraction reported as BASELINE asks, "
                                  "VALU issue fraction alongside"},
         }
+        if world == 1 and not args.no_method_iteration and args.variant == "surfel" and (args.W, args.H) == (1920, 1080):
+            out["method_iteration"] = method_iteration(device)
         if world == 1 and not args.no_cpu_baseline:
             og = scenes.random_out_grads(args.variant, args.W, args.H, seed=0)
             out["cpu_baseline"] = cpu_baseline(args.variant, sc, og)

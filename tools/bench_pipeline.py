@@ -24,19 +24,10 @@ import ref_geo_torch                   # noqa: E402
 import ref_loss_torch                  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--decode", default="hip", choices=["hip", "torch"])
-    ap.add_argument("--loss", default="bench", choices=["bench", "full-hip", "full-torch"],
-                    help="bench: L1 + linear aux (bench.py's loss); full-*: the reference's L1+SSIM + normal/dist regularisers + scaling loss, "
-                         "fused HIP kernels or the reference's torch formulas")
-    ap.add_argument("--Na", type=int, default=72000)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    a = ap.parse_args()
-    dev = torch.device("cuda:0")
+def build(a, dev, seed=0):
+    """-> (step, st): one scaffold-2dgs training iteration on a synthetic anchor scene; a has .decode, .loss, .Na."""
     W, H, k, A = 1920, 1080, 10, 32
-    sc = scenes.make_scene("surfel", a.Na, W, H, seed=0, color_mode="precomp")
+    sc = scenes.make_scene("surfel", a.Na, W, H, seed=seed, color_mode="precomp")
     t = hiprun.to_dev(sc, dev)
     rs = hiprun.settings("surfel", t)
     fs = sf.GaussianRasterizationSettings(**rs._asdict())
@@ -106,6 +97,20 @@ def main():
         opt.step(); opt.zero_grad(set_to_none=True)
         st["P"] = xyz.shape[0]; st["Nv"] = int(vmask.sum()) if "Nv" not in st else st["Nv"]
 
+    return step, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--decode", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--loss", default="bench", choices=["bench", "full-hip", "full-torch"],
+                    help="bench: L1 + linear aux (bench.py's loss); full-*: the reference's L1+SSIM + normal/dist regularisers + scaling loss, "
+                         "fused HIP kernels or the reference's torch formulas")
+    ap.add_argument("--Na", type=int, default=72000)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    a = ap.parse_args()
+    step, st = build(a, torch.device("cuda:0"))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
