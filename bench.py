@@ -271,11 +271,12 @@ def main():
                 traffic = None
         raster_fwd = ms["preprocess"] + ms["depth_order"] + ms["binning"] + ms["blend_fwd"]
         raster_bwd = ms["bwd_memset"] + ms["blend_bwd"] + ms["preprocess_bwd"]
-        # informational: wave-level VALU instructions per launch of the dominant kernel (committed PMC pass of the same workload,
-        # profiles/r01_pmc_summary.json; the counter was calibrated against a kernel of known instruction count, tools/microbench) over the
-        # live duration.  No utilisation fraction is derived: a pure v_fma_f32 stream reaches ~600 G wave-instructions/s on this device
-        # (tools/microbench/valu_peak.py) and the blend kernels sustain more than that, i.e. part of their instruction mix issues beside
-        # the fp32 pipe -- the figure only shows that the kernel is instruction-bound, not bandwidth-bound.
+        # informational second ceiling for the dominant kernel: VALU issue rate.  Instruction count per launch from the committed PMC pass of
+        # the same workload (profiles/r01_pmc_summary.json, SQ_INSTS_VALU; the counter was calibrated against a kernel of known instruction
+        # count, tools/microbench/valu_count.py: +0.15 %); duration measured live.  Peak: CDNA4 CUs have four SIMD-32 units, so a wave64
+        # VALU instruction issues in 2 cycles: 256 CU x 4 SIMD x 2.4 GHz / 2 = 1228.8 G wave-instructions/s (= the 157.3 TFLOP/s fp32 vector
+        # peak of MI355X_MICROARCH.md / 128 flop per wave64 FMA).  tools/microbench/valu_ops.py measures 1020 G/s for independent v_mov_b32
+        # and 810 G/s for dependent v_fma_f32 chains on this device.
         valu = None
         pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         vidx = {"ewa": 0, "surfel": 1, "plane": 2}[args.variant]
@@ -283,9 +284,9 @@ def main():
             try:
                 insts = json.load(open(pj)).get(f"k_blend_{'bwd' if dom == 'blend_bwd' else 'fwd'}<{vidx}>", {}).get("SQ_INSTS_VALU")
                 if insts:
-                    valu = {"wave_insts_per_launch": int(insts), "achieved_Ginst_s": round(insts / (ms[dom] * 1e-3) / 1e9, 1),
-                            "v_fma_f32_stream_Ginst_s": 600.0, "source": "profiles/r01_pmc_summary.json SQ_INSTS_VALU / live avg_launch_ms; "
-                            "tools/microbench/valu_peak.py"}
+                    rate = insts / (ms[dom] * 1e-3)
+                    valu = {"wave_insts_per_launch": int(insts), "achieved_Ginst_s": round(rate / 1e9, 1), "peak_Ginst_s": 1228.8,
+                            "frac": round(rate / 1228.8e9, 4), "source": "profiles/r01_pmc_summary.json SQ_INSTS_VALU / live avg_launch_ms"}
             except Exception:
                 valu = None
         out = {
@@ -308,7 +309,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(ms[dom], 4),
-                         "valu_instructions": valu,
+                         "valu_issue": valu,
                          "note": "blend is VALU/atomic-bound by construction (SURVEY §7-5); HBM fraction reported as BASELINE asks"},
         }
         if world == 1 and not args.no_method_iteration and args.variant == "surfel" and (args.W, args.H) == (1920, 1080):
