@@ -74,12 +74,12 @@ def make_step(variant, sc, device):
     P, W, H = t["means3D"].shape[0], int(t["W"]), int(t["H"])
     ns = t["scales"].shape[1]
     use_sh = t.get("shs") is not None
-    # Learning rates: the reference's per-group ratios, scaled so that 100+ Adam steps against the random target do not move the scene away
+    # Learning rates: the reference's per-group ratios, scaled so that 100+ Adam steps against the random target (or 2000) do not move the scene away
     # from the SURVEY 8d distribution the workload is defined on (Adam's step is ~lr per iteration whatever the gradient: with the
     # reference's absolute rates on these post-activation parameters the splat sizes random-walk by +-50 % within 100 steps, and the tile
     # instance count -- hence the work per step -- with them).  The optimiser work per step is the same; config reports R before / after.
-    cols = [("means3D", 3, 1.6e-7), ("scales", ns, 5e-6), ("rotations", 4, 1e-6), ("opacities", 1, 1e-5)]
-    cols.append(("shs", 48, 2.5e-5) if use_sh else ("colors_precomp", 3, 2.5e-5))
+    cols = [("means3D", 3, 1.6e-8), ("scales", ns, 5e-7), ("rotations", 4, 1e-7), ("opacities", 1, 1e-6)]
+    cols.append(("shs", 48, 2.5e-6) if use_sh else ("colors_precomp", 3, 2.5e-6))
     # structure-of-arrays inside the flat leaf: [means 3P | scales nsP | rotations 4P | opacity P | colour cP], so every parameter view
     # handed to the rasterizer is contiguous (an [P,13] array-of-structs layout costs one strided copy per parameter per iteration)
     sizes = [P * n for _, n, _ in cols]
