@@ -1,8 +1,10 @@
 // gsr_api.hip -- C ABI of libgsrast_hip.so (see include/gsrast.h): arena carving, stage orchestration, errors.
 #include "gsr_common.h"
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 int gsr_tile_sort_passes(int T);
 
@@ -31,16 +33,18 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug)
 
 // ------------------------------------------------------------------------------------------------ stage profiler
 // Optional: HIP events recorded on the launch stream around every stage; read back with gsr_profile_read.
-// Used by bench.py for the live kernel durations behind the roofline figure.  Not thread-safe (bench is single-threaded).
+// Used by bench.py for the live kernel durations behind the roofline figure.  One mutex guards the record lists, so concurrent
+// forwards from several host threads / streams only serialise on the bookkeeping (a few hundred ns), never on the GPU work.
 #include <vector>
 struct ProfRec { int label; hipEvent_t a, b; };
-static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::atomic<bool> g_prof_on{false};
 static std::vector<ProfRec> g_prof;
 static std::vector<ProfRec> g_prof_free;
 static double g_prof_ms[GSR_PROF_LABELS];
 static uint64_t g_prof_n[GSR_PROF_LABELS];
 
-static void prof_drain()
+static void prof_drain()      // caller holds g_prof_mu
 {
     for (auto& r : g_prof) {
         float ms = 0.f;
@@ -53,19 +57,27 @@ static void prof_drain()
 }
 struct ProfScope {
     ProfRec r; bool on; hipStream_t s;
-    ProfScope(int label, hipStream_t s_) : on(g_prof_on), s(s_)
+    ProfScope(int label, hipStream_t s_) : on(g_prof_on.load(std::memory_order_relaxed)), s(s_)
     {
         if (!on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof.size() >= 8192) prof_drain();
         if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
         else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
         r.label = label;
         (void)hipEventRecord(r.a, s);
     }
-    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); g_prof.push_back(r); } }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(r);
+    }
 };
 extern "C" int gsr_profile_enable(int32_t enable)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     prof_drain();
     g_prof_on = enable != 0;
     for (int i = 0; i < GSR_PROF_LABELS; i++) { g_prof_ms[i] = 0; g_prof_n[i] = 0; }
@@ -73,6 +85,7 @@ extern "C" int gsr_profile_enable(int32_t enable)
 }
 extern "C" int gsr_profile_read(double* ms_total, uint64_t* counts)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     prof_drain();
     for (int i = 0; i < GSR_PROF_LABELS; i++) { ms_total[i] = g_prof_ms[i]; counts[i] = g_prof_n[i]; }
     return 0;
@@ -175,19 +188,40 @@ static int check_cfg(const gsr_cfg* cfg, const gsr_inputs* in)
 // ------------------------------------------------------------------------------------------------ pinned mailbox
 // num_rendered travels through one mapped, pinned host word per device that the last scan kernel writes directly
 // (system-scope store): the forward's single sync is then a bare hipStreamSynchronize, no D2H copy command.
-struct Mailbox { uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev[16] = {}; unsigned next = 0; };
+// Concurrency: a forward owns its slot from `take_slot` until it has read the word back.  Slots are handed out by an atomic ticket
+// and guarded by a per-slot busy flag, so forwards running concurrently on several host threads / streams of one device never share
+// a word (round 1 used an unsynchronised `next++`); with more than GSR_MAIL_SLOTS forwards in flight the caller spins for a free slot.
+#define GSR_MAIL_SLOTS 64
+struct Mailbox {
+    uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev[GSR_MAIL_SLOTS] = {};
+    std::atomic<unsigned> next{0};
+    std::atomic<int> busy[GSR_MAIL_SLOTS];
+};
 static Mailbox g_mail[64];
+static std::mutex g_mail_mu;
+static unsigned take_slot(Mailbox* m)
+{
+    for (;;) {
+        const unsigned s = m->next.fetch_add(1u, std::memory_order_relaxed) % GSR_MAIL_SLOTS;
+        int expect = 0;
+        if (m->busy[s].compare_exchange_strong(expect, 1, std::memory_order_acquire)) return s;
+    }
+}
+static void release_slot(Mailbox* m, unsigned s) { m->busy[s].store(0, std::memory_order_release); }
 static Mailbox* mailbox()
 {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
     Mailbox& m = g_mail[d];
+    std::lock_guard<std::mutex> lk(g_mail_mu);
     if (!m.host) {
         void* h = nullptr; void* dp = nullptr;
-        if (hipHostMalloc(&h, 16 * 64, hipHostMallocMapped) != hipSuccess) return nullptr;     // 16 slots, one cache line each
+        if (hipHostMalloc(&h, GSR_MAIL_SLOTS * 64, hipHostMallocMapped) != hipSuccess) return nullptr;     // one cache line per slot
         if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
-        for (int i = 0; i < 16; i++)
+        for (int i = 0; i < GSR_MAIL_SLOTS; i++) {
+            m.busy[i].store(0);
             if (hipEventCreateWithFlags(&m.ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
+        }
         m.host = (uint32_t*)h; m.dev = (uint32_t*)dp;
     }
     return &m;
@@ -205,7 +239,8 @@ extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void
     if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
     { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
     Mailbox* mb = mailbox();
-    const unsigned slot = mb ? (mb->next++ & 15u) : 0u;
+    const unsigned slot = mb ? take_slot(mb) : 0u;
+    struct SlotGuard { Mailbox* m; unsigned s; ~SlotGuard() { if (m) release_slot(m, s); } } guard{mb, slot};
     { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb ? mb->dev + 16 * slot : nullptr, s)) return 1; }
     // the one host<->device sync of the forward (reference: cudaMemcpy of point_offsets[P-1], rasterizer_impl.cu:281)
     if (mb) {
@@ -274,7 +309,8 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
     BinView b = gsr_carve_bin(cfg->variant, cap, cfg->W, cfg->H, binning);
     ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, img);
     if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
-    const unsigned slot = mb->next++ & 15u;
+    const unsigned slot = take_slot(mb);
+    struct SlotGuard { Mailbox* m; unsigned s; ~SlotGuard() { release_slot(m, s); } } guard{mb, slot};
     { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
     { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s)) return 1; }
     GSR_CHECK(hipEventRecord(mb->ev[slot], s), "event record");

@@ -13,220 +13,7 @@
 //     than one-atomic-per-pixel.
 // Behaviour follows 3DGS forward.cu:261-374 / backward.cu:399-557, PLANE forward.cu:273-407 / backward.cu:399-614,
 // SURFEL forward.cu:256-448 / backward.cu:143-447 (thresholds, ordering, recurrences); see DESIGN.md.
-#include "gsr_common.h"
-#include <cstdlib>
-
-struct BlendParams {
-    int W, H, gx, gy, variant, render_geo, xcd_remap;
-    float fx, fy;
-    const uint2* ranges;
-    const uint32_t* point_list;
-    const float4* cull;
-    const float4* rec;
-    const float* bg;
-    float* final_T;
-    uint32_t* n_contrib;
-    // forward outputs
-    float* out_color; float* out_others; int32_t* out_observe; float* out_all_map; float* out_plane_depth;
-    // backward inputs
-    const float* dL_dcolor; const float* dL_dothers; const float* dL_dout_all_map; const float* dL_dplane_depth;
-    const float* all_map_pixels;
-    float* acc;
-};
-
-// Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md); give each XCD a contiguous band of tiles so that
-// neighbouring tiles -- which share most of their splats -- hit the same 4 MiB L2.  Bijective for any T; speed only.
-__device__ __forceinline__ int tile_of_block(int b, int T, int remap)
-{
-    if (!remap) return b;
-    const int q = T >> 3, r = T & 7, xcd = b & 7, idx = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-// ---- DPP wave reduction: total of v over the 64 lanes, returned wave-uniform ------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    v += dpp_f<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-    v += dpp_f<0x141, 0xF>(v);   // row_half_mirror
-    v += dpp_f<0x140, 0xF>(v);   // row_mirror        -> every lane holds its row's sum
-    v += dpp_f<0x142, 0xA>(v);   // row_bcast15 into rows 1,3
-    v += dpp_f<0x143, 0xC>(v);   // row_bcast31 into rows 2,3 -> lanes 48..63 hold the wave total
-    return v;
-}
-// ---- transpose-reduce: K per-lane components -> ONE register, lane (48 + c) holds the wave total of component c.
-// Each level halves the number of live registers instead of running K separate 6-step butterflies:
-//   xor 1, xor 2 : select + quad_perm DPP add          (3 VALU per merge)
-//   xor 4, xor 8 : bank-masked row_shl/row_shr DPP adds (the DPP bank mask does the select)
-//   rows         : lane-wise xor 16 / xor 32 (ds_bpermute)
-// 16 components cost ~45 VALU instead of 16 x 7, and the result feeds a single 16-lane atomic instruction.
-template <int QP>
-__device__ __forceinline__ float merge_quad(float a, float b, bool sel)
-{
-    const float keep = sel ? b : a, give = sel ? a : b;
-    return keep + dpp_f<QP, 0xF>(give);
-}
-// xor 4 / xor 8 level: lanes with the level bit clear keep a and add a[l + S], the others keep b and add b[l - S].  The DPP bank
-// mask does the lane selection, so each half is ONE v_add_f32_dpp accumulating into w.  The compiler cannot form this itself (it
-// materialises update_dpp(0, x) with a zero-fill and a separate add: 7 VALU instead of 3 per merge), hence the inline assembly; the
-// leading s_nop covers the "VALU write -> DPP read" hazard the assembler does not see inside an asm block.
-template <int S>
-__device__ __forceinline__ float merge_row(float a, float b, bool sel)
-{
-    float w = sel ? b : a;
-    if (S == 4)
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_add_f32_dpp %0, %2, %0 row_shr:4 row_mask:0xf bank_mask:0xa"
-            : "+v"(w) : "v"(a), "v"(b));
-    else
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0x3\n\tv_add_f32_dpp %0, %2, %0 row_shr:8 row_mask:0xf bank_mask:0xc"
-            : "+v"(w) : "v"(a), "v"(b));
-    return w;
-}
-// lane-wise sum across the four 16-lane rows (every row ends up with the totals).  row_bcast cannot be used here:
-// the lanes of a row hold DIFFERENT components, so the exchange must be lane l <-> l^16, l^32.  gfx950 has VALU-only
-// row/half swaps (v_permlane16_swap / v_permlane32_swap), so no trip through the LDS crossbar (ds_bpermute):
-//   permlane16_swap(w,w) -> {[r0,r0,r2,r2], [r1,r1,r3,r3]}, permlane32_swap(w,w) -> {[lo,lo], [hi,hi]}.
-__device__ __forceinline__ float rows_to_row3(float w)
-{
-    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-    u2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(w), __float_as_uint(w), false, false);
-    w = __uint_as_float(a.x) + __uint_as_float(a.y);
-    u2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(w), __float_as_uint(w), false, false);
-    return __uint_as_float(b.x) + __uint_as_float(b.y);
-}
-// lane 48+c <- total of v[c], c in [0,16)
-__device__ __forceinline__ float reduce16(const float* v, int lane)
-{
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-    float r[8], q[4], p[2];
-#pragma unroll
-    for (int i = 0; i < 8; i++) r[i] = merge_quad<0xB1>(v[2 * i], v[2 * i + 1], b0);
-#pragma unroll
-    for (int i = 0; i < 4; i++) q[i] = merge_quad<0x4E>(r[2 * i], r[2 * i + 1], b1);
-#pragma unroll
-    for (int i = 0; i < 2; i++) p[i] = merge_row<4>(q[2 * i], q[2 * i + 1], b2);   // row_shl:4 / row_shr:4
-    const float w = merge_row<8>(p[0], p[1], b3);                                   // row_shl:8 / row_shr:8
-    return rows_to_row3(w);
-}
-// lane 56+c (and 48+c) <- total of v[c], c in [0,8)
-__device__ __forceinline__ float reduce8(const float* v, int lane)
-{
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-    float r[4], q[2];
-#pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = merge_quad<0xB1>(v[2 * i], v[2 * i + 1], b0);
-#pragma unroll
-    for (int i = 0; i < 2; i++) q[i] = merge_quad<0x4E>(r[2 * i], r[2 * i + 1], b1);
-    float w = merge_row<4>(q[0], q[1], b2);
-    w += dpp_f<0x128, 0xF>(w);   // row_ror:8 -> sum over the row, component = lane & 7
-    return rows_to_row3(w);
-}
-// ---- the same reduction on the MATRIX pipe (idle in this VALU-bound kernel).  v_mfma_f32_16x16x4_f32 computes
-// D[i][j] += sum_k A[i][k] * B[k][j] with lane l holding A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15].  Feeding the
-// per-lane gradient term of component c as A and the one-hot column selector B_c[k][j] = (j == c) accumulates
-// D[i][c] = sum_k v_c[lane i + 16k]; after N such MFMAs lane l holds, for component l&15, four partial rows
-// (D[4(l>>4)+r][l&15], r = 0..3): three adds and the two row swaps finish the sum.  Exact fp32 (an FMA chain with
-// multiplier 1.0), deterministic order, ~22 VALU + N MFMAs instead of ~55 VALU for 16 components.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <int N>
-__device__ __forceinline__ float reduce_mfma(const float* v, int lane)
-{
-    f32x4_t acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
-    float sel = ((lane & 15) == 0) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int c = 0; c < N; c++) {
-        if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c], sel, acc1, 0, 0, 0);
-        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c], sel, acc0, 0, 0, 0);
-        if (c + 1 < N) sel = dpp_f<0x111, 0xF>(sel);      // row_shr:1 -> selector of column c+1
-    }
-    const f32x4_t a = acc0 + acc1;
-    return rows_to_row3((a.x + a.y) + (a.z + a.w));        // every lane l: total of component l & 15
-}
-
-// lane 62 <- total of a, lane 63 <- total of b
-__device__ __forceinline__ float reduce2(float a, float b, int lane)
-{
-    float w = merge_quad<0xB1>(a, b, lane & 1);
-    w += dpp_f<0x4E, 0xF>(w);    // xor 2
-    w += dpp_f<0x124, 0xF>(w);   // row_ror:4
-    w += dpp_f<0x128, 0xF>(w);   // row_ror:8
-    return rows_to_row3(w);
-}
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    return v;
-}
-
-__device__ __forceinline__ void atomic_addf(float* p, float v) { unsafeAtomicAdd(p, v); }
-// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence; blend outputs are tolerance-checked.
-__device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
-
-// Packed records are written by the preprocess kernel and are read-only in both blend kernels.  Loading them through
-// the constant address space lets the backend use scalar (SMEM) loads for the wave-uniform address even in the
-// backward kernel, where the atomics into `acc` would otherwise defeat the no-clobber analysis.
-typedef float f4_t __attribute__((ext_vector_type(4)));
-typedef const f4_t __attribute__((address_space(4))) * const_rec_ptr;
-__device__ __forceinline__ float4 ldc(const float4* p, int k)
-{
-    const_rec_ptr c = (const_rec_ptr)(p + k);
-    const f4_t v = *c;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
-// ---- sub-tile cull: can splat `id` reach alpha >= 1/255 anywhere in the 8x8 block whose first pixel is (ox,oy)?
-// Skipping is result-neutral (a skipped splat fails the reference's alpha gate for every pixel of the block), so the
-// test only has to be conservative.  SURFEL: bounding box of the contribution region.  EWA/PLANE: exact minimum of
-// the conic form q(d) = A dx^2 + 2B dx dy + C dy^2 over the block rectangle (centre inside -> 0, else the best of the
-// four edges, each a clamped 1-D parabola) against 2*ln(255*opacity) (with the safety margin added in preprocess).
-// minimum of q(d) = A dx^2 + 2B dx dy + C dy^2 over the rectangle [X0, X0+7] x [Y0, Y0+7] (d relative to the conic centre):
-// 0 when the centre is inside, else the best of the four edges, each a clamped 1-D parabola.
-__device__ __forceinline__ float conic_min_over_block(float A, float B, float C, float X0, float Y0)
-{
-    const float X1 = X0 + 7.f, Y1 = Y0 + 7.f;
-    if (X0 <= 0.f && X1 >= 0.f && Y0 <= 0.f && Y1 >= 0.f) return 0.f;
-    const float rC = __builtin_amdgcn_rcpf(C), rA = __builtin_amdgcn_rcpf(A);
-    float dy = fminf(fmaxf(-B * X0 * rC, Y0), Y1);
-    float qmin = A * X0 * X0 + 2.f * B * X0 * dy + C * dy * dy;
-    dy = fminf(fmaxf(-B * X1 * rC, Y0), Y1);
-    qmin = fminf(qmin, A * X1 * X1 + 2.f * B * X1 * dy + C * dy * dy);
-    float dx = fminf(fmaxf(-B * Y0 * rA, X0), X1);
-    qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * Y0 + C * Y0 * Y0);
-    dx = fminf(fmaxf(-B * Y1 * rA, X0), X1);
-    qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * Y1 + C * Y1 * Y1);
-    return qmin;
-}
-template <int V>
-__device__ __forceinline__ bool cull_hit(const float4* __restrict__ cull, uint32_t id, float ox, float oy)
-{
-    if (V == GSR_SURFEL) {
-        // union of the projected ellipse {A dx^2 + 2B dx dy + C dy^2 <= 1} about (a.x, a.y) and the low-pass disc of radius^2 b.y about
-        // (b.z, b.w); b.y < 0: no pixel can reach alpha >= 1/255; A = B = C = 0: culling disabled for this splat
-        const float4 a = cull[2 * (size_t)id], b = cull[2 * (size_t)id + 1];
-        if (!(b.y >= 0.f)) return false;
-        const float ex0 = ox - b.z, ey0 = oy - b.w;
-        const float ddx = fmaxf(fmaxf(ex0, -(ex0 + 7.f)), 0.f), ddy = fmaxf(fmaxf(ey0, -(ey0 + 7.f)), 0.f);
-        if (ddx * ddx + ddy * ddy <= b.y) return true;
-        return !(conic_min_over_block(a.z, a.w, b.x, ox - a.x, oy - a.y) > 1.0f);      // NaN -> keep
-    } else {
-        const float4 a = cull[2 * (size_t)id], b = cull[2 * (size_t)id + 1];
-        const float A = a.z, B = a.w, C = b.x, tt = b.y;
-        if (!(tt > 0.f)) return false;
-        const float qmin = conic_min_over_block(A, B, C, ox - a.x, oy - a.y);
-        return !(qmin > tt);      // NaN -> keep
-    }
-}
-
-static constexpr float NEAR_N = 0.2f, FAR_N = 100.0f, FILTER_INV_SQ = 2.0f;
+#include "gsr_blend_common.h"
 
 // =================================================================================================== forward
 template <int V>
@@ -300,7 +87,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
                 const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
                 const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
-                const float rpz = rcp_(ppz);
+                const float rpz = rcp_nr(ppz);
                 const float sx = ppx * rpz, sy = ppy * rpz;
                 const float rho3d = sx * sx + sy * sy;
                 const float dx = q2.y - pxf, dy = q2.z - pyf;
@@ -397,12 +184,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     float dLp0 = 0, dLp1 = 0, dLp2 = 0;
     if (inside && p.dL_dcolor) { dLp0 = p.dL_dcolor[pix_id]; dLp1 = p.dL_dcolor[HW + pix_id]; dLp2 = p.dL_dcolor[2 * HW + pix_id]; }
     const float bg_dot_dpixel = p.bg[0] * dLp0 + p.bg[1] * dLp1 + p.bg[2] * dLp2;
-    float ar0 = 0, ar1 = 0, ar2 = 0;
+    float arA = 0;      // collapsed accum recurrence (all channels)
     const float ddelx_dx = 0.5f * p.W, ddely_dy = 0.5f * p.H;
 
     // PLANE (backward.cu:433,460-490)
     const bool geo = (V == GSR_PLANE) && p.render_geo;
-    float dA[5] = { 0, 0, 0, 0, 0 }, accA[5] = { 0, 0, 0, 0, 0 };
+    float dA[5] = { 0, 0, 0, 0, 0 };
     if (geo && inside) {
         const float rayx = (float)((pxf - p.W * 0.5) / p.fx), rayy = (float)((pyf - p.H * 0.5) / p.fy);
         if (p.dL_dout_all_map)
@@ -420,8 +207,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     float dL_dreg = 0, dL_ddepth = 0, dL_daccum = 0, dN0 = 0, dN1 = 0, dN2 = 0, dL_dmedian_depth = 0;
     float dMN0 = 0, dMN1 = 0, dMN2 = 0;
     uint32_t median_contributor = 0;
-    float accum_depth_rec = 0, accum_alpha_rec = 0, an0 = 0, an1 = 0, an2 = 0;
-    float final_D = 0, final_D2 = 0, final_A = 0, last_dL_dT = 0;
+    float final_D = 0, final_D2 = 0, final_A = 0;
     if (V == GSR_SURFEL && inside) {
         median_contributor = p.n_contrib[pix_id + HW];
         if (p.dL_dothers) {
@@ -455,36 +241,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2);
                 // pins every loop-carried recurrence to one register across both back edges (the early-out below and the loop latch):
                 // without it the register allocator reconciles them with a block of v_mov per pair (ISA: -10 VALU in the surfel loop)
-                if (V == GSR_PLANE) asm volatile("" : "+v"(T), "+v"(ar0), "+v"(ar1), "+v"(ar2), "+v"(accA[0]), "+v"(accA[1]), "+v"(accA[2]), "+v"(accA[3]), "+v"(accA[4]));
-                else asm volatile("" : "+v"(T), "+v"(ar0), "+v"(ar1), "+v"(ar2));
+                asm volatile("" : "+v"(T), "+v"(arA));
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
                 const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
                 const float G = __expf(power);
                 const float alpha = fminf(0.99f, q1.y * G);
                 const bool ok = active && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
                 if (__ballot(ok) == 0) continue;
-                // Branch-free: a lane that does not contribute runs the same instructions with alpha = 0 (its recurrences become the
+                // Branch-free: a lane that does not contribute runs the same instructions with alpha = 0 (its recurrence becomes the
                 // identity) and dL_dalpha = 0 (all its gradient terms vanish), so no per-value zero initialisation and no divergent
                 // region is needed; G is sanitised because exp(power > 0) may overflow and inf * 0 would poison the sums.
                 const float al = ok ? alpha : 0.0f, Gm = ok ? G : 0.0f;
                 const float r1a = rcp_(1.f - al);
                 T = T * r1a;
                 const float dchannel_dcolor = al * T;
-                float dL_dalpha = (q1.z - ar0) * dLp0 + (q1.w - ar1) * dLp1 + (q2.x - ar2) * dLp2;
+                // Every "(c - accum_c) * dL_dc" term of the reference (backward.cu:503-520; PLANE :563-579) is linear in the channel value, so
+                // the per-channel accum recurrences collapse into ONE on u = sum_ch c_ch dL_ch:  dL_dalpha = (u - A) T,  A <- al u + (1 - al) A.
+                float u = q1.z * dLp0 + q1.w * dLp1 + q2.x * dLp2;
                 const float g_c0 = dchannel_dcolor * dLp0, g_c1 = dchannel_dcolor * dLp1, g_c2 = dchannel_dcolor * dLp2;
-                // accum_rec of the NEXT (nearer) contributor: folded now instead of carrying last_alpha / last_color per lane
-                ar0 = al * q1.z + (1.f - al) * ar0; ar1 = al * q1.w + (1.f - al) * ar1; ar2 = al * q2.x + (1.f - al) * ar2;
                 float g_am[5] = { 0, 0, 0, 0, 0 };
                 if (geo) {
                     const float4 q3 = ldc(r, 3);
                     const float am[5] = { q2.y, q2.z, q2.w, q3.x, q3.y };
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
-                        dL_dalpha += (am[c] - accA[c]) * dA[c];
+                        u += am[c] * dA[c];
                         g_am[c] = dchannel_dcolor * dA[c];
-                        accA[c] = al * am[c] + (1.f - al) * accA[c];
                     }
                 }
+                float dL_dalpha = u - arA;
+                arA = al * u + (1.f - al) * arA;
                 dL_dalpha *= T;
                 dL_dalpha += (-T_final * r1a) * bg_dot_dpixel;
                 dL_dalpha = ok ? dL_dalpha : 0.0f;
@@ -519,13 +305,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 }
             } else {
                 const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2), q3 = ldc(r, 3), q4 = ldc(r, 4);
-                asm volatile("" : "+v"(T), "+v"(ar0), "+v"(ar1), "+v"(ar2), "+v"(last_dL_dT), "+v"(accum_depth_rec), "+v"(accum_alpha_rec), "+v"(an0), "+v"(an1), "+v"(an2));   // see the EWA path
+                asm volatile("" : "+v"(T), "+v"(arA));   // see the EWA path
                 const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
                 const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
                 const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
                 const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
-                const float rpz = (ppz == 0.0f) ? 0.0f : rcp_(ppz);      // keeps s (hence rho, G <= 1) finite on lanes that will not contribute
+                const float rpz = (ppz == 0.0f) ? 0.0f : rcp_nr(ppz);      // keeps s (hence rho, G <= 1) finite on lanes that will not contribute
                 const float sx = ppx * rpz, sy = ppy * rpz;
                 const float rho3d = sx * sx + sy * sy;
                 const float dx = q2.y - pxf, dy = q2.z - pyf;
@@ -548,24 +334,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 const float r1a = rcp_(1.f - al);
                 T = T * r1a;
                 const float w = al * T;
-                float dL_dalpha = (q3.w - ar0) * dLp0 + (q4.x - ar1) * dLp1 + (q4.y - ar2) * dLp2;
                 const float g_c0 = w * dLp0, g_c1 = w * dLp1, g_c2 = w * dLp2;
-                ar0 = al * q3.w + (1.f - al) * ar0; ar1 = al * q4.x + (1.f - al) * ar1; ar2 = al * q4.y + (1.f - al) * ar2;
                 const float rcd = rcp_(cd);
                 const float m_d = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcd);
                 const float dmd_dd = ((FAR_N * NEAR_N) / (FAR_N - NEAR_N)) * rcd * rcd;
                 float dL_dz = (ok && idx0 + 1u == median_contributor) ? dL_dmedian_depth : 0.0f;      // contributor == median_contributor-1
                 const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-                dL_dalpha += dL_dweight - last_dL_dT;
-                last_dL_dT = dL_dweight * al + (1 - al) * last_dL_dT;
                 const float dL_dmd = 2.0f * w * (m_d * final_A - final_D) * dL_dreg;
                 dL_dz += dL_dmd * dmd_dd;
-                dL_dalpha += (cd - accum_depth_rec) * dL_ddepth;
-                accum_depth_rec = al * cd + (1.f - al) * accum_depth_rec;
-                dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
-                accum_alpha_rec = al + (1.f - al) * accum_alpha_rec;
-                dL_dalpha += (q3.x - an0) * dN0 + (q3.y - an1) * dN1 + (q3.z - an2) * dN2;
-                an0 = al * q3.x + (1.f - al) * an0; an1 = al * q3.y + (1.f - al) * an1; an2 = al * q3.z + (1.f - al) * an2;
+                // colour, distortion weight (last_dL_dT), depth, alpha and normal are all "channels" of the same recurrence (backward.cu:
+                // 300-375): collapsed into one on u (see the EWA path) -- nine per-lane recurrences fewer than the literal form
+                const float u = (q3.w * dLp0 + q4.x * dLp1 + q4.y * dLp2) + dL_dweight + cd * dL_ddepth + dL_daccum + (q3.x * dN0 + q3.y * dN1 + q3.z * dN2);
+                float dL_dalpha = u - arA;
+                arA = al * u + (1.f - al) * arA;
                 // fork quirk (backward.cu:381): median-normal gradient is added for every contributing splat
                 const float g_n0 = w * dN0 + okf * dMN0, g_n1 = w * dN1 + okf * dMN1, g_n2 = w * dN2 + okf * dMN2;
                 dL_dalpha *= T;
@@ -643,6 +424,15 @@ int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
     p.dL_dcolor = og->dL_dcolor; p.dL_dothers = og->dL_dothers; p.dL_dout_all_map = og->dL_dout_all_map;
     p.dL_dplane_depth = og->dL_dplane_depth; p.all_map_pixels = og->all_map_pixels;
     p.acc = acc;
+    // GSR_BWD=px (default): the pixel-parallel kernel below; GSR_BWD=sp: the splat-parallel backward of gsr_blend_sp.hip.  Both pass the
+    // full parity suite; measured on MI355X (300k surfels, 1080p, round 2): px 0.525 ms, sp 0.692 ms (0.484 ms without its LDS-table
+    // adds) -- DESIGN.md section 4 has the counters.  The default is whichever measures faster.
+    static int use_sp = -1;
+    if (use_sp < 0) { const char* e = getenv("GSR_BWD"); use_sp = (e && e[0] == 's') ? 1 : 0; }
+    if (use_sp) {
+        if (gsr_launch_blend_bwd_sp(p, cfg->variant, s)) return 1;
+        return gsr_check_launch("blend_bwd_sp", s, cfg->debug);
+    }
     dim3 grid(p.gx * p.gy), block(256);
     static int mfma_red = -1;
     // MEASURED (MI355X, 300k splats 1080p): MFMA reduction 1.65 ms vs DPP tree 1.04 ms (surfel), 1.08 vs 0.67 (EWA):

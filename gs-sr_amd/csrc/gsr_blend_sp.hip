@@ -1,0 +1,445 @@
+// gsr_blend_sp.hip -- SPLAT-PARALLEL blend backward (round 2).  Same results as k_blend_bwd (gsr_blend.hip) within float rounding.
+//
+// k_blend_bwd puts one PIXEL in each lane and walks the splats: every (block, splat) step ends with a 16-component cross-lane
+// transpose-reduce (~51 VALU) and a 16-lane float atomic, and only 46 % of the lanes of an 8x8 block carry a contributing pair.
+// Here the roles are swapped:
+//   * lane = SPLAT.  A wave is four independent 16-lane rows; row b owns one 4x4 pixel block of the wave's 8x8 quadrant and
+//     holds, one per lane, 16 splats of that block's culled queue (their packed records live in VGPRs for 16 pixel steps).
+//     4x4 blocks are culled with the same exact region test as the 8x8 blocks of the forward: 69 % of the lane slots carry a
+//     contributing pair instead of 46 % (measured on the BASELINE scene).
+//   * the row walks its block's 16 PIXELS; the pixels' constants (upstream gradients, final T, M1, M2, contributor counts) stay in
+//     the registers of the lane that loaded them (lane j <-> pixel j of the block) and reach the 16 splat lanes through DPP
+//     row_newbcast:i, fused into the consuming VOP2 instruction wherever a constant is used as a plain multiplicand / addend
+//     (first version: broadcast reads from an LDS copy -- 8 ds_read_b128 per step kept the LDS pipe 71 % busy, 0.87 ms).  The reference's ten per-pixel recurrences (T, accum colour / depth / alpha / normal, last_dL_dT;
+//     SURFEL backward.cu:279-447) collapse algebraically into two: every "(c - accum_c) * dL_dc" term is linear in the channel
+//     value, so with u_j = sum_ch c_{j,ch} dL_ch
+//           dL_dalpha_j = u_j T_j - (sum_{k deeper than j} w_k u_k + T_final <bg, dL_dC>) / (1 - alpha_j),   w_k = alpha_k T_k,
+//           T_j = T_behind / prod_{k deeper or equal j} (1 - alpha_k).
+//     Both are SCANS over the row (4 in-place DPP steps each, lane 0 = deepest), chained from one 16-splat load of the row to the
+//     next through a per-pixel carry (T, S) held, again, by lane j of the row.  No forward-side checkpoints are needed: the chain starts at the stored
+//     final T / last contributor exactly like the reference's replay.
+//   * each lane accumulates its splat's 9 / 16 / 18 gradient components in REGISTERS over the 16 pixels -- no cross-lane
+//     reduction at all -- and adds them once per load into a per-tile LDS table indexed by the tile-list entry (ds_add_f32);
+//     the table is flushed once per tile with one 16-lane atomic per list entry that received anything (37 % of the tile
+//     instances contribute to no pixel and cost nothing): 0.87 M accumulator line-operations per launch instead of 1.92 M.
+// Reference semantics: 3DGS backward.cu:399-557, SURFEL backward.cu:143-447, PLANE backward.cu:399-614 (gates, thresholds, the
+// median-normal quirk, no gradient through the 0.99 clamp test); see DESIGN.md "splat-parallel backward".
+#include "gsr_blend_common.h"
+
+#if defined(SP_WPE)
+#define SP_OCC __attribute__((amdgpu_waves_per_eu(SP_WPE, SP_WPE)))
+#else
+#define SP_OCC
+#endif
+#if 0
+#define SP_WPE 3               // waves per SIMD the register budget is sized for (3 -> 168 VGPRs: no spills in the 16 unrolled pixel steps)
+#endif
+#define SP_CH 256                 // tile-list entries per chunk (LDS table / queues); longer lists take several chunks
+
+template <int V> struct SpTraits;
+template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 9; };
+template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = 17; };
+template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 19; };
+
+// inclusive scans along the 16 lanes of each DPP row, lane 0 first, in place.  A lane whose source would lie outside the row is
+// disabled by the hardware (bound_ctrl off) and keeps its value -- exactly the Hillis-Steele step.  s_nop 1 = the two wait states
+// between a VALU write and a DPP read of the same VGPR, which the assembler cannot see inside an asm block.
+__device__ __forceinline__ float row_scan_mul(float x)
+{
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float row_scan_add(float x)
+{
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ uint32_t row_max_u32(uint32_t v)      // every lane of a 16-lane row <- the row's maximum
+{
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 16));
+    return v;
+}
+__device__ __forceinline__ void lds_addf(float* p, float v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// ---- row broadcast of lane I: DPP row_newbcast (gfx90a+), either materialised (mov) or fused into the consuming VOP2 operation.
+// The fused forms are inline assembly (hipcc folds a DPP mov into its consumer only sporadically); their DPP operand is always a
+// LONG-LIVED per-pixel constant register, never a value produced by the preceding instructions, so the "VALU write -> DPP read"
+// wait states are satisfied by construction -- tools/audit_dpp.py checks that on the generated ISA after every build.
+template <int I> __device__ __forceinline__ float bc_mov(float c)
+{
+    float r;
+    asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(c), "n"(I));
+    return r;
+}
+template <int I> __device__ __forceinline__ uint32_t bc_movu(uint32_t c)
+{
+    uint32_t r;
+    asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(c), "n"(I));
+    return r;
+}
+template <int I> __device__ __forceinline__ float bc_mul(float c, float x)               // bcast(c) * x
+{
+    float r;
+    asm volatile("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(c), "v"(x), "n"(I));
+    return r;
+}
+template <int I> __device__ __forceinline__ float bc_add(float c, float x)               // bcast(c) + x
+{
+    float r;
+    asm volatile("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(c), "v"(x), "n"(I));
+    return r;
+}
+template <int I> __device__ __forceinline__ float bc_fmac(float acc, float c, float x)   // acc + bcast(c) * x
+{
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(x), "n"(I));
+    return acc;
+}
+// lane I of each row -> every lane of the row, for a value that is (re)written inside the loop: builtin form, so that the compiler
+// sees the DPP read and places the wait states itself
+template <int I> __device__ __forceinline__ float bc_fresh(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + I, 0xf, 0xf, true));
+}
+
+// Opaque in-place use of the accumulators at the end of every pixel step.  The accumulations are pure arithmetic whose only reader is
+// the table flush after step 15, so LLVM sinks each step's gradient maths below all later steps and keeps ~8 values per step alive
+// for it (216 live VGPRs at step 13); pinned, every step finishes its own work.
+template <int N> __device__ __forceinline__ void sp_pin(float* a)
+{
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]));
+    if constexpr (N > 9) asm volatile("" : "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+    if constexpr (N > 16) asm volatile("" : "+v"(a[16]), "+v"(a[17]));
+}
+
+// per-pixel constants, lane j of a row holds those of pixel j of the row's 4x4 block
+template <int V> struct SpPix;
+template <> struct SpPix<GSR_EWA> { float dLp0, dLp1, dLp2, Tc, Sc, rowx, rowy; uint32_t last; };
+template <> struct SpPix<GSR_PLANE> { float dLp0, dLp1, dLp2, dA0, dA1, dA2, dA3, dA4, Tc, Sc, rowx, rowy; uint32_t last; };
+template <> struct SpPix<GSR_SURFEL> {
+    float dLp0, dLp1, dLp2, dLd, dLa, dLr, dN0, dN1, dN2, dLmd, dMN0, dMN1, dMN2, fA, fD, fD2, Tc, Sc, rowx, rowy;
+    uint32_t last, med;
+};
+
+// one pixel step of a row: pixel I of the block against the 16 splats held by the row's lanes
+template <int V, int I, int NACC>
+__device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
+                                        bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc)
+{
+    const float pxf = K.rowx + (float)(I & 3), pyf = K.rowy + (float)(I >> 2);
+    const uint32_t last = bc_movu<I>(K.last);
+    if constexpr (V != GSR_SURFEL) {
+        const float dx = q0.x - pxf, dy = q0.y - pyf;
+        const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+        const float G = __expf(power);
+        const float alpha = fminf(0.99f, q1.y * G);
+        const bool ok = valid & (idx0 < last) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
+        const float al = ok ? alpha : 0.0f, Gm = ok ? G : 0.0f;
+        const float om = 1.f - al;
+        const float pi = row_scan_mul(om);
+        const float Tj = bc_fresh<I>(K.Tc) * rcp_(pi);
+        const float w = al * Tj;
+        float u = bc_mul<I>(K.dLp0, q1.z);
+        u = bc_fmac<I>(u, K.dLp1, q1.w);
+        u = bc_fmac<I>(u, K.dLp2, q2.x);
+        if constexpr (V == GSR_PLANE) {
+            if (geo) {
+                u = bc_fmac<I>(u, K.dA0, q2.y); u = bc_fmac<I>(u, K.dA1, q2.z); u = bc_fmac<I>(u, K.dA2, q2.w);
+                u = bc_fmac<I>(u, K.dA3, q3.x); u = bc_fmac<I>(u, K.dA4, q3.y);
+            }
+        }
+        const float wu = w * u;
+        const float si = row_scan_add(wu);
+        const float Scb = bc_fresh<I>(K.Sc);
+        const float Sfx = Scb + (si - wu);
+        const float r1a = rcp_(om);
+        const float dL_dalpha = ok ? (u * Tj - Sfx * r1a) : 0.0f;
+        {   // new carry of pixel I = the state in front of lane 15's splat
+            const float nT = bc_fresh<15>(Tj), nS = bc_fresh<15>(Scb + si);
+            const bool mine = (j == I);
+            K.Tc = mine ? nT : K.Tc; K.Sc = mine ? nS : K.Sc;
+        }
+        const float dL_dG = q1.y * dL_dalpha;
+        const float gdx = Gm * dx, gdy = Gm * dy;
+        const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+        const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+        const float g_mx = dL_dG * dG_ddelx * ddelx_dx;
+        const float g_my = dL_dG * dG_ddely * ddely_dy;
+        acc[0] = bc_fmac<I>(acc[0], K.dLp0, w); acc[1] = bc_fmac<I>(acc[1], K.dLp1, w); acc[2] = bc_fmac<I>(acc[2], K.dLp2, w);
+        acc[3] += Gm * dL_dalpha;
+        acc[4] += g_mx; acc[5] += g_my;
+        acc[6] += -0.5f * gdx * dx * dL_dG;
+        acc[7] += -0.5f * gdx * dy * dL_dG;
+        acc[8] += -0.5f * gdy * dy * dL_dG;
+        if constexpr (V == GSR_PLANE) {
+            acc[9] += fabsf(g_mx); acc[10] += fabsf(g_my);
+            if (geo) {
+                acc[11] = bc_fmac<I>(acc[11], K.dA0, w); acc[12] = bc_fmac<I>(acc[12], K.dA1, w); acc[13] = bc_fmac<I>(acc[13], K.dA2, w);
+                acc[14] = bc_fmac<I>(acc[14], K.dA3, w); acc[15] = bc_fmac<I>(acc[15], K.dA4, w);
+            }
+        }
+    } else {
+        const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
+        const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
+        const float opa = q2.w;
+        const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
+        const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
+        const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
+        const float rpz = (ppz == 0.0f) ? 0.0f : rcp_nr(ppz);
+        const float sx = ppx * rpz, sy = ppy * rpz;
+        const float rho3d = sx * sx + sy * sy;
+        const float dx = q2.y - pxf, dy = q2.z - pyf;
+        const float rho2d = FILTER_INV_SQ * (dx * dx + dy * dy);
+        const float rho = fminf(rho3d, rho2d);
+        const bool b3 = rho3d <= rho2d;
+        const float c_d = b3 ? (sx * Tw0 + sy * Tw1) + Tw2 : Tw2;
+        const float power = -0.5f * rho;
+        const float G = __expf(power);
+        const float alpha = fminf(0.99f, opa * G);
+        const bool ok = valid & (idx0 < last) & !(ppz == 0.0f) & !(c_d < NEAR_N) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
+        const float al = ok ? alpha : 0.0f, cd = ok ? c_d : 1.0f, okf = ok ? 1.0f : 0.0f;
+        const float om = 1.f - al;
+        const float pi = row_scan_mul(om);
+        const float Tj = bc_fresh<I>(K.Tc) * rcp_(pi);
+        const float w = al * Tj;
+        const float rcd = rcp_(cd);
+        const float m_d = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcd);
+        const float dmd_dd = ((FAR_N * NEAR_N) / (FAR_N - NEAR_N)) * rcd * rcd;
+        // dL_dweight = (M2 + m^2 A - 2 m M1) dL_dreg  (SURFEL backward.cu:347-364, with the final A, M1, M2 of the pixel)
+        float t1 = bc_mul<I>(K.fA, m_d * m_d);
+        t1 = bc_add<I>(K.fD2, t1);
+        const float t2 = bc_mul<I>(K.fD, m_d);
+        t1 = fmaf(-2.0f, t2, t1);
+        const float dL_dweight = bc_mul<I>(K.dLr, t1);
+        float u = bc_add<I>(K.dLa, dL_dweight);
+        u = bc_fmac<I>(u, K.dLd, cd);
+        u = bc_fmac<I>(u, K.dLp0, q3.w); u = bc_fmac<I>(u, K.dLp1, q4.x); u = bc_fmac<I>(u, K.dLp2, q4.y);
+        u = bc_fmac<I>(u, K.dN0, q3.x); u = bc_fmac<I>(u, K.dN1, q3.y); u = bc_fmac<I>(u, K.dN2, q3.z);
+        const float wu = w * u;
+        const float si = row_scan_add(wu);
+        const float Scb = bc_fresh<I>(K.Sc);
+        const float Sfx = Scb + (si - wu);
+        const float r1a = rcp_(om);
+        const float dL_dalpha = ok ? (u * Tj - Sfx * r1a) : 0.0f;
+        {
+            const float nT = bc_fresh<15>(Tj), nS = bc_fresh<15>(Scb + si);
+            const bool mine = (j == I);
+            K.Tc = mine ? nT : K.Tc; K.Sc = mine ? nS : K.Sc;
+        }
+        const uint32_t med = bc_movu<I>(K.med);
+        const float dLmd = bc_mov<I>(K.dLmd);
+        float dL_dz = (ok & (idx0 + 1u == med)) ? dLmd : 0.0f;      // contributor == median_contributor-1
+        // dL_dmd = 2 w (m A - M1) dL_dreg
+        const float t3 = bc_mul<I>(K.fA, m_d) - bc_mov<I>(K.fD);
+        const float dL_dmd = bc_mul<I>(K.dLr, 2.0f * w * t3);
+        dL_dz += dL_dmd * dmd_dd;
+        dL_dz = bc_fmac<I>(dL_dz, K.dLd, w);
+        const float dL_dG = opa * dL_dalpha;
+        const float dL_dG3 = b3 ? dL_dG : 0.0f, dL_dG2 = b3 ? 0.0f : dL_dG, dL_dz3 = b3 ? dL_dz : 0.0f;
+        const float dL_dsx = dL_dG3 * -G * sx + dL_dz3 * Tw0;
+        const float dL_dsy = dL_dG3 * -G * sy + dL_dz3 * Tw1;
+        const float dpx = dL_dsx * rpz, dpy = dL_dsy * rpz, dpz = -(dpx * sx + dpy * sy);
+        const float tux = dpy * lz - dpz * ly, tuy = dpz * lx - dpx * lz, tuz = dpx * ly - dpy * lx;
+        const float tvx = ky * dpz - kz * dpy, tvy = kz * dpx - kx * dpz, tvz = kx * dpy - ky * dpx;
+        // accumulator layout (SURFEL): 0-2 colour, 3 opacity, 4-6 normal, 7-15 transMat, 16-17 mean2D
+        acc[0] = bc_fmac<I>(acc[0], K.dLp0, w); acc[1] = bc_fmac<I>(acc[1], K.dLp1, w); acc[2] = bc_fmac<I>(acc[2], K.dLp2, w);
+        acc[3] += G * dL_dalpha;
+        acc[4] = bc_fmac<I>(acc[4], K.dN0, w); acc[5] = bc_fmac<I>(acc[5], K.dN1, w); acc[6] = bc_fmac<I>(acc[6], K.dN2, w);
+        acc[4] = bc_fmac<I>(acc[4], K.dMN0, okf); acc[5] = bc_fmac<I>(acc[5], K.dMN1, okf); acc[6] = bc_fmac<I>(acc[6], K.dMN2, okf);   // median-normal quirk (backward.cu:381)
+        acc[7] += tux; acc[8] += tuy; acc[9] += tuz; acc[10] += tvx; acc[11] += tvy; acc[12] += tvz;
+        acc[13] += dL_dz3 * sx - (pxf * tux + pyf * tvx);
+        acc[14] += dL_dz3 * sy - (pxf * tuy + pyf * tvy);
+        acc[15] += dL_dz - (pxf * tuz + pyf * tvz);
+        acc[16] += dL_dG2 * (-G * FILTER_INV_SQ * dx);
+        acc[17] += dL_dG2 * (-G * FILTER_INV_SQ * dy);
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
+{
+    using TR = SpTraits<V>;
+    constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
+    constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
+    constexpr int NACC = TR::NACC, TS = TR::TS;
+
+    __shared__ float s_table[SP_CH * TS];                   // [entry][component]
+    __shared__ uint32_t s_ids[SP_CH];
+    __shared__ uint16_t s_mask[SP_CH];                      // bit (BY * 4 + BX): entry reaches 4x4 block (BX, BY) of the tile
+    __shared__ uint8_t s_queue[4 * 4 * SP_CH];              // [wave][block][position] -> chunk-local entry, list order
+    __shared__ uint32_t s_wmax[4];
+
+    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap);
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = lane >> 4, j = lane & 15;                 // row (= 4x4 block of the quadrant), slot / pixel inside it
+    const int qx = tx * GSR_TILE + (wave & 1) * GSR_SUB, qy = ty * GSR_TILE + (wave >> 1) * GSR_SUB;
+    const int px = qx + (b & 1) * 4 + (j & 3), py = qy + (b >> 1) * 4 + (j >> 2);
+    const bool inside = px < p.W && py < p.H;
+    const uint2 range = p.ranges[tile];
+    const size_t HW = (size_t)p.W * p.H;
+    const uint32_t pix_id = inside ? (uint32_t)p.W * py + px : 0u;
+
+    // ---------------------------------------------------------------- per-pixel constants (lane = pixel), kept in registers
+    SpPix<V> K;
+    const float T_final = inside ? p.final_T[pix_id] : 0.f;
+    K.last = inside ? p.n_contrib[pix_id] : 0u;
+    K.dLp0 = K.dLp1 = K.dLp2 = 0.f;
+    if (inside && p.dL_dcolor) { K.dLp0 = p.dL_dcolor[pix_id]; K.dLp1 = p.dL_dcolor[HW + pix_id]; K.dLp2 = p.dL_dcolor[2 * HW + pix_id]; }
+    K.rowx = (float)(qx + (b & 1) * 4); K.rowy = (float)(qy + (b >> 1) * 4);
+    K.Tc = T_final;                                          // the chain starts behind the last contributor ...
+    K.Sc = T_final * (p.bg[0] * K.dLp0 + p.bg[1] * K.dLp1 + p.bg[2] * K.dLp2);      // ... with the background term of dL_dalpha folded in
+    const bool geo = (V == GSR_PLANE) && p.render_geo;
+    if constexpr (V == GSR_PLANE) {
+        float dA[5] = { 0, 0, 0, 0, 0 };
+        if (geo && inside) {                                 // PLANE backward.cu:433,460-490: plane-depth chain folded into the all_map gradients
+            const float rayx = (float)(((float)px - p.W * 0.5) / p.fx), rayy = (float)(((float)py - p.H * 0.5) / p.fy);
+            if (p.dL_dout_all_map)
+                for (int c = 0; c < 5; c++) dA[c] = p.dL_dout_all_map[c * HW + pix_id];
+            const float nx = p.all_map_pixels[pix_id], ny = p.all_map_pixels[HW + pix_id], nz = p.all_map_pixels[2 * HW + pix_id];
+            const float distance = p.all_map_pixels[4 * HW + pix_id];
+            const float tmp = (float)(nx * rayx + ny * rayy + nz + 1.0e-8);
+            const float dpd = p.dL_dplane_depth ? p.dL_dplane_depth[pix_id] : 0.f;
+            dA[4] += (-dpd / tmp);
+            dA[0] += dpd * (distance / (tmp * tmp) * rayx);
+            dA[1] += dpd * (distance / (tmp * tmp) * rayy);
+            dA[2] += dpd * (distance / (tmp * tmp));
+        }
+        K.dA0 = dA[0]; K.dA1 = dA[1]; K.dA2 = dA[2]; K.dA3 = dA[3]; K.dA4 = dA[4];
+    }
+    if constexpr (V == GSR_SURFEL) {
+        K.dLd = K.dLa = K.dLr = K.dN0 = K.dN1 = K.dN2 = K.dLmd = K.dMN0 = K.dMN1 = K.dMN2 = K.fD = K.fD2 = 0.f;
+        K.med = 0; K.fA = 1.f - T_final;
+        if (inside) {                                        // SURFEL backward.cu:205-243
+            K.med = p.n_contrib[pix_id + HW];
+            if (p.dL_dothers) {
+                const float* g = p.dL_dothers;
+                K.dLd = g[0 * HW + pix_id]; K.dLa = g[1 * HW + pix_id]; K.dN0 = g[2 * HW + pix_id]; K.dN1 = g[3 * HW + pix_id]; K.dN2 = g[4 * HW + pix_id];
+                K.dLmd = g[5 * HW + pix_id]; K.dLr = g[6 * HW + pix_id]; K.dMN0 = g[8 * HW + pix_id]; K.dMN1 = g[9 * HW + pix_id]; K.dMN2 = g[10 * HW + pix_id];
+            }
+            K.fD = p.final_T[pix_id + HW]; K.fD2 = p.final_T[pix_id + 2 * HW];
+        }
+    }
+    const uint32_t mlast_row = row_max_u32(K.last);                                 // deepest contributor of this 4x4 block
+    uint32_t mlast_b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) mlast_b[k] = (uint32_t)__builtin_amdgcn_readlane((int)mlast_row, 16 * k);
+    const uint32_t wmax = max(max(mlast_b[0], mlast_b[1]), max(mlast_b[2], mlast_b[3]));
+    if (lane == 0) s_wmax[wave] = wmax;
+    __syncthreads();
+    const uint32_t tile_max = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    if (tile_max == 0) return;                              // block-uniform
+
+    uint8_t* myqueue = s_queue + (wave * 4 + b) * SP_CH;
+    int bitk[4];                                            // bit of block k (row k of this wave) in the 16-bit tile mask
+#pragma unroll
+    for (int k = 0; k < 4; k++) bitk[k] = (((wave >> 1) * 2 + (k >> 1)) * 4) + ((wave & 1) * 2 + (k & 1));
+    const float ddelx_dx = 0.5f * p.W, ddely_dy = 0.5f * p.H;
+
+    const int nchunks = (int)((tile_max + SP_CH - 1) / SP_CH);
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const uint32_t cbase = (uint32_t)ch * SP_CH;
+        const uint32_t n = min((uint32_t)SP_CH, tile_max - cbase);
+        // ------------------------------------------------------------ stage: ids, 4x4-block masks, zero the table
+        {
+            const uint32_t t = threadIdx.x;
+            if (t < n) {
+                const uint32_t id = p.point_list[range.x + cbase + t];
+                s_ids[t] = id;
+                const float4 ca = p.cull[2 * (size_t)id], cb = p.cull[2 * (size_t)id + 1];
+                uint32_t m = 0;
+#pragma unroll
+                for (int by = 0; by < 4; by++)
+#pragma unroll
+                    for (int bx = 0; bx < 4; bx++)
+                        if (cull_hit_rec<V>(ca, cb, (float)(tx * GSR_TILE + bx * 4), (float)(ty * GSR_TILE + by * 4), 3.f)) m |= 1u << (by * 4 + bx);
+                s_mask[t] = (uint16_t)m;
+            }
+            for (uint32_t q = t; q < n * TS; q += 256) s_table[q] = 0.f;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ per-wave queues (list order), one per 4x4 block
+        uint32_t cnt[4] = { 0, 0, 0, 0 };
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const uint32_t m16 = (e < n) ? (uint32_t)s_mask[e] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool hit = ((m16 >> bitk[k]) & 1u) && (cbase + e < mlast_b[k]);
+                const uint64_t bm = __ballot(hit);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                if (hit) s_queue[(wave * 4 + k) * SP_CH + cnt[k] + rank] = (uint8_t)e;
+                cnt[k] += (uint32_t)__popcll(bm);
+            }
+        }
+        const int Qmine = (int)(b == 0 ? cnt[0] : (b == 1 ? cnt[1] : (b == 2 ? cnt[2] : cnt[3])));
+        const int loads = (int)((max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])) + 15u) >> 4);
+
+        // ------------------------------------------------------------ 16 splats per row x 16 pixel steps
+        for (int ld = 0; ld < loads; ld++) {
+            const int pos = Qmine - 1 - (16 * ld + j);      // lane 0 = deepest entry of this load
+            const bool valid = pos >= 0;
+            const uint32_t e = valid ? (uint32_t)myqueue[pos] : 0u;
+            const uint32_t gid = s_ids[e];
+            const uint32_t idx0 = cbase + e;                // 0-based position in the tile list == the reference's `contributor`
+            const float4* __restrict__ r = p.rec + (size_t)gid * ST;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 q0 = valid ? r[0] : z4, q1 = valid ? r[1] : z4, q2 = valid ? r[2] : z4;
+            float4 q3 = z4, q4 = z4;
+            if (V != GSR_EWA) q3 = valid ? r[3] : z4;
+            if (V == GSR_SURFEL) q4 = valid ? r[4] : z4;
+            float acc[NACC];
+#pragma unroll
+            for (int c = 0; c < NACC; c++) acc[c] = 0.f;
+            // `never` is a wave-uniform, never-true condition the compiler cannot fold: the (untaken) scalar branch after every step ends
+            // the basic block, so the 16 unrolled steps are scheduled one at a time -- as ONE block the scheduler overlaps them and the
+            // kernel needs 280+ VGPRs (one wave per SIMD); split, every step's temporaries die inside the step.
+            const bool never = p.gx == 0x7fffffff;
+#define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc); sp_pin<NACC>(acc); if (never) asm volatile("s_nop 0");
+            SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6) SP_STEP(7)
+            SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11) SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
+#undef SP_STEP
+#ifndef SP_EXPERIMENT_NO_TABLE
+            if (valid) {
+                float* t = s_table + e * TS;
+#pragma unroll
+                for (int c = 0; c < NACC; c++) lds_addf(t + c, acc[c]);
+            }
+#else
+            if (valid && acc[0] == 12345.f) s_table[e * TS] = acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7] + acc[8];
+#endif
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ flush: one 16-lane atomic per entry that received anything
+        for (uint32_t e = threadIdx.x >> 4; e < n; e += 16) {
+            const uint32_t c = threadIdx.x & 15u;
+            float* dst = p.acc + (size_t)s_ids[e] * AS;
+            if ((int)c < NACC) {
+                const float v = s_table[e * TS + c];
+                if (v != 0.f) atomic_addf(dst + c, v);
+            }
+            if (NACC > 16 && (int)c < NACC - 16) {
+                const float v = s_table[e * TS + 16 + c];
+                if (v != 0.f) atomic_addf(dst + 16 + c, v);
+            }
+        }
+        if (ch > 0) __syncthreads();
+    }
+}
+
+int gsr_launch_blend_bwd_sp(const BlendParams& p, int variant, hipStream_t s)
+{
+    dim3 grid(p.gx * p.gy), block(256);
+    switch (variant) {
+    case GSR_EWA: hipLaunchKernelGGL(k_blend_bwd_sp<GSR_EWA>, grid, block, 0, s, p); break;
+    case GSR_PLANE: hipLaunchKernelGGL(k_blend_bwd_sp<GSR_PLANE>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(k_blend_bwd_sp<GSR_SURFEL>, grid, block, 0, s, p); break;
+    }
+    return 0;
+}

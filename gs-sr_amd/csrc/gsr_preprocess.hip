@@ -96,6 +96,10 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
         // cull record for the blend kernels: conic form + 2*tau (the pair contributes iff dT Q d <= 2 tau)
         cull0 = make_float4(pix, piy, conA, conB);
         cull1 = make_float4(conC, two_tau(o), 0.f, 0.f);
+        // the block test (gsr_blend.hip conic_min_over_block) assumes a positive-definite form: fp32 cancellation in det = a c - b^2 can
+        // leave a huge / near-degenerate splat with an indefinite conic, whose per-pixel gates the reference would still evaluate.
+        // Anything doubtful disables culling for this splat (A = B = C = 0 with tt > 0 always hits), as for surfels.
+        if (!(conA > 0.f && conC > 0.f && conA * conC - conB * conB > 0.f)) { cull0.z = 0.f; cull0.w = 0.f; cull1.x = 0.f; if (!(cull1.y > 0.f)) cull1.y = -1.f; }
         if (p.no_cull) { cull0 = make_float4(pix, piy, 0.f, 0.f); cull1 = make_float4(0.f, 1.0f, 0.f, 0.f); }
     } while (0);
 

@@ -7,6 +7,7 @@ imgBuffer) are torch tensors allocated here; the arenas are saved for backward.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -20,7 +21,13 @@ def cpu_deep_copy_tuple(input_tuple):
 
 # Expected number of tile instances per (device, variant, W, H): sizes the binning arena of the NEXT forward so that
 # stage 2 can be enqueued without waiting for the host to learn num_rendered (gsr_forward).  GSR_SPECULATIVE=0 disables.
+# Policy (per key): the hint is a slowly decaying running maximum of the instance counts seen (max(R, 0.9 * previous hint)), so
+# alternating cameras / scenes with different counts at one resolution do not overflow on every other call; after two overflows
+# in a row the key falls back to the reference-shaped stage1 -> sync -> stage2 path for the next 8 calls.  `capacity_hint` lets a
+# caller that knows better pass the expected count itself.  Guarded by a lock: the dicts are the only Python-side shared state.
 _R_HINT = {}
+_R_OVERFLOWS = {}     # key -> [consecutive overflows, calls left on the exact path]
+_HINT_LOCK = threading.Lock()
 _SPECULATIVE = os.environ.get("GSR_SPECULATIVE", "1") != "0"
 
 
@@ -46,7 +53,8 @@ def _prepare(variant, means3D, sh, colors_precomp, opacities, scales, rotations,
     return cfg, inp, keep, P, M
 
 
-def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, all_map, settings):
+def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, all_map, settings,
+            capacity_hint=None):
     """Returns (num_rendered, outputs dict, radii, geomBuffer, binningBuffer, imgBuffer)."""
     L = lib()
     dev = means3D.device
@@ -79,7 +87,15 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
     o = Outputs(ptr(outs["color"]), ptr(outs.get("others")), ptr(outs.get("observe")), ptr(outs.get("all_map")),
                 ptr(outs.get("plane_depth")))
     key = (dev.index, variant, W, H)
-    hint = _R_HINT.get(key) if (_SPECULATIVE and not cfg.debug) else None
+    hint = None
+    if _SPECULATIVE and not cfg.debug:
+        with _HINT_LOCK:
+            st = _R_OVERFLOWS.get(key)
+            if st is not None and st[1] > 0:
+                st[1] -= 1                      # this key overflowed repeatedly: exact path for a while
+            else:
+                hint = capacity_hint if capacity_hint is not None else _R_HINT.get(key)
+    overflowed = False
     with torch.cuda.device(dev):
         if hint is not None:
             # steady state: one call, no GPU idle gap at the sync (arena sized from the previous call + 25 % head-room)
@@ -88,6 +104,7 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
             check(L.gsr_forward(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(), ptr(img),
                                 img.numel(), ptr(radii), C.byref(o), C.byref(R), C.byref(ovf), s), "forward")
             if ovf.value:
+                overflowed = True
                 binning = _bytes(L.gsr_binning_bytes(variant, R.value, W, H), dev)
                 if "observe" in outs:
                     outs["observe"].zero_()
@@ -98,7 +115,16 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
             binning = _bytes(L.gsr_binning_bytes(variant, R.value, W, H), dev)
             check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
                                        ptr(img), img.numel(), R.value, C.byref(o), s), "forward")
-    _R_HINT[key] = int(R.value)
+    with _HINT_LOCK:
+        prev = _R_HINT.get(key)
+        _R_HINT[key] = int(R.value) if (prev is None or overflowed) else max(int(R.value), int(0.9 * prev))
+        st = _R_OVERFLOWS.setdefault(key, [0, 0])
+        if overflowed:
+            st[0] += 1
+            if st[0] >= 2:
+                st[0], st[1] = 0, 8
+        elif hint is not None:
+            st[0] = 0
     return int(R.value), outs, radii, geom, binning, img
 
 

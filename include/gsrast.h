@@ -28,6 +28,11 @@
  *     default stream; pass torch.cuda.current_stream().cuda_stream from PyTorch.
  *   - Matrices follow the reference's row-vector convention: p_view = [x y z 1] * viewmatrix (16 floats, row-major).
  *   - Layouts: images are CHW float32; radii/out_observe are int32; quaternions are (w,x,y,z).
+ *   - Threading: every entry point may be called concurrently from several host threads and on several streams of one device.
+ *     All per-call state lives in caller-owned buffers.  The library's only process-wide state is (i) one pinned mailbox per
+ *     device for the num_rendered read-back, whose slots are handed out with an atomic ticket + per-slot busy flag (a forward owns
+ *     its slot until it has read the word), (ii) the optional stage profiler (gsr_profile_*), a mutex-guarded event list, and
+ *     (iii) read-once environment switches.  tests/test_gpu_stress.py runs forwards from two threads on two streams.
  */
 #ifndef GSRAST_H
 #define GSRAST_H
