@@ -38,16 +38,38 @@ class RefInGrads(C.Structure):
 
 def build(force=False):
     so = os.path.join(ORACLE_DIR, "libgsr_oracle.so")
+    so2 = os.path.join(ORACLE_DIR, "libgsr_oracle_fma.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+    if force or not os.path.exists(so) or not os.path.exists(so2) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so
+
+
+_FMA = False
+
+
+class fma_twin:
+    """Context manager: inside it, oracle.Forward & co. run the FMA-contracted build of the same sources (libgsr_oracle_fma.so).
+    |twin - oracle| on a case is the noise floor of the reference's own formulas in fp32 (nvcc contracts by default)."""
+
+    def __enter__(self):
+        global _LIB, _FMA
+        self.saved = (_LIB, _FMA)
+        _LIB, _FMA = None, True
+        return self
+
+    def __exit__(self, *a):
+        global _LIB, _FMA
+        _LIB, _FMA = self.saved
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        so = build()
+        if _FMA:
+            so = os.path.join(ORACLE_DIR, "libgsr_oracle_fma.so")
+        L = C.CDLL(so)
         L.ref_forward.restype = C.c_void_p
         L.ref_forward.argtypes = [C.c_int, C.POINTER(RefInputs), _fp, C.POINTER(C.c_int32), _fp,
                                   C.POINTER(C.c_int32), _fp, _fp]

@@ -25,13 +25,16 @@ def _relerr(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
 
 
-def _img_close(a, b, tol=RGB_TOL, frac=1e-4):
+def _img_close(a, b, tol=RGB_TOL, frac=1e-4, floor=None):
     """<= tol everywhere, except a vanishing fraction of pixels where a 1-ulp difference in exp() flips one of the
-    reference's discrete gates (alpha<1/255, T<1e-4; SURVEY §7 hard part 1)."""
+    reference's discrete gates (alpha<1/255, T<1e-4; SURVEY §7 hard part 1).  `floor` = the same output from the FMA-contracted
+    build of the oracle: where given, the allowed fraction is max(frac, 1.5 x the oracle's own self-difference)."""
     d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
     scale = max(1.0, float(np.abs(b).max()))
     bad = (d > tol * scale).mean()
-    assert bad <= frac, f"{bad:.2e} of pixels differ by more than {tol * scale:.1e} (max {d.max():.3e})"
+    if floor is not None:
+        frac = max(frac, 1.5 * float((np.abs(np.asarray(floor, np.float64) - np.asarray(b, np.float64)) > tol * scale).mean()))
+    assert bad <= frac, f"{bad:.2e} of pixels differ by more than {tol * scale:.1e} (max {d.max():.3e}; allowed {frac:.2e})"
 
 
 def _counts_close(a, b):
@@ -42,16 +45,60 @@ def _counts_close(a, b):
     assert d.max() <= 2 and (d > 0).sum() <= max(2, int(1e-3 * a.size)), (int(d.max()), int((d > 0).sum()))
 
 
-def _grad_close(a, b, tol=GRAD_TOL, frac=2e-3):
-    """Gradient parity: relative L2 error <= tol AND at most `frac` of the elements off by more than tol*max|ref|.
+def _grad_close(a, b, tol=GRAD_TOL, frac=2e-3, floor=None):
+    """Gradient parity, three criteria:
+      (1) relative L2 error <= tol;
+      (2) at most `frac` of the elements off by more than tol * max|ref|;
+      (3) PER ELEMENT, |a - b| <= tol * |b| + tol * rms(b) on >= 1 - frac of the elements (north_star: "1e-3 on gradients").
     A handful of outliers is inherent: one-ulp differences (FMA contraction, exp) flip discrete gates / the surfel
     rho3d<=rho2d kink for single (pixel, splat) pairs and re-route that pair's whole gradient.  Building the ORACLE
-    itself with -ffp-contract=fast moves dL_drotations by 1e-3*max on 8 of 16000 elements (parity)."""
+    itself with -ffp-contract=fast moves dL_drotations by 1e-3*max on 8 of 16000 elements (parity).
+    `floor` = the same gradient from the FMA-contracted build of the oracle (BASELINE-size cases): each of the three bars then
+    becomes max(nominal, 1.5 x what the oracle differs from itself by; 3 x for the untrimmed L2), plus (4) relative L2 without the
+    1e-4 worst elements <= max(tol, floor).  At 300k surfels a single edge-on surfel (ray-splat intersection s = p.xy / p.z with
+    p.z ~ 0) moves the relative L2 of dL_dmeans3D by 0.16 between the two oracle builds; measured (profiles/r02_full_size_parity*):
+    the HIP path sits at about HALF the oracle's self-difference on every gradient of every surfel case."""
     a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
-    l2 = np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)
-    out = (np.abs(a - b) > tol * (np.abs(b).max() + 1e-30)).mean()
-    assert l2 <= tol, f"relative L2 error {l2:.2e} > {tol}"
-    assert out <= frac, f"{out:.2e} of elements off by more than {tol}*max (max rel {_relerr(a, b):.2e})"
+    rms = np.sqrt((b * b).mean())
+
+    def metrics(x):
+        e = np.abs(x - b)
+        keep = np.argsort(e)[:e.size - int(np.ceil(1e-4 * e.size))]          # drops the 1e-4 worst-conditioned elements
+        return (np.linalg.norm(x - b) / (np.linalg.norm(b) + 1e-30), (e > tol * (np.abs(b).max() + 1e-30)).mean(),
+                (e > tol * np.abs(b) + tol * rms).mean(), np.linalg.norm((x - b)[keep]) / (np.linalg.norm(b[keep]) + 1e-30))
+    l2, out, per, l2t = metrics(a)
+    bars = [tol, frac, frac, tol]
+    if floor is not None:
+        f = metrics(np.asarray(floor, np.float64).reshape(-1))
+        # untrimmed L2 at this size is one or two ill-conditioned splats against each other: 3 x floor; everything else 1.5 x / 1 x
+        bars = [max(tol, 3.0 * f[0]), max(frac, 1.5 * f[1]), max(frac, 1.5 * f[2]), max(tol, f[3])]
+    assert l2 <= bars[0], f"relative L2 error {l2:.2e} > {bars[0]:.2e}"
+    assert out <= bars[1], f"{out:.2e} of elements off by more than {tol}*max (max rel {_relerr(a, b):.2e}; allowed {bars[1]:.2e})"
+    assert per <= bars[2], f"{per:.2e} of elements fail |a-b| <= {tol}|b| + {tol} rms(b) (allowed {bars[2]:.2e})"
+    if floor is not None:
+        assert l2t <= bars[3], f"relative L2 error without the 1e-4 worst elements {l2t:.2e} > {bars[3]:.2e}"
+
+
+def _ncontrib_close(nc_hip, nc_ref, ft_hip, ft_ref):
+    """n_contrib (index of the last contributing splat) is bit-exact except where a float gate sits within rounding of its threshold:
+    (A) the termination gate test_T < 1e-4: one side accepted a splat the other stopped at, so the smaller final T lies within
+        1e-6 of 1e-4; or
+    (B) a gate on the LAST contributor itself (alpha < 1/255, the surfel depth / p.z gates): one side blends one more splat, and the
+        two final T differ by that splat's (1 - alpha) -- both sides then agree on every earlier splat, so T_a / T_b is within
+        [0.01, 1) (alpha <= 0.99) but NOT equal.
+    Anything else (equal T but different index, ...) is a logic divergence and fails.  Returns the mismatch fraction."""
+    nc_hip = np.asarray(nc_hip); nc_ref = np.asarray(nc_ref)
+    bad = nc_hip != nc_ref
+    if bad.any():
+        a = np.asarray(ft_hip, np.float64)[bad]; b = np.asarray(ft_ref, np.float64)[bad]
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        gate_a = np.abs(lo - 1e-4) <= 1e-6
+        gate_b = (lo < hi) & (lo >= 0.0099 * hi)
+        unexplained = ~(gate_a | gate_b)
+        assert not unexplained.any(), f"{int(unexplained.sum())} n_contrib mismatches away from every float gate"
+    frac = float(bad.mean())
+    assert frac <= 1e-4, f"n_contrib differs on {frac:.2e} of the pixels"
+    return frac
 
 
 CASES = [
@@ -82,7 +129,9 @@ def test_forward_backward_parity(variant, cm, P, W, H, pose):
         assert np.array_equal(st["ranges"][touched], rr[touched])
         assert np.all(st["ranges"][~touched, 0] == st["ranges"][~touched, 1])
         ft, nc = f.image_state()
-        assert (st["n_contrib"] == nc).mean() > 0.9999
+        _ncontrib_close(st["n_contrib"][0], nc[0], st["final_T"][0], ft[0])
+        if variant == "surfel":
+            assert (st["n_contrib"][1] == nc[1]).mean() > 0.9999          # median contributor: behind the T > 0.5 gate
         # ---- images
         _img_close(st["color"], f.color)
         _img_close(st["final_T"], ft)
@@ -360,3 +409,62 @@ def test_full_size_properties(variant):
     # determinism of the forward
     res3 = hr.run(variant, sc)
     assert np.array_equal(res3["color"], res["color"])
+
+
+# ---- BASELINE full size against the oracle: 300k gaussians, 1920x1080, seeds {0,1,2}, both poses, both colour modes.
+# The oracle runs the whole workload in ~2 s on the GPU host's cores, so there is no reason to stop at properties.
+FULL_CASES = [
+    ("surfel", "precomp", 0, 0), ("surfel", "precomp", 1, 0), ("surfel", "precomp", 2, 1), ("surfel", "sh", 1, 1),
+    ("ewa", "precomp", 0, 0), ("ewa", "sh", 1, 0), ("ewa", "precomp", 2, 1), ("ewa", "sh", 0, 1),
+    ("plane", "precomp", 0, 0), ("plane", "precomp", 1, 1), ("plane", "sh", 2, 0),
+]
+
+
+@pytest.mark.parametrize("variant,cm,seed,pose", FULL_CASES)
+def test_full_size_oracle_parity(variant, cm, seed, pose):
+    """Integer stages bit-exact; images <= 1e-4 and gradients <= 1e-3 against the oracle, each bar relaxed at most to 1.5 x the
+    oracle's own FMA-contraction self-difference measured on the same case (the noise floor of the reference's formulas in fp32)."""
+    hr = _hiprun()
+    P, W, H = 300000, 1920, 1080
+    sc = scenes.make_scene(variant, P, W, H, seed=seed, color_mode=cm, pose=pose, bg=(0.1, 0.3, 0.2) if seed else (0.0, 0.0, 0.0))
+    og = scenes.random_out_grads(variant, W, H, seed=seed)           # SURVEY 8d: N(0,1)/N
+    with oracle.fma_twin():
+        with oracle.Forward(sc, variant) as f2:
+            g2 = f2.backward(**og)
+            fl = dict(color=f2.color.copy(), others=None if f2.others is None else f2.others.copy(),
+                      all_map=None if f2.out_all_map is None else f2.out_all_map.copy(),
+                      plane_depth=None if f2.plane_depth is None else f2.plane_depth.copy(), final_T=f2.image_state()[0])
+    with oracle.Forward(sc, variant) as f:
+        g = f.backward(**og)
+        st = hr.run_raw(variant, sc)
+        assert st["R"] == f.R
+        assert np.array_equal(st["radii"], f.radii)
+        assert np.array_equal(st["tiles_touched"], f.tiles_touched())
+        assert np.array_equal(st["point_list"], f.point_list())
+        rr = f.ranges(); touched = rr[:, 1] > rr[:, 0]
+        assert np.array_equal(st["ranges"][touched], rr[touched])
+        ft, nc = f.image_state()
+        _ncontrib_close(st["n_contrib"][0], nc[0], st["final_T"][0], ft[0])
+        _img_close(st["color"], f.color, floor=fl["color"])
+        _img_close(st["final_T"][0], ft[0], floor=fl["final_T"][0])
+        if variant == "surfel":
+            for ch in (0, 1, 2, 3, 4, 6):
+                _img_close(st["others"][ch], f.others[ch], floor=fl["others"][ch])
+            # median depth / index / normal sit behind the T > 0.5 gate: equal wherever the median splat agrees
+            same = st["others"][7] == f.others[7]
+            assert same.mean() >= 1 - max(1e-4, 1.5 * float((fl["others"][7] != f.others[7]).mean()))
+            for ch in (5, 8, 9, 10):
+                assert (np.abs(st["others"][ch] - f.others[ch])[same] > 1e-4 * max(1.0, np.abs(f.others[ch]).max())).mean() <= 1e-5
+        if variant == "plane":
+            _counts_close(st["observe"], f.observe)
+            _img_close(st["all_map"], f.out_all_map, floor=fl["all_map"])
+            _img_close(st["plane_depth"], f.plane_depth, frac=1e-3, floor=fl["plane_depth"])
+        res = hr.run(variant, sc, og)
+    gg = res["grads"]
+    pairs = [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"),
+             ("dL_dopacities", "dL_dopacity"), ("dL_dmeans2D", "dL_dmeans2D")]
+    pairs.append(("dL_dshs", "dL_dsh") if cm == "sh" else ("dL_dcolors_precomp", "dL_dcolors"))
+    if variant == "plane":
+        pairs += [("dL_dall_map", "dL_dall_map"), ("dL_dmeans2D_abs", "dL_dmeans2D_abs")]
+    for a, b in pairs:
+        _grad_close(gg[a], g[b], floor=g2[b])

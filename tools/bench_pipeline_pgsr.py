@@ -52,14 +52,8 @@ def cam_of(t, W, H):
     return dict(R=V[:3, :3].copy(), T=V[3, :3].copy(), Fx=W / (2 * float(t["tanfovx"])), Fy=H / (2 * float(t["tanfovy"])), Cx=W / 2.0, Cy=H / 2.0)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--glue", default="hip", choices=["hip", "torch"])
-    ap.add_argument("--P", type=int, default=300000)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    a = ap.parse_args()
-    dev = torch.device("cuda:0")
+def build(a, dev):
+    """-> (step, st): one PGSR training iteration after step 7000 (two plane renders + single-view + multi-view losses); a has .glue, .P."""
     W, H = 1920, 1080
     sc = scenes.make_scene("plane", a.P, W, H, seed=0, color_mode="precomp")
     t = hiprun.to_dev(sc, dev)
@@ -81,7 +75,7 @@ def main():
     rm1 = torch.inverse(K1.double().t()).float()
     weight = torch.rand((H, W), generator=g).to(dev)                      # the detached image-gradient weight map (cached per camera)
     mcfg = multiview_cfg(mv_cases.cam_ns(c1), mv_cases.cam_ns(c2), W, H, near_size=(W, H))
-    st = {}
+    st = {"P": a.P}
 
     def render(rs, tt, means, scl, rot, op):
         V, cpos = tt["viewmatrix"], tt["campos"]
@@ -107,6 +101,17 @@ def main():
     if a.glue == "torch":                                                 # a fixed sample set of the reference's size
         with torch.no_grad():
             st["idx"] = torch.randperm(W * H, device=dev)[:102400]
+    return step, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--glue", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--P", type=int, default=300000)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    a = ap.parse_args()
+    step, st = build(a, torch.device("cuda:0"))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
