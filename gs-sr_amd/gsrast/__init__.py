@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libgsrast_hip.so")   # override: experiments only
 
 EWA, SURFEL, PLANE = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp = C.c_void_p
 
@@ -52,6 +52,12 @@ class MvCfg(C.Structure):
                 [("v2n", C.c_float * 12), ("n2v", C.c_float * 12), ("ncc_scale", C.c_float), ("noise_th", C.c_float), ("patch", C.c_int32)])
 
 
+class TsdfSparse(C.Structure):
+    """gsr_tsdf_sparse (include/gsrast.h)."""
+    _fields_ = [("keys", _vp), ("slot", _vp), ("coord", _vp), ("stamp", _vp), ("list", _vp), ("counters", _vp), ("tsdf", _vp), ("weight", _vp),
+                ("color", _vp), ("cap_hash_log2", C.c_uint32), ("cap_blocks", C.c_uint32), ("voxel_length", C.c_float), ("sdf_trunc", C.c_float)]
+
+
 class LodCfg(C.Structure):
     _fields_ = [("voxel_size", C.c_float), ("fork", C.c_float), ("standard_dist", C.c_float), ("resolution_scale", C.c_float),
                 ("coarse_index", C.c_int32), ("mode", C.c_int32)]
@@ -59,7 +65,7 @@ class LodCfg(C.Structure):
 
 EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward_scratch_bytes",
            "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_visible_filter",
-           "gsr_tsdf_integrate", "gsr_tsdf_integrate_dense", "gsr_loss_l1_linear", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
+           "gsr_tsdf_integrate", "gsr_tsdf_integrate_dense", "gsr_tsdf_sparse_integrate", "gsr_tsdf_sparse_merge", "gsr_loss_l1_linear", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
            "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward",
            "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_octree_visible",
            "gsr_loss_plane_mv_scratch_bytes", "gsr_loss_plane_mv_geo", "gsr_loss_plane_mv_ncc",
@@ -104,6 +110,11 @@ def lib():
     L.gsr_tsdf_integrate_dense.restype = C.c_int
     L.gsr_tsdf_integrate_dense.argtypes = [C.c_int32] * 3 + [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                            _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _vp, _vp, _vp, _vp]
+    L.gsr_tsdf_sparse_integrate.restype = C.c_int
+    L.gsr_tsdf_sparse_integrate.argtypes = [C.POINTER(TsdfSparse), C.c_int32, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32), _vp]
+    L.gsr_tsdf_sparse_merge.restype = C.c_int
+    L.gsr_tsdf_sparse_merge.argtypes = [C.POINTER(TsdfSparse), C.c_int32, _vp, _vp, _vp, _vp, _vp]
     L.gsr_loss_l1_linear.restype = C.c_int
     L.gsr_loss_l1_linear.argtypes = [C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp]
     L.gsr_loss_l1_ssim_scratch_bytes.restype = sz; L.gsr_loss_l1_ssim_scratch_bytes.argtypes = [C.c_int32] * 3

@@ -2,7 +2,7 @@
 compute_unbounded_tsdf (gssr/utils/mesh_utils.py:195-246) as one streaming kernel."""
 import torch
 
-from . import lib, check, ptr, stream_ptr, dev_f32
+from . import lib, check, ptr, stream_ptr, dev_f32, TsdfSparse
 
 
 def tsdf_integrate_(points, full_proj_transform, depthmap, rgbmap, sdf_trunc, tsdfs, rgbs, weights):
@@ -83,3 +83,161 @@ def merge_volumes_(tsdf, weight, color, group=None):
     tsdf.copy_(torch.where(nz, acc / weight.clamp_min(1e-30), torch.zeros_like(acc)))
     color.copy_(torch.where(nz.unsqueeze(-1), cacc / weight.clamp_min(1e-30).unsqueeze(-1), torch.zeros_like(cacc)))
     return tsdf, weight, color
+
+
+class ScalableTSDFVolume:
+    """Block-sparse TSDF volume with the call shape of o3d.pipelines.integration.ScalableTSDFVolume as GS-SR drives it
+    (gssr/utils/mesh_utils.py:154-178: `ScalableTSDFVolume(voxel_length, sdf_trunc, RGB8)`, `integrate(rgbd, intrinsic, extrinsic)` with
+    depth_scale 1 and depth_trunc; extract_mesh.py:125-128 picks voxel_length = depth_trunc / 1024 and sdf_trunc = 5 voxels -- a dense
+    grid of that resolution would be >= 1024^3 voxels, here only the 16^3 units near the observed surface exist).
+    Open3D is not part of the reference tree: PARITY UNPINNED (algorithm restated from Open3D 0.18's published sources, see
+    csrc/gsr_tsdf_sparse.hip); tests pin the HIP volume against a plain-C restatement on the CPU and, unit by unit, against
+    DenseTSDFVolume.
+
+    capacity_units bounds the number of 16^3 units (80 KB each: tsdf + weight + 3 colour floats per voxel); exceeding it raises.
+    Multi-GPU (extract_mesh_split.py:54-128): every rank integrates its own tile's frames, `merge_()` fuses the volumes of all ranks
+    (weighted running averages are associative), `merge_from(other)` fuses two volumes on one device."""
+
+    RES = 16
+
+    def __init__(self, voxel_length, sdf_trunc, capacity_units=16384, device="cuda", depth_sampling_stride=4):
+        self.voxel_length = float(voxel_length)
+        self.sdf_trunc = float(sdf_trunc)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ScalableTSDFVolume lives on a HIP device; there is no CPU path")
+        self.stride = int(depth_sampling_stride)
+        self.cap = int(capacity_units)
+        self.log2 = max(4, (2 * self.cap - 1).bit_length())
+        d = self.device
+        self.keys = torch.full((1 << self.log2,), -1, dtype=torch.int64, device=d)
+        self.slot = torch.zeros((1 << self.log2,), dtype=torch.int32, device=d)
+        self.coord = torch.zeros((self.cap, 3), dtype=torch.int32, device=d)
+        self.stamp = torch.zeros((self.cap,), dtype=torch.int32, device=d)
+        self.list = torch.zeros((self.cap,), dtype=torch.int32, device=d)
+        self.counters = torch.zeros((4,), dtype=torch.int32, device=d)
+        V = self.RES ** 3
+        self.tsdf = torch.zeros((self.cap, V), dtype=torch.float32, device=d)
+        self.weight = torch.zeros((self.cap, V), dtype=torch.float32, device=d)
+        self.color = torch.zeros((self.cap, V, 3), dtype=torch.float32, device=d)
+        self.frame = 0
+        self.last_touched = 0
+
+    def _struct(self):
+        return TsdfSparse(ptr(self.keys), ptr(self.slot), ptr(self.coord), ptr(self.stamp), ptr(self.list), ptr(self.counters), ptr(self.tsdf),
+                          ptr(self.weight), ptr(self.color), self.log2, self.cap, self.voxel_length, self.sdf_trunc)
+
+    def integrate(self, rgb, depth, fx, fy, cx, cy, extrinsic, depth_trunc=float("inf"), quantize_rgb8=True):
+        """rgb [3,H,W] in [0,1], depth [1,H,W] or [H,W] (0 = invalid, as mesh_utils.py:165-166 writes for masked pixels),
+        extrinsic 4x4 world->camera (Open3D convention)."""
+        import ctypes as C
+        d = dev_f32(depth, "depth", allow_empty=False)
+        c = dev_f32(rgb, "rgb", allow_empty=False)
+        if quantize_rgb8:        # mesh_utils.py:170 converts colours to uint8 before fusion
+            c = (torch.clamp(c, 0.0, 1.0) * 255).to(torch.uint8).to(torch.float32).contiguous()
+        H, W = int(d.shape[-2]), int(d.shape[-1])
+        E = torch.as_tensor(extrinsic, dtype=torch.float64).reshape(4, 4).cpu()
+        Pm = torch.linalg.inv(E)
+        Ea = (C.c_float * 12)(*[float(v) for v in E[:3].reshape(-1).tolist()])
+        Pa = (C.c_float * 12)(*[float(v) for v in Pm[:3].reshape(-1).tolist()])
+        self.frame += 1
+        n = C.c_uint32(0)
+        st = self._struct()
+        with torch.cuda.device(self.device):
+            check(lib().gsr_tsdf_sparse_integrate(C.byref(st), W, H, ptr(d), ptr(c), float(fx), float(fy), float(cx), float(cy), Ea, Pa,
+                                                  float(min(depth_trunc, 3.0e38)), self.stride, self.frame, C.byref(n), stream_ptr(self.device)),
+                  "tsdf_sparse_integrate")
+        self.last_touched = int(n.value)
+        return self
+
+    @property
+    def num_units(self):
+        return int(self.counters[0].item())
+
+    def units(self):
+        """-> (coords [n,3] int32, tsdf [n,16,16,16], weight [n,16,16,16], color [n,16,16,16,3]) views of the allocated units
+        (voxel index x-major, z fastest, like Open3D's UniformTSDFVolume::IndexOf)."""
+        n, R = self.num_units, self.RES
+        return self.coord[:n], self.tsdf[:n].view(n, R, R, R), self.weight[:n].view(n, R, R, R), self.color[:n].view(n, R, R, R, 3)
+
+    def merge_units_(self, coords, tsdf, weight, color):
+        """self <- weighted merge with the given units (tensors shaped like `units()`, on this device)."""
+        import ctypes as C
+        n = int(coords.shape[0])
+        if n == 0:
+            return self
+        co = coords.to(torch.int32).contiguous()
+        t, w, c = (x.to(torch.float32).contiguous() for x in (tsdf, weight, color))
+        st = self._struct()
+        with torch.cuda.device(self.device):
+            check(lib().gsr_tsdf_sparse_merge(C.byref(st), n, ptr(co), ptr(t), ptr(w), ptr(c), stream_ptr(self.device)), "tsdf_sparse_merge")
+        return self
+
+    def merge_from(self, other):
+        """Fuses another volume (same voxel_length / sdf_trunc) into this one, e.g. the volumes of two tiles on one device."""
+        if abs(other.voxel_length - self.voxel_length) > 0 or abs(other.sdf_trunc - self.sdf_trunc) > 0:
+            raise RuntimeError("merge_from: volumes must share voxel_length and sdf_trunc")
+        co, t, w, c = other.units()
+        return self.merge_units_(co.to(self.device), t.to(self.device), w.to(self.device), c.to(self.device))
+
+    def merge_(self, group=None):
+        """Fuses the volumes of all ranks; afterwards every rank holds the same fused volume (unit numbering may differ between ranks).
+        One all_gather of the unit counts, then one padded all_gather per array: the payload is the allocated units only."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self
+        co, t, w, c = self.units()
+        merged = merge_unit_lists(*gather_unit_lists(co, t.reshape(len(co), -1), w.reshape(len(co), -1), c.reshape(len(co), -1, 3), group))
+        fresh = ScalableTSDFVolume(self.voxel_length, self.sdf_trunc, max(self.cap, int(merged[0].shape[0])), self.device, self.stride)
+        fresh.merge_units_(*merged)
+        fresh.frame = self.frame
+        self.__dict__.update(fresh.__dict__)
+        return self
+
+    def to_dense(self, origin_unit, dims_units):
+        """Dense (tsdf, weight, color) arrays over a box of units [origin_unit, origin_unit + dims_units): test / export helper."""
+        R = self.RES
+        ox, oy, oz = (int(v) for v in origin_unit); nx, ny, nz = (int(v) for v in dims_units)
+        T = torch.zeros((nx * R, ny * R, nz * R), dtype=torch.float32, device=self.device)
+        Wt = torch.zeros_like(T); Cc = torch.zeros((nx * R, ny * R, nz * R, 3), dtype=torch.float32, device=self.device)
+        co, t, w, c = self.units()
+        for k in range(co.shape[0]):
+            x, y, z = (int(v) for v in co[k].tolist())
+            x -= ox; y -= oy; z -= oz
+            if 0 <= x < nx and 0 <= y < ny and 0 <= z < nz:
+                sl = (slice(x * R, (x + 1) * R), slice(y * R, (y + 1) * R), slice(z * R, (z + 1) * R))
+                T[sl] = t[k]; Wt[sl] = w[k]; Cc[sl] = c[k]
+        return T, Wt, Cc
+
+
+def gather_unit_lists(coords, tsdf, weight, color, group=None):
+    """all_gather of per-rank unit lists (any device / backend): -> concatenated (coords, tsdf, weight, color) of every rank."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([coords.shape[0]], dtype=torch.int64, device=coords.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+
+    def gather(x):
+        pad = torch.zeros((m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        pad[: x.shape[0]] = x
+        out = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(out, pad, group=group)
+        return torch.cat([o[:k] for o, k in zip(out, counts)], dim=0)
+    return gather(coords.contiguous()), gather(tsdf.contiguous()), gather(weight.contiguous()), gather(color.contiguous())
+
+
+def merge_unit_lists(coords, tsdf, weight, color):
+    """Weighted merge of a concatenated unit list with repeated coordinates (pure torch, any device):
+    tsdf = sum(w * tsdf) / sum(w), colour likewise, weight = sum(w).  -> (unique coords [m,3], tsdf [m,V], weight [m,V], color [m,V,3])"""
+    uniq, inv = torch.unique(coords.to(torch.int64), dim=0, return_inverse=True)
+    m = uniq.shape[0]
+    W = torch.zeros((m,) + tuple(weight.shape[1:]), dtype=torch.float32, device=weight.device).index_add_(0, inv, weight)
+    T = torch.zeros_like(W).index_add_(0, inv, tsdf * weight)
+    Cc = torch.zeros((m,) + tuple(color.shape[1:]), dtype=torch.float32, device=color.device).index_add_(0, inv, color * weight.unsqueeze(-1))
+    nz = W > 0
+    T = torch.where(nz, T / W.clamp_min(1e-30), torch.zeros_like(T))
+    Cc = torch.where(nz.unsqueeze(-1), Cc / W.clamp_min(1e-30).unsqueeze(-1), torch.zeros_like(Cc))
+    return uniq.to(torch.int32), T, W, Cc

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 
 enum gsr_variant {
     GSR_EWA = 0,     /* diff_gaussian_rasterization : 3DGS EWA splats, RGB only                          */
@@ -169,6 +169,31 @@ int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* or
                              const float* rgb /*[3,H,W]*/, float fx, float fy, float cx, float cy,
                              const float* extrinsic /*[16] HOST, row-major world->camera*/,
                              float* tsdf, float* weight, float* color /*[nx,ny,nz,3]*/, void* stream);
+/* Block-sparse TSDF volume = the role of o3d.pipelines.integration.ScalableTSDFVolume in the reference's mesh extraction
+ * (gssr/utils/mesh_utils.py:154-178, extract_mesh.py:125-128: voxel_length = depth_trunc / 1024, sdf_trunc = 5 * voxel_length;
+ * extract_mesh_split.py:91-119 fuses the frames of every tile into one such volume).  Open3D 0.18 is NOT part of /root/reference:
+ * the algorithm is restated from its published sources (ScalableTSDFVolume::Integrate, UniformTSDFVolume::
+ * IntegrateWithDepthToCameraDistanceMultiplier) and its PARITY IS UNPINNED.  Units of 16^3 voxels in a hash map keyed by the unit
+ * coordinate floor(p / (16 * voxel_length)); a frame opens every unit overlapping [p - sdf_trunc, p + sdf_trunc] for every
+ * `stride`-th valid depth pixel's world point p and applies the gsr_tsdf_integrate_dense voxel rule to each opened unit once.
+ * All buffers are caller-owned device memory: keys [2^cap_hash_log2] int64 filled with -1, slot [2^cap_hash_log2] int32,
+ * coord [cap_blocks,3] int32, stamp/list [cap_blocks], counters [4] int32 zero-filled, pools tsdf/weight [cap_blocks,4096] and
+ * color [cap_blocks,4096,3] float32 ZERO-FILLED.  counters[0] = units allocated so far. */
+typedef struct gsr_tsdf_sparse {
+    void* keys; int32_t* slot; int32_t* coord; uint32_t* stamp; int32_t* list; int32_t* counters;
+    float* tsdf; float* weight; float* color;
+    uint32_t cap_hash_log2, cap_blocks;
+    float voxel_length, sdf_trunc;
+} gsr_tsdf_sparse;
+/* One frame.  extrinsic = world->camera, pose = camera->world (both [12] HOST, row-major 3x4); `frame` must be a fresh non-zero
+ * number per call.  Synchronises the stream once (reads the number of units to integrate); *n_touched_host receives it. */
+int gsr_tsdf_sparse_integrate(const gsr_tsdf_sparse* vol, int32_t W, int32_t H, const float* depth /*[H,W]*/, const float* rgb /*[3,H,W]*/,
+                              float fx, float fy, float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc,
+                              int32_t stride, uint32_t frame, uint32_t* n_touched_host, void* stream);
+/* vol <- weighted merge with n_units units given as (coords [n,3] int32, tsdf/weight [n,4096], color [n,4096,3]): the fusion step of
+ * extract_mesh_split.py when every GPU integrated its own tile's frames (running averages are associative in (sum w*tsdf, sum w)). */
+int gsr_tsdf_sparse_merge(const gsr_tsdf_sparse* vol, int32_t n_units, const int32_t* coords, const float* tsdf, const float* weight,
+                          const float* color, void* stream);
 /* Fused image-side loss right behind the rasterizer (the L1 term of gssr/scene/vanilla_scene.py:63-69
  * plus a linear functional of the auxiliary maps): loss = mean|color - gt| + sum(aux * waux); one streaming pass
  * writes dL/dcolor = sign(color-gt)/n and accumulates the scalar into *loss_out (device, caller zero-fills).

@@ -1245,6 +1245,110 @@ void ref_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* o
     }
 }
 
+/* ---- block-sparse TSDF volume: CPU restatement of csrc/gsr_tsdf_sparse.hip, i.e. of Open3D 0.18's ScalableTSDFVolume::Integrate
+   (cpp/open3d/pipelines/integration/ScalableTSDFVolume.cpp) as the reference drives it (gssr/utils/mesh_utils.py:154-178).
+   PARITY UNPINNED: Open3D is a pip dependency of the reference (requirements.txt:6), absent here, and no reference test holds vectors.
+   Units of 16^3 voxels keyed by floor(p / unit_len); per frame every `stride`-th valid depth pixel opens the units overlapping
+   [p - trunc, p + trunc]; each opened unit is integrated once with the uniform-volume voxel rule (ref_tsdf_integrate_dense). */
+#include <stdlib.h>
+#include <string.h>
+struct RefSparse {
+    float vl, trunc;
+    int n, cap;
+    int32_t* coord;     /* [n][3] in first-touch order */
+    float *tsdf, *weight, *color;
+};
+typedef struct RefSparse RefSparse;
+RefSparse* ref_tsdf_sparse_new(float voxel_length, float sdf_trunc)
+{
+    RefSparse* v = (RefSparse*)calloc(1, sizeof(RefSparse));
+    v->vl = voxel_length; v->trunc = sdf_trunc;
+    return v;
+}
+void ref_tsdf_sparse_free(RefSparse* v)
+{
+    if (!v) return;
+    free(v->coord); free(v->tsdf); free(v->weight); free(v->color); free(v);
+}
+static int sparse_find(const RefSparse* v, int x, int y, int z)
+{
+    for (int i = v->n - 1; i >= 0; i--)      /* newest first: neighbouring pixels hit the units opened a moment ago */
+        if (v->coord[3*i] == x && v->coord[3*i+1] == y && v->coord[3*i+2] == z) return i;
+    return -1;
+}
+static int sparse_open(RefSparse* v, int x, int y, int z)
+{
+    int i = sparse_find(v, x, y, z);
+    if (i >= 0) return i;
+    if (v->n == v->cap) {
+        const int nc = v->cap ? 2 * v->cap : 256;
+        v->coord = (int32_t*)realloc(v->coord, (size_t)nc * 3 * sizeof(int32_t));
+        v->tsdf = (float*)realloc(v->tsdf, (size_t)nc * 4096 * sizeof(float));
+        v->weight = (float*)realloc(v->weight, (size_t)nc * 4096 * sizeof(float));
+        v->color = (float*)realloc(v->color, (size_t)nc * 4096 * 3 * sizeof(float));
+        v->cap = nc;
+    }
+    i = v->n++;
+    v->coord[3*i] = x; v->coord[3*i+1] = y; v->coord[3*i+2] = z;
+    memset(v->tsdf + (size_t)i * 4096, 0, 4096 * sizeof(float));
+    memset(v->weight + (size_t)i * 4096, 0, 4096 * sizeof(float));
+    memset(v->color + (size_t)i * 4096 * 3, 0, 4096 * 3 * sizeof(float));
+    return i;
+}
+void ref_tsdf_sparse_integrate(RefSparse* v, int32_t W, int32_t H, const float* depth, const float* rgb, float fx, float fy, float cx, float cy,
+                               const float* E /*[12] world->camera*/, const float* P /*[12] camera->world*/, float dtrunc, int32_t stride)
+{
+    const float unit_len = v->vl * 16, inv_unit = 1.0f / unit_len, rfx = 1.0f / fx, rfy = 1.0f / fy;
+    int ntouched = 0, tcap = 1024;
+    int* touched = (int*)malloc((size_t)tcap * sizeof(int));
+    const int n0 = v->n;
+    unsigned char* seen = (unsigned char*)calloc((size_t)(n0 > 0 ? n0 : 1), 1);      /* units that existed before this frame */
+    for (int vv = 0; vv < H; vv += stride)
+        for (int u = 0; u < W; u += stride) {
+            const float d = depth[(size_t)vv * W + u];
+            if (!(d > 0.f) || d > dtrunc) continue;
+            const float xc = ((float)u - cx) * d * rfx, yc = ((float)vv - cy) * d * rfy;
+            const float p[3] = { P[0]*xc + P[1]*yc + P[2]*d + P[3], P[4]*xc + P[5]*yc + P[6]*d + P[7], P[8]*xc + P[9]*yc + P[10]*d + P[11] };
+            int lo[3], hi[3], ok = 1;
+            for (int a = 0; a < 3; a++) {
+                lo[a] = (int)floorf((p[a] - v->trunc) * inv_unit);
+                hi[a] = (int)floorf((p[a] + v->trunc) * inv_unit);
+                if (lo[a] < -(1 << 20) + 1 || hi[a] > (1 << 20) - 2 || hi[a] - lo[a] > 3) ok = 0;
+            }
+            if (!ok) continue;
+            for (int x = lo[0]; x <= hi[0]; x++)
+                for (int y = lo[1]; y <= hi[1]; y++)
+                    for (int z = lo[2]; z <= hi[2]; z++) {
+                        const int before = v->n;
+                        const int i = sparse_open(v, x, y, z);
+                        const int is_new = (v->n != before);
+                        if (is_new || (i < n0 && !seen[i])) {
+                            if (i < n0) seen[i] = 1;
+                            if (ntouched == tcap) { tcap *= 2; touched = (int*)realloc(touched, (size_t)tcap * sizeof(int)); }
+                            touched[ntouched++] = i;
+                        }
+                    }
+        }
+    float E16[16];
+    for (int k = 0; k < 12; k++) E16[k] = E[k];
+    E16[12] = E16[13] = E16[14] = 0.f; E16[15] = 1.f;
+    for (int t = 0; t < ntouched; t++) {
+        const int i = touched[t];
+        const float origin[3] = { (float)v->coord[3*i] * unit_len, (float)v->coord[3*i+1] * unit_len, (float)v->coord[3*i+2] * unit_len };
+        ref_tsdf_integrate_dense(16, 16, 16, origin, v->vl, v->trunc, dtrunc, W, H, depth, rgb, fx, fy, cx, cy, E16,
+                                 v->tsdf + (size_t)i * 4096, v->weight + (size_t)i * 4096, v->color + (size_t)i * 4096 * 3);
+    }
+    free(touched); free(seen);
+}
+int32_t ref_tsdf_sparse_num_units(const RefSparse* v) { return v->n; }
+void ref_tsdf_sparse_get(const RefSparse* v, int32_t* coord, float* tsdf, float* weight, float* color)
+{
+    memcpy(coord, v->coord, (size_t)v->n * 3 * sizeof(int32_t));
+    memcpy(tsdf, v->tsdf, (size_t)v->n * 4096 * sizeof(float));
+    memcpy(weight, v->weight, (size_t)v->n * 4096 * sizeof(float));
+    memcpy(color, v->color, (size_t)v->n * 4096 * 3 * sizeof(float));
+}
+
 /* simple-knn (submodules/simple-knn/simple_knn.cu:148-184): mean of the squared distances to the 3 nearest
    neighbours.  Brute force; the Morton/box pruning of the source is an acceleration structure only. */
 void ref_dist2(int32_t P, const float* pts, float* out)

@@ -307,3 +307,39 @@ def loss_plane_geo(depth, alpha, normal, weight, ray_mat, lam):
     L.ref_loss_plane_geo(C.c_int32(H), C.c_int32(W), _p(d), _p(a), _p(n), _p(w), _p(rm), C.c_float(lam), _p(out["loss"]), _p(out["dL_ddepth"]),
                          _p(out["dL_dnormal"]), _p(out["depth_normal"]))
     return out
+
+
+class SparseTSDF:
+    """oracle/gsr_oracle.c ref_tsdf_sparse_*: CPU restatement of the block-sparse (Open3D ScalableTSDFVolume-style) integration."""
+
+    def __init__(self, voxel_length, sdf_trunc):
+        L = lib()
+        L.ref_tsdf_sparse_new.restype = C.c_void_p; L.ref_tsdf_sparse_new.argtypes = [C.c_float, C.c_float]
+        L.ref_tsdf_sparse_free.argtypes = [C.c_void_p]
+        L.ref_tsdf_sparse_integrate.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _fp, _fp, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp,
+                                                C.c_float, C.c_int32]
+        L.ref_tsdf_sparse_num_units.restype = C.c_int32; L.ref_tsdf_sparse_num_units.argtypes = [C.c_void_p]
+        L.ref_tsdf_sparse_get.argtypes = [C.c_void_p] * 5
+        self.L = L
+        self.h = L.ref_tsdf_sparse_new(float(voxel_length), float(sdf_trunc))
+
+    def integrate(self, rgb, depth, fx, fy, cx, cy, extrinsic, depth_trunc=3.0e38, stride=4):
+        d, c = _f32(depth), _f32(rgb)
+        H, W = d.shape[-2], d.shape[-1]
+        E = np.asarray(extrinsic, np.float64).reshape(4, 4)
+        Ea = np.ascontiguousarray(E[:3].reshape(-1), np.float32); Pa = np.ascontiguousarray(np.linalg.inv(E)[:3].reshape(-1), np.float32)
+        self.L.ref_tsdf_sparse_integrate(self.h, W, H, _p(d), _p(c), float(fx), float(fy), float(cx), float(cy), _p(Ea), _p(Pa),
+                                         float(min(depth_trunc, 3.0e38)), int(stride))
+
+    def units(self):
+        n = self.L.ref_tsdf_sparse_num_units(self.h)
+        co = np.zeros((n, 3), np.int32); t = np.zeros((n, 16, 16, 16), np.float32); w = np.zeros_like(t); c = np.zeros((n, 16, 16, 16, 3), np.float32)
+        if n:
+            self.L.ref_tsdf_sparse_get(self.h, co.ctypes.data, t.ctypes.data, w.ctypes.data, c.ctypes.data)
+        return co, t, w, c
+
+    def __del__(self):
+        try:
+            self.L.ref_tsdf_sparse_free(self.h)
+        except Exception:
+            pass

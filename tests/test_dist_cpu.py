@@ -134,3 +134,35 @@ def _shared_worker(rank, world, port):
 
 def test_allreduce_shared_anchor_grads_world2_gloo():
     mp.spawn(_shared_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _sparse_merge_worker(rank, world, port):
+    """Every rank owns a different set of block-sparse TSDF units (with overlap); gather_unit_lists + merge_unit_lists -- the transport of
+    ScalableTSDFVolume.merge_() -- must give every rank the same weighted fusion."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "gs-sr_amd"))
+    from gsrast.tsdf import gather_unit_lists, merge_unit_lists
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(11)
+    V = 64                                                    # voxels per unit in this test (the helpers are shape-agnostic)
+    all_co = torch.tensor([[0, 0, 0], [1, 0, 0], [0, 2, -1], [5, 5, 5], [-3, 1, 0]], dtype=torch.int32)
+    own = [[0, 1, 2], [1, 2, 3, 4]][rank]                      # units 1 and 2 are seen by both ranks
+    t_all = torch.rand(2, 5, V, generator=g); w_all = torch.randint(0, 4, (2, 5, V), generator=g).float(); c_all = torch.rand(2, 5, V, 3, generator=g)
+    co, t, w, c = gather_unit_lists(all_co[own], t_all[rank][own], w_all[rank][own], c_all[rank][own])
+    assert co.shape[0] == 7
+    mco, mt, mw, mc = merge_unit_lists(co, t, w, c)
+    assert mco.shape[0] == 5
+    for i, k in enumerate(mco.tolist()):
+        j = [tuple(x) for x in all_co.tolist()].index(tuple(k))
+        ws = [w_all[r][j] for r in range(2) if j in [[0, 1, 2], [1, 2, 3, 4]][r]]
+        ts = [t_all[r][j] for r in range(2) if j in [[0, 1, 2], [1, 2, 3, 4]][r]]
+        wt = sum(ws)
+        exp = torch.where(wt > 0, sum(a * b for a, b in zip(ts, ws)) / wt.clamp_min(1e-30), torch.zeros(V))
+        assert torch.equal(mw[i], wt) and torch.allclose(mt[i], exp, atol=1e-6)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_sparse_tsdf_merge_world2_gloo():
+    mp.spawn(_sparse_merge_worker, args=(2, _free_port()), nprocs=2, join=True)

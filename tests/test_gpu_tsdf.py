@@ -1,0 +1,140 @@
+"""GPU tests (pytest -m gpu) of the block-sparse TSDF volume (gsrast.tsdf.ScalableTSDFVolume -> gsr_tsdf_sparse_* of the C ABI):
+against the CPU oracle (same allocated units, weights bit-exact), against the dense HIP volume unit by unit (bit-exact: same voxel
+rule), and the multi-tile fusion of extract_mesh_split.py:54-128 (two per-tile volumes merged == all frames into one volume)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import tsdf_cases
+
+pytestmark = pytest.mark.gpu
+
+VL, TR, DT = 0.02, 0.1, 6.0
+
+
+def _hip_volume(frs, cap=4096):
+    from gsrast.tsdf import ScalableTSDFVolume
+    vol = ScalableTSDFVolume(VL, TR, capacity_units=cap)
+    for f in frs:
+        vol.integrate(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda(), f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT)
+    return vol
+
+
+def _oracle_units(frs):
+    v = oracle.SparseTSDF(VL, TR)
+    for f in frs:
+        v.integrate(tsdf_cases.rgb8(f["rgb"]), f["depth"], f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT)
+    return v.units()
+
+
+def _compare(vol, ref):
+    co, t, w, c = (x.cpu().numpy() for x in vol.units())
+    rco, rt, rw, rc = ref
+    got = {tuple(k): i for i, k in enumerate(co.tolist())}
+    want = {tuple(k): i for i, k in enumerate(rco.tolist())}
+    assert set(got) == set(want), (len(got), len(want), len(set(got) ^ set(want)))       # same units opened
+    nbad = ntot = 0
+    for k, i in got.items():
+        j = want[k]
+        nbad += int((w[i] != rw[j]).sum()); ntot += w[i].size                                # v_rcp_f32 vs IEEE division at a gate
+        same = w[i] == rw[j]
+        # v_rcp_f32 in the projection can round a voxel into the neighbouring pixel: counted, must stay a vanishing fraction
+        nbad += int((np.abs(t[i][same] - rt[j][same]) > 1e-4).sum())
+        nbad += int((np.abs(c[i][same] - rc[j][same]).max(-1) > 0.05).sum())
+    assert nbad <= 2e-4 * ntot, (nbad, ntot)
+    return len(got)
+
+
+def test_sparse_volume_matches_oracle_and_dense():
+    from gsrast.tsdf import DenseTSDFVolume
+    frs = tsdf_cases.frames(4)
+    vol = _hip_volume(frs)
+    n = _compare(vol, _oracle_units(frs))
+    assert 50 < n < 4000 and vol.last_touched > 0
+    # unit by unit against the dense HIP volume over the bounding box: a unit opened at frame k has exactly the dense volume's
+    # contributions of frames >= k; units opened by the FIRST frame must equal the dense volume bit for bit
+    first = _hip_volume(frs[:1])
+    co = first.units()[0].cpu().numpy()
+    lo, hi = co.min(0), co.max(0) + 1
+    dense = DenseTSDFVolume((lo * np.float32(VL * 16)).tolist(), VL, tuple(int(d) * 16 for d in (hi - lo)), TR)
+    f = frs[0]
+    dense.integrate(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda(), f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT)
+    T, Wt, C = first.to_dense(lo, hi - lo)
+    alloc = torch.zeros_like(Wt, dtype=torch.bool)
+    for k in co:
+        x, y, z = (k - lo) * 16
+        alloc[x:x + 16, y:y + 16, z:z + 16] = True
+    dW = (Wt != dense.weight) & alloc
+    assert dW.float().mean().item() < 1e-4                                                  # float32 voxel-centre rounding only
+    ok = alloc & ~dW
+    assert ((T[ok] - dense.tsdf[ok]).abs() > 2e-4).float().mean().item() < 1e-3      # voxel centres: unit origin + offset vs grid origin + offset (float32)
+    # what the dense volume updated OUTSIDE the allocated units is free space in front of the surface (tsdf clamped to 1): the band
+    # around the zero crossing -- everything marching cubes needs -- lives in the allocated units
+    out = (dense.weight > 0) & ~alloc
+    assert (dense.tsdf[out] < 1.0).float().mean().item() < 0.02
+
+
+def test_two_tile_volumes_merge_to_the_joint_volume():
+    """extract_mesh_split.py:91-119 integrates the frames of every tile into ONE volume; here each 'tile' integrates its own frames on the
+    device and the volumes are fused afterwards -- merge_from on one device, merge_() through torch.distributed (single-process group)."""
+    import os
+    import torch.distributed as dist
+    frs = tsdf_cases.frames(6, seed=3)
+    a, b = _hip_volume(frs[:3]), _hip_volume(frs[3:])
+    a.merge_from(b)
+    ref = _oracle_units(frs)
+    co, t, w, c = (x.cpu().numpy() for x in a.units())
+    want = {tuple(k): i for i, k in enumerate(ref[0].tolist())}
+    assert set(map(tuple, co.tolist())) == set(want)
+    nbad = ntot = 0
+    for i, k in enumerate(co.tolist()):
+        j = want[tuple(k)]
+        nbad += int((w[i] != ref[2][j]).sum()); ntot += w[i].size
+        same = w[i] == ref[2][j]
+        nbad += int((np.abs(t[i][same] - ref[1][j][same]) > 2e-4).sum())
+    assert nbad <= 2e-4 * ntot, (nbad, ntot)
+    # the distributed entry point with a one-rank group (the N-rank path is covered by tests/test_dist_cpu.py on gloo and, when the
+    # box has >= 2 GPUs, by tests/test_gpu_multi.py on RCCL)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        n0 = a.num_units
+        a.merge_()
+        assert a.num_units == n0
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
+def test_capacity_overflow_raises():
+    from gsrast.tsdf import ScalableTSDFVolume
+    f = tsdf_cases.frames(1)[0]
+    vol = ScalableTSDFVolume(VL, TR, capacity_units=16)
+    with pytest.raises(RuntimeError, match="capacity exhausted"):
+        vol.integrate(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda(), f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT)
+
+
+def test_reference_default_resolution_runs_without_a_dense_grid():
+    """extract_mesh.py:125-128: voxel = depth_trunc / 1024, sdf_trunc = 5 voxels.  A dense grid of that resolution is >= 1024^3 voxels
+    (21 GB); the sparse volume allocates only the band around the surface."""
+    from gsrast.tsdf import ScalableTSDFVolume
+    W, H = 480, 360
+    depth_trunc = 8.0
+    vl = depth_trunc / 1024
+    vol = ScalableTSDFVolume(vl, 5 * vl, capacity_units=60000)
+    u, v = np.meshgrid(np.arange(W), np.arange(H))
+    for k in range(3):
+        depth = (4.0 + 0.4 * np.sin(u / 40.0 + k) + 0.3 * np.cos(v / 30.0)).astype(np.float32)[None]
+        rgb = np.random.default_rng(k).uniform(0, 1, (3, H, W)).astype(np.float32)
+        E = np.eye(4, dtype=np.float32); E[0, 3] = 0.02 * k
+        vol.integrate(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), 420.0, 420.0, W / 2, H / 2, E, depth_trunc=depth_trunc)
+    n = vol.num_units
+    co, t, w, c = vol.units()
+    assert 1000 < n < 60000
+    assert (w > 0).any(dim=-1).any(dim=-1).any(dim=-1).float().mean().item() > 0.9          # nearly every opened unit received samples
+    # surface voxels carry |tsdf| < 1 with both signs (a zero crossing exists for marching cubes)
+    tt = t[w > 0]
+    assert (tt < 0).any() and (tt > 0).any() and tt.abs().max().item() <= 1.0
