@@ -79,19 +79,58 @@ def worker(args):
     return summary
 
 
+def gpu_numa_cpus(gpu_index):
+    """CPUs of the NUMA node the GPU's PCIe function sits on (sysfs), or None when that cannot be told."""
+    try:
+        import glob
+        drm = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/numa_node"), key=lambda q: int(q.split("card")[1].split("/")[0]))
+        render = [q for q in drm if os.path.exists(os.path.join(os.path.dirname(q), "mem_info_vram_total"))] or drm
+        node = int(open(render[gpu_index]).read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return cpus or None
+    except Exception:
+        return None
+
+
 def spawn(args):
-    """Parent: start one child per GPU with the torchrun environment contract (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*)."""
+    """Parent: start one child per GPU with the torchrun environment contract (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*).
+    Every worker is pinned: HIP_VISIBLE_DEVICES = its GPU (the process sees exactly one device, LOCAL_RANK-independent code paths
+    cannot land on GPU 0 by accident) and, where sysfs tells the GPU's NUMA node, CPU affinity to that node's cores.  The children
+    are polled: when one exits non-zero the others are terminated instead of waiting in a collective until the backend times out."""
     n = args.gpus
     procs = []
+    pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # the directory that holds gsrast/ and the drop-in packages
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if args.backend == "nccl" else str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(args.port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        if args.backend == "nccl":
+            visible = os.environ.get("HIP_VISIBLE_DEVICES")
+            ids = visible.split(",") if visible else [str(i) for i in range(n)]
+            env["HIP_VISIBLE_DEVICES"] = ids[r % len(ids)]
         cmd = [sys.executable, "-m", "gsrast.launch_tiles", "--data", args.data, "--output", args.output, "--entry", args.entry,
                "--backend", args.backend, "--gpus", str(n), "--_child"]
-        procs.append(subprocess.Popen(cmd, env=env))
+        cpus = gpu_numa_cpus(r) if (args.backend == "nccl" and not args.no_affinity) else None
+        pre = (lambda c=cpus: os.sched_setaffinity(0, c)) if cpus else None
+        procs.append(subprocess.Popen(cmd, env=env, preexec_fn=pre))
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:              # a dead rank leaves the others blocked in barrier / init_process_group
+                    q.terminate()
     return rc
 
 
@@ -103,6 +142,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--port", type=int, default=29531)
+    ap.add_argument("--no-affinity", action="store_true", help="do not pin workers to the CPUs of their GPU's NUMA node")
     ap.add_argument("--_child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     if args._child or "RANK" in os.environ or args.gpus == 1:

@@ -12,7 +12,10 @@ import torch.distributed as dist
 
 
 def list_tiles(data_dir):
-    """tile_XXXX sub-directories in sorted order (train_split.py:15-16 uses sorted(os.listdir) filtered on 'tile_')."""
+    """tile_<digits> sub-directories in SORTED order.  The reference (train_split.py:15-16) takes os.listdir() order filtered on
+    startswith('tile_') -- unsorted and platform-dependent -- so its tile_%04d OUTPUT index follows listdir order; here the index
+    follows the sorted names (deterministic across ranks, which the sharding needs).  INTEGRATION.md notes the difference for anyone
+    comparing per-tile outputs with a reference run."""
     return sorted(d for d in os.listdir(data_dir) if re.fullmatch(r"tile_\d+", d) and os.path.isdir(os.path.join(data_dir, d)))
 
 

@@ -106,6 +106,13 @@ def test_launch_tiles_two_workers_gloo():
             assert txt[0] == src and int(txt[1]) == k and txt[2] == "cpu"
             ranks.add(txt[3])
         assert ranks == {"rank0", "rank1"}
+        # a rank that dies must end the job promptly (the surviving rank would otherwise sit in the barrier until the backend times out)
+        import time
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-m", "gsrast.launch_tiles", "--data", data, "--output", out + "2", "--gpus", "2",
+                            "--backend", "gloo", "--port", str(_free_port()), "--entry", "tile_entry_fixture:train_tile_rank1_dies"],
+                           env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode != 0 and time.time() - t0 < 120
 
 
 def _shared_worker(rank, world, port):
