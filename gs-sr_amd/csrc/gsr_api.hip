@@ -112,12 +112,12 @@ GeomView gsr_carve_geom(int variant, int P, void* base)
     g.cull = take<float4>(p, n * 2);
     g.rec = take<float4>(p, n * gsr_rec_stride(variant));
     g.clamped = take<uint32_t>(p, n);
-    g.sorted_idx = take<uint32_t>(p, n);     // == vals_a of the depth sort
+    g.vals_a = take<uint32_t>(p, n);
     g.offsets = take<uint32_t>(p, n);
     g.keys_b = take<uint32_t>(p, n);
-    g.vals_a = g.sorted_idx;
     g.vals_b = take<uint32_t>(p, n);
-    g.hist = take<uint32_t>(p, (size_t)256 * nblk + 256);   // histogram matrix + digit totals
+    g.sorted_idx = g.vals_a;                 // four sort passes: identity -> vals_b -> vals_a -> vals_b -> vals_a (gsr_launch_depth_order)
+    g.hist = take<uint32_t>(p, (size_t)2048 * nblk + 2048);   // 11-bit digits: histogram matrix + digit totals
     g.scan_tmp = take<uint32_t>(p, gsr_div_up((uint32_t)n, GSR_SCAN_BLOCK) + 64);
     g.counters = take<uint32_t>(p, 64);
     g.bytes = (size_t)(p - reinterpret_cast<char*>(base));

@@ -10,6 +10,7 @@
 //   4. tile ranges from key boundaries (identifyTileRanges, rasterizer_impl.cu:116-138).
 // Stability of every pass makes the result identical to the reference's single 64-bit sort.
 #include "gsr_common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -48,7 +49,7 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* lds /*
 
 // ------------------------------------------------------------------------------------------------ generic scan
 // in-place exclusive scan of n words by ONE block (n is small: histograms, block sums)
-__global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, uint32_t n, uint32_t* total_out)
+__global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, uint32_t n, uint32_t* total_out, uint32_t* host_word)
 {
     __shared__ uint32_t lds[17];
     const uint32_t chunk = (n + blockDim.x - 1) / blockDim.x;
@@ -59,7 +60,10 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, u
     uint32_t incl = block_incl_scan(sum, lds, &tot);
     uint32_t run = incl - sum;
     for (uint32_t i = b; i < e; i++) { uint32_t v = data[i]; data[i] = run; run += v; }
-    if (total_out && threadIdx.x == 0) *total_out = tot;
+    if (threadIdx.x == 0) {
+        if (total_out) *total_out = tot;
+        if (host_word) __hip_atomic_store(host_word, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // mapped pinned word: no D2H copy command
+    }
 }
 
 // exclusive scan of every row of a [rows x cols] matrix in place, one block per row (coalesced), row totals to tot[].
@@ -81,14 +85,16 @@ __global__ void __launch_bounds__(256) k_scan_rows(uint32_t* __restrict__ data, 
 }
 
 // ------------------------------------------------------------------------------------------------ radix sort
+// Digits of up to 11 bits: NB = histogram bins the kernel is built for (256 for <= 8-bit digits, 2048 for 9..11 bits; the wide form is
+// an A/B option of the depth order only, see gsr_launch_depth_order).
 // per-block digit histogram, hist[d * nblk + blk]
-template <int ITEMS>
+template <int ITEMS, int NB>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev,
                                                                  int shift, uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk)
 {
-    __shared__ uint32_t h[256];
+    __shared__ uint32_t h[NB];
     if (n_dev) n = min(n, *n_dev);       // device-side element count (speculative forward): n is then the capacity
-    h[threadIdx.x] = 0;
+    for (uint32_t d = threadIdx.x; d < NB; d += GSR_SORT_THREADS) h[d] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (GSR_SORT_THREADS * ITEMS);
 #pragma unroll 4
@@ -97,29 +103,47 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t*
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x <= mask) hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+    for (uint32_t d = threadIdx.x; d <= mask; d += GSR_SORT_THREADS) hist[d * nblk + blockIdx.x] = h[d];
+}
+
+// exclusive prefix over (mask + 1) <= NB per-digit values held DPT per thread (digit d = DPT * tid + k); returns through arr[]
+template <int NB>
+__device__ __forceinline__ void digit_excl_scan(const uint32_t* v, uint32_t* out_excl, uint32_t* lds)
+{
+    constexpr int DPT = NB / GSR_SORT_THREADS;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < DPT; k++) sum += v[k];
+    uint32_t tot;
+    const uint32_t incl = block_incl_scan(sum, lds, &tot);
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < DPT; k++) { out_excl[k] = run; run += v[k]; }
 }
 
 // stable scatter.  Order inside a block is (wave, item, lane): wave w owns 64*ITEMS consecutive keys.
-template <int ITEMS>
+template <int ITEMS, int NB>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                     uint32_t n, const uint32_t* __restrict__ n_dev, int shift, int bits,
                                                                     const uint32_t* __restrict__ hist, uint32_t nblk, const uint32_t* __restrict__ digit_tot)
 {
+    constexpr int DPT = NB / GSR_SORT_THREADS;
     if (n_dev) n = min(n, *n_dev);
-    __shared__ uint32_t cnt[4][256];
-    __shared__ uint32_t gbase[256], lbase[256];
+    __shared__ uint32_t cnt[4][NB];
+    __shared__ uint32_t gbase[NB], lbase[NB];
     __shared__ uint32_t skey[(GSR_SORT_THREADS * ITEMS)], sval[(GSR_SORT_THREADS * ITEMS)];
     __shared__ uint32_t lds[17];
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * 256; i += GSR_SORT_THREADS) (&cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 4 * NB; i += GSR_SORT_THREADS) (&cnt[0][0])[i] = 0;
     {   // global base of digit d for this block = (#keys with a smaller digit) + (#keys with digit d in earlier blocks)
-        const uint32_t t = (threadIdx.x <= mask) ? digit_tot[threadIdx.x] : 0;
-        uint32_t tot;
-        const uint32_t incl = block_incl_scan(t, lds, &tot);
-        if (threadIdx.x <= mask) gbase[threadIdx.x] = (incl - t) + hist[threadIdx.x * nblk + blockIdx.x];
+        uint32_t t[DPT], ex[DPT];
+#pragma unroll
+        for (int k = 0; k < DPT; k++) { const uint32_t d = DPT * threadIdx.x + k; t[k] = (d <= mask) ? digit_tot[d] : 0; }
+        digit_excl_scan<NB>(t, ex, lds);
+#pragma unroll
+        for (int k = 0; k < DPT; k++) { const uint32_t d = DPT * threadIdx.x + k; if (d <= mask) gbase[d] = ex[k] + hist[d * nblk + blockIdx.x]; }
     }
     __syncthreads();
 
@@ -149,15 +173,20 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     }
     __syncthreads();
     // per-digit totals of the block -> exclusive prefix over the digits = position of the digit's run inside the block
-    uint32_t tot_d = 0;
-    if (threadIdx.x <= mask) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) { uint32_t t = cnt[w][threadIdx.x]; cnt[w][threadIdx.x] = tot_d; tot_d += t; }
-    }
     {
-        uint32_t tot;
-        const uint32_t incl = block_incl_scan(tot_d, lds, &tot);
-        if (threadIdx.x <= mask) lbase[threadIdx.x] = incl - tot_d;
+        uint32_t tot_d[DPT], ex[DPT];
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+            const uint32_t d = DPT * threadIdx.x + k;
+            tot_d[k] = 0;
+            if (d <= mask) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) { uint32_t t = cnt[w][d]; cnt[w][d] = tot_d[k]; tot_d[k] += t; }
+            }
+        }
+        digit_excl_scan<NB>(tot_d, ex, lds);
+#pragma unroll
+        for (int k = 0; k < DPT; k++) { const uint32_t d = DPT * threadIdx.x + k; if (d <= mask) lbase[d] = ex[k]; }
     }
     __syncthreads();
     // stage the block's keys/values in LDS in digit order, then write each digit's run with consecutive lanes on consecutive
@@ -183,6 +212,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     }
 }
 
+// hist must hold (2^bits_per_pass) * nblk + 2^bits_per_pass words (nblk for the 1024-key geometry)
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
                          bool* result_in_b, hipStream_t s, bool big_blocks)
@@ -190,7 +220,8 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
     // keys per block: 1024 (many blocks: small inputs are latency-bound) or 4096 (longer digit runs -> full-line writes on big inputs).
     // The histogram area is always sized for the 1024-key geometry, the larger upper bound.
     const uint32_t nblk = gsr_div_up(n, GSR_SORT_THREADS * (big_blocks ? 16u : (uint32_t)GSR_SORT_ITEMS));
-    uint32_t* digit_tot = hist + (size_t)256 * nblk;      // 256 words behind the histogram matrix
+    const bool wide = bits_per_pass > 8;      // 2048-bin kernels
+    uint32_t* digit_tot = hist + (size_t)(wide ? 2048 : 256) * nblk;      // behind the histogram matrix
     // identity_vals: the first pass generates value i for element i instead of reading vals_a
     uint32_t *kin = keys_a, *vin = identity_vals ? nullptr : vals_a, *kout = keys_b, *vout = vals_b;
     bool in_b = false;
@@ -200,11 +231,22 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         int passes_left = (remaining + bits_per_pass - 1) / bits_per_pass;
         int bits = (remaining + passes_left - 1) / passes_left;
         uint32_t mask = (1u << bits) - 1u;
-        if (big_blocks) hipLaunchKernelGGL(k_radix_hist<16>, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, n_dev, shift, mask, hist, nblk);
-        else hipLaunchKernelGGL(k_radix_hist<GSR_SORT_ITEMS>, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, n, n_dev, shift, mask, hist, nblk);
+        const dim3 g(nblk), b(GSR_SORT_THREADS);
+        if (wide) {
+            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, hist, nblk);
+            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, hist, nblk);
+        } else {
+            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, hist, nblk);
+            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, hist, nblk);
+        }
         hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, hist, nblk, digit_tot);
-        if (big_blocks) hipLaunchKernelGGL(k_radix_scatter<16>, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
-        else hipLaunchKernelGGL(k_radix_scatter<GSR_SORT_ITEMS>, dim3(nblk), dim3(GSR_SORT_THREADS), 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
+        if (wide) {
+            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
+            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
+        } else {
+            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
+            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
+        }
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         if (vin == nullptr) { vin = vout; vout = vals_a; }     // first pass generated identity values into vals_b
@@ -229,32 +271,24 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_local(const uint32_t
     if (i < P) offsets[i] = incl;
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_add(uint32_t P, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_prefix,
-                                                                uint32_t* __restrict__ counters, uint32_t* __restrict__ host_word)
-{
-    const uint32_t i = blockIdx.x * GSR_SCAN_BLOCK + threadIdx.x;
-    if (i < P) {
-        uint32_t v = offsets[i] + block_prefix[blockIdx.x];
-        offsets[i] = v;
-        if (i == P - 1) {                      // num_rendered: device copy + mapped pinned host word (no D2H copy command)
-            counters[0] = v;
-            if (host_word) { __hip_atomic_store(host_word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-        }
-    }
-}
-
 int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s)
 {
     const uint32_t P = (uint32_t)cfg->P;
     bool in_b = false;
-    // keys: depth_key (A) <-> keys_b; values: identity -> vals_b <-> vals_a
-    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, 8, true, g.hist, &in_b, s, false);
-    // 4 passes: keys end in depth_key (A).  values: pass1 -> vals_b, pass2 -> vals_a, pass3 -> vals_b, pass4 -> vals_a
-    // (gsr_radix_sort_pairs alternates vout between vals_b and vals_a), so the ids end in vals_a == sorted_idx.
+    // Four 8-bit passes: keys depth_key (A) <-> keys_b end in A, ids: identity -> vals_b -> vals_a -> vals_b -> vals_a (= sorted_idx).
+    // GSR_DEPTH_BITS=11 selects three 11-bit passes instead (33 >= 32 bits, bit-identical result, kept for A/B): MEASURED SLOWER on
+    // MI355X at P = 300k -- depth_order 0.080 -> 0.106 ms.  A pass costs ~14 us of launch latency + ~2 us per 256 bins (the
+    // digit-major histogram matrix is written / scanned / read with a block-count stride), so 2048 bins cost more than the pass saved.
+    static int depth_bits = -1;
+    if (depth_bits < 0) { const char* e = getenv("GSR_DEPTH_BITS"); depth_bits = (e && atoi(e) == 11) ? 11 : 8; }
+    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, depth_bits, true, g.hist, &in_b, s, false);
+    if (depth_bits == 11)      // odd pass count: the ids ended in vals_b, bring them to sorted_idx (= vals_a)
+        GSR_CHECK(hipMemcpyAsync(g.sorted_idx, g.vals_b, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, s), "copy sorted ids");
     const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
     hipLaunchKernelGGL(k_offsets_local, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, g.sorted_idx, g.tiles_touched, P, g.offsets, g.scan_tmp);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nblk, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_offsets_add, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, P, g.offsets, g.scan_tmp, g.counters, host_word_dev);
+    // the single-block scan of the block sums also publishes num_rendered (device word + mapped pinned host word): k_duplicate adds the
+    // block prefix itself, so the third prefix kernel of round 1 (k_offsets_add) is gone
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nblk, g.counters, host_word_dev);
     return gsr_check_launch("depth_order", s, cfg->debug);
 }
 
@@ -265,15 +299,19 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
 // lanes looping over hundreds of tiles -- and the key/value stores are fully coalesced.  Order within a gaussian is (y outer, x inner),
 // as in the reference's nested loop.
 __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ offsets,
-                                                   const uint32_t* __restrict__ tiles_touched, const ushort4* __restrict__ rect, int gx,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap)
+                                                   const uint32_t* __restrict__ block_prefix, const uint32_t* __restrict__ tiles_touched,
+                                                   const ushort4* __restrict__ rect, int gx,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap,
+                                                   uint2* __restrict__ ranges, uint32_t T)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x);          // position in depth order
+    if (i < T) ranges[i] = make_uint2(0u, 0u);                           // the cudaMemset of rasterizer_impl.cu:310, folded in (k_tile_ranges runs later)
     const bool v = i < P;
     const uint32_t g = v ? sorted_idx[i] : 0u;
     const uint32_t cnt = v ? tiles_touched[g] : 0u;
-    const uint32_t incl = v ? offsets[i] : 0u;                            // inclusive prefix of tiles_touched in depth order
+    // inclusive prefix of tiles_touched in depth order = block-local prefix (k_offsets_local) + exclusive prefix of the block sums
+    const uint32_t incl = v ? offsets[i] + block_prefix[i / GSR_SCAN_BLOCK] : 0u;
     ushort4 r = make_ushort4(0, 0, 1, 1);
     if (cnt) r = rect[g];
     const uint32_t wave_base = __shfl(incl - cnt, 0, 64);
@@ -338,14 +376,13 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
 {
     const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     const int T = gx * gy;
-    GSR_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)T * sizeof(uint2), s), "memset ranges");
-    if (R == 0) return 0;
+    if (R == 0) { GSR_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)T * sizeof(uint2), s), "memset ranges"); return 0; }
     // unsorted instances go to the buffer from which an integral number of passes lands in (tile_keys, point_list)
     const int passes = gsr_tile_sort_passes(T);
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
-    hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up(cfg->P, 256)), dim3(256), 0, s, (uint32_t)cfg->P, g.sorted_idx, g.offsets,
-                       g.tiles_touched, g.rect, gx, k0, v0, R);
+    hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P, g.sorted_idx, g.offsets, g.scan_tmp,
+                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T);
     bool in_b = false;
     gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19));
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);

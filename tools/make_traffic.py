@@ -9,7 +9,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 files = []
-for d in glob.glob(os.path.join(out, "pmc_*", "*")):
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+for d in glob.glob(os.path.join(out, "pmc_%s_*" % tag if tag != "r01" else "pmc_*", "*")):
     cands = sorted(glob.glob(os.path.join(d, "*_counter_collection.csv")), key=os.path.getmtime)
     if cands:
         files.append(cands[-1])          # newest pass only (gpurun_out accumulates across calls)
@@ -19,6 +20,8 @@ for f in files:
         if not (k.startswith("void k_") or k.startswith("k_")):
             continue
         name = k.split("(")[0].replace("void ", "").replace(", false>", ">").replace(", true>", ",mfma>")
+        if "k_blend_bwd_sp" in name and "sp" not in os.path.basename(os.path.dirname(os.path.dirname(f))):
+            continue
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = {"k_blend_fwd<0>": "ewa:blend_fwd", "k_blend_fwd<1>": "surfel:blend_fwd", "k_blend_fwd<2>": "plane:blend_fwd",
          "k_blend_bwd<0>": "ewa:blend_bwd", "k_blend_bwd<1>": "surfel:blend_bwd", "k_blend_bwd<2>": "plane:blend_bwd"}
@@ -36,6 +39,5 @@ for k, v in sorted(agg.items()):
         if k in names:
             traffic[names[k]] = int(hbm)
 json.dump(traffic, open(tj, "w"), indent=1, sort_keys=True)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic, indent=1))
