@@ -166,21 +166,41 @@ def _head(mlp):
     return mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias
 
 
+def feature_bank_blend(anchor, feat, vis_idx, campos, mlp_feature_bank):
+    """The `use_feat_bank` branch of generate_neural_gaussians (scaffold_scene.py:45-56 / octree_scene.py:45-56): per visible anchor
+    a softmax over three resolutions, w = softmax(Linear(32,3)(relu(Linear(4,32)([view, dist])))), and
+        feat' = feat[::4].repeat(4) * w0 + feat[::2].repeat(2) * w1 + feat * w2.
+    Plain differentiable torch on the Nv visible rows (four tiny ops; the branch is off by default in the reference,
+    scaffold_gaussian.py:40), written back into an (Na, 32) array so that the fused kernel's gather by vis_idx is unchanged."""
+    W1, b1, W2, b2 = _head(mlp_feature_bank)
+    vi = vis_idx.long()
+    a = anchor.index_select(0, vi); f = feat.index_select(0, vi)
+    ob = a - campos
+    dist = ob.norm(dim=1, keepdim=True)
+    x = torch.cat([ob / dist, dist], dim=1)
+    w = torch.softmax(torch.relu(x @ W1.t() + b1) @ W2.t() + b2, dim=1)
+    fb = f[:, ::4].repeat(1, 4) * w[:, :1] + f[:, ::2].repeat(1, 2) * w[:, 1:2] + f * w[:, 2:]
+    return torch.zeros_like(feat).index_copy(0, vi, fb)
+
+
 def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_color, campos, visible_mask=None, vis_idx=None,
                      appearance=None, level=None, opacity_scale=None, add_opacity_dist=False, add_cov_dist=False, add_color_dist=False,
-                     use_feat_bank=False):
+                     use_feat_bank=False, mlp_feature_bank=None):
     """-> (xyz, color, opacity, scaling, rot, neural_opacity, mask), the `is_training=True` tuple of the reference.
 
     anchor (Na,3), feat (Na,32), offset (Na,k,3), scaling (Na,6) = get_scaling; `appearance` = embedding_appearance row of this camera
     ((A,) tensor, keeps its autograd link to the embedding table); `level` (Na,) or (Na,1) when add_level; `opacity_scale` (Na,) = the
-    Octree progressive ratio with prog[~transition_mask] = 1.  `visible_mask` (bool, Na) or `vis_idx` (int32 indices) selects the anchors."""
-    if use_feat_bank:
-        raise NotImplementedError("gsrast.decode: use_feat_bank=True is not covered by the fused kernel")
+    Octree progressive ratio with prog[~transition_mask] = 1.  `visible_mask` (bool, Na) or `vis_idx` (int32 indices) selects the anchors.
+    `use_feat_bank=True` (+ `mlp_feature_bank`) = the reference's view-adaptive feature branch, see feature_bank_blend."""
+    if use_feat_bank and mlp_feature_bank is None:
+        raise RuntimeError("gsrast.decode: use_feat_bank=True needs mlp_feature_bank (get_featurebank_mlp of the gaussian model)")
     if feat.shape[1] != 32:
         raise NotImplementedError("gsrast.decode: feat_dim must be 32")
     Na, k = offset.shape[0], offset.shape[1]
     if vis_idx is None:
         vis_idx = torch.arange(Na, dtype=torch.int32, device=anchor.device) if visible_mask is None else compact_visible(visible_mask)
+    if use_feat_bank:
+        feat = feature_bank_blend(anchor, feat, vis_idx, campos, mlp_feature_bank)
     heads = _head(mlp_opacity) + _head(mlp_cov) + _head(mlp_color)
     A = 0 if appearance is None else appearance.numel()
     lvl = None if level is None else level.reshape(-1)

@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def make_case(Na=500, k=10, A=32, dist_o=False, dist_c=False, dist_k=False, level=False, progressive=False, vis_frac=0.7, seed=0):
+def make_case(Na=500, k=10, A=32, dist_o=False, dist_c=False, dist_k=False, level=False, progressive=False, vis_frac=0.7, seed=0, feat_bank=False):
     r = np.random.default_rng(seed)
     F = 32
     c = {"k": k, "dist_o": dist_o, "dist_c": dist_c, "dist_k": dist_k}
@@ -25,6 +25,8 @@ def make_case(Na=500, k=10, A=32, dist_o=False, dist_c=False, dist_k=False, leve
     p["W1c"], p["b1c"] = lin(32, 35 + int(dist_c) + lv); p["W2c"], p["b2c"] = lin(7 * k, 32)
     p["W1k"], p["b1k"] = lin(32, 35 + int(dist_k) + lv + A); p["W2k"], p["b2k"] = lin(3 * k, 32)
     p["app"] = r.normal(0, 1, A).astype(np.float32) if A else None
+    if feat_bank:      # mlp_feature_bank: Linear(view_dim + 1 = 4, 32) - ReLU - Linear(32, 3) - Softmax (scaffold_gaussian.py:133-139)
+        p["W1b"], p["b1b"] = lin(32, 4); p["W2b"], p["b2b"] = lin(3, 32)
     c["params"] = p
     return c
 

@@ -108,6 +108,7 @@ def _fill_linear(lin, W, b):
 def decode_fixture(name, octree, **kw):
     import decode_cases
     case = decode_cases.make_case(Na=160, **kw)
+    bank = bool(kw.get("feat_bank"))
     p = case["params"]
     A = 0 if p["app"] is None else p["app"].size
     if octree:
@@ -118,7 +119,7 @@ def decode_fixture(name, octree, **kw):
     else:
         mod = ref_import("gssr.gaussian.scaffold_gaussian"); scn = ref_import("gssr.scene.scaffold_scene")
         cfg = mod.ScaffoldGaussianConfig(); Gauss, Scene = mod.ScaffoldGaussian, scn.ScaffoldScene
-    cfg.n_offsets = case["k"]; cfg.appearance_dim = A; cfg.use_feat_bank = False
+    cfg.n_offsets = case["k"]; cfg.appearance_dim = A; cfg.use_feat_bank = bank
     cfg.add_opacity_dist, cfg.add_cov_dist, cfg.add_color_dist = case["dist_o"], case["dist_c"], case["dist_k"]
     g = Gauss(cfg, device="cpu")
     uid = 2
@@ -130,6 +131,8 @@ def decode_fixture(name, octree, **kw):
     _fill_linear(g.mlp_opacity[0], p["W1o"], p["b1o"]); _fill_linear(g.mlp_opacity[2], p["W2o"], p["b2o"])
     _fill_linear(g.mlp_cov[0], p["W1c"], p["b1c"]); _fill_linear(g.mlp_cov[2], p["W2c"], p["b2c"])
     _fill_linear(g.mlp_color[0], p["W1k"], p["b1k"]); _fill_linear(g.mlp_color[2], p["W2k"], p["b2k"])
+    if bank:
+        _fill_linear(g.mlp_feature_bank[0], p["W1b"], p["b1b"]); _fill_linear(g.mlp_feature_bank[2], p["W2b"], p["b2b"])
     leaf = lambda a: torch.tensor(a).requires_grad_(True)
     g._anchor = leaf(case["anchor"]); g._anchor_feat = leaf(case["feat"]); g._offset = leaf(case["offset"])
     g._scaling = leaf(np.log(case["scaling"]))                     # get_scaling = exp(_scaling)
@@ -156,6 +159,9 @@ def decode_fixture(name, octree, **kw):
           "g_scaling": g._scaling.grad / torch.tensor(case["scaling"])}      # d/d get_scaling = d/d _scaling / exp(_scaling)
     for head, m in (("o", g.mlp_opacity), ("c", g.mlp_cov), ("k", g.mlp_color)):
         gr[f"g_W1{head}"], gr[f"g_b1{head}"], gr[f"g_W2{head}"], gr[f"g_b2{head}"] = m[0].weight.grad, m[0].bias.grad, m[2].weight.grad, m[2].bias.grad
+    if bank:
+        m = g.mlp_feature_bank
+        gr["g_W1b"], gr["g_b1b"], gr["g_W2b"], gr["g_b2b"] = m[0].weight.grad, m[0].bias.grad, m[2].weight.grad, m[2].bias.grad
     if A:
         gr["g_app"] = emb.grad[uid]
         assert not emb.grad[[0, 1, 3, 4]].any()
@@ -518,6 +524,7 @@ if __name__ == "__main__":
     decode_fixture("ref_decode_scaffold.npz", octree=False)
     decode_fixture("ref_decode_scaffold_dist.npz", octree=False, A=0, k=5, dist_o=True, dist_c=True, dist_k=True, seed=1)
     decode_fixture("ref_decode_octree.npz", octree=True, level=True, progressive=True, A=16, k=12, dist_k=True, seed=2)
+    decode_fixture("ref_decode_scaffold_featbank.npz", octree=False, feat_bank=True, A=8, k=6, seed=4)      # use_feat_bank=True branch
     for m in ("floor", "round", "ceil", "progressive"):
         lod_fixture(m)
     l1_ssim_fixture()

@@ -5,8 +5,8 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app")
-DECODE = ("ref_decode_scaffold", "ref_decode_scaffold_dist", "ref_decode_octree")
+PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app", "W1b", "b1b", "W2b", "b2b")
+DECODE = ("ref_decode_scaffold", "ref_decode_scaffold_dist", "ref_decode_octree", "ref_decode_scaffold_featbank")
 
 
 def load(name):
@@ -20,7 +20,7 @@ def decode_case(name):
     case = {"k": int(z["k"]), "dist_o": bool(z["dist_o"]), "dist_c": bool(z["dist_c"]), "dist_k": bool(z["dist_k"])}
     for n in ("anchor", "feat", "offset", "scaling", "level", "opacity_scale", "campos", "vis_idx"):
         case[n] = z.get("in_" + n)
-    case["params"] = {n: z.get("p_" + n) for n in PARAM_NAMES}
+    case["params"] = {n: z.get("p_" + n) for n in PARAM_NAMES if (z.get("p_" + n) is not None or not n.endswith("b"))}
     dL = {n: z["dL_" + n] for n in ("xyz", "color", "opacity", "scaling", "rot")}
     exp = {n: z[n] for n in ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask")}
     grads = {n[2:]: v for n, v in z.items() if n.startswith("g_")}

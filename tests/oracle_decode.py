@@ -45,7 +45,60 @@ def _pack(case):
     return cfg, inp, prm, (arr, vis, par)
 
 
+# ---- use_feat_bank branch (scaffold_scene.py:45-56): numpy restatement in front of the C oracle, float64 inside
+def _bank(case):
+    p = case["params"]
+    vis = np.asarray(case["vis_idx"], np.int64)
+    a = case["anchor"][vis].astype(np.float64); f = case["feat"][vis].astype(np.float64)
+    ob = a - case["campos"].astype(np.float64)
+    dist = np.linalg.norm(ob, axis=1, keepdims=True); view = ob / dist
+    x = np.concatenate([view, dist], 1)
+    pre = x @ p["W1b"].astype(np.float64).T + p["b1b"]; h = np.maximum(pre, 0)
+    z = h @ p["W2b"].astype(np.float64).T + p["b2b"]
+    e = np.exp(z - z.max(1, keepdims=True)); w = e / e.sum(1, keepdims=True)
+    f4 = np.tile(f[:, ::4], (1, 4)); f2 = np.tile(f[:, ::2], (1, 2))
+    fb = f4 * w[:, :1] + f2 * w[:, 1:2] + f * w[:, 2:]
+    return dict(vis=vis, ob=ob, dist=dist, view=view, x=x, pre=pre, h=h, w=w, f=f, f4=f4, f2=f2, fb=fb)
+
+
+def _with_bank(case):
+    """-> (case for the C oracle with the blended features and without the bank parameters, cache)"""
+    if case["params"].get("W1b") is None:
+        return case, None
+    c = _bank(case)
+    feat = np.zeros_like(case["feat"]); feat[c["vis"]] = c["fb"].astype(np.float32)
+    inner = dict(case); inner["feat"] = feat
+    inner["params"] = {k: v for k, v in case["params"].items() if not k.endswith("b") or k in ("b1o", "b2o", "b1c", "b2c", "b1k", "b2k")}
+    return inner, c
+
+
+def _bank_backward(case, c, out):
+    """chains the C oracle's gradient w.r.t. the blended features (rows of the visible anchors) through the blend"""
+    p = case["params"]
+    gfb = out["feat"][c["vis"]].astype(np.float64)
+    w, f, f4, f2 = c["w"], c["f"], c["f4"], c["f2"]
+    gw = np.stack([(gfb * f4).sum(1), (gfb * f2).sum(1), (gfb * f).sum(1)], 1)
+    gf = gfb * w[:, 2:]
+    t4 = gfb * w[:, :1]; t2 = gfb * w[:, 1:2]
+    for j in range(32):
+        gf[:, (j % 8) * 4] += t4[:, j]
+        gf[:, (j % 16) * 2] += t2[:, j]
+    gz = w * (gw - (gw * w).sum(1, keepdims=True))
+    gW2 = gz.T @ c["h"]; gb2 = gz.sum(0)
+    gh = (gz @ p["W2b"].astype(np.float64)) * (c["pre"] > 0)
+    gW1 = gh.T @ c["x"]; gb1 = gh.sum(0)
+    gx = gh @ p["W1b"].astype(np.float64)
+    gview, gdist = gx[:, :3], gx[:, 3:4]
+    gob = gview / c["dist"] - (gview * c["view"]).sum(1, keepdims=True) * c["view"] / c["dist"] + gdist * c["view"]
+    feat = np.zeros_like(out["feat"]); feat[c["vis"]] = gf.astype(np.float32)
+    out["feat"] = feat
+    out["anchor"] = out["anchor"].copy(); out["anchor"][c["vis"]] += gob.astype(np.float32)
+    out.update(W1b=gW1.astype(np.float32), b1b=gb1.astype(np.float32), W2b=gW2.astype(np.float32), b2b=gb2.astype(np.float32))
+    return out
+
+
 def forward(case):
+    case, _ = _with_bank(case)
     L = oracle.lib()
     L.refd_forward.restype = C.c_int64
     cfg, inp, prm, keep = _pack(case)
@@ -64,6 +117,8 @@ def forward(case):
 
 def backward(case, mask, dL):
     """dL: dict xyz/color/opacity/scaling/rot (compacted rows) -> dict of gradients (anchor, feat, offset, scaling, params...)."""
+    outer = case
+    case, bank = _with_bank(case)
     L = oracle.lib()
     L.refd_backward.restype = None
     cfg, inp, prm, keep = _pack(case)
@@ -79,6 +134,8 @@ def backward(case, mask, dL):
                     _p(d["opacity"]), _p(d["scaling"]), _p(d["rot"]), _p(out["anchor"]), _p(out["feat"]), _p(out["offset"]),
                     _p(out["scaling"]), C.byref(gp))
     out.update({n: g[n] for n in PARAM_NAMES if g[n] is not None})
+    if bank is not None:
+        out = _bank_backward(outer, bank, out)
     return out
 
 

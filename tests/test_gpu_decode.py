@@ -23,7 +23,8 @@ def _run_hip(case, dL=None):
                                   (par["W1o"], par["b1o"], par["W2o"], par["b2o"]), (par["W1c"], par["b1c"], par["W2c"], par["b2c"]),
                                   (par["W1k"], par["b1k"], par["W2k"], par["b2k"]), t(case["campos"]), vis_idx=vis, appearance=par["app"],
                                   level=t(case["level"]), opacity_scale=t(case["opacity_scale"]), add_opacity_dist=case["dist_o"],
-                                  add_cov_dist=case["dist_c"], add_color_dist=case["dist_k"])
+                                  add_cov_dist=case["dist_c"], add_color_dist=case["dist_k"], use_feat_bank="W1b" in par,
+                                  mlp_feature_bank=(par["W1b"], par["b1b"], par["W2b"], par["b2b"]) if "W1b" in par else None)
     names = ("xyz", "color", "opacity", "scaling", "rot", "neural_opacity", "mask")
     res = dict(zip(names, out))
     grads = None
