@@ -26,20 +26,20 @@
 // median-normal quirk, no gradient through the 0.99 clamp test); see DESIGN.md "splat-parallel backward".
 #include "gsr_blend_common.h"
 
-#if defined(SP_WPE)
-#define SP_OCC __attribute__((amdgpu_waves_per_eu(SP_WPE, SP_WPE)))
-#else
-#define SP_OCC
+#ifndef SP_WPE
+#define SP_WPE 4                  // measured: 3 waves/SIMD (144 VGPRs) 0.693 ms, 4 (128, 3 spills) 0.633 ms, 5 (96, 37 spills) 0.759 ms
 #endif
+#define SP_OCC __attribute__((amdgpu_waves_per_eu(SP_WPE, SP_WPE)))
 #if 0
 #define SP_WPE 3               // waves per SIMD the register budget is sized for (3 -> 168 VGPRs: no spills in the 16 unrolled pixel steps)
 #endif
-#define SP_CH 256                 // tile-list entries per chunk (LDS table / queues); longer lists take several chunks
+#define SP_CH 256                 // tile-list entries per chunk (queues, masks); longer lists take several chunks
+#define SP_CAP 112                // rows of a wave's private accumulation table (entries of the chunk that reach the wave's quadrant)
 
 template <int V> struct SpTraits;
-template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 9; };
-template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = 17; };
-template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 19; };
+template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10; };
+template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = 16; };
+template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 18; };
 
 // inclusive scans along the 16 lanes of each DPP row, lane 0 first, in place.  A lane whose source would lie outside the row is
 // disabled by the hardware (bound_ctrl off) and keeps its value -- exactly the Hillis-Steele step.  s_nop 1 = the two wait states
@@ -269,8 +269,10 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
     constexpr int NACC = TR::NACC, TS = TR::TS;
 
-    __shared__ float s_table[SP_CH * TS];                   // [entry][component]
+    __shared__ float2 s_wtab[4 * SP_CAP * (TS / 2)];        // [wave][compact entry][component pair]: PRIVATE to the wave, plain read-add-write
+    __shared__ uint8_t s_cidx[4 * SP_CH];                   // [wave][entry] -> row of the wave's table, 0xFF: the entry does not reach the quadrant
     __shared__ uint32_t s_ids[SP_CH];
+    __shared__ uint32_t s_over;
     __shared__ uint16_t s_mask[SP_CH];                      // bit (BY * 4 + BX): entry reaches 4x4 block (BX, BY) of the tile
     __shared__ uint8_t s_queue[4 * 4 * SP_CH];              // [wave][block][position] -> chunk-local entry, list order
     __shared__ uint32_t s_wmax[4];
@@ -336,17 +338,22 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     const uint32_t tile_max = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     if (tile_max == 0) return;                              // block-uniform
 
-    uint8_t* myqueue = s_queue + (wave * 4 + b) * SP_CH;
+    const uint8_t* myqueue = s_queue + (wave * 4 + b) * SP_CH;
     int bitk[4];                                            // bit of block k (row k of this wave) in the 16-bit tile mask
 #pragma unroll
     for (int k = 0; k < 4; k++) bitk[k] = (((wave >> 1) * 2 + (k >> 1)) * 4) + ((wave & 1) * 2 + (k & 1));
     const float ddelx_dx = 0.5f * p.W, ddely_dy = 0.5f * p.H;
 
-    const int nchunks = (int)((tile_max + SP_CH - 1) / SP_CH);
-    for (int ch = nchunks - 1; ch >= 0; --ch) {
-        const uint32_t cbase = (uint32_t)ch * SP_CH;
-        const uint32_t n = min((uint32_t)SP_CH, tile_max - cbase);
-        // ------------------------------------------------------------ stage: ids, 4x4-block masks, zero the table
+    // The tile list is consumed from its deep end in chunks of <= SP_CH entries [lo, hi).  A chunk whose entries overflow a wave's
+    // SP_CAP-row table (dense scenes) is re-staged at half the length: 112 rows always hold a 112-entry chunk.
+    float2* mytab = s_wtab + wave * SP_CAP * (TS / 2);
+    uint8_t* mycidx = s_cidx + wave * SP_CH;
+    uint32_t hi = tile_max, want = SP_CH;
+    if (threadIdx.x == 0) s_over = 0;
+    while (hi > 0) {
+        const uint32_t n = min(want, hi);
+        const uint32_t cbase = hi - n;
+        // ------------------------------------------------------------ stage: ids, 4x4-block masks
         {
             const uint32_t t = threadIdx.x;
             if (t < n) {
@@ -361,23 +368,38 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
                         if (cull_hit_rec<V>(ca, cb, (float)(tx * GSR_TILE + bx * 4), (float)(ty * GSR_TILE + by * 4), 3.f)) m |= 1u << (by * 4 + bx);
                 s_mask[t] = (uint16_t)m;
             }
-            for (uint32_t q = t; q < n * TS; q += 256) s_table[q] = 0.f;
         }
         __syncthreads();
-        // ------------------------------------------------------------ per-wave queues (list order), one per 4x4 block
-        uint32_t cnt[4] = { 0, 0, 0, 0 };
+        // ------------------------------------------------------------ per-wave queues (list order), one per 4x4 block, and table rows
+        uint32_t cnt[4] = { 0, 0, 0, 0 }, cany = 0;
         for (uint32_t e0 = 0; e0 < n; e0 += 64) {
             const uint32_t e = e0 + lane;
             const uint32_t m16 = (e < n) ? (uint32_t)s_mask[e] : 0u;
+            bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const bool hit = ((m16 >> bitk[k]) & 1u) && (cbase + e < mlast_b[k]);
+                any = any || hit;
                 const uint64_t bm = __ballot(hit);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
                 if (hit) s_queue[(wave * 4 + k) * SP_CH + cnt[k] + rank] = (uint8_t)e;
                 cnt[k] += (uint32_t)__popcll(bm);
             }
+            const uint64_t am = __ballot(any);
+            const uint32_t arank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+            if (e < n) mycidx[e] = any ? (uint8_t)min(cany + arank, 255u) : (uint8_t)0xFF;
+            cany += (uint32_t)__popcll(am);
         }
+        if (cany > SP_CAP && lane == 0) s_over = 1;
+        __syncthreads();
+        if (s_over) {                                       // block-uniform: redo this chunk shorter (n > SP_CAP here, so it terminates)
+            __syncthreads();
+            if (threadIdx.x == 0) s_over = 0;
+            want = (n + 1) / 2;
+            __syncthreads();
+            continue;
+        }
+        for (uint32_t q = lane; q < cany * (TS / 2); q += 64) mytab[q] = make_float2(0.f, 0.f);
         const int Qmine = (int)(b == 0 ? cnt[0] : (b == 1 ? cnt[1] : (b == 2 ? cnt[2] : cnt[3])));
         const int loads = (int)((max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])) + 15u) >> 4);
 
@@ -390,13 +412,13 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             const uint32_t idx0 = cbase + e;                // 0-based position in the tile list == the reference's `contributor`
             const float4* __restrict__ r = p.rec + (size_t)gid * ST;
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 q0 = valid ? r[0] : z4, q1 = valid ? r[1] : z4, q2 = valid ? r[2] : z4;
+            const float4 q0 = valid ? r[0] : z4, q1 = valid ? r[1] : z4, q2 = valid ? r[2] : z4;
             float4 q3 = z4, q4 = z4;
             if (V != GSR_EWA) q3 = valid ? r[3] : z4;
             if (V == GSR_SURFEL) q4 = valid ? r[4] : z4;
-            float acc[NACC];
+            float acc[TS];
 #pragma unroll
-            for (int c = 0; c < NACC; c++) acc[c] = 0.f;
+            for (int c = 0; c < TS; c++) acc[c] = 0.f;
             // `never` is a wave-uniform, never-true condition the compiler cannot fold: the (untaken) scalar branch after every step ends
             // the basic block, so the 16 unrolled steps are scheduled one at a time -- as ONE block the scheduler overlaps them and the
             // kernel needs 280+ VGPRs (one wave per SIMD); split, every step's temporaries die inside the step.
@@ -406,30 +428,42 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11) SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
 #undef SP_STEP
 #ifndef SP_EXPERIMENT_NO_TABLE
-            if (valid) {
-                float* t = s_table + e * TS;
+            // Add the 16 x 4 (block, splat) partials of this load into the wave's table.  The same splat can sit in several ROWS of one
+            // load (it reaches several blocks), never twice in one row: the four rows go one after the other, each a plain
+            // read-add-write (DS operations of a wave execute in order) -- no LDS float atomics, which cost ~2 cycles per LANE
+            // (18 x 64-lane ds_add_f32 per load kept the LDS pipe busy for a third of the first version's run time).
+            const uint32_t cid = valid ? (uint32_t)mycidx[e] : 0u;
 #pragma unroll
-                for (int c = 0; c < NACC; c++) lds_addf(t + c, acc[c]);
+            for (int rr = 0; rr < 4; rr++) {
+                if (b == rr && valid) {
+                    float2* t = mytab + cid * (TS / 2);
+#pragma unroll
+                    for (int c = 0; c < TS / 2; c++) { float2 v = t[c]; v.x += acc[2 * c]; v.y += acc[2 * c + 1]; t[c] = v; }
+                }
             }
-#else
-            if (valid && acc[0] == 12345.f) s_table[e * TS] = acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7] + acc[8];
 #endif
         }
         __syncthreads();
-        // ------------------------------------------------------------ flush: one 16-lane atomic per entry that received anything
+        // ------------------------------------------------------------ combine the four waves' tables; one 16-lane atomic per entry that received anything
         for (uint32_t e = threadIdx.x >> 4; e < n; e += 16) {
             const uint32_t c = threadIdx.x & 15u;
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const uint32_t ci = s_cidx[w * SP_CH + e];
+                if (ci != 0xFFu) {
+                    const float* t = reinterpret_cast<const float*>(s_wtab + (w * SP_CAP + ci) * (TS / 2));
+                    if ((int)c < NACC) v0 += t[c];
+                    if (NACC > 16 && (int)c < NACC - 16) v1 += t[16 + c];
+                }
+            }
             float* dst = p.acc + (size_t)s_ids[e] * AS;
-            if ((int)c < NACC) {
-                const float v = s_table[e * TS + c];
-                if (v != 0.f) atomic_addf(dst + c, v);
-            }
-            if (NACC > 16 && (int)c < NACC - 16) {
-                const float v = s_table[e * TS + 16 + c];
-                if (v != 0.f) atomic_addf(dst + 16 + c, v);
-            }
+            if (v0 != 0.f) atomic_addf(dst + c, v0);
+            if (NACC > 16 && v1 != 0.f) atomic_addf(dst + 16 + c, v1);
         }
-        if (ch > 0) __syncthreads();
+        hi = cbase;
+        want = SP_CH;
+        if (hi > 0) __syncthreads();
     }
 }
 
