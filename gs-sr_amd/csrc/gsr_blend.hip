@@ -424,11 +424,11 @@ int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
     p.dL_dcolor = og->dL_dcolor; p.dL_dothers = og->dL_dothers; p.dL_dout_all_map = og->dL_dout_all_map;
     p.dL_dplane_depth = og->dL_dplane_depth; p.all_map_pixels = og->all_map_pixels;
     p.acc = acc;
-    // GSR_BWD=px (default): the pixel-parallel kernel below; GSR_BWD=sp: the splat-parallel backward of gsr_blend_sp.hip.  Both pass the
-    // full parity suite; measured on MI355X (300k surfels, 1080p, round 2): px 0.525 ms, sp 0.692 ms (0.484 ms without its LDS-table
-    // adds) -- DESIGN.md section 4 has the counters.  The default is whichever measures faster.
+    // GSR_BWD=sp (default): the splat-parallel backward of gsr_blend_sp.hip; GSR_BWD=px: the pixel-parallel kernel below (round 1's
+    // formulation, kept switchable for A/B).  Both pass the full parity suite incl. the 300k / 1080p oracle cases.  Measured on MI355X,
+    // 300k splats, 1080p (round 2): surfel sp 0.486 / px 0.524 ms, EWA 0.390 / 0.483, PLANE 0.331 / 0.372 -- DESIGN.md section 4.
     static int use_sp = -1;
-    if (use_sp < 0) { const char* e = getenv("GSR_BWD"); use_sp = (e && e[0] == 's') ? 1 : 0; }
+    if (use_sp < 0) { const char* e = getenv("GSR_BWD"); use_sp = (e && e[0] == 'p') ? 0 : 1; }
     if (use_sp) {
         if (gsr_launch_blend_bwd_sp(p, cfg->variant, s)) return 1;
         return gsr_check_launch("blend_bwd_sp", s, cfg->debug);
