@@ -316,7 +316,7 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(f"{args.variant}:{dom}")
+                traffic = json.load(open(tj)).get(f"{args.variant}:{dom}" + ("_sp" if (dom == "blend_bwd" and bwd_sp) else ""))
             except Exception:
                 traffic = None
         raster_fwd = ms["preprocess"] + ms["depth_order"] + ms["binning"] + ms["blend_fwd"]
@@ -328,11 +328,13 @@ def main():
         # peak of MI355X_MICROARCH.md / 128 flop per wave64 FMA).  tools/microbench/valu_ops.py measures 1020 G/s for independent v_mov_b32
         # and 810 G/s for dependent v_fma_f32 chains on this device.
         valu = None
+        bwd_sp = not os.environ.get("GSR_BWD", "sp").startswith("p")      # which backward formulation the library runs (gsr_blend.hip)
         pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_summary.json", "r01_pmc_summary.json")) if os.path.exists(q)), "")
         vidx = {"ewa": 0, "surfel": 1, "plane": 2}[args.variant]
         if os.path.exists(pj) and args.P == 300000 and (args.W, args.H) == (1920, 1080) and args.color_mode == "precomp":
             try:
-                insts = json.load(open(pj)).get(f"k_blend_{'bwd' if dom == 'blend_bwd' else 'fwd'}<{vidx}>", {}).get("SQ_INSTS_VALU")
+                kname = (f"k_blend_bwd_sp<{vidx}>" if bwd_sp else f"k_blend_bwd<{vidx}>") if dom == "blend_bwd" else f"k_blend_fwd<{vidx}>"
+                insts = json.load(open(pj)).get(kname, {}).get("SQ_INSTS_VALU")
                 if insts:
                     rate = insts / (ms[dom] * 1e-3)
                     valu = {"wave_insts_per_launch": int(insts), "achieved_Ginst_s": round(rate / 1e9, 1), "peak_Ginst_s": 1228.8,
@@ -357,7 +359,7 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in ms.items()},
             "stage_algorithmic_GBps": {k: round(b / (ms[k] * 1e-3) / 1e9, 1) for k, b in
                                        stage_bytes(args.variant, args.color_mode, args.P, R, N, T).items() if ms.get(k, 0) > 0},
-            "roofline": {"kernel": f"k_blend_{'bwd' if dom == 'blend_bwd' else 'fwd'}<{args.variant}>", "bound": "hbm",
+            "roofline": {"kernel": (f"k_blend_bwd_sp<{args.variant}>" if bwd_sp else f"k_blend_bwd<{args.variant}>") if dom == "blend_bwd" else f"k_blend_fwd<{args.variant}>", "bound": "hbm",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(ms[dom], 4),

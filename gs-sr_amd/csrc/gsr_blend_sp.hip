@@ -188,9 +188,9 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
         const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
         const float opa = q2.w;
-        const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
-        const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
-        const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
+        const float kx = msub_rn(pxf, Tw0, Tu0), ky = msub_rn(pxf, Tw1, Tu1), kz = msub_rn(pxf, Tw2, Tu2);      // unfused, see msub_rn
+        const float lx = msub_rn(pyf, Tw0, Tv0), ly = msub_rn(pyf, Tw1, Tv1), lz = msub_rn(pyf, Tw2, Tv2);
+        const float ppx = det2_rn(ky, lz, kz, ly), ppy = det2_rn(kz, lx, kx, lz), ppz = det2_rn(kx, ly, ky, lx);
         const float rpz = (ppz == 0.0f) ? 0.0f : rcp_nr(ppz);
         const float sx = ppx * rpz, sy = ppy * rpz;
         const float rho3d = sx * sx + sy * sy;

@@ -99,7 +99,13 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
         // the block test (gsr_blend.hip conic_min_over_block) assumes a positive-definite form: fp32 cancellation in det = a c - b^2 can
         // leave a huge / near-degenerate splat with an indefinite conic, whose per-pixel gates the reference would still evaluate.
         // Anything doubtful disables culling for this splat (A = B = C = 0 with tt > 0 always hits), as for surfels.
-        if (!(conA > 0.f && conC > 0.f && conA * conC - conB * conB > 0.f)) { cull0.z = 0.f; cull0.w = 0.f; cull1.x = 0.f; if (!(cull1.y > 0.f)) cull1.y = -1.f; }
+        // the same goes for a conic whose float32 evaluation at the far corner of the rect cancels below the 2 tau margin (huge needles)
+        {
+            const float D = 1.5f * my_radius + 8.f;
+            if (!(conA > 0.f && conC > 0.f && conA * conC - conB * conB > 0.f) || !((conA + 2.f * fabsf(conB) + conC) * D * D < 2.5e4f)) {
+                cull0.z = 0.f; cull0.w = 0.f; cull1.x = 0.f; if (!(cull1.y > 0.f)) cull1.y = -1.f;
+            }
+        }
         if (p.no_cull) { cull0 = make_float4(pix, piy, 0.f, 0.f); cull1 = make_float4(0.f, 1.0f, 0.f, 0.f); }
     } while (0);
 
@@ -174,22 +180,34 @@ __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
         if (tt > 0) {
             cull0 = make_float4(pix, piy, 0.f, 0.f);
             cull1 = make_float4(0.f, 0.5f * tt * 1.001f + 0.01f, pix, piy);
-            const float* Tu = T; const float* Tv = T + 3; const float* Tw = T + 6;
-            const float t3[3] = { tt, tt, -1.0f };
-            auto qd = [&](const float* X, const float* Y) { return t3[0] * X[0] * Y[0] + t3[1] * X[1] * Y[1] + t3[2] * X[2] * Y[2]; };
-            const float w = qd(Tw, Tw);
-            const float tw2 = T[8] * T[8];
-            if (w < -1e-4f * tw2 && T[8] > 0) {
-                const float iw = 1.0f / w;
-                const float cx = qd(Tu, Tw) * iw, cy = qd(Tv, Tw) * iw;
-                float sxx = cx * cx - qd(Tu, Tu) * iw, syy = cy * cy - qd(Tv, Tv) * iw;
-                const float sxy = cx * cy - qd(Tu, Tv) * iw;
-                sxx += 0.25f + 1e-6f * cx * cx; syy += 0.25f + 1e-6f * cy * cy;
-                const float det = sxx * syy - sxy * sxy;
-                if (sxx > 0 && syy > 0 && det > 1e-6f * sxx * syy && isfinite(cx) && isfinite(cy) && isfinite(det)) {
-                    const float k = 1.0f / (1.02f * det);
-                    cull0 = make_float4(cx, cy, syy * k, -sxy * k);
-                    cull1.x = sxx * k;
+            // The dual-conic sums cancel (tt Tu.x Tw.x + tt Tu.y Tw.y - Tu.z Tw.z, and c c^T - S/w with both terms ~1/w^2 for splats
+            // close to edge-on): in float32 the centre of a x20 needle came out wrong by a few pixels and the blend skipped a splat with
+            // alpha 0.2-0.3 on five pixels (randomised sweep, surfel seed 28, rounds 1-2 -- the float64 and float32 replays of the
+            // reference formulas agree with the oracle there, the culled kernel did not).  Evaluated in float64 the cancellation error is
+            // 1e-9 of what it was; the inflation terms stay.  ~60 DP operations per visible surfel, once per forward.
+            const double Tud[3] = { T[0], T[1], T[2] }, Tvd[3] = { T[3], T[4], T[5] }, Twd[3] = { T[6], T[7], T[8] };
+            const double t3[3] = { (double)tt, (double)tt, -1.0 };
+            auto qd = [&](const double* X, const double* Y) { return t3[0] * X[0] * Y[0] + t3[1] * X[1] * Y[1] + t3[2] * X[2] * Y[2]; };
+            const double w = qd(Twd, Twd);
+            const double tw2 = Twd[2] * Twd[2];
+            if (w < -1e-4 * tw2 && T[8] > 0) {
+                const double iw = 1.0 / w;
+                const double cx = qd(Tud, Twd) * iw, cy = qd(Tvd, Twd) * iw;
+                double sxx = cx * cx - qd(Tud, Tud) * iw, syy = cy * cy - qd(Tvd, Tvd) * iw;
+                const double sxy = cx * cy - qd(Tud, Tvd) * iw;
+                sxx += 0.25 + 1e-6 * cx * cx; syy += 0.25 + 1e-6 * cy * cy;
+                const double det = sxx * syy - sxy * sxy;
+                if (sxx > 0 && syy > 0 && det > 1e-6 * sxx * syy && isfinite(cx) && isfinite(cy) && isfinite(det)) {
+                    const double k = 1.0 / (1.02 * det);
+                    const float A = (float)(syy * k), B = (float)(-sxy * k), C = (float)(sxx * k);
+                    // the float32 form the blend kernels evaluate must itself be a usable ellipse (huge needles: A C - B^2 can round to <= 0)
+                    // ... and its float32 evaluation at distance D from the centre cancels three terms of size ~ (A + 2|B| + C) D^2 down to ~1:
+                    // keep the conic only while that rounding error stays inside the 2 % inflation (D: centre to the far corner of the rect)
+                    const float D = sqrtf((float)((cx - pix) * (cx - pix) + (cy - piy) * (cy - piy))) + 1.5f * radius + 8.f;
+                    if (A > 0.f && C > 0.f && A * C - B * B > 0.f && isfinite(A) && isfinite(C) && (A + 2.f * fabsf(B) + C) * D * D < 2.5e4f) {
+                        cull0 = make_float4((float)cx, (float)cy, A, B);
+                        cull1.x = C;
+                    }
                 }
             }
         } else {

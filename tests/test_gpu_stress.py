@@ -122,3 +122,23 @@ def test_heavy_tiles_with_depth_ties():
         assert np.array_equal(st["ranges"], f.ranges())
         assert np.array_equal(st["point_list"], f.point_list())
         assert np.abs(st["color"] - f.color).max() < 1e-4
+
+
+@pytest.mark.parametrize("variant", ["surfel", "ewa", "plane"])
+@pytest.mark.parametrize("seed", [2028, 2007, 2014])
+def test_needle_splats_are_not_culled_away(variant, seed):
+    """Regression (round 2): x20 needle splats close to edge-on.  The float32 evaluation of the surfel cull conic put its centre a few
+    pixels off and the blend skipped a splat with alpha 0.2-0.3 on five pixels (randomised sweep, surfel seed 28: final T 1.66e-4 against
+    1.25e-4 in the oracle AND in float64) -- the only case of the sweep beyond the oracle's FMA noise floor in rounds 1 and 2.  The conic is
+    now built in float64 and dropped (cull disabled for the splat) when its float32 evaluation would cancel below the margin."""
+    import hiprun
+    sc = scenes.make_scene(variant, 2511, 166, 128, seed=seed, sigma_px=1.5825703, pose=0, scale_modifier=1.06444595)
+    sc["scales"][:, 0] *= 20.0
+    st = hiprun.run_raw(variant, sc)
+    with oracle.Forward(sc, variant) as f:
+        ft, nc = f.image_state()
+        d = np.abs(st["color"] - f.color).max(0)
+        assert (d > 1e-4).mean() <= 1e-4, int((d > 1e-4).sum())
+        sat = ft[0] < 1e-3                                   # deeply saturated pixels: hundreds of contributors, T is the sensitive quantity
+        rel = np.abs(st["final_T"][0] - ft[0])[sat] / ft[0][sat]
+        assert rel.size == 0 or np.quantile(rel, 0.999) < 1e-3, float(rel.max())

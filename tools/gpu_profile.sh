@@ -17,9 +17,10 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_r02_$i -- $B > /dev/null 2>&1; echo "pmc pass $i ($set) rc=$?"
 done
+# the pixel-parallel backward (GSR_BWD=px) for the A/B record, then the other two variants
 for v in ewa plane; do
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_r02_$v -- $B --variant $v > /dev/null 2>&1; echo "pmc $v rc=$?"
 done
-GSR_BWD=sp timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pmc_r02_sp1 -- $B > /dev/null 2>&1; echo "pmc sp rc=$?"
-GSR_BWD=sp timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_LDS_ATOMIC SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $R/gpurun_out/pmc_r02_sp2 -- $B > /dev/null 2>&1; echo "pmc sp2 rc=$?"
+GSR_BWD=px timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pmc_r02_px1 -- $B > /dev/null 2>&1; echo "pmc px rc=$?"
+GSR_BWD=px timeout 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_LDS_ATOMIC SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $R/gpurun_out/pmc_r02_px2 -- $B > /dev/null 2>&1; echo "pmc px2 rc=$?"
 find $O/stats -name "*kernel_stats.csv" | head -2

@@ -20,11 +20,10 @@ for f in files:
         if not (k.startswith("void k_") or k.startswith("k_")):
             continue
         name = k.split("(")[0].replace("void ", "").replace(", false>", ">").replace(", true>", ",mfma>")
-        if "k_blend_bwd_sp" in name and "sp" not in os.path.basename(os.path.dirname(os.path.dirname(f))):
-            continue
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = {"k_blend_fwd<0>": "ewa:blend_fwd", "k_blend_fwd<1>": "surfel:blend_fwd", "k_blend_fwd<2>": "plane:blend_fwd",
-         "k_blend_bwd<0>": "ewa:blend_bwd", "k_blend_bwd<1>": "surfel:blend_bwd", "k_blend_bwd<2>": "plane:blend_bwd"}
+         "k_blend_bwd<0>": "ewa:blend_bwd", "k_blend_bwd<1>": "surfel:blend_bwd", "k_blend_bwd<2>": "plane:blend_bwd",
+         "k_blend_bwd_sp<0>": "ewa:blend_bwd_sp", "k_blend_bwd_sp<1>": "surfel:blend_bwd_sp", "k_blend_bwd_sp<2>": "plane:blend_bwd_sp"}
 traffic = {}
 tj = os.path.join(root, "profiles", "traffic.json")
 if os.path.exists(tj):
