@@ -42,7 +42,7 @@ def test_decode_exports_match_header():
     b = Ld.gsd_backward_scratch_bytes(__import__("ctypes").byref(c))
     assert 60000 * 416 * 4 <= b <= 60000 * 416 * 4 + (16 << 20)        # feature-major columns + partial tiles
     assert Ld.gsd_forward_scratch_bytes(60000) < (1 << 17)           # weight image (101 KB) + scan temporaries
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="mlp_feature_bank"):      # the feature-bank branch needs its MLP (get_featurebank_mlp)
         decode.neural_gaussians(torch.zeros(2, 3), torch.zeros(2, 32), torch.zeros(2, 10, 3), torch.zeros(2, 6), None, None, None,
                                 torch.zeros(3), use_feat_bank=True)
 
