@@ -312,6 +312,7 @@ def main():
         ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items()}
         dom, dom_bytes = ("blend_bwd", bwd_b) if ms["blend_bwd"] >= ms["blend_fwd"] else ("blend_fwd", fwd_b)
         achieved = dom_bytes / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+        bwd_sp = not os.environ.get("GSR_BWD", "sp").startswith("p")      # which backward formulation the library runs (gsr_blend.hip)
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
@@ -328,7 +329,6 @@ def main():
         # peak of MI355X_MICROARCH.md / 128 flop per wave64 FMA).  tools/microbench/valu_ops.py measures 1020 G/s for independent v_mov_b32
         # and 810 G/s for dependent v_fma_f32 chains on this device.
         valu = None
-        bwd_sp = not os.environ.get("GSR_BWD", "sp").startswith("p")      # which backward formulation the library runs (gsr_blend.hip)
         pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_summary.json", "r01_pmc_summary.json")) if os.path.exists(q)), "")
         vidx = {"ewa": 0, "surfel": 1, "plane": 2}[args.variant]
         if os.path.exists(pj) and args.P == 300000 and (args.W, args.H) == (1920, 1080) and args.color_mode == "precomp":
