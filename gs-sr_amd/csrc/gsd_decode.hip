@@ -280,6 +280,15 @@ __device__ __forceinline__ void img_to_lds(float* lds, int dst_slot, const float
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // B-operand tiles of x = [feat 32 | view 3, dist | level, 1, 0, 0 | 0...] for anchor `a` (all zero for padding anchors)
+// Row v of the visible-anchor list: anchor index, or "inactive" for rows past Nv AND for padding rows (vis_idx[v] < 0).  The padded form
+// (gsd_compact_visible_padded: vis_idx has Na entries, -1 behind the visible ones, Nv = Na) lets the caller enqueue the decode without
+// first reading the number of visible anchors back to the host.
+__device__ __forceinline__ bool row_anchor(const int32_t* __restrict__ vis_idx, int v, int Nv, int& a)
+{
+    const int a0 = v < Nv ? vis_idx[v] : -1;
+    a = a0 >= 0 ? a0 : 0;
+    return a0 >= 0;
+}
 __device__ __forceinline__ void load_xb(const DecArgs& p, int a, bool active, int kk, f32x4 (&xb)[3], float (&vw)[3], float& dist)
 {
     const float4* f4 = reinterpret_cast<const float4*>(p.in.feat + (size_t)a * GSD_FEAT);
@@ -342,8 +351,8 @@ __global__ void __launch_bounds__(GSD_BLOCK) k_dec_opacity(DecArgs p, const floa
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kk = lane >> 4, k = p.cfg.k;
     for (int tile = blockIdx.x * (GSD_BLOCK / 64) + wave; tile < n_tiles; tile += gridDim.x * (GSD_BLOCK / 64)) {
         const int v = tile * 16 + n;
-        const bool active = v < p.cfg.Nv;
-        const int a = p.in.vis_idx[active ? v : 0];
+        int a;
+        const bool active = row_anchor(p.in.vis_idx, v, p.cfg.Nv, a);
         f32x4 xb[3], acc[2], hb[2];
         float vw[3], dist;
         load_xb(p, a, active, kk, xb, vw, dist);
@@ -361,11 +370,14 @@ __global__ void __launch_bounds__(GSD_BLOCK) k_dec_opacity(DecArgs p, const floa
                 neural_opacity[(size_t)v * k + j] = o;
                 mask[(size_t)v * k + j] = o > 0.0f ? 1 : 0;
                 cnt += o > 0.0f ? 1u : 0u;
+            } else if (v < p.cfg.Nv && j < k) {      // padding row: emits nothing
+                neural_opacity[(size_t)v * k + j] = 0.0f;
+                mask[(size_t)v * k + j] = 0;
             }
         }
         cnt += __shfl_xor(cnt, 16, 64);
         cnt += __shfl_xor(cnt, 32, 64);
-        if (active && kk == 0) counts[v] = cnt;
+        if (v < p.cfg.Nv && kk == 0) counts[v] = active ? cnt : 0u;
     }
 }
 
@@ -385,8 +397,8 @@ __device__ __forceinline__ void emit_head(const DecArgs& p, const float* __restr
     const int n_ot = HEAD == 1 ? (k + 1) >> 1 : (k + 3) >> 2;
     for (int tile = blockIdx.x * (GSD_BLOCK / 64) + wave; tile < n_tiles; tile += gridDim.x * (GSD_BLOCK / 64)) {
         const int v = tile * 16 + n;
-        const bool active = v < p.cfg.Nv;
-        const int a = p.in.vis_idx[active ? v : 0];
+        int a;
+        const bool active = row_anchor(p.in.vis_idx, v, p.cfg.Nv, a);
         f32x4 xb[3], acc[2], hb[2];
         float vw[3], dist;
         load_xb(p, a, active, kk, xb, vw, dist);
@@ -483,8 +495,8 @@ __device__ __forceinline__ void bwd_head(const BwdArgs& p, float* lds)
     float* __restrict__ sc = p.sc;
     for (int tile = blockIdx.x * (GSD_BLOCK / 64) + wave; tile < p.n_tiles; tile += gridDim.x * (GSD_BLOCK / 64)) {
         const int v = tile * 16 + n;
-        const bool active = v < d.cfg.Nv;
-        const int a = d.in.vis_idx[active ? v : 0];
+        int a;
+        const bool active = row_anchor(d.in.vis_idx, v, d.cfg.Nv, a);
         f32x4 xb[3], acc[2], hb[2], dh[2];
         float vw[3], dist;
         load_xb(d, a, active, kk, xb, vw, dist);
@@ -621,8 +633,8 @@ __global__ void __launch_bounds__(GSD_BLOCK) k_dec_bwd_dx(DecArgs p, const float
     for (int tile = blockIdx.x * (GSD_BLOCK / 64) + wave; tile < n_tiles; tile += gridDim.x * (GSD_BLOCK / 64)) {
         const int v = tile * 16 + n;
         if (tile * 16 >= p.cfg.Nv) continue;
-        const bool active = v < p.cfg.Nv;
-        const int a = p.in.vis_idx[active ? v : 0];
+        int a;
+        const bool active = row_anchor(p.in.vis_idx, v, p.cfg.Nv, a);
         f32x4 dx[3];
 #pragma unroll
         for (int xt = 0; xt < 3; xt++) dx[xt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -857,6 +869,28 @@ extern "C" int gsd_compact_visible(const uint8_t* mask, int32_t Na, int32_t* vis
     return gsr_check_launch("gsd_compact_visible", s, false);
 }
 
+// The same compaction WITHOUT the host synchronisation: vis_idx gets all Na entries, the visible anchors' indices first (ascending) and -1
+// behind them; the caller runs the decode with Nv = Na and the kernels skip the padding rows.  *count_dev (device, may be NULL) receives
+// the number of visible anchors.
+extern "C" int gsd_compact_visible_padded(const uint8_t* mask, int32_t Na, int32_t* vis_idx, uint32_t* count_dev, void* scratch,
+                                          size_t scratch_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (Na <= 0) return 0;
+    if (!mask || !vis_idx || !scratch || scratch_bytes < gsd_compact_scratch_bytes(Na)) {
+        gsr_set_error("gsd_compact_visible_padded: null pointer or scratch too small"); return 1;
+    }
+    uint32_t* total = (uint32_t*)scratch;
+    uint32_t* pos = (uint32_t*)((char*)scratch + 256);
+    uint32_t* sums = (uint32_t*)((char*)pos + gsr_align((size_t)Na * sizeof(uint32_t)));
+    GSR_CHECK(hipMemsetAsync(vis_idx, 0xFF, (size_t)Na * sizeof(int32_t), s), "gsd_compact_visible_padded: fill");
+    hipLaunchKernelGGL(k_flags, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos);
+    launch_scan(pos, (uint32_t)Na, sums, total, s);
+    hipLaunchKernelGGL(k_scatter_idx, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos, vis_idx);
+    if (count_dev) GSR_CHECK(hipMemcpyAsync(count_dev, total, sizeof(uint32_t), hipMemcpyDeviceToDevice, s), "gsd_compact_visible_padded: count");
+    return gsr_check_launch("gsd_compact_visible_padded", s, false);
+}
+
 static int fwd_checks(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, void* scratch, size_t scratch_bytes, const char* who)
 {
     if (check_cfg(cfg, in, p)) return 1;
@@ -1086,6 +1120,7 @@ __global__ void __launch_bounds__(ST_BLOCK) k_stats_apply(int Nv, int k, const i
     for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) p += ws[w];
     if (v >= Nv) return;
     const int a = vis_idx[v];
+    if (a < 0) return;                                                // padding row (gsd_compact_visible_padded)
     float s = 0.f;
     for (int j = 0; j < k; ++j) { const float o = nop[(size_t)v * k + j]; s += o < 0.f ? 0.f : o; }
     opacity_accum[a] += s; anchor_demon[a] += 1.f;                    // one thread per visible anchor, anchors distinct: plain read-modify-write

@@ -13,7 +13,7 @@ from . import check, dev_f32, lib, ptr, stream_ptr
 
 _vp = C.c_void_p
 PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app")
-EXPORTS = ["gsd_compact_scratch_bytes", "gsd_compact_visible", "gsd_forward_scratch_bytes", "gsd_forward_stage1", "gsd_forward_stage2",
+EXPORTS = ["gsd_compact_scratch_bytes", "gsd_compact_visible", "gsd_compact_visible_padded", "gsd_forward_scratch_bytes", "gsd_forward_stage1", "gsd_forward_stage2",
            "gsd_forward", "gsd_backward_scratch_bytes", "gsd_backward", "gsd_training_stats_scratch_bytes", "gsd_training_stats"]
 
 
@@ -52,6 +52,8 @@ def _lib():
         L.gsd_compact_scratch_bytes.restype = sz; L.gsd_compact_scratch_bytes.argtypes = [C.c_int32]
         L.gsd_compact_visible.restype = C.c_int
         L.gsd_compact_visible.argtypes = [_vp, C.c_int32, _vp, C.POINTER(C.c_uint32), _vp, sz, _vp]
+        L.gsd_compact_visible_padded.restype = C.c_int
+        L.gsd_compact_visible_padded.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, sz, _vp]
         L.gsd_forward_scratch_bytes.restype = sz; L.gsd_forward_scratch_bytes.argtypes = [C.c_int32]
         L.gsd_forward_stage1.restype = C.c_int
         L.gsd_forward_stage1.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, _vp, C.POINTER(C.c_uint32), _vp, sz, _vp]
@@ -71,8 +73,11 @@ def _lib():
     return L
 
 
-def compact_visible(visible_mask):
-    """nonzero(visible_mask) as int32 indices (ascending), computed on the device with one synchronisation for the count."""
+def compact_visible(visible_mask, padded=False):
+    """nonzero(visible_mask) as int32 indices (ascending), computed on the device.
+    padded=False: exact length, one host synchronisation for the count (the reference's boolean indexing synchronises the same way).
+    padded=True : NO synchronisation -- the result has Na entries, the visible indices first and -1 behind them; the decode and the
+                  statistics kernels skip the padding rows (include/gsdecode.h gsd_compact_visible_padded)."""
     if not visible_mask.is_cuda:
         raise RuntimeError("visible_mask must be a CUDA tensor")
     m = visible_mask.contiguous()
@@ -81,6 +86,9 @@ def compact_visible(visible_mask):
     L = _lib()
     idx = torch.empty(Na, dtype=torch.int32, device=m.device)
     scratch = torch.empty(L.gsd_compact_scratch_bytes(Na), dtype=torch.uint8, device=m.device)
+    if padded:
+        check(L.gsd_compact_visible_padded(ptr(m), Na, ptr(idx), None, ptr(scratch), scratch.numel(), stream_ptr(m.device)), "compact_visible")
+        return idx
     n = C.c_uint32(0)
     check(L.gsd_compact_visible(ptr(m), Na, ptr(idx), C.byref(n), ptr(scratch), scratch.numel(), stream_ptr(m.device)), "compact_visible")
     return idx[: n.value]
@@ -185,21 +193,25 @@ def feature_bank_blend(anchor, feat, vis_idx, campos, mlp_feature_bank):
 
 def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_color, campos, visible_mask=None, vis_idx=None,
                      appearance=None, level=None, opacity_scale=None, add_opacity_dist=False, add_cov_dist=False, add_color_dist=False,
-                     use_feat_bank=False, mlp_feature_bank=None):
+                     use_feat_bank=False, mlp_feature_bank=None, padded=False):
     """-> (xyz, color, opacity, scaling, rot, neural_opacity, mask), the `is_training=True` tuple of the reference.
 
     anchor (Na,3), feat (Na,32), offset (Na,k,3), scaling (Na,6) = get_scaling; `appearance` = embedding_appearance row of this camera
     ((A,) tensor, keeps its autograd link to the embedding table); `level` (Na,) or (Na,1) when add_level; `opacity_scale` (Na,) = the
     Octree progressive ratio with prog[~transition_mask] = 1.  `visible_mask` (bool, Na) or `vis_idx` (int32 indices) selects the anchors.
-    `use_feat_bank=True` (+ `mlp_feature_bank`) = the reference's view-adaptive feature branch, see feature_bank_blend."""
+    `use_feat_bank=True` (+ `mlp_feature_bank`) = the reference's view-adaptive feature branch, see feature_bank_blend.
+    `padded=True` (or a `vis_idx` from compact_visible(mask, padded=True)): no host synchronisation for the visible-anchor count; the returned
+    `neural_opacity` / `mask` then have Na * k rows (zeros behind the visible anchors' rows) -- what training_stats_ accepts as is."""
     if use_feat_bank and mlp_feature_bank is None:
         raise RuntimeError("gsrast.decode: use_feat_bank=True needs mlp_feature_bank (get_featurebank_mlp of the gaussian model)")
     if feat.shape[1] != 32:
         raise NotImplementedError("gsrast.decode: feat_dim must be 32")
     Na, k = offset.shape[0], offset.shape[1]
     if vis_idx is None:
-        vis_idx = torch.arange(Na, dtype=torch.int32, device=anchor.device) if visible_mask is None else compact_visible(visible_mask)
+        vis_idx = torch.arange(Na, dtype=torch.int32, device=anchor.device) if visible_mask is None else compact_visible(visible_mask, padded)
     if use_feat_bank:
+        if padded or (vis_idx.numel() and bool((vis_idx[-1:] < 0).any())):
+            raise RuntimeError("gsrast.decode: use_feat_bank needs the exact visible list (padded=False)")
         feat = feature_bank_blend(anchor, feat, vis_idx, campos, mlp_feature_bank)
     heads = _head(mlp_opacity) + _head(mlp_cov) + _head(mlp_color)
     A = 0 if appearance is None else appearance.numel()

@@ -87,6 +87,11 @@ typedef struct gsd_in_grads {
 size_t gsd_compact_scratch_bytes(int32_t Na);
 int gsd_compact_visible(const uint8_t* mask, int32_t Na, int32_t* vis_idx, uint32_t* count_host, void* scratch, size_t scratch_bytes,
                         void* stream);
+/* The same compaction without the host synchronisation: vis_idx has Na entries, the visible anchors' indices first (ascending) and -1 behind
+ * them ("padding rows"); run the decode with cfg.Nv = Na -- every gsd_* kernel skips rows whose index is negative (they emit nothing, their
+ * neural_opacity / mask rows are written as 0).  *count_dev (DEVICE, may be NULL) receives the number of visible anchors. */
+int gsd_compact_visible_padded(const uint8_t* mask, int32_t Na, int32_t* vis_idx, uint32_t* count_dev, void* scratch, size_t scratch_bytes,
+                               void* stream);
 
 /* stage 1: opacity head -> neural_opacity [Nv*k], mask [Nv*k] (u8), row_offset [Nv] (exclusive prefix of per-anchor emitted counts);
    *P_host = total, valid on return (one stream synchronisation).  scratch >= gsd_forward_scratch_bytes(Nv). */

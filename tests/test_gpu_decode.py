@@ -135,3 +135,40 @@ def test_octree_visible_matches_oracle(mode):
     if mode == "progressive":
         assert np.abs(out["prog_ratio"].cpu().numpy().ravel() - pr)[ok].max() < 1e-3 or True
         assert (out["transition_mask"].cpu().numpy() != tr).mean() < 2e-4
+
+
+def test_padded_visible_list_gives_identical_gaussians_without_the_count_sync():
+    """compact_visible(mask, padded=True): Na entries, -1 behind the visible indices, no host synchronisation.  The decode must emit exactly
+    the Gaussians of the exact list (bit-identical outputs, equal gradients), write zero neural_opacity / mask rows for the padding, and the
+    statistics kernel must skip the padding rows."""
+    from gsrast import decode
+    case = decode_cases.make_case(Na=5000, seed=9, vis_frac=0.6)
+    t = lambda a: None if a is None else torch.tensor(a, device=DEV)
+    vmask = torch.zeros(5000, dtype=torch.bool, device=DEV); vmask[torch.tensor(case["vis_idx"], dtype=torch.long, device=DEV)] = True
+    res = []
+    for padded in (False, True):
+        leaves = {n: t(case[n]).requires_grad_(True) for n in GRAD_LEAVES}
+        par = {n: (None if v is None else t(v).requires_grad_(True)) for n, v in case["params"].items()}
+        vis = decode.compact_visible(vmask, padded=padded)
+        out = decode.neural_gaussians(leaves["anchor"], leaves["feat"], leaves["offset"], leaves["scaling"],
+                                      (par["W1o"], par["b1o"], par["W2o"], par["b2o"]), (par["W1c"], par["b1c"], par["W2c"], par["b2c"]),
+                                      (par["W1k"], par["b1k"], par["W2k"], par["b2k"]), t(case["campos"]), vis_idx=vis, appearance=par["app"])
+        loss = sum((o * (i + 1.0)).sum() for i, o in enumerate(out[:5]))
+        loss.backward()
+        acc = [torch.zeros(5000, 1, device=DEV), torch.zeros(5000, 1, device=DEV), torch.zeros(5000 * case["k"], 1, device=DEV), torch.zeros(5000 * case["k"], 1, device=DEV)]
+        P = out[0].shape[0]
+        g2 = torch.rand(P, 3, generator=torch.Generator().manual_seed(1)).to(DEV); upd = (torch.arange(P, device=DEV) % 3) != 0
+        decode.training_stats_(*acc, g2, out[5], upd, out[6], vis_idx=vis)
+        res.append((vis, [o.detach() for o in out], {n: v.grad for n, v in leaves.items()}, {n: v.grad for n, v in par.items() if v is not None}, acc))
+    (v0, o0, gl0, gp0, a0), (v1, o1, gl1, gp1, a1) = res
+    Nv, k = v0.numel(), case["k"]
+    assert v1.numel() == 5000 and torch.equal(v1[:Nv], v0) and bool((v1[Nv:] == -1).all())
+    for a, b in zip(o0[:5], o1[:5]):
+        assert torch.equal(a, b)
+    assert torch.equal(o1[5][:Nv * k], o0[5]) and float(o1[5][Nv * k:].abs().max()) == 0.0 and not bool(o1[6][Nv * k:].any())
+    for n in gl0:
+        assert torch.allclose(gl0[n], gl1[n], rtol=1e-5, atol=1e-6), n
+    for n in gp0:
+        assert torch.allclose(gp0[n], gp1[n], rtol=1e-4, atol=1e-5), n
+    for a, b in zip(a0, a1):
+        assert torch.equal(a, b)

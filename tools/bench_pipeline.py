@@ -66,7 +66,7 @@ def build(a, dev, seed=0):
             vmask = radii > 0
         app = emb.weight[1]
         if a.decode == "hip":
-            vis_idx = decode.compact_visible(vmask)           # once per iteration, shared by the decode and the statistics
+            vis_idx = decode.compact_visible(vmask, padded=True)   # once per iteration, shared by the decode and the statistics; no host sync
             xyz, color, opacity, scl, rot, nop, mask = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos,
                                                                               vis_idx=vis_idx, appearance=app)
         else:
