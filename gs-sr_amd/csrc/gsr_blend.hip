@@ -84,9 +84,9 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2), q3 = ldc(r, 3), q4 = ldc(r, 4);
                 const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
                 const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
-                const float kx = msub_rn(pxf, Tw0, Tu0), ky = msub_rn(pxf, Tw1, Tu1), kz = msub_rn(pxf, Tw2, Tu2);      // unfused, see msub_rn
-                const float lx = msub_rn(pyf, Tw0, Tv0), ly = msub_rn(pyf, Tw1, Tv1), lz = msub_rn(pyf, Tw2, Tv2);
-                const float ppx = det2_rn(ky, lz, kz, ly), ppy = det2_rn(kz, lx, kx, lz), ppz = det2_rn(kx, ly, ky, lx);
+                const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
+                const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
+                const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
                 const float rpz = rcp_nr(ppz);
                 const float sx = ppx * rpz, sy = ppy * rpz;
                 const float rho3d = sx * sx + sy * sy;
@@ -308,9 +308,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 asm volatile("" : "+v"(T), "+v"(arA));   // see the EWA path
                 const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
                 const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
-                const float kx = msub_rn(pxf, Tw0, Tu0), ky = msub_rn(pxf, Tw1, Tu1), kz = msub_rn(pxf, Tw2, Tu2);      // unfused, see msub_rn
-                const float lx = msub_rn(pyf, Tw0, Tv0), ly = msub_rn(pyf, Tw1, Tv1), lz = msub_rn(pyf, Tw2, Tv2);
-                const float ppx = det2_rn(ky, lz, kz, ly), ppy = det2_rn(kz, lx, kx, lz), ppz = det2_rn(kx, ly, ky, lx);
+                const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
+                const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
+                const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
                 const float rpz = (ppz == 0.0f) ? 0.0f : rcp_nr(ppz);      // keeps s (hence rho, G <= 1) finite on lanes that will not contribute
                 const float sx = ppx * rpz, sy = ppy * rpz;
                 const float rho3d = sx * sx + sy * sy;

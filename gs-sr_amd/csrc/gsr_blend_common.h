@@ -167,25 +167,9 @@ __device__ __forceinline__ float rcp_nr(float x)
     return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
 
-// Ray-splat intersection p = k x l of the surfel variant, k = x Tw - Tu, l = y Tw - Tv (SURFEL forward.cu:282-300, backward.cu:300-318): every
-// product and every difference rounded on its own, in the reference's expression order.  For an edge-on surfel p.z is the difference of
-// two nearly equal products; with FMA contraction (the rest of these kernels) the compiler decides which product is kept exact, and that
-// choice -- not the final 1/p.z -- moved five pixels of one splat beyond the oracle's FMA noise floor in the randomised sweep (surfel seed 28,
-// rounds 1 and 2).  Unfused, the HIP value of p is bit-identical to the oracle's.  Cost: +9 VALU per pair.
-// (__fmul_rn / __fsub_rn are plain `*` / `-` in this ROCm and get contracted; the pragma removes the `contract` flag from the operations.)
-__device__ __forceinline__ float msub_rn(float a, float b, float c)
-{
-#pragma clang fp contract(off)
-    const float m = a * b;
-    return m - c;
-}
-__device__ __forceinline__ float det2_rn(float a, float b, float c, float d)
-{
-#pragma clang fp contract(off)
-    const float m = a * b, n = c * d;
-    return m - n;
-}
-
+// (Round 2 tried the ray-splat intersection p = k x l of the surfel variant with every product and difference rounded on its own -- bit-identical
+// to the oracle's p -- while chasing the one parity-sweep case beyond the noise floor; the cause was the cull conic (gsr_preprocess.hip), the
+// unfused form cost +9 VALU per pair and changed nothing, so the contracted expressions stay.)
 // Packed records are written by the preprocess kernel and are read-only in both blend kernels.  Loading them through
 // the constant address space lets the backend use scalar (SMEM) loads for the wave-uniform address even in the
 // backward kernel, where the atomics into `acc` would otherwise defeat the no-clobber analysis.

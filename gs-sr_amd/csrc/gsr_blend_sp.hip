@@ -188,9 +188,9 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
         const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
         const float opa = q2.w;
-        const float kx = msub_rn(pxf, Tw0, Tu0), ky = msub_rn(pxf, Tw1, Tu1), kz = msub_rn(pxf, Tw2, Tu2);      // unfused, see msub_rn
-        const float lx = msub_rn(pyf, Tw0, Tv0), ly = msub_rn(pyf, Tw1, Tv1), lz = msub_rn(pyf, Tw2, Tv2);
-        const float ppx = det2_rn(ky, lz, kz, ly), ppy = det2_rn(kz, lx, kx, lz), ppz = det2_rn(kx, ly, ky, lx);
+        const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
+        const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
+        const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
         const float rpz = (ppz == 0.0f) ? 0.0f : rcp_nr(ppz);
         const float sx = ppx * rpz, sy = ppy * rpz;
         const float rho3d = sx * sx + sy * sy;
@@ -436,7 +436,6 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6) SP_STEP(7)
             SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11) SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
 #undef SP_STEP
-#ifndef SP_EXPERIMENT_NO_TABLE
             // Add the 16 x 4 (block, splat) partials of this load into the wave's table.  The same splat can sit in several ROWS of one
             // load (it reaches several blocks), never twice in one row: the four rows go one after the other, each a plain
             // read-add-write (DS operations of a wave execute in order) -- no LDS float atomics, which cost ~2 cycles per LANE
@@ -450,7 +449,6 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
                     for (int c = 0; c < TS / 2; c++) { float2 v = t[c]; v.x += acc[2 * c]; v.y += acc[2 * c + 1]; t[c] = v; }
                 }
             }
-#endif
         }
         __syncthreads();
         // ------------------------------------------------------------ combine the four waves' tables; one 16-lane atomic per entry that received anything
