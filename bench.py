@@ -213,8 +213,10 @@ def method_iteration(device, which, steps=20):
     this repo, with GPU-kernel time (torch.profiler / roctracer: every kernel of the process, C-ABI launches included) beside wall time.
       scaffold-2dgs (configs[1]): prefilter (scaffold_filter) -> neural-Gaussian decode (72k anchors x 10 offsets -> ~320k Gaussians) ->
         diff_surfel_rasterization -> L1+SSIM, normal + distortion regularisers, scaling loss -> backward -> densification statistics -> Adam.
-      pgsr (configs[2], after step 7000): activations -> per-Gaussian all_map -> diff_plane_rasterization for the view AND its neighbour ->
-        L1+SSIM + single-view normal loss + multi-view geometric / NCC losses -> backward -> Adam (P = 300k explicit Gaussians).
+      octree-pgsr (configs[2], after step 7000), for the view AND its neighbour camera: octree level-of-detail mask + prefilter ->
+        neural-Gaussian decode (74k anchors x 10 offsets on 6 levels -> ~300k Gaussians) -> per-Gaussian all_map -> diff_plane_rasterization;
+        then L1+SSIM + single-view normal loss + multi-view geometric / NCC losses + scaling loss -> backward -> statistics -> Adam.
+      pgsr: the same losses and two renders on P = 300k explicit Gaussians (vanilla PGSR, no decode).
     `value` above times the hot path itself (rasterizer + image loss + Adam on explicit Gaussians), which the roofline / stage figures refer to."""
     import types
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -222,6 +224,9 @@ def method_iteration(device, which, steps=20):
     if which == "scaffold-2dgs":
         import bench_pipeline
         step, st = bench_pipeline.build(types.SimpleNamespace(decode="hip", loss="full-hip", Na=72000), device)
+    elif which == "octree-pgsr":
+        import bench_pipeline_octree_pgsr
+        step, st = bench_pipeline_octree_pgsr.build(types.SimpleNamespace(Na=74000), device)
     else:
         import bench_pipeline_pgsr
         step, st = bench_pipeline_pgsr.build(types.SimpleNamespace(glue="hip", P=300000), device)
@@ -327,7 +332,9 @@ def main():
         # count, tools/microbench/valu_count.py: +0.15 %); duration measured live.  Peak: CDNA4 CUs have four SIMD-32 units, so a wave64
         # VALU instruction issues in 2 cycles: 256 CU x 4 SIMD x 2.4 GHz / 2 = 1228.8 G wave-instructions/s (= the 157.3 TFLOP/s fp32 vector
         # peak of MI355X_MICROARCH.md / 128 flop per wave64 FMA).  tools/microbench/valu_ops.py measures 1020 G/s for independent v_mov_b32
-        # and 810 G/s for dependent v_fma_f32 chains on this device.
+        # and 810 G/s for dependent v_fma_f32 chains on this device.  tools/microbench/valu_rate.hip (profiles/r02_valu_issue_microbench.txt)
+        # measures the ceilings by operand kind: only VGPR-only fma / mul / add reach ~890 G/s; any DPP form, any SGPR operand and
+        # v_min / v_max issue at ~575 G/s, transcendentals at ~300 G/s -- the instruction mix of these kernels caps them well below 1228.8.
         valu = None
         pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_summary.json", "r01_pmc_summary.json")) if os.path.exists(q)), "")
         vidx = {"ewa": 0, "surfel": 1, "plane": 2}[args.variant]
@@ -338,7 +345,8 @@ def main():
                 if insts:
                     rate = insts / (ms[dom] * 1e-3)
                     valu = {"wave_insts_per_launch": int(insts), "achieved_Ginst_s": round(rate / 1e9, 1), "peak_Ginst_s": 1228.8,
-                            "frac": round(rate / 1228.8e9, 4), "source": f"profiles/{os.path.basename(pj)} SQ_INSTS_VALU / live avg_launch_ms"}
+                            "frac": round(rate / 1228.8e9, 4),
+                            "measured_ceilings_Ginst_s": {"vgpr_only_fma": 890, "dpp_or_sgpr_operand": 575, "transcendental": 300}, "source": f"profiles/{os.path.basename(pj)} SQ_INSTS_VALU / live avg_launch_ms"}
             except Exception:
                 valu = None
         out = {
@@ -373,7 +381,7 @@ def main():
         except Exception:
             pass
         if world == 1 and not args.no_method_iteration and args.variant == "surfel" and (args.W, args.H) == (1920, 1080):
-            out["method_iteration"] = {"scaffold-2dgs": method_iteration(device, "scaffold-2dgs"), "pgsr": method_iteration(device, "pgsr")}
+            out["method_iteration"] = {m: method_iteration(device, m) for m in ("scaffold-2dgs", "octree-pgsr", "pgsr")}
         if world == 1 and not args.no_cpu_baseline:
             og = scenes.random_out_grads(args.variant, args.W, args.H, seed=0)
             out["cpu_baseline"], ref = cpu_baseline(args.variant, sc, og)

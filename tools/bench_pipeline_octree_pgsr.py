@@ -1,0 +1,117 @@
+"""End-to-end octree-pgsr iteration after step 7000 on synthetic anchors (BASELINE.json configs[2]: OctreePGSRScene.get_train_loss_dict,
+gssr/scene/octree_pgsr_scene.py:26-45), for the view camera AND the neighbour camera:
+    level-of-detail mask + frustum prefilter (gsr_octree_visible) -> neural-Gaussian decode -> per-Gaussian all_map ->
+    diff_plane_rasterization fwd
+then L1+SSIM + single-view normal loss + multi-view geometric / NCC losses + scaling loss -> backward (both renders, both decodes) ->
+training statistics -> fused Adam.  Na anchors x k=10 offsets on 6 octree levels, sized so that ~300k Gaussians reach the rasterizer
+per camera at 1920x1080.  One JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gs-sr_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import hiprun                          # noqa: E402
+import mv_cases                        # noqa: E402
+import scenes                          # noqa: E402
+import diff_plane_rasterization as dpr   # noqa: E402
+import scaffold_filter as sf           # noqa: E402
+from bench_pipeline_pgsr import cam_of   # noqa: E402
+from gsrast import decode, octree      # noqa: E402
+from gsrast.losses import l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss  # noqa: E402
+from gsrast.plane_prep import plane_input_all_map  # noqa: E402
+
+
+def build(a, dev, seed=0):
+    """-> (step, st): one octree-pgsr training iteration (step > 7000); a has .Na."""
+    W, H, k, A, LEVELS, FORK = 1920, 1080, 10, 32, 6, 2.0
+    sc = scenes.make_scene("plane", a.Na, W, H, seed=seed, color_mode="precomp")
+    t = hiprun.to_dev(sc, dev)
+    cam2 = scenes.make_camera(W, H, W / (2 * sc["tanfovx"]), H / (2 * sc["tanfovy"]), yaw_deg=3.0, t=(-0.15, 0.02, 0.0))
+    t2 = dict(t); t2.update({n: torch.tensor(cam2[n], device=dev) for n in ("viewmatrix", "projmatrix", "campos")})
+    views = []
+    for tt in (t, t2):
+        views.append((tt, hiprun.settings("plane", tt), sf.GaussianRasterizationSettings(**hiprun.settings("ewa", tt)._asdict())))
+    g = torch.Generator(device="cpu").manual_seed(7)
+    anchor = t["means3D"].clone().requires_grad_(True)
+    s3 = t["scales"]                                          # (Na,3) world-space sigma of the synthetic scene (one axis flat)
+    ext = s3.max(dim=1, keepdim=True)[0]
+    scaling_log = torch.log(torch.cat([3.0 * ext.expand(-1, 3), 2.0 * s3], dim=1)).requires_grad_(True)
+    feat = torch.randn(a.Na, 32, generator=g).to(dev).requires_grad_(True)
+    offset = (0.5 * torch.randn(a.Na, k, 3, generator=g)).to(dev).requires_grad_(True)
+    rot_anchor = torch.nn.functional.normalize(torch.randn(a.Na, 4, generator=g), dim=1).to(dev)
+    level = torch.randint(0, LEVELS, (a.Na, 1), generator=g).to(dev)
+    extra_level = torch.zeros(a.Na, device=dev)
+    dist = (t["means3D"] - t["campos"]).norm(dim=1)
+    standard_dist = float(dist.median()) * FORK ** 3.5         # median anchor predicts level 3.5: levels 0..3 or 0..4 of 0..5 pass the mask
+    voxel_size = float(ext.median()) * 8.0
+    mlp = lambda i, o, act: torch.nn.Sequential(torch.nn.Linear(i, 32), torch.nn.ReLU(True), torch.nn.Linear(32, o), act).to(dev)
+    torch.manual_seed(3)
+    mlp_o, mlp_c, mlp_k = mlp(35, k, torch.nn.Tanh()), mlp(35, 7 * k, torch.nn.Identity()), mlp(35 + A, 3 * k, torch.nn.Sigmoid())
+    emb = torch.nn.Embedding(4, A).to(dev)
+    params = [anchor, scaling_log, feat, offset, emb.weight] + [p for m in (mlp_o, mlp_c, mlp_k) for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15, fused=True)
+    gt = torch.rand((3, H, W), generator=g).to(dev)
+    gray1 = gt.mean(0, keepdim=True).contiguous(); gray2 = torch.rand((1, H, W), generator=g).to(dev)
+    c1, c2 = cam_of(t, W, H), cam_of(t2, W, H)
+    K1 = torch.tensor([[c1["Fx"], 0, c1["Cx"]], [0, c1["Fy"], c1["Cy"]], [0, 0, 1]], device=dev)
+    rm1 = torch.inverse(K1.double().t()).float()
+    weight = torch.rand((H, W), generator=g).to(dev)
+    mcfg = multiview_cfg(mv_cases.cam_ns(c1), mv_cases.cam_ns(c2), W, H, near_size=(W, H))
+    acc = {"opacity_accum": torch.zeros(a.Na, 1, device=dev), "anchor_demon": torch.zeros(a.Na, 1, device=dev),
+           "offset_gradient_accum": torch.zeros(a.Na * k, 1, device=dev), "offset_denom": torch.zeros(a.Na * k, 1, device=dev)}
+    st = {}
+
+    def render(view, cam_id, scaling):
+        tt, rs, fs = view
+        vis = octree.octree_visible(fs, anchor, level, scaling, rot_anchor, voxel_size, FORK, standard_dist, LEVELS, dist2level="round",
+                                    extra_level=extra_level)   # set_anchor_mask + prefilter_voxel, no host sync
+        vis_idx = decode.compact_visible(vis["visible_mask"], padded=True)
+        xyz, color, opacity, scl, rot, nop, mask = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, tt["campos"],
+                                                                          vis_idx=vis_idx, appearance=emb.weight[cam_id])
+        am = plane_input_all_map(xyz, rot, scl, tt["viewmatrix"], tt["campos"])
+        m2 = torch.zeros_like(xyz, requires_grad=True); m2a = torch.zeros_like(xyz, requires_grad=True)
+        img, radii, obs, oam, pd = dpr.GaussianRasterizer(rs)(means3D=xyz, means2D=m2, means2D_abs=m2a, opacities=opacity, colors_precomp=color,
+                                                             scales=scl, rotations=rot, all_map=am)
+        return img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vis["visible_mask"]
+
+    def step():
+        scaling = torch.exp(scaling_log)
+        img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask = render(views[0], 1, scaling)
+        _, _, _, pd2, _, _, _, _, _, _ = render(views[1], 2, scaling)
+        loss = l1_ssim(img, gt, 0.2) + plane_geo_loss(pd, oam, rm1, weight, 0.015)[0] + 0.01 * scl.prod(dim=1).mean()
+        geo, ncc = plane_multiview_loss(pd, pd2, oam[0:3], oam[4:5], gray1, gray2, mcfg, 0.03, 0.15)
+        (loss + geo + ncc).backward()
+        decode.training_stats_(acc["opacity_accum"], acc["anchor_demon"], acc["offset_gradient_accum"], acc["offset_denom"], m2.grad, nop, radii > 0,
+                               mask, vis_idx=vis_idx)
+        opt.step(); opt.zero_grad(set_to_none=True)
+        if "P" not in st:
+            st["P"] = int(mask.sum()); st["Nv"] = int(vmask.sum())
+
+    return step, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--Na", type=int, default=74000)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    a = ap.parse_args()
+    step, st = build(a, torch.device("cuda:0"))
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"pipeline": "octree-pgsr (step > 7000: LOD mask + prefilter + decode + plane render, twice; single-view + multi-view losses)",
+                      "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps, "ms_per_iter": round(1e3 * dt / a.steps, 3),
+                      "iters_per_s": round(a.steps / dt, 1)}))
+
+
+if __name__ == "__main__":
+    main()
