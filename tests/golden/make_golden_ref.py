@@ -46,6 +46,10 @@ Pinned (reference file:line -> fixture):
         hands to the plane rasterizer, captured from a stub rasterizer, + autograd of sum(all_map * dL) to means3D / rotations.
         quaternion_to_matrix comes from pytorch3d (absent third-party dependency, unpinned in requirements.txt): the generator supplies its
         published formula.
+  ref_ply_layout.npz
+        gssr/gaussian/vanilla_gaussian.py:140-214, scaffold_gaussian.py:388-456, octree_gaussian.py:276-360: save_gaussians / load_gaussians of
+        the three models with plyfile's describe / read replaced by probes (the vertex table's column names and values out, the same table
+        back in): the point-cloud column layout and the flatten / reshape conventions of both directions.
   ref_loss_plane_geo.npz
         gssr/scene/pgsr_scene.py:227-238 render_normal (normal_from_depth_image, gssr/utils/graphics_utils.py:139-146),
         pgsr_scene.py:32-58 _get_img_grad_weight / erode, combined exactly as pgsr_scene.py:108-112 (the single-view normal loss);
@@ -513,7 +517,68 @@ def tsdf_fixture():
          rgb=np.stack(rgbs), points=got["points"], sdf_trunc=trunc, tsdf=got["tsdf"], verts=verts, voxel_size=voxel, vert_rgb=np.asarray(mesh.vertex_colors))
 
 
+# ----------------------------------------------------------------------------------------------------------------- point-cloud files
+class _PlyVertex:
+    """What `plydata.elements[0]` has to offer the reference's load_gaussians: column access by name and `.properties[i].name`."""
+    def __init__(self, rec):
+        self.rec = rec
+        self.properties = [types.SimpleNamespace(name=n) for n in rec.dtype.names]
+
+    def __getitem__(self, name):
+        return self.rec[name]
+
+
+def ply_fixture():
+    """VanillaGaussian / ScaffoldGaussian / OctreeGaussian save_gaussians + load_gaussians.  plyfile is absent: `PlyElement.describe` is
+    replaced by a probe that captures the structured array the reference hands to it (= the file's vertex table, names and values), and
+    `PlyData.read` by one that serves that table back, so what is pinned is the reference's column layout and its (N, C, S) <-> flat
+    conventions in both directions -- not plyfile's container, which tests/test_ply_cpu.py checks against the PLY specification."""
+    g = torch.Generator().manual_seed(21)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    _tensor = torch.tensor
+    torch.tensor = lambda *a, **k: _tensor(*a, **{**k, "device": "cpu"}) if "device" in k else _tensor(*a, **k)
+    _ones = torch.ones
+    torch.ones = lambda *a, **k: _ones(*a, **{**k, "device": "cpu"}) if "device" in k else _ones(*a, **k)
+    out = {}
+    try:
+        for tag, modname, clsname, attrs in (
+                ("vanilla", "gssr.gaussian.vanilla_gaussian", "VanillaGaussian",
+                 dict(_xyz=rnd(6, 3), _features_dc=rnd(6, 1, 3), _features_rest=rnd(6, 15, 3), _opacity=rnd(6, 1), _scaling=rnd(6, 3), _rotation=rnd(6, 4),
+                      max_sh_degree=3)),
+                ("scaffold", "gssr.gaussian.scaffold_gaussian", "ScaffoldGaussian",
+                 dict(_anchor=rnd(5, 3), _offset=rnd(5, 10, 3), _anchor_feat=rnd(5, 32), _opacity=rnd(5, 1), _scaling=rnd(5, 6), _rotation=rnd(5, 4))),
+                ("octree", "gssr.gaussian.octree_gaussian", "OctreeGaussian",
+                 dict(_anchor=rnd(5, 3), _offset=rnd(5, 10, 3), _anchor_feat=rnd(5, 32), _opacity=rnd(5, 1), _scaling=rnd(5, 6), _rotation=rnd(5, 4),
+                      _level=torch.randint(0, 4, (5, 1), generator=g), _extra_level=torch.rand(5, generator=g), voxel_size=0.03125, standard_dist=6.5))):
+            mod = ref_import(modname)
+            cls = getattr(mod, clsname)
+            obj = _bare(cls, **attrs)
+            got = {}
+            mod.PlyElement.describe = lambda elements, name: got.update(rec=elements.copy(), element=name)
+            obj.save_gaussians("unused.ply")
+            rec = got["rec"]
+            assert got["element"] == "vertex" and all(rec.dtype[n] == np.dtype("f4") for n in rec.dtype.names)
+            out[tag + "_names"] = np.array(rec.dtype.names)
+            out[tag + "_table"] = np.stack([rec[n] for n in rec.dtype.names], axis=1).astype(np.float32)
+            for k, v in attrs.items():
+                if torch.is_tensor(v):
+                    out[f"{tag}_in{k}"] = v.numpy()
+            mod.PlyData.read = lambda path: types.SimpleNamespace(elements=[_PlyVertex(rec)])
+            fresh = _bare(cls, **({"max_sh_degree": 3} if tag == "vanilla" else {}))
+            fresh.load_gaussians("unused.ply")
+            for k in attrs:
+                v = getattr(fresh, k, None)
+                if torch.is_tensor(v):
+                    out[f"{tag}_loaded{k}"] = v.detach().numpy()
+                elif k in ("voxel_size", "standard_dist"):
+                    out[f"{tag}_loaded_{k}"] = np.float32(float(v))
+    finally:
+        torch.tensor = _tensor; torch.ones = _ones
+    save("ref_ply_layout.npz", **out)
+
+
 if __name__ == "__main__":
+    ply_fixture()
     cov3d_fixture()
     densify_stats_fixture()
     training_stats_fixture()
