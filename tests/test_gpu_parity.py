@@ -2,6 +2,7 @@
 CPU oracle on identical inputs.  Bars (BASELINE.json north_star): bit-exact for integer/index work (radii,
 tiles_touched, sorted instance list, tile ranges, out_observe); <=1e-4 on rendered RGB/depth/normal maps; <=1e-3
 relative on gradients."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -468,3 +469,15 @@ def test_full_size_oracle_parity(variant, cm, seed, pose):
         pairs += [("dL_dall_map", "dL_dall_map"), ("dL_dmeans2D_abs", "dL_dmeans2D_abs")]
     for a, b in pairs:
         _grad_close(gg[a], g[b], floor=g2[b])
+
+
+def test_pixel_parallel_backward_kept_switchable():
+    """GSR_BWD=px selects round 1's pixel-parallel backward (kept for A/B, gsr_blend.hip).  The library reads the switch once per process,
+    so the parity cases above are re-run in a child process with it set: the kernel nobody runs by default has to stay parity-green."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSR_BWD="px")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity or test_edge_cases",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
