@@ -173,3 +173,29 @@ def test_concurrent_forwards_on_two_threads_and_streams():
     for t in th:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
+def test_dense_tile_lists_backward_through_the_chunk_halving_path(variant):
+    """Every splat reaches every quadrant of every tile and every tile list holds all 420 of them: a 256-entry chunk overflows the 112-row
+    per-wave gradient table of the splat-parallel backward, so each chunk is re-staged at half length (twice).  All gradients against the
+    oracle, for the three variants."""
+    hr = _hr()
+    W, H = 160, 96
+    P, sigma = (900, 60.0) if variant == "surfel" else (420, 260.0)      # surfels that large would cross the camera plane and be dropped
+    sc = scenes.make_scene(variant, P, W, H, seed=53, sigma_px=sigma)
+    sc["opacities"][:] = 0.015                      # transmittance stays alive to the end of every list
+    og = scenes.random_out_grads(variant, W, H, seed=53, scale=1.0)
+    with oracle.Forward(sc, variant) as f:
+        g = f.backward(**og)
+        st = hr.run_raw(variant, sc)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        assert st["R"] == f.R and f.R > (0.35 if variant == "surfel" else 0.8) * P * T
+        assert (st["n_contrib"][0] > 256).mean() > 0.5, (st["n_contrib"][0] > 256).mean()      # most pixels replay more than one 256-entry chunk
+        res = hr.run(variant, sc, og)
+    names = [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"), ("dL_dopacities", "dL_dopacity"),
+             ("dL_dcolors_precomp" if sc.get("colors_precomp") is not None else "dL_dshs", "dL_dcolors" if sc.get("colors_precomp") is not None else "dL_dsh"),
+             ("dL_dmeans2D", "dL_dmeans2D")]
+    for a, b in names:
+        x, y = res["grads"][a].astype(np.float64), np.asarray(g[b], np.float64).reshape(res["grads"][a].shape)
+        assert np.linalg.norm(x - y) <= 1e-3 * np.linalg.norm(y) + 1e-12, (variant, a, np.linalg.norm(x - y) / np.linalg.norm(y))
