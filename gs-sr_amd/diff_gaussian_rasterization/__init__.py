@@ -43,6 +43,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
                               geomBuffer, binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)     # an output the loss does not use arrives as None (a null pointer for the kernels), not as a zero-filled image
         return outs["color"], radii
 
     @staticmethod

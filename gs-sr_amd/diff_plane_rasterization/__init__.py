@@ -42,6 +42,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(out_all_map, colors_precomp, all_maps, means3D, scales, rotations, cov3Ds_precomp, radii,
                               sh, opacities, geomBuffer, binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii, out_observe)
+        ctx.set_materialize_grads(False)     # an output the loss does not use arrives as None (a null pointer for the kernels), not as a zero-filled image
         return outs["color"], radii, out_observe, out_all_map, out_plane_depth
 
     @staticmethod

@@ -135,6 +135,7 @@ class _NeuralDecode(torch.autograd.Function):
                               nop, row_offset, scratch, *[prm[nm] for nm in PARAM_NAMES])
         mask_b = mask.view(torch.bool)
         ctx.mark_non_differentiable(nop, mask_b)
+        ctx.set_materialize_grads(False)     # no zero-filled (Nv*k) gradient tensors for nop / mask (or an unused output) on every backward
         return xyz, color, opacity, scl, rot, nop, mask_b
 
     @staticmethod

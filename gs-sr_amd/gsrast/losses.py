@@ -57,12 +57,13 @@ class _L1SSIM(torch.autograd.Function):
         ctx.save_for_backward(dimg)
         parts = out[:2].detach()
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)
         return out[2], parts
 
     @staticmethod
     def backward(ctx, g, _g_parts):
         (dimg,) = ctx.saved_tensors
-        return dimg * g, None, None
+        return (None if g is None else dimg * g), None, None
 
 
 def l1_ssim(image, gt, lambda_dssim=0.2, return_parts=False):
@@ -105,12 +106,13 @@ class _SurfelGeo(torch.autograd.Function):
         parts = out[:2].detach()
         extras = [parts] + ([depth, nw, sn] if want_maps else [])
         ctx.mark_non_differentiable(*extras)
+        ctx.set_materialize_grads(False)     # the extra outputs are plain values: no zero-filled (3,H,W) gradients for them on every backward
         return (out[2], *extras)
 
     @staticmethod
     def backward(ctx, g, *_):
         (dL,) = ctx.saved_tensors
-        return dL * g, None, None, None, None, None, None
+        return (None if g is None else dL * g), None, None, None, None, None, None
 
 
 def surfel_geo_loss(allmap, ray_mat, normal_rot, depth_ratio=0.0, lambda_normal=0.05, lambda_dist=0.0, return_maps=False):
@@ -134,7 +136,8 @@ class _PlaneGeo(torch.autograd.Function):
         dev = am.device
         out = torch.empty(3, dtype=torch.float32, device=dev)
         dD = torch.empty_like(d)
-        dA = torch.zeros_like(am)                       # channels 3 (alpha, detached) and 4 (distance) get no gradient here
+        dA = torch.empty_like(am)                       # the kernel writes every pixel of the three normal channels;
+        dA[3:].zero_()                                  # channels 3 (alpha, detached) and 4 (distance) get no gradient here
         dn = torch.empty(3, H, W, dtype=torch.float32, device=dev) if want_map else None
         scratch = torch.empty(max(L.gsr_loss_surfel_geo_scratch_bytes(H, W), 8), dtype=torch.uint8, device=dev)
         alpha = am[3]
@@ -143,11 +146,14 @@ class _PlaneGeo(torch.autograd.Function):
         ctx.save_for_backward(dD, dA)
         extras = [out[:1].detach()] + ([dn] if want_map else [])
         ctx.mark_non_differentiable(*extras)
+        ctx.set_materialize_grads(False)
         return (out[2], *extras)
 
     @staticmethod
     def backward(ctx, g, *_):
         dD, dA = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None, None, None
         return dD * g, dA * g, None, None, None, None
 
 
@@ -256,15 +262,17 @@ class _PlaneMultiview(torch.autograd.Function):
         aux = {"pixel_noise": noise.view(H, W), "d_mask": dmask.view(H, W).bool(), "weights": weight.view(H, W), "indices": idx,
                "ncc": ncc[: idx.numel()], "ncc_mask": cmask[: idx.numel()].bool(), "stats": stats}
         ctx.mark_non_differentiable(*[v for v in aux.values()])
+        ctx.set_materialize_grads(False)     # seven auxiliary outputs (H*W masks, sample lists): no zero-filled gradients for them
         return (geo, nccl, *aux.values())
 
     @staticmethod
     def backward(ctx, g_geo, g_ncc, *_):
         gD, gN, gNm, gDs, sg, sn = ctx.saved_tensors
         s0, s1, s2, s3 = ctx.shapes
-        a = g_geo * sg
-        b = g_ncc * sn
-        return ((gD * a).view(s0), (gN * a).view(s1), (gNm * b).view(s2), (gDs * b).view(s3), None, None, None, None, None, None, None, None)
+        a = None if g_geo is None else g_geo * sg          # a loss the caller did not use sends no gradient
+        b = None if g_ncc is None else g_ncc * sn
+        return (None if a is None else (gD * a).view(s0), None if a is None else (gN * a).view(s1),
+                None if b is None else (gNm * b).view(s2), None if b is None else (gDs * b).view(s3), None, None, None, None, None, None, None, None)
 
 
 _MV_AUX = ("pixel_noise", "d_mask", "weights", "indices", "ncc", "ncc_mask", "stats")

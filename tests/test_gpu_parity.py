@@ -481,3 +481,46 @@ def test_pixel_parallel_backward_kept_switchable():
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("variant", ["surfel", "plane"])
+def test_unused_outputs_send_no_gradient_tensor(variant):
+    """The autograd bridges do not ask autograd to materialise zero gradients for outputs the loss never touched (set_materialize_grads(False)):
+    such an output reaches the kernels as a null pointer.  The gradients must equal those of the same loss written with explicit zero
+    weights on every output (what the reference's materialised zeros amount to)."""
+    hr = _hiprun()
+    import torch
+    W, H = 200, 120
+    sc = scenes.make_scene(variant, 2500, W, H, seed=77)
+    t = hr.to_dev(sc, "cuda")
+    rs = hr.settings(variant, t)
+    gsel = torch.Generator().manual_seed(5)
+    wsel = torch.rand((1, H, W), generator=gsel).cuda()
+
+    def run(explicit_zeros):
+        leaves = {k: t[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations")}
+        m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        kw = dict(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], colors_precomp=leaves["colors_precomp"],
+                  scales=leaves["scales"], rotations=leaves["rotations"])
+        if variant == "surfel":
+            color, radii, others = hr.dsr.GaussianRasterizer(rs)(**kw)
+            loss = (others[0:1] * wsel).sum()                      # depth channel only: `color` is never used
+            if explicit_zeros:
+                loss = loss + (color * 0.0).sum()
+        else:
+            m2a = torch.zeros_like(leaves["means3D"], requires_grad=True)
+            am = t["all_map"].clone().requires_grad_(True); leaves["all_map"] = am
+            color, radii, obs, oam, pd = hr.dpr.GaussianRasterizer(rs)(means2D_abs=m2a, all_map=am, **kw)
+            loss = (pd * wsel).sum()                               # plane depth only: colour and all_map maps unused
+            if explicit_zeros:
+                loss = loss + (color * 0.0).sum() + (oam * 0.0).sum()
+        loss.backward()
+        return {k: v.grad.detach().cpu().numpy() for k, v in leaves.items()}, m2.grad.detach().cpu().numpy()
+
+    ga, ma = run(False)
+    gb, mb = run(True)
+    for k in ga:
+        d = np.linalg.norm(ga[k].astype(np.float64) - gb[k])               # two runs of the backward differ by the order of the float atomics
+        assert d <= 1e-4 * np.linalg.norm(gb[k].astype(np.float64)) + 1e-30, (k, d)
+        assert k == "colors_precomp" or np.abs(gb[k]).max() > 0, k          # the colour image is unused: its parameters get exact zeros
+    assert np.linalg.norm(ma.astype(np.float64) - mb) <= 1e-4 * np.linalg.norm(mb.astype(np.float64))
