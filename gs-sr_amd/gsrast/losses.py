@@ -42,7 +42,8 @@ def l1_plus_linear(color, gt, aux=None, waux=None, root=False):
 
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, gt, lambda_dssim):
+    def forward(ctx, image, gt, lambda_dssim, unit_upstream=False):
+        ctx.unit = bool(unit_upstream)
         x = dev_f32(image, "image", allow_empty=False)
         y = dev_f32(gt, "gt", allow_empty=False)
         if x.dim() != 3 or x.shape != y.shape:
@@ -63,14 +64,17 @@ class _L1SSIM(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g_parts):
         (dimg,) = ctx.saved_tensors
-        return (None if g is None else dimg * g), None, None
+        return (None if g is None else (dimg if ctx.unit else dimg * g)), None, None, None
 
 
-def l1_ssim(image, gt, lambda_dssim=0.2, return_parts=False):
+def l1_ssim(image, gt, lambda_dssim=0.2, return_parts=False, unit_upstream=False):
     """(1 - lambda) * |image - gt|.mean() + lambda * (1 - ssim(image, gt)) -- the sum of the reference's `L1_loss` and `ssim_loss`
     entries (gssr/scene/vanilla_scene.py:63-69) -- with value and dL/dimage from two fused HIP kernels.  `return_parts=True` also returns
-    the (non-differentiable) tensor [mean|image-gt|, mean SSIM] for logging."""
-    loss, parts = _L1SSIM.apply(image, gt, lambda_dssim)
+    the (non-differentiable) tensor [mean|image-gt|, mean SSIM] for logging.
+    `unit_upstream=True` (here and in the geometric losses below) is the caller's promise that this value enters the total loss with weight
+    exactly 1 -- as every entry of GS-SR's `sum(loss_dict.values())` does -- so that backward hands out the gradient computed in forward as
+    it is instead of multiplying a full-size map by the upstream scalar 1."""
+    loss, parts = _L1SSIM.apply(image, gt, lambda_dssim, bool(unit_upstream))
     return (loss, parts) if return_parts else loss
 
 
@@ -86,7 +90,8 @@ def camera_ray_matrices(world_view_transform, full_proj_transform, W, H):
 
 class _SurfelGeo(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist, want_maps):
+    def forward(ctx, allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist, want_maps, unit_upstream=False):
+        ctx.unit = bool(unit_upstream)
         am = dev_f32(allmap, "allmap", allow_empty=False)
         if am.dim() != 3 or am.shape[0] != 11:
             raise RuntimeError("allmap must be (11, H, W)")
@@ -112,19 +117,20 @@ class _SurfelGeo(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *_):
         (dL,) = ctx.saved_tensors
-        return (None if g is None else dL * g), None, None, None, None, None, None
+        return (None if g is None else (dL if ctx.unit else dL * g)), None, None, None, None, None, None, None
 
 
-def surfel_geo_loss(allmap, ray_mat, normal_rot, depth_ratio=0.0, lambda_normal=0.05, lambda_dist=0.0, return_maps=False):
+def surfel_geo_loss(allmap, ray_mat, normal_rot, depth_ratio=0.0, lambda_normal=0.05, lambda_dist=0.0, return_maps=False, unit_upstream=False):
     """lambda_normal * normal_loss + lambda_dist * dist_loss of TwoDGSScene.get_loss_dict (gssr/scene/twodgs_scene.py:25-35) computed
     straight from the rasterizer's allmap, fused with the render() post-processing (:88-115) and depth_to_normal.
     -> loss, parts=[mean normal error, mean distortion]  (+ depth (1,H,W), normal (3,H,W), surf_normal (3,H,W) when return_maps)."""
-    return _SurfelGeo.apply(allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist, bool(return_maps))
+    return _SurfelGeo.apply(allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist, bool(return_maps), bool(unit_upstream))
 
 
 class _PlaneGeo(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plane_depth, out_all_map, weight, ray_mat, lambda_normal, want_map):
+    def forward(ctx, plane_depth, out_all_map, weight, ray_mat, lambda_normal, want_map, unit_upstream=False):
+        ctx.unit = bool(unit_upstream)
         d = dev_f32(plane_depth, "plane_depth", allow_empty=False)
         am = dev_f32(out_all_map, "out_all_map", allow_empty=False)
         if am.dim() != 3 or am.shape[0] != 5 or d.numel() != am.shape[1] * am.shape[2]:
@@ -153,16 +159,18 @@ class _PlaneGeo(torch.autograd.Function):
     def backward(ctx, g, *_):
         dD, dA = ctx.saved_tensors
         if g is None:
-            return None, None, None, None, None, None
-        return dD * g, dA * g, None, None, None, None
+            return None, None, None, None, None, None, None
+        if ctx.unit:
+            return dD, dA, None, None, None, None, None
+        return dD * g, dA * g, None, None, None, None, None
 
 
-def plane_geo_loss(plane_depth, out_all_map, ray_mat, weight=None, lambda_normal=0.015, return_map=False):
+def plane_geo_loss(plane_depth, out_all_map, ray_mat, weight=None, lambda_normal=0.015, return_map=False, unit_upstream=False):
     """PGSR single-view normal loss (gssr/scene/pgsr_scene.py:105-112): lambda * mean(weight * |depth_normal - rendered_normal|.sum(0)) with
     depth_normal = normal_from_depth_image(plane_depth) * alpha.detach(), straight from the rasterizer outputs.  ray_mat = inverse(K^T) of
     `get_calib_matrix_nerf`; weight = the detached image-gradient weight map (per camera, cacheable) or None.
     -> loss, [mean weighted L1]  (+ depth_normal (3,H,W) when return_map)."""
-    return _PlaneGeo.apply(plane_depth, out_all_map, weight, ray_mat, lambda_normal, bool(return_map))
+    return _PlaneGeo.apply(plane_depth, out_all_map, weight, ray_mat, lambda_normal, bool(return_map), bool(unit_upstream))
 
 
 def multiview_cfg(view_cam, near_cam, W, H, near_size=None, gray_size=None, patch_size=3, pixel_noise_threshold=1.0):

@@ -151,3 +151,29 @@ def test_l1_plus_linear_root_flag_same_gradients():
     assert torch.equal(grads[0][1], grads[1][1]) and torch.equal(grads[0][2], grads[1][2])
     ref = (c - gt).abs().mean() + (a * w).sum()
     assert abs(grads[0][0] - ref.item()) < 1e-3 * abs(ref.item()) + 1e-5
+
+
+def test_unit_upstream_flag_same_gradients_and_unused_loss_sends_none():
+    """unit_upstream=True (the loss enters the total with weight 1, as in GS-SR's sum(loss_dict.values())) returns the stored gradient without the
+    full-size multiply by the upstream scalar: bit-identical to the default path when that scalar is 1; and a loss value that is computed but
+    never used sends no gradient at all."""
+    from gsrast.losses import camera_ray_matrices, l1_ssim, plane_geo_loss, surfel_geo_loss
+    g = torch.Generator().manual_seed(1)
+    H, W = 48, 80
+    img = torch.rand(3, H, W, generator=g).to(DEV); gt = torch.rand(3, H, W, generator=g).to(DEV)
+    am = torch.rand(11, H, W, generator=g).to(DEV) + 0.2
+    oam = torch.rand(5, H, W, generator=g).to(DEV) + 0.1; pd = torch.rand(1, H, W, generator=g).to(DEV) + 1.0
+    rm = torch.eye(3, device=DEV) + 0.01 * torch.rand(3, 3, generator=g).to(DEV); nr = torch.eye(3, device=DEV)
+    out = []
+    for unit in (False, True):
+        a, b, c, d = (t.clone().requires_grad_(True) for t in (img, am, oam, pd))
+        total = (l1_ssim(a, gt, 0.2, unit_upstream=unit) + surfel_geo_loss(b, rm, nr, 0.0, 0.05, 100.0, unit_upstream=unit)[0]
+                 + plane_geo_loss(d, c, rm, None, 0.015, unit_upstream=unit)[0])
+        total.backward()
+        out.append([t.grad.clone() for t in (a, b, c, d)])
+    for x, y in zip(*out):
+        assert torch.equal(x, y) and x.abs().max() > 0
+    a = img.clone().requires_grad_(True); b = am.clone().requires_grad_(True)
+    unused = surfel_geo_loss(b, rm, nr, 0.0, 0.05, 100.0)[0]          # computed, not part of the total
+    l1_ssim(a, gt, 0.2).backward()
+    assert b.grad is None and a.grad is not None and unused.item() == unused.item()

@@ -84,7 +84,7 @@ def build(a, dev, seed=0):
         if a.loss == "bench":
             loss = l1_plus_linear(img, gt, allmap, wmap) + reg
         elif a.loss == "full-hip":
-            loss = l1_ssim(img, gt, 0.2) + surfel_geo_loss(allmap, rm, nr, 0.0, 0.05, 100.0)[0] + reg
+            loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + surfel_geo_loss(allmap, rm, nr, 0.0, 0.05, 100.0, unit_upstream=True)[0] + reg
         else:
             loss = ref_loss_torch.loss(img.unsqueeze(0), gt.unsqueeze(0), 0.2)[0] + ref_geo_torch.geo_loss(allmap, wvt, fpt, 0.0, 0.05, 100.0)[0] + reg
         loss.backward()

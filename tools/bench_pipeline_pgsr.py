@@ -89,7 +89,7 @@ def build(a, dev):
         img, radii, obs, oam, pd = render(rs1, t, xyz, scl, rot, op)
         _, _, _, _, pd2 = render(rs2, t2, xyz, scl, rot, op)
         if a.glue == "hip":
-            loss = l1_ssim(img, gt, 0.2) + plane_geo_loss(pd, oam, rm1, weight, 0.015)[0]
+            loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + plane_geo_loss(pd, oam, rm1, weight, 0.015, unit_upstream=True)[0]
             geo, ncc = plane_multiview_loss(pd, pd2, oam[0:3], oam[4:5], gray1, gray2, mcfg, 0.03, 0.15)
         else:
             loss = ref_loss_torch.loss(img.unsqueeze(0), gt.unsqueeze(0), 0.2)[0] + ref_geo_torch.plane_geo_loss(pd.squeeze(0), oam, K1, weight, 0.015)[0]

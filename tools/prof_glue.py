@@ -1,3 +1,4 @@
+"""Per-iteration GPU time of the torch glue ops (zero fills, scalar multiplies, gradient accumulation adds ...) around the HIP kernels of a\ncomplete method iteration, grouped by op and input shape:  python tools/prof_glue.py octree|scaffold"""
 import sys, os, types, torch
 sys.path.insert(0, "tools")
 which = sys.argv[1]
