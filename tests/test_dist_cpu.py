@@ -173,3 +173,25 @@ def _sparse_merge_worker(rank, world, port):
 
 def test_sparse_tsdf_merge_world2_gloo():
     mp.spawn(_sparse_merge_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_launch_tiles_two_workers_per_gpu_gloo():
+    """--workers-per-gpu 2 on 2 'GPUs' (gloo dry run): four ranks, every one of 5 tiles trained exactly once, rank r on device r % 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        data = os.path.join(tmp, "scene"); out = os.path.join(tmp, "out")
+        for i in range(5):
+            os.makedirs(os.path.join(data, f"tile_{i:04d}"))
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "gs-sr_amd"), os.path.join(root, "tests"), os.environ.get("PYTHONPATH", "")]))
+        env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+        r = subprocess.run([sys.executable, "-m", "gsrast.launch_tiles", "--data", data, "--output", out, "--gpus", "2", "--workers-per-gpu", "2",
+                            "--backend", "gloo", "--port", str(_free_port()), "--entry", "tile_entry_fixture:train_tile"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        summary = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert summary["tiles"] == 5 and summary["workers"] == 4 and summary["iterations"] == 35
+        ranks = [open(os.path.join(out, f"tile_{k:04d}", "chkpnt", "done.txt")).read().split()[3] for k in range(5)]
+        assert set(ranks) == {"rank0", "rank1", "rank2", "rank3"}
