@@ -6,8 +6,9 @@
 //   * the tile's depth-sorted splat list is consumed 64 at a time: lane l fetches instance l's conservative
 //     screen box, tests it against the wave's sub-tile, and a 64-bit ballot gives the queue of splats that can
 //     touch this sub-tile at all -- non-contributing (pixel, splat) pairs are skipped a whole wave at a time;
-//   * the surviving splat's packed record is fetched through a wave-uniform address (scalar/broadcast load of
-//     3-5 dwordx4), so per pair the VALU only does blend maths;
+//   * forward: the surviving candidates' packed records are staged in wave-private LDS by the lanes that tested them and read back
+//     through a wave-uniform address (broadcast ds_read_b128), so the blend maths has VGPR operands only; the pixel-parallel backward
+//     (GSR_BWD=px) fetches them with scalar loads (3-5 s_load_dwordx4 per pair);
 //   * backward: per-pixel partial gradients are summed across the wave with DPP row reductions and ONE lane issues
 //     the atomics into a packed per-gaussian accumulator (<= 20 floats, one or two cache lines) -- 64x fewer atomics
 //     than one-atomic-per-pixel.
@@ -20,6 +21,7 @@ template <int V>
 __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
 {
     constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
+    __shared__ float4 s_rec[4 * ST * 64];               // [wave][record quarter][candidate slot]: private to the wave, no barrier
     const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -50,14 +52,25 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         const uint32_t id = v ? p.point_list[i] : 0u;
         const bool hit = v && cull_hit<V>(p.cull, id, (float)ox, (float)oy);
         uint64_t m = __ballot(hit);
+        // Every lane whose candidate survives the cull stages that candidate's packed record in the wave's LDS slots: one burst of vector
+        // loads per 64 candidates instead of a scalar-load round trip per pair.  The pair loop reads the record back through a wave-uniform
+        // LDS address (broadcast ds_read_b128), so the blend maths runs on VGPR operands only -- on gfx950 a VALU instruction with an SGPR
+        // operand issues in ~4.2 cycles against ~2.7 for VGPR-only fma / mul / add (tools/microbench/valu_rate.hip), and the 6 v_mov the
+        // two-SGPR fmas of the surfel intersection needed are gone.  Measured: surfel 0.234 -> 0.201 ms, EWA 0.233 -> 0.189, PLANE 0.199 -> 0.176.
+        if (hit) {
+            const float4* __restrict__ rr = p.rec + (size_t)id * ST;
+#pragma unroll
+            for (int k = 0; k < ST; k++) s_rec[(wave * ST + k) * 64 + lane] = rr[k];      // [wave][k][slot]: lane-contiguous 16-byte stores
+        }
         while (m) {
             const int j = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
-            const float4* __restrict__ r = p.rec + (size_t)gid * ST;
             const uint32_t contributor = base - range.x + (uint32_t)j + 1u;
+            const float4* lr = s_rec + wave * ST * 64 + j;
+#define FWD_LD(k) lr[(k) * 64]
             if (V != GSR_SURFEL) {
-                const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2);      // scalar loads: the out_observe atomic must not demote them to VMEM
+                const float4 q0 = FWD_LD(0), q1 = FWD_LD(1), q2 = FWD_LD(2);
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
                 const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
                 const float alpha = fminf(0.99f, q1.y * __expf(power));
@@ -74,14 +87,14 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                     const float w = alpha * T;
                     C0 += q1.z * w; C1 += q1.w * w; C2 += q2.x * w;
                     if (V == GSR_PLANE && p.render_geo) {
-                        const float4 q3 = ldc(r, 3);
+                        const float4 q3 = FWD_LD(3);
                         A0 += q2.y * w; A1 += q2.z * w; A2 += q2.w * w; A3 += q3.x * w; A4 += q3.y * w;
                     }
                     T = test_T;
                     last_contributor = contributor;
                 }
             } else {
-                const float4 q0 = ldc(r, 0), q1 = ldc(r, 1), q2 = ldc(r, 2), q3 = ldc(r, 3), q4 = ldc(r, 4);
+                const float4 q0 = FWD_LD(0), q1 = FWD_LD(1), q2 = FWD_LD(2), q3 = FWD_LD(3), q4 = FWD_LD(4);
                 const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
                 const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
                 const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
