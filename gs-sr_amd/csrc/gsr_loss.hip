@@ -22,6 +22,13 @@
 __constant__ float c_win[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f, 2.130055279e-01f, 2.660117149e-01f,
                                 2.130055279e-01f, 1.093606874e-01f, 3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f};
 
+// The 11 window taps in VGPRs: as wave-uniform constants the compiler keeps them in SGPRs, and on gfx950 a VALU instruction with an SGPR
+// operand issues in ~4.2 cycles against ~2.7 for VGPR-only fma (tools/microbench/valu_rate.hip); every one of the ~440 filter fmas per
+// thread has a tap as an operand.
+#define SS_LOAD_TAPS(w)                                                          \
+    float w[11];                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 11; i_++) { w[i_] = c_win[i_]; asm volatile("" : "+v"(w[i_])); }
+
 __device__ __forceinline__ float block_sum256(float v, float* red)
 {
 #pragma unroll
@@ -39,6 +46,7 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, const float* __r
     __shared__ float sx[SS_P][SS_LD], sy[SS_P][SS_LD];
     __shared__ float h[5][SS_P][SS_T + 1];
     __shared__ float red[4];
+    SS_LOAD_TAPS(wt)
     const int c = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     const float* ip = img + (size_t)c * H * W;
     const float* gp = gt + (size_t)c * H * W;
@@ -61,7 +69,7 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, const float* __r
 #pragma unroll
             for (int o = 0; o < SS_B; o++) {
                 if (t - o >= 0 && t - o < 11) {
-                    const float w = c_win[t - o];
+                    const float w = wt[t - o];
                     a[o] = fmaf(w, u, a[o]); b[o] = fmaf(w, v, b[o]); aa[o] = fmaf(w, uu, aa[o]); bb[o] = fmaf(w, vv, bb[o]); ab[o] = fmaf(w, uv, ab[o]);
                 }
             }
@@ -84,7 +92,7 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, const float* __r
 #pragma unroll
         for (int o = 0; o < SS_B; o++) {
             if (t - o >= 0 && t - o < 11) {
-                const float w = c_win[t - o];
+                const float w = wt[t - o];
 #pragma unroll
                 for (int k = 0; k < 5; k++) q[k][o] = fmaf(w, hv[k], q[k][o]);
             }
@@ -125,6 +133,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
 {
     __shared__ float sm[3][SS_P][SS_LD];
     __shared__ float h[3][SS_P][SS_T + 1];
+    SS_LOAD_TAPS(wt)
     const int c = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
     for (int e = threadIdx.x; e < SS_P * SS_P; e += 256) {
         const int ly = e / SS_P, lx = e % SS_P, gy = y0 + ly - SS_R, gx = x0 + lx - SS_R;
@@ -147,7 +156,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
 #pragma unroll
             for (int o = 0; o < SS_B; o++) {
                 if (t - o >= 0 && t - o < 11) {
-                    const float w = c_win[t - o];
+                    const float w = wt[t - o];
                     a[0][o] = fmaf(w, v0, a[0][o]); a[1][o] = fmaf(w, v1, a[1][o]); a[2][o] = fmaf(w, v2, a[2][o]);
                 }
             }
@@ -170,7 +179,7 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
 #pragma unroll
         for (int o = 0; o < SS_B; o++) {
             if (t - o >= 0 && t - o < 11) {
-                const float w = c_win[t - o];
+                const float w = wt[t - o];
                 q[0][o] = fmaf(w, v0, q[0][o]); q[1][o] = fmaf(w, v1, q[1][o]); q[2][o] = fmaf(w, v2, q[2][o]);
             }
         }
