@@ -26,13 +26,20 @@
 // median-normal quirk, no gradient through the 0.99 clamp test); see DESIGN.md "splat-parallel backward".
 #include "gsr_blend_common.h"
 
-#ifndef SP_WPE
-#define SP_WPE 4                  // measured: 3 waves/SIMD (144 VGPRs) 0.693 ms, 4 (128, 3 spills) 0.633 ms, 5 (96, 37 spills) 0.759 ms
+// Waves per SIMD the register budget of each variant is sized for.  SURFEL (128 VGPRs, 12 spills outside the step loop): 3 waves 0.693 ms,
+// 4 waves 0.633, 5 waves (96 VGPRs, 37 spills) 0.759 -- measured on the first table version; EWA needs 94 VGPRs and runs 5 waves per SIMD:
+// 0.387 -> 0.355 ms; PLANE needs 113-115 and stays at 4.
+#ifndef SP_WPE_EWA
+#define SP_WPE_EWA 5
 #endif
-#define SP_OCC __attribute__((amdgpu_waves_per_eu(SP_WPE, SP_WPE)))
-#if 0
-#define SP_WPE 3               // waves per SIMD the register budget is sized for (3 -> 168 VGPRs: no spills in the 16 unrolled pixel steps)
+#ifndef SP_WPE_PLANE
+#define SP_WPE_PLANE 4
 #endif
+#ifndef SP_WPE_SURFEL
+#define SP_WPE_SURFEL 4
+#endif
+template <int V> struct SpOcc { static constexpr int WPE = (V == GSR_EWA) ? SP_WPE_EWA : (V == GSR_PLANE ? SP_WPE_PLANE : SP_WPE_SURFEL); };
+#define SP_OCC __attribute__((amdgpu_waves_per_eu(SpOcc<V>::WPE, SpOcc<V>::WPE)))
 #define SP_CH 256                 // tile-list entries per chunk (queues, masks); longer lists take several chunks
 #define SP_CAP 112                // rows of a wave's private accumulation table (entries of the chunk that reach the wave's quadrant)
 
