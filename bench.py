@@ -59,9 +59,9 @@ def stage_bytes(variant, color_mode, P, R, N, T):
 
 def make_step(variant, sc, device):
     """One training iteration.  All gaussian parameters live in ONE flat leaf z (contiguous blocks: means 3P, scales 2P|3P,
-    rotations 4P, opacity P, colour 3P|48P); params = z * lr_scale (per block), optimised by a single fused-Adam group with
-    lr=1: Adam's step is invariant to gradient scale, so the effective per-column learning rates are exactly lr_scale --
-    the per-group rates of gssr/gaussian/*.setup_optimizers -- with one optimizer kernel instead of one per group.
+    rotations 4P, opacity P, colour 3P|48P), optimised by gsrast.optim.Adam (one fused HIP kernel, include/gsrast.h gsr_adam_step) whose
+    per-element `lr_scale` carries the per-group rates of gssr/gaussian/*.setup_optimizers -- one optimizer kernel instead of one per group.
+    (GSR_BENCH_TORCH_ADAM=1 selects the earlier form: params = z * lr_scale under torch's fused Adam with lr = 1.)
     The auxiliary-map loss is linear in the 11 (5) channels so autograd hands the rasterizer a dense dL_dothers without
     materialising one zero-padded [11,H,W] tensor per sliced channel; every gradient path of the backward kernel is live."""
     import hiprun
@@ -84,8 +84,14 @@ def make_step(variant, sc, device):
     # handed to the rasterizer is contiguous (an [P,13] array-of-structs layout costs one strided copy per parameter per iteration)
     sizes = [P * n for _, n, _ in cols]
     lr_scale = torch.cat([torch.full((P * n,), lr, device=device) for _, n, lr in cols])
-    z = (torch.cat([t[k].reshape(-1) for k, _, _ in cols]) / lr_scale).clone().requires_grad_(True)
-    opt = torch.optim.Adam([z], lr=1.0, eps=1e-15, fused=True)
+    torch_adam = os.environ.get("GSR_BENCH_TORCH_ADAM", "0") == "1"
+    if torch_adam:
+        z = (torch.cat([t[k].reshape(-1) for k, _, _ in cols]) / lr_scale).clone().requires_grad_(True)
+        opt = torch.optim.Adam([z], lr=1.0, eps=1e-15, fused=True)
+    else:
+        from gsrast.optim import Adam
+        z = torch.cat([t[k].reshape(-1) for k, _, _ in cols]).clone().requires_grad_(True)
+        opt = Adam([{"params": [z], "lr": 1.0, "lr_scale": lr_scale}], lr=0.0, eps=1e-15)
     g = torch.Generator(device="cpu").manual_seed(1234)
     gt = torch.rand((3, H, W), generator=g).to(device)
     N = float(W * H)
@@ -106,7 +112,7 @@ def make_step(variant, sc, device):
     m2a = torch.zeros((P, 3), dtype=torch.float32, device=device, requires_grad=True) if variant == "plane" else None
 
     def step():
-        prm = z * lr_scale
+        prm = z * lr_scale if torch_adam else z
         parts = torch.split(prm, sizes)                                 # backward = one cat, not one zero-pad per slice
         v = {k: parts[i].view(P, n) for i, (k, n, _) in enumerate(cols)}
         kw = dict(means3D=v["means3D"], means2D=means2D, opacities=v["opacities"], scales=v["scales"], rotations=v["rotations"])
@@ -137,7 +143,7 @@ def make_step(variant, sc, device):
         """The scene dict with the parameters as they are now (for the R-after figure)."""
         cur = dict(sc)
         with torch.no_grad():
-            parts = torch.split(z * lr_scale, sizes)
+            parts = torch.split(z * lr_scale if torch_adam else z, sizes)
             for i, (k, n, _) in enumerate(cols):
                 a = parts[i].view(P, n).cpu().numpy()
                 cur[k] = a.reshape(P, 16, 3) if k == "shs" else (a.reshape(P) if k == "opacities" and sc[k].ndim == 1 else a)

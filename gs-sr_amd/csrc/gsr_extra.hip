@@ -1,6 +1,7 @@
 // gsr_extra.hip -- adjacent kernels of the hot path:
 //   gsr_tsdf_integrate : per-frame TSDF voxel update, the in-repo definition gssr/utils/mesh_utils.py:195-246
 //   gsr_dist2          : simple_knn.distCUDA2 (mean squared distance to the 3 nearest neighbours)
+#include <algorithm>
 #include "gsr_common.h"
 
 // torch.nn.functional.grid_sample(mode='bilinear', padding_mode='border', align_corners=True), one sample.
@@ -253,6 +254,122 @@ extern "C" int gsr_loss_l1_linear(int64_t n_color, const float* color, const flo
     hipLaunchKernelGGL(k_loss_l1_linear, dim3(2048), dim3(256), 0, (hipStream_t)stream, n4c, n_color, color, gt, dL_dcolor, n4a,
                        n_aux > 0 ? n_aux : 0, aux, waux, 1.0f / (float)n_color, loss_out);
     return gsr_check_launch("loss_l1_linear", (hipStream_t)stream, false);
+}
+
+// ---- fused Adam step (the optimizer of every Gaussian model: `torch.optim.Adam(l, lr=0.0, eps=1e-15)`, gssr/gaussian/vanilla_gaussian.py:120-139,
+// stepped once per iteration by gssr/engine/trainer.py:127).  One streaming pass over (param, grad, exp_avg, exp_avg_sq) with the arithmetic of
+// torch's single-tensor implementation:  m += (g - m)(1 - b1);  v = v b2 + g g (1 - b2);  p -= step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps),
+// step_size = lr / (1 - b1^t) (both bias corrections formed on the host in double, as torch does).  28 bytes per parameter: HBM-bound.
+__global__ void __launch_bounds__(256) k_adam(int64_t n4, int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, float step_size, float w1, float b2, float w2, float inv_bc2_sqrt, float eps,
+                                              const float* __restrict__ lr_scale)
+{
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv, float sc) {
+        mm = mm + (gg - mm) * w1;
+        vv = vv * b2 + gg * gg * w2;
+        const float denom = sqrtf(vv) * inv_bc2_sqrt + eps;
+        pp = pp - (step_size * sc) * (mm / denom);
+    };
+    for (int64_t i = t0; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (lr_scale) sc = reinterpret_cast<const float4*>(lr_scale)[i];
+        upd(pp.x, gg.x, mm.x, vv.x, sc.x); upd(pp.y, gg.y, mm.y, vv.y, sc.y); upd(pp.z, gg.z, mm.z, vv.z, sc.z); upd(pp.w, gg.w, mm.w, vv.w, sc.w);
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (int64_t i = 4 * n4 + t0; i < n; i += stride) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        upd(pp, g[i], mm, vv, lr_scale ? lr_scale[i] : 1.0f);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+extern "C" int gsr_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float step_size, double beta1,
+                             double beta2, float bias_correction2_sqrt, float eps, const float* lr_scale, void* stream)
+{
+    if (n <= 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) { gsr_set_error("adam_step: null pointer"); return 1; }
+    if (!(bias_correction2_sqrt > 0.0f)) { gsr_set_error("adam_step: bias_correction2_sqrt must be > 0 (step >= 1)"); return 1; }
+    const bool al = (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)lr_scale) & 15) == 0;
+    const int64_t n4 = al ? n / 4 : 0;
+    const int64_t work = n4 > 0 ? n4 : n;
+    const int blocks = (int)std::min<int64_t>((work + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n4, n, param, grad, exp_avg, exp_avg_sq, step_size, (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), 1.0f / bias_correction2_sqrt, eps, lr_scale);      // 1 - beta in double first, as torch forms its lerp weights
+    return gsr_check_launch("adam_step", (hipStream_t)stream, false);
+}
+
+// Several parameter tensors in ONE launch (a model has 6-20 of them, most of them tiny: a launch per tensor would cost more than the update).
+// The table travels as a kernel argument; block b works on 4096 consecutive elements of the tensor whose [first_block, next first_block) holds b.
+#define GSR_ADAM_MAX 24
+#define GSR_ADAM_CHUNK 4096
+struct AdamEntry { float* p; const float* g; float* m; float* v; const float* sc; int64_t n; float step_size, w1, b2, w2, inv_bc2_sqrt, eps; uint32_t first_block, vec; };
+struct AdamTable { int32_t count; int32_t pad; AdamEntry e[GSR_ADAM_MAX]; };
+
+__global__ void __launch_bounds__(256) k_adam_multi(AdamTable T)
+{
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < T.count; i++) k = (blockIdx.x >= T.e[i].first_block) ? i : k;      // wave-uniform: scalar loop over <= 24 entries
+    const AdamEntry& E = T.e[k];
+    const int64_t base = (int64_t)(blockIdx.x - E.first_block) * GSR_ADAM_CHUNK;
+    const int64_t end = min(E.n, base + GSR_ADAM_CHUNK);
+    const float step_size = E.step_size, w1 = E.w1, b2 = E.b2, w2 = E.w2, ibc = E.inv_bc2_sqrt, eps = E.eps;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv, float sc) {
+        mm = mm + (gg - mm) * w1;
+        vv = vv * b2 + gg * gg * w2;
+        const float denom = sqrtf(vv) * ibc + eps;
+        pp = pp - (step_size * sc) * (mm / denom);
+    };
+    if (E.vec) {                                   // all five pointers 16-byte aligned: base is a multiple of 4096 elements
+        for (int64_t i = base + 4 * (int64_t)threadIdx.x; i + 3 < end; i += 1024) {
+            float4 pp = *reinterpret_cast<float4*>(E.p + i), mm = *reinterpret_cast<float4*>(E.m + i), vv = *reinterpret_cast<float4*>(E.v + i);
+            const float4 gg = *reinterpret_cast<const float4*>(E.g + i);
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (E.sc) sc = *reinterpret_cast<const float4*>(E.sc + i);
+            upd(pp.x, gg.x, mm.x, vv.x, sc.x); upd(pp.y, gg.y, mm.y, vv.y, sc.y); upd(pp.z, gg.z, mm.z, vv.z, sc.z); upd(pp.w, gg.w, mm.w, vv.w, sc.w);
+            *reinterpret_cast<float4*>(E.p + i) = pp; *reinterpret_cast<float4*>(E.m + i) = mm; *reinterpret_cast<float4*>(E.v + i) = vv;
+        }
+        const int64_t tail = base + ((end - base) & ~(int64_t)3);
+        for (int64_t i = tail + threadIdx.x; i < end; i += 256) {
+            float pp = E.p[i], mm = E.m[i], vv = E.v[i];
+            upd(pp, E.g[i], mm, vv, E.sc ? E.sc[i] : 1.0f);
+            E.p[i] = pp; E.m[i] = mm; E.v[i] = vv;
+        }
+    } else {
+        for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+            float pp = E.p[i], mm = E.m[i], vv = E.v[i];
+            upd(pp, E.g[i], mm, vv, E.sc ? E.sc[i] : 1.0f);
+            E.p[i] = pp; E.m[i] = mm; E.v[i] = vv;
+        }
+    }
+}
+
+extern "C" int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor* t, void* stream)
+{
+    if (count < 0 || (count > 0 && !t)) { gsr_set_error("adam_step_multi: bad table"); return 1; }
+    for (int32_t i0 = 0; i0 < count; i0 += GSR_ADAM_MAX) {
+        AdamTable T; T.count = 0; T.pad = 0;
+        uint32_t blocks = 0;
+        for (int32_t i = i0; i < count && T.count < GSR_ADAM_MAX; i++) {
+            const gsr_adam_tensor& a = t[i];
+            if (a.n <= 0) continue;
+            if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq || !(a.bias_correction2_sqrt > 0.0f)) {
+                gsr_set_error("adam_step_multi: tensor %d: null pointer or bias_correction2_sqrt <= 0", i); return 1;
+            }
+            AdamEntry& E = T.e[T.count++];
+            E.p = a.param; E.g = a.grad; E.m = a.exp_avg; E.v = a.exp_avg_sq; E.sc = a.lr_scale; E.n = a.n;
+            E.step_size = a.step_size; E.w1 = (float)(1.0 - a.beta1); E.b2 = (float)a.beta2; E.w2 = (float)(1.0 - a.beta2);
+            E.inv_bc2_sqrt = 1.0f / a.bias_correction2_sqrt; E.eps = a.eps;
+            E.first_block = blocks;
+            E.vec = ((((uintptr_t)a.param | (uintptr_t)a.grad | (uintptr_t)a.exp_avg | (uintptr_t)a.exp_avg_sq | (uintptr_t)a.lr_scale) & 15) == 0) ? 1u : 0u;
+            blocks += (uint32_t)((a.n + GSR_ADAM_CHUNK - 1) / GSR_ADAM_CHUNK);
+        }
+        if (blocks) hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T);
+    }
+    return gsr_check_launch("adam_step_multi", (hipStream_t)stream, false);
 }
 
 // ---- distCUDA2 (simple-knn/simple_knn.cu:186-222): mean squared distance to the 3 nearest neighbours.

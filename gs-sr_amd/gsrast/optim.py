@@ -1,0 +1,97 @@
+"""Fused Adam for the Gaussian models (include/gsrast.h gsr_adam_step).
+
+The reference builds `torch.optim.Adam(l, lr=0.0, eps=1e-15)` with one parameter group per tensor (gssr/gaussian/vanilla_gaussian.py:120-139,
+scaffold_gaussian.py setup_optimizers), rewrites `param_group['lr']` from its schedulers, steps it once per iteration
+(gssr/engine/trainer.py:127-128) and edits `optimizer.state[param]['exp_avg' / 'exp_avg_sq']` when it densifies or prunes
+(`cat_tensors_to_optimizer`, `_prune_optimizer`, `replace_tensor_to_optimizer`).  `gsrast.optim.Adam` is a subclass of `torch.optim.Adam`
+with the same constructor, param groups, state keys ('step', 'exp_avg', 'exp_avg_sq') and state_dict, so all of that code runs unchanged;
+only `step()` differs: every float32 HIP parameter is updated by ONE streaming kernel (28 bytes per parameter) instead of torch's
+op-by-op update.  Parameters the kernel does not cover (other dtypes / devices, sparse gradients) and the options it does not implement
+(amsgrad, weight_decay, maximize, capturable, differentiable) go through torch's own implementation.
+A param group may carry `lr_scale` (float32 tensor shaped like its parameter): a per-element multiplier of the group's learning rate, for
+models that keep all their parameters in one flat tensor (bench.py)."""
+import ctypes as C
+import math
+
+import torch
+
+from . import check, lib, stream_ptr
+
+
+class _AdamTensor(C.Structure):          # include/gsrast.h gsr_adam_tensor
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr_scale", C.c_void_p),
+                ("n", C.c_int64), ("beta1", C.c_double), ("beta2", C.c_double), ("step_size", C.c_float), ("bias_correction2_sqrt", C.c_float),
+                ("eps", C.c_float), ("pad_", C.c_float)]
+
+
+def _covered(p, group):
+    return (p.is_cuda and p.dtype == torch.float32 and p.grad is not None and not p.grad.is_sparse and p.grad.dtype == torch.float32
+            and p.is_contiguous() and not group.get("amsgrad", False) and group.get("weight_decay", 0) == 0 and not group.get("maximize", False)
+            and not group.get("capturable", False) and not group.get("differentiable", False))
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+        kw.setdefault("foreach", False); kw.setdefault("fused", False)        # the fallback path: torch's plain per-tensor implementation
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = lib()
+        rest = []                                  # (group, params) torch handles itself
+        batch = {}                                 # device -> list of table entries (one launch per 24 tensors)
+        keep = []                                  # contiguous copies that must outlive the launch call
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            lr = group["lr"]
+            if isinstance(lr, torch.Tensor):
+                lr = float(lr)
+            sc = group.get("lr_scale")             # optional: one learning-rate multiplier per element (float32, shaped like the parameter)
+            other = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not _covered(p, group):
+                    other.append(p)
+                    continue
+                st = self.state[p]
+                if len(st) == 0:                   # same lazy state as torch.optim.Adam._init_group
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                t = float(st["step"])
+                m, v = st["exp_avg"], st["exp_avg_sq"]
+                if not (m.is_contiguous() and v.is_contiguous()):
+                    st["exp_avg"], st["exp_avg_sq"] = m, v = m.contiguous(), v.contiguous()
+                g = p.grad
+                if not g.is_contiguous():
+                    g = g.contiguous(); keep.append(g)
+                if sc is not None and (sc.numel() != p.numel() or sc.dtype != torch.float32 or not sc.is_contiguous() or sc.device != p.device):
+                    raise RuntimeError("gsrast.optim.Adam: lr_scale must be a contiguous float32 tensor with one entry per parameter element")
+                batch.setdefault(p.device, []).append(
+                    (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 0 if sc is None else sc.data_ptr(), p.numel(), beta1, beta2,
+                     lr / (1.0 - beta1 ** t), math.sqrt(1.0 - beta2 ** t), group["eps"], 0.0))
+            if other:
+                rest.append((group, other))
+        for dev, entries in batch.items():
+            table = (_AdamTensor * len(entries))(*entries)
+            with torch.cuda.device(dev):
+                check(L.gsr_adam_step_multi(len(entries), table, stream_ptr(dev)), "adam_step_multi")
+        if rest:                                   # uncovered parameters: exactly torch's update, on a view of the groups that holds only them
+            saved = [(g, g["params"]) for g, _ in rest]
+            groups = self.param_groups
+            try:
+                for g, ps in rest:
+                    g["params"] = ps
+                self.param_groups = [g for g, _ in rest]
+                super().step()
+            finally:
+                self.param_groups = groups
+                for g, ps in saved:
+                    g["params"] = ps
+        return loss

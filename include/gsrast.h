@@ -200,6 +200,28 @@ int gsr_tsdf_sparse_merge(const gsr_tsdf_sparse* vol, int32_t n_units, const int
  * dL/daux is waux itself, so nothing is written for it. */
 int gsr_loss_l1_linear(int64_t n_color, const float* color, const float* gt, float* dL_dcolor,
                        int64_t n_aux, const float* aux, const float* waux, float* loss_out, void* stream);
+/* Fused Adam step over one parameter tensor -- the optimizer every Gaussian model of the reference steps once per iteration
+ * (`torch.optim.Adam(l, lr=0.0, eps=1e-15)`, gssr/gaussian/vanilla_gaussian.py:120-139; gssr/engine/trainer.py:127), with the arithmetic of torch's
+ * single-tensor implementation (no amsgrad, no weight decay):
+ *   exp_avg += (grad - exp_avg)(1 - beta1);  exp_avg_sq = exp_avg_sq beta2 + grad^2 (1 - beta2);
+ *   param  -= step_size * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps)
+ * step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t), both formed by the caller in double; the betas are doubles
+ * because the weights 1 - beta are rounded to float after the subtraction, as torch does.  lr_scale (or NULL): one
+ * multiplier of step_size per element.  All pointers device float32 of n elements; one streaming pass, no host synchronisation. */
+int gsr_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float step_size, double beta1, double beta2,
+                  float bias_correction2_sqrt, float eps, const float* lr_scale, void* stream);
+/* The same update for `count` parameter tensors in one launch per 24 tensors (a model has 6-20 parameter tensors, most of them tiny).
+ * `t` is a HOST array; every entry carries its own hyper-parameters (the reference gives every tensor its own param group / learning rate). */
+typedef struct gsr_adam_tensor {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    const float* lr_scale;            /* optional per-element multiplier of step_size, or NULL */
+    int64_t n;
+    double beta1, beta2;
+    float step_size;                  /* lr / (1 - beta1^t) */
+    float bias_correction2_sqrt;      /* sqrt(1 - beta2^t) */
+    float eps, pad_;
+} gsr_adam_tensor;
+int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor* t, void* stream);
 /* Octree-GS level-of-detail mask fused with the prefilter (OctreeGaussianModel.set_anchor_mask / map_to_int_level,
  * gssr/gaussian/octree_gaussian.py:184-203,255-267; OctreeScene.prefilter_voxel, gssr/scene/octree_scene.py:136-172):
  *   dist = |anchor + (voxel_size/2)/fork^level - campos| * resolution_scale;  pred = log2(standard_dist/dist)/log2(fork) + extra_level

@@ -1,0 +1,77 @@
+"""GPU: gsrast.optim.Adam (one fused HIP kernel per parameter tensor, include/gsrast.h gsr_adam_step) against the numpy oracle and against
+torch.optim.Adam on the same parameters -- including the per-group learning-rate rewrites and the optimizer-state surgery the reference's
+densification performs (gssr/gaussian/vanilla_gaussian.py: cat_tensors_to_optimizer / _prune_optimizer)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_optim
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _models(seed, shapes, lrs, cls):
+    g = torch.Generator().manual_seed(seed)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+    return ps, cls([{"params": [p], "lr": lr, "name": f"g{i}"} for i, (p, lr) in enumerate(zip(ps, lrs))], lr=0.0, eps=1e-15)
+
+
+def test_fused_adam_matches_oracle_and_torch():
+    from gsrast.optim import Adam
+    shapes = [(30001, 3), (30001, 1), (30001, 15, 3), (7,), (1,)]
+    lrs = [1.6e-4, 5e-2, 1.25e-4, 1e-3, 1e-2]
+    pa, oa = _models(3, shapes, lrs, Adam)
+    pb, ob = _models(3, shapes, lrs, lambda groups, **kw: torch.optim.Adam(groups, foreach=False, **kw))
+    st = [(p.detach().cpu().numpy().copy(), np.zeros(s, np.float32), np.zeros(s, np.float32)) for p, s in zip(pa, shapes)]
+    g = torch.Generator().manual_seed(9)
+    for t in range(1, 7):
+        if t == 4:                                                   # the reference's schedulers rewrite param_group['lr'] every iteration
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 3.0e-5
+            lrs[0] = 3.0e-5
+        grads = [torch.randn(s, generator=g) * (0.1 if t % 2 else 3.0) for s in shapes]
+        for ps in (pa, pb):
+            for p, gr in zip(ps, grads):
+                p.grad = gr.to(DEV)
+        oa.step(); ob.step()
+        oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
+        for i, (gr, lr) in enumerate(zip(grads, lrs)):
+            st[i] = oracle_optim.adam_step(st[i][0], gr.numpy(), st[i][1], st[i][2], t, lr, eps=1e-15)
+            sa = oa.state[pa[i]]
+            assert set(sa.keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sa["step"]) == t
+            assert np.allclose(sa["exp_avg"].cpu().numpy(), st[i][1], rtol=1e-5, atol=2e-6)
+            assert np.allclose(sa["exp_avg_sq"].cpu().numpy(), st[i][2], rtol=1e-5, atol=1e-12)
+            assert np.allclose(pa[i].detach().cpu().numpy(), st[i][0], rtol=0, atol=1e-4 * lr + 5e-7), (t, i)
+            assert np.allclose(pa[i].detach().cpu().numpy(), pb[i].detach().cpu().numpy(), rtol=0, atol=1e-4 * lr + 5e-7), (t, i)
+    assert oa.state_dict()["param_groups"][0]["name"] == "g0" and len(oa.state_dict()["state"]) == len(shapes)
+
+
+def test_state_surgery_of_densification_and_uncovered_parameters():
+    """cat_tensors_to_optimizer-style surgery (new Parameter, concatenated moments under the new key) keeps working, a parameter without
+    gradient is skipped, and a float64 parameter goes through torch's own update."""
+    from gsrast.optim import Adam
+    g = torch.Generator().manual_seed(2)
+    p = torch.nn.Parameter(torch.randn(100, 3, generator=g).to(DEV)); q = torch.nn.Parameter(torch.randn(5, generator=g).double().to(DEV))
+    r = torch.nn.Parameter(torch.randn(4, generator=g).to(DEV))
+    opt = Adam([{"params": [p], "lr": 1e-2, "name": "xyz"}, {"params": [q], "lr": 1e-2, "name": "f64"}, {"params": [r], "lr": 1e-2, "name": "nograd"}],
+               lr=0.0, eps=1e-15)
+    p.grad = torch.ones_like(p); q.grad = torch.ones_like(q)
+    r0 = r.detach().clone(); q0 = q.detach().clone()
+    opt.step()
+    assert torch.equal(r, r0) and len(opt.state[r]) == 0
+    assert torch.allclose(q, q0 - 1e-2, atol=1e-9) and opt.state[q]["exp_avg"].dtype == torch.float64
+    group = opt.param_groups[0]
+    stored = opt.state.pop(group["params"][0])
+    ext = torch.randn(20, 3, generator=g).to(DEV)
+    stored["exp_avg"] = torch.cat((stored["exp_avg"], torch.zeros_like(ext)), dim=0)
+    stored["exp_avg_sq"] = torch.cat((stored["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+    group["params"][0] = torch.nn.Parameter(torch.cat((p.detach(), ext), dim=0).requires_grad_(True))
+    opt.state[group["params"][0]] = stored
+    newp = group["params"][0]
+    before = newp.detach().clone()
+    newp.grad = torch.ones_like(newp)
+    opt.step()
+    assert float(opt.state[newp]["step"]) == 2.0 and opt.state[newp]["exp_avg"].shape == (120, 3)
+    d = before - newp.detach()
+    assert torch.all(d > 0) and torch.allclose(d[:100], d[:1].expand(100, 3), atol=1e-7)

@@ -22,6 +22,7 @@ from gsrast import decode              # noqa: E402
 from gsrast.losses import camera_ray_matrices, l1_plus_linear, l1_ssim, surfel_geo_loss  # noqa: E402
 import ref_geo_torch                   # noqa: E402
 import ref_loss_torch                  # noqa: E402
+from gsrast.optim import Adam          # noqa: E402
 
 
 def build(a, dev, seed=0):
@@ -44,7 +45,7 @@ def build(a, dev, seed=0):
     mlp_o, mlp_c, mlp_k = mlp(35, k, torch.nn.Tanh()), mlp(35, 7 * k, torch.nn.Identity()), mlp(35 + A, 3 * k, torch.nn.Sigmoid())
     emb = torch.nn.Embedding(4, A).to(dev)
     params = [anchor, scaling_log, feat, offset, emb.weight] + [p for m in (mlp_o, mlp_c, mlp_k) for p in m.parameters()]
-    opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15, fused=True)
+    opt = (Adam(params, lr=1e-4, eps=1e-15) if os.environ.get("GSR_PIPE_TORCH_ADAM", "0") != "1" else torch.optim.Adam(params, lr=1e-4, eps=1e-15, fused=True))
     gt = torch.rand((3, H, W), generator=g).to(dev)
     N = float(W * H)
     gtn = torch.nn.functional.normalize(torch.randn((3, H, W), generator=g), dim=0)

@@ -24,6 +24,7 @@ from bench_pipeline_pgsr import cam_of   # noqa: E402
 from gsrast import decode, octree      # noqa: E402
 from gsrast.losses import l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss  # noqa: E402
 from gsrast.plane_prep import plane_input_all_map  # noqa: E402
+from gsrast.optim import Adam          # noqa: E402
 
 
 def build(a, dev, seed=0):
@@ -54,7 +55,7 @@ def build(a, dev, seed=0):
     mlp_o, mlp_c, mlp_k = mlp(35, k, torch.nn.Tanh()), mlp(35, 7 * k, torch.nn.Identity()), mlp(35 + A, 3 * k, torch.nn.Sigmoid())
     emb = torch.nn.Embedding(4, A).to(dev)
     params = [anchor, scaling_log, feat, offset, emb.weight] + [p for m in (mlp_o, mlp_c, mlp_k) for p in m.parameters()]
-    opt = torch.optim.Adam(params, lr=1e-4, eps=1e-15, fused=True)
+    opt = (Adam(params, lr=1e-4, eps=1e-15) if os.environ.get("GSR_PIPE_TORCH_ADAM", "0") != "1" else torch.optim.Adam(params, lr=1e-4, eps=1e-15, fused=True))
     gt = torch.rand((3, H, W), generator=g).to(dev)
     gray1 = gt.mean(0, keepdim=True).contiguous(); gray2 = torch.rand((1, H, W), generator=g).to(dev)
     c1, c2 = cam_of(t, W, H), cam_of(t2, W, H)

@@ -25,6 +25,7 @@ import scenes                          # noqa: E402
 import diff_plane_rasterization as dpr   # noqa: E402
 from gsrast.losses import l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss  # noqa: E402
 from gsrast.plane_prep import plane_input_all_map  # noqa: E402
+from gsrast.optim import Adam          # noqa: E402
 
 
 def q2m(q):
@@ -67,7 +68,7 @@ def build(a, dev):
     rot_raw = t["rotations"].clone().requires_grad_(True)
     op_raw = torch.logit(t["opacities"].clamp(1e-4, 1 - 1e-4)).requires_grad_(True)
     col = t["colors_precomp"].clone().requires_grad_(True)
-    opt = torch.optim.Adam([xyz, scl_log, rot_raw, op_raw, col], lr=1e-4, eps=1e-15, fused=True)
+    opt = (Adam([xyz, scl_log, rot_raw, op_raw, col], lr=1e-4, eps=1e-15) if os.environ.get("GSR_PIPE_TORCH_ADAM", "0") != "1" else torch.optim.Adam([xyz, scl_log, rot_raw, op_raw, col], lr=1e-4, eps=1e-15, fused=True))
     gt = torch.rand((3, H, W), generator=g).to(dev)
     gray1 = gt.mean(0, keepdim=True).contiguous(); gray2 = torch.rand((1, H, W), generator=g).to(dev)
     c1, c2 = cam_of(t, W, H), cam_of(t2, W, H)
