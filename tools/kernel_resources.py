@@ -13,8 +13,10 @@ FLAGS = {"gsr_preprocess.hip": PRE, "gsr_extra.hip": PRE, "gsr_mvloss.hip": PRE,
 
 
 def demangle(names):
+    if not names:
+        return names
     try:
-        out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
+        out = subprocess.run(["c++filt"] + names, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=60).stdout.split("\n")
         return [o.split("(")[0].replace("void ", "") for o in out[:len(names)]]
     except Exception:
         return names
