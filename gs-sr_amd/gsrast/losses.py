@@ -229,10 +229,17 @@ def sample_valid_pixels(d_mask, num_sample, generator=None, seed=None):
 
 class _PlaneMultiview(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plane_depth, near_plane_depth, normal, distance, gray, near_gray, cfg, lambda_geo, lambda_ncc, num_sample, indices, generator):
+    def forward(ctx, plane_depth, near_plane_depth, normal, distance, gray, near_gray, cfg, lambda_geo, lambda_ncc, num_sample, indices, generator,
+                all_map=None):
         import ctypes as C
         d = dev_f32(plane_depth, "plane_depth", allow_empty=False)
         nd = dev_f32(near_plane_depth, "near_plane_depth", allow_empty=False)
+        am = None
+        if all_map is not None:                  # normal = channels 0-2, distance = channel 4 of the rasterizer's out_all_map: ONE gradient tensor back
+            am = dev_f32(all_map, "out_all_map", allow_empty=False)
+            if am.dim() != 3 or am.shape[0] != 5:
+                raise RuntimeError("plane_multiview_loss: out_all_map must be (5, H, W)")
+            normal, distance = am[0:3], am[4:5]
         nm = dev_f32(normal, "rendered_normal", allow_empty=False)
         ds = dev_f32(distance, "rendered_distance", allow_empty=False)
         g = dev_f32(gray, "gray", allow_empty=False)
@@ -255,7 +262,12 @@ class _PlaneMultiview(torch.autograd.Function):
         if indices is None:
             indices = sample_valid_pixels(dmask, num_sample, generator)
         idx = indices.to(device=dev, dtype=torch.int32).contiguous()
-        gNm, gDs = f(3, H, W), f(H, W)
+        if am is not None:
+            gAM = f(5, H, W); gAM[3].zero_()
+            gNm, gDs = gAM[0:3], gAM[4]
+        else:
+            gAM = None
+            gNm, gDs = f(3, H, W), f(H, W)
         ncc = f(max(idx.numel(), 1))
         cmask = torch.empty(max(idx.numel(), 1), dtype=torch.uint8, device=dev)
         check(L.gsr_loss_plane_mv_ncc(C.byref(cfg), int(idx.numel()), ptr(idx), ptr(weight), ptr(nm), ptr(ds), ptr(g), ptr(ng), ptr(ncc), ptr(cmask),
@@ -265,7 +277,8 @@ class _PlaneMultiview(torch.autograd.Function):
         # d mean / d x = (d sum / d x) / count; an empty mask leaves zero maps, so the clamp only avoids 0/0
         sg = float(lambda_geo) / torch.clamp(stats[1], min=1.0)
         sn = float(lambda_ncc) / torch.clamp(stats[4], min=1.0)
-        ctx.save_for_backward(gD, gN, gNm, gDs, sg, sn)
+        ctx.save_for_backward(gD, gN, gNm if gAM is None else gAM, gDs, sg, sn)
+        ctx.whole = gAM is not None
         ctx.shapes = (plane_depth.shape, near_plane_depth.shape, normal.shape, distance.shape)
         aux = {"pixel_noise": noise.view(H, W), "d_mask": dmask.view(H, W).bool(), "weights": weight.view(H, W), "indices": idx,
                "ncc": ncc[: idx.numel()], "ncc_mask": cmask[: idx.numel()].bool(), "stats": stats}
@@ -279,15 +292,18 @@ class _PlaneMultiview(torch.autograd.Function):
         s0, s1, s2, s3 = ctx.shapes
         a = None if g_geo is None else g_geo * sg          # a loss the caller did not use sends no gradient
         b = None if g_ncc is None else g_ncc * sn
-        return (None if a is None else (gD * a).view(s0), None if a is None else (gN * a).view(s1),
-                None if b is None else (gNm * b).view(s2), None if b is None else (gDs * b).view(s3), None, None, None, None, None, None, None, None)
+        gd, gn = (None, None) if a is None else ((gD * a).view(s0), (gN * a).view(s1))
+        if ctx.whole:                              # gNm is the whole (5,H,W) gradient of out_all_map
+            return (gd, gn, None, None, None, None, None, None, None, None, None, None, None if b is None else gNm * b)
+        return (gd, gn, None if b is None else (gNm * b).view(s2), None if b is None else (gDs * b).view(s3), None, None, None, None, None, None, None,
+                None, None)
 
 
 _MV_AUX = ("pixel_noise", "d_mask", "weights", "indices", "ncc", "ncc_mask", "stats")
 
 
 def plane_multiview_loss(plane_depth, near_plane_depth, rendered_normal, rendered_distance, gray, near_gray, cfg, lambda_geo=0.03, lambda_ncc=0.15,
-                         num_sample=102400, indices=None, generator=None, return_aux=False):
+                         num_sample=102400, indices=None, generator=None, return_aux=False, out_all_map=None):
     """PGSR multi-view losses (gssr/scene/pgsr_scene.py:113-204): -> (geo_loss, ncc_loss) [, aux dict].
 
     plane_depth (1,H,W) / rendered_normal (3,H,W) / rendered_distance (1,H,W): this view's render; near_plane_depth: `nearest_render_pkg
@@ -295,9 +311,11 @@ def plane_multiview_loss(plane_depth, near_plane_depth, rendered_normal, rendere
     cfg = multiview_cfg(viewpoint_cam, near_cam, W, H, patch_size=config.patch_size, pixel_noise_threshold=config.pixel_noise_threshold).
     `indices` (int32 pixel indices, -1 = unused) overrides the random sample of at most `num_sample` (= config.nunm_sample) valid pixels.
     Both losses are 0 with zero gradients when their mask is empty (the reference's `if d_mask.sum() > 0` / `if mask.sum() > 0`), decided on
-    the device: no host synchronisation."""
+    the device: no host synchronisation.
+    `out_all_map=` (the rasterizer's (5,H,W) output) may replace `rendered_normal` / `rendered_distance` (pass None for both): the loss then sends
+    ONE gradient tensor to out_all_map instead of two sliced ones that autograd pads to five channels and adds up."""
     out = _PlaneMultiview.apply(plane_depth, near_plane_depth, rendered_normal, rendered_distance, gray, near_gray, cfg, lambda_geo, lambda_ncc,
-                                int(num_sample), indices, generator)
+                                int(num_sample), indices, generator, out_all_map)
     if return_aux:
         return out[0], out[1], dict(zip(_MV_AUX, out[2:]))
     return out[0], out[1]

@@ -160,3 +160,29 @@ def test_multiview_other_patch_sizes(patch):
         sc = 0.15 / on["stats"][1]
         assert _rel(g["rendered_normal"].reshape(3, -1) / 3.0, sc * on["g_normal"]) < 5e-3
         assert _rel(g["rendered_distance"].reshape(-1) / 3.0, sc * on["g_dist"]) < 5e-3
+
+
+def test_out_all_map_argument_gives_the_same_loss_and_gradients():
+    """plane_multiview_loss(..., None, None, ..., out_all_map=oam) == the call with the two slices oam[0:3], oam[4:5]; the gradient arrives as one
+    (5,H,W) tensor with a zero alpha channel."""
+    import mv_cases
+    from gsrast.losses import multiview_cfg, plane_multiview_loss
+    c = mv_cases.plane_pair(W=96, H=64, seed=3, tex=2.0)
+    dev = "cuda:0"
+    t = lambda a: torch.tensor(a, device=dev)
+    cfg = multiview_cfg(mv_cases.cam_ns(c["view"]), mv_cases.cam_ns(c["near"]), c["W"], c["H"], near_size=(c["W"], c["H"]))
+    idx = torch.arange(0, c["W"] * c["H"], 3, dtype=torch.int32, device=dev)
+    res = []
+    for whole in (False, True):
+        pd = t(c["plane_depth"]).requires_grad_(True); pd2 = t(c["near_plane_depth"]).requires_grad_(True)
+        oam = torch.cat([t(c["rendered_normal"]), torch.ones(1, c["H"], c["W"], device=dev), t(c["rendered_distance"])], dim=0).requires_grad_(True)
+        if whole:
+            geo, ncc = plane_multiview_loss(pd, pd2, None, None, t(c["gray"]), t(c["near_gray"]), cfg, indices=idx, out_all_map=oam)
+        else:
+            geo, ncc = plane_multiview_loss(pd, pd2, oam[0:3], oam[4:5], t(c["gray"]), t(c["near_gray"]), cfg, indices=idx)
+        (geo + ncc).backward()
+        res.append((geo.item(), ncc.item(), pd.grad.clone(), pd2.grad.clone(), oam.grad.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and abs(res[0][1] - res[1][1]) <= 1e-5 * abs(res[0][1])
+    for a, b in zip(res[0][2:], res[1][2:]):       # overlapping patches add their gradients with float atomics: the order differs from run to run
+        assert (a - b).norm() <= 1e-5 * b.norm()
+    assert res[1][4][3].abs().max() == 0 and res[1][4][0:3].abs().max() > 0

@@ -85,7 +85,7 @@ def build(a, dev, seed=0):
         img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask = render(views[0], 1, scaling)
         _, _, _, pd2, _, _, _, _, _, _ = render(views[1], 2, scaling)
         loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + plane_geo_loss(pd, oam, rm1, weight, 0.015, unit_upstream=True)[0] + 0.01 * scl.prod(dim=1).mean()
-        geo, ncc = plane_multiview_loss(pd, pd2, oam[0:3], oam[4:5], gray1, gray2, mcfg, 0.03, 0.15)
+        geo, ncc = plane_multiview_loss(pd, pd2, None, None, gray1, gray2, mcfg, 0.03, 0.15, out_all_map=oam)
         (loss + geo + ncc).backward()
         decode.training_stats_(acc["opacity_accum"], acc["anchor_demon"], acc["offset_gradient_accum"], acc["offset_denom"], m2.grad, nop, radii > 0,
                                mask, vis_idx=vis_idx)

@@ -91,7 +91,7 @@ def build(a, dev):
         _, _, _, _, pd2 = render(rs2, t2, xyz, scl, rot, op)
         if a.glue == "hip":
             loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + plane_geo_loss(pd, oam, rm1, weight, 0.015, unit_upstream=True)[0]
-            geo, ncc = plane_multiview_loss(pd, pd2, oam[0:3], oam[4:5], gray1, gray2, mcfg, 0.03, 0.15)
+            geo, ncc = plane_multiview_loss(pd, pd2, None, None, gray1, gray2, mcfg, 0.03, 0.15, out_all_map=oam)
         else:
             loss = ref_loss_torch.loss(img.unsqueeze(0), gt.unsqueeze(0), 0.2)[0] + ref_geo_torch.plane_geo_loss(pd.squeeze(0), oam, K1, weight, 0.015)[0]
             # the reference draws its <= 102400 samples with np.random.choice on the host; here a device-side draw so that only the op chain is timed
