@@ -117,7 +117,7 @@ GeomView gsr_carve_geom(int variant, int P, void* base)
     g.keys_b = take<uint32_t>(p, n);
     g.vals_b = take<uint32_t>(p, n);
     g.sorted_idx = g.vals_a;                 // four sort passes: identity -> vals_b -> vals_a -> vals_b -> vals_a (gsr_launch_depth_order)
-    g.hist = take<uint32_t>(p, (size_t)2048 * nblk + 2048);   // 11-bit digits: histogram matrix + digit totals
+    g.hist = take<uint32_t>(p, gsr_sort_hist_words(nblk, 2048));   // sized for 11-bit digits (GSR_DEPTH_BITS=11)
     g.scan_tmp = take<uint32_t>(p, gsr_div_up((uint32_t)n, GSR_SCAN_BLOCK) + 64);
     g.counters = take<uint32_t>(p, 64);
     g.bytes = (size_t)(p - reinterpret_cast<char*>(base));
@@ -135,7 +135,7 @@ BinView gsr_carve_bin(int variant, uint32_t R, int W, int H, void* base)
     b.tile_keys = take<uint32_t>(p, n);
     b.keys_b = take<uint32_t>(p, n);
     b.vals_b = take<uint32_t>(p, n);
-    b.hist = take<uint32_t>(p, (size_t)256 * nblk + 256);
+    b.hist = take<uint32_t>(p, gsr_sort_hist_words(nblk, 256));
     b.scan_tmp = take<uint32_t>(p, 64);
     b.bytes = (size_t)(p - reinterpret_cast<char*>(base));
     return b;

@@ -66,31 +66,15 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, u
     }
 }
 
-// exclusive scan of every row of a [rows x cols] matrix in place, one block per row (coalesced), row totals to tot[].
-// Used on the digit-major histogram hist[d * nblk + blk]: rows = digits, cols = sort blocks.
-__global__ void __launch_bounds__(256) k_scan_rows(uint32_t* __restrict__ data, uint32_t cols, uint32_t* __restrict__ tot)
-{
-    __shared__ uint32_t lds[17];
-    uint32_t* row = data + (size_t)blockIdx.x * cols;
-    uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < cols; c0 += 256) {
-        const uint32_t i = c0 + threadIdx.x;
-        const uint32_t v = (i < cols) ? row[i] : 0;
-        uint32_t t;
-        const uint32_t incl = block_incl_scan(v, lds, &t);
-        if (i < cols) row[i] = carry + incl - v;
-        carry += t;
-    }
-    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
-}
-
 // ------------------------------------------------------------------------------------------------ radix sort
 // Digits of up to 11 bits: NB = histogram bins the kernel is built for (256 for <= 8-bit digits, 2048 for 9..11 bits; the wide form is
 // an A/B option of the depth order only, see gsr_launch_depth_order).
-// per-block digit histogram, hist[d * nblk + blk]
+// per-block digit histogram, block-major: H[blk * NB + d]; the same counts are added into the histogram of the block's group of
+// GSR_SORT_GROUP blocks, GH[(blk / GROUP) * NB + d] (device atomics, zeroed beforehand), so that a scatter block finds the number of
+// keys in front of its own with ~ groups + GROUP coalesced row reads instead of a separate scan kernel over the whole matrix.
 template <int ITEMS, int NB>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev,
-                                                                 int shift, uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk)
+                                                                 int shift, uint32_t mask, uint32_t* __restrict__ H, uint32_t* __restrict__ GH)
 {
     __shared__ uint32_t h[NB];
     if (n_dev) n = min(n, *n_dev);       // device-side element count (speculative forward): n is then the capacity
@@ -103,7 +87,12 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t*
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d <= mask; d += GSR_SORT_THREADS) hist[d * nblk + blockIdx.x] = h[d];
+    uint32_t* grow = GH + (size_t)(blockIdx.x / GSR_SORT_GROUP) * NB;
+    for (uint32_t d = threadIdx.x; d < NB; d += GSR_SORT_THREADS) {
+        const uint32_t c = h[d];
+        H[(size_t)blockIdx.x * NB + d] = c;
+        if (c) atomicAdd(&grow[d], c);
+    }
 }
 
 // exclusive prefix over (mask + 1) <= NB per-digit values held DPT per thread (digit d = DPT * tid + k); returns through arr[]
@@ -126,7 +115,8 @@ template <int ITEMS, int NB>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                     uint32_t n, const uint32_t* __restrict__ n_dev, int shift, int bits,
-                                                                    const uint32_t* __restrict__ hist, uint32_t nblk, const uint32_t* __restrict__ digit_tot)
+                                                                    const uint32_t* __restrict__ H, const uint32_t* __restrict__ GH, uint32_t ngroups,
+                                                                    uint32_t* __restrict__ GH_next)
 {
     constexpr int DPT = NB / GSR_SORT_THREADS;
     if (n_dev) n = min(n, *n_dev);
@@ -137,13 +127,42 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * NB; i += GSR_SORT_THREADS) (&cnt[0][0])[i] = 0;
-    {   // global base of digit d for this block = (#keys with a smaller digit) + (#keys with digit d in earlier blocks)
-        uint32_t t[DPT], ex[DPT];
+    {   // global base of digit d for this block = (#keys with a smaller digit) + (#keys with digit d in earlier blocks): the group
+        // histograms of the earlier groups + the block histograms of the earlier blocks of this group (coalesced NB-word rows)
+        const uint32_t grp = blockIdx.x / GSR_SORT_GROUP;
+        uint32_t t[DPT], before[DPT], ex[DPT];
 #pragma unroll
-        for (int k = 0; k < DPT; k++) { const uint32_t d = DPT * threadIdx.x + k; t[k] = (d <= mask) ? digit_tot[d] : 0; }
+        for (int k = 0; k < DPT; k++) { t[k] = 0; before[k] = 0; }
+        // rows are requested eight at a time (independent loads in flight): a rolled loop would pay one L2 round trip per row
+        for (uint32_t g0 = 0; g0 < ngroups; g0 += 8) {
+#pragma unroll
+            for (int k = 0; k < DPT; k++) {
+                const uint32_t d = DPT * threadIdx.x + k;
+                uint32_t c[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) c[u] = (d <= mask && g0 + u < ngroups) ? GH[(size_t)(g0 + u) * NB + d] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) { t[k] += c[u]; if (g0 + u < grp) before[k] += c[u]; }
+            }
+        }
+        {
+            const uint32_t b0 = grp * GSR_SORT_GROUP;
+#pragma unroll
+            for (int k = 0; k < DPT; k++) {
+                const uint32_t d = DPT * threadIdx.x + k;
+                uint32_t c[GSR_SORT_GROUP - 1];
+#pragma unroll
+                for (int u = 0; u < GSR_SORT_GROUP - 1; u++) c[u] = (d <= mask && b0 + u < blockIdx.x) ? H[(size_t)(b0 + u) * NB + d] : 0u;
+#pragma unroll
+                for (int u = 0; u < GSR_SORT_GROUP - 1; u++) before[k] += c[u];
+            }
+        }
         digit_excl_scan<NB>(t, ex, lds);
 #pragma unroll
-        for (int k = 0; k < DPT; k++) { const uint32_t d = DPT * threadIdx.x + k; if (d <= mask) gbase[d] = ex[k] + hist[d * nblk + blockIdx.x]; }
+        for (int k = 0; k < DPT; k++) { const uint32_t d = DPT * threadIdx.x + k; if (d <= mask) gbase[d] = ex[k] + before[k]; }
+        // the other group-histogram buffer is the next pass's: clear it here (this pass only reads GH)
+        if (GH_next && blockIdx.x < ngroups)
+            for (uint32_t d = threadIdx.x; d < NB; d += GSR_SORT_THREADS) GH_next[(size_t)blockIdx.x * NB + d] = 0;
     }
     __syncthreads();
 
@@ -212,40 +231,43 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     }
 }
 
-// hist must hold (2^bits_per_pass) * nblk + 2^bits_per_pass words (nblk for the 1024-key geometry)
+// hist must hold gsr_sort_hist_words(nblk for the 1024-key geometry, NB) words, NB = 256 (digits <= 8 bits) or 2048
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
-                         bool* result_in_b, hipStream_t s, bool big_blocks)
+                         bool* result_in_b, hipStream_t s, bool big_blocks, bool group0_zeroed)
 {
     // keys per block: 1024 (many blocks: small inputs are latency-bound) or 4096 (longer digit runs -> full-line writes on big inputs).
     // The histogram area is always sized for the 1024-key geometry, the larger upper bound.
-    const uint32_t nblk = gsr_div_up(n, GSR_SORT_THREADS * (big_blocks ? 16u : (uint32_t)GSR_SORT_ITEMS));
+    const uint32_t nblk = gsr_sort_blocks(n, big_blocks);
     const bool wide = bits_per_pass > 8;      // 2048-bin kernels
-    uint32_t* digit_tot = hist + (size_t)(wide ? 2048 : 256) * nblk;      // behind the histogram matrix
+    const uint32_t NB = wide ? 2048u : 256u;
+    const uint32_t ngroups = gsr_div_up(nblk, GSR_SORT_GROUP);
+    uint32_t* GH[2] = { hist, hist + (size_t)NB * ngroups };
+    uint32_t* H = hist + 2 * (size_t)NB * ngroups;
+    if (!group0_zeroed) GSR_CHECK(hipMemsetAsync(GH[0], 0, (size_t)NB * ngroups * sizeof(uint32_t), s), "memset group histogram");
     // identity_vals: the first pass generates value i for element i instead of reading vals_a
     uint32_t *kin = keys_a, *vin = identity_vals ? nullptr : vals_a, *kout = keys_b, *vout = vals_b;
     bool in_b = false;
-    for (int shift = begin_bit; shift < end_bit;) {
+    int pass = 0;
+    for (int shift = begin_bit; shift < end_bit; pass++) {
         // balance the digits over the remaining passes
         int remaining = end_bit - shift;
         int passes_left = (remaining + bits_per_pass - 1) / bits_per_pass;
         int bits = (remaining + passes_left - 1) / passes_left;
         uint32_t mask = (1u << bits) - 1u;
         const dim3 g(nblk), b(GSR_SORT_THREADS);
+        uint32_t* gh = GH[pass & 1];
+        uint32_t* gh_next = (passes_left > 1) ? GH[(pass + 1) & 1] : nullptr;
         if (wide) {
-            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, hist, nblk);
-            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, hist, nblk);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh);
+            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next);
+            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next);
         } else {
-            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, hist, nblk);
-            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, hist, nblk);
-        }
-        hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, hist, nblk, digit_tot);
-        if (wide) {
-            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
-            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
-        } else {
-            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
-            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, hist, nblk, digit_tot);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh);
+            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next);
+            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next);
         }
         uint32_t* t;
         t = kin; kin = kout; kout = t;
@@ -271,6 +293,13 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_local(const uint32_t
     if (i < P) offsets[i] = incl;
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
+uint32_t gsr_depth_sort_digit_bins()
+{
+    static int depth_bits = -1;
+    if (depth_bits < 0) { const char* e = getenv("GSR_DEPTH_BITS"); depth_bits = (e && atoi(e) == 11) ? 11 : 8; }
+    return depth_bits == 11 ? 2048u : 256u;
+}
+
 int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s)
 {
     const uint32_t P = (uint32_t)cfg->P;
@@ -279,9 +308,9 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
     // GSR_DEPTH_BITS=11 selects three 11-bit passes instead (33 >= 32 bits, bit-identical result, kept for A/B): MEASURED SLOWER on
     // MI355X at P = 300k -- depth_order 0.080 -> 0.106 ms.  A pass costs ~14 us of launch latency + ~2 us per 256 bins (the
     // digit-major histogram matrix is written / scanned / read with a block-count stride), so 2048 bins cost more than the pass saved.
-    static int depth_bits = -1;
-    if (depth_bits < 0) { const char* e = getenv("GSR_DEPTH_BITS"); depth_bits = (e && atoi(e) == 11) ? 11 : 8; }
-    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, depth_bits, true, g.hist, &in_b, s, false);
+    const int depth_bits = gsr_depth_sort_digit_bins() == 2048 ? 11 : 8;
+    // the preprocess kernel cleared the first group-histogram buffer (gsr_preprocess.hip: PreParams::zero_ptr)
+    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, depth_bits, true, g.hist, &in_b, s, false, true);
     if (depth_bits == 11)      // odd pass count: the ids ended in vals_b, bring them to sorted_idx (= vals_a)
         GSR_CHECK(hipMemcpyAsync(g.sorted_idx, g.vals_b, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, s), "copy sorted ids");
     const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
@@ -302,11 +331,12 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
                                                    const uint32_t* __restrict__ block_prefix, const uint32_t* __restrict__ tiles_touched,
                                                    const ushort4* __restrict__ rect, int gx,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap,
-                                                   uint2* __restrict__ ranges, uint32_t T)
+                                                   uint2* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ zero_ptr, uint32_t zero_n)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x);          // position in depth order
     if (i < T) ranges[i] = make_uint2(0u, 0u);                           // the cudaMemset of rasterizer_impl.cu:310, folded in (k_tile_ranges runs later)
+    for (uint32_t z = i; z < zero_n; z += gridDim.x * blockDim.x) zero_ptr[z] = 0u;      // first group-histogram buffer of the tile sort that follows
     const bool v = i < P;
     const uint32_t g = v ? sorted_idx[i] : 0u;
     const uint32_t cnt = v ? tiles_touched[g] : 0u;
@@ -382,9 +412,9 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P, g.sorted_idx, g.offsets, g.scan_tmp,
-                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T);
+                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256));
     bool in_b = false;
-    gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19));
+    gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true);
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
     return gsr_check_launch("binning", s, cfg->debug);
 }

@@ -95,6 +95,13 @@ int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const in
                               const float* acc, const gsr_in_grads* ig, hipStream_t s);
 
 // generic device-wide primitives (gsr_binning.hip)
+// Histogram scratch of the sort: [2 group-histogram buffers of NB * groups words][block histograms NB * nblk], groups = ceil(nblk / 16).
+// `group0_zeroed`: the caller's preceding kernel already zeroed the first NB * groups words (gsr_sort_group_words) -- otherwise a memset does.
+#define GSR_SORT_GROUP 16
+static inline uint32_t gsr_sort_blocks(uint32_t n, bool big_blocks) { return gsr_div_up(n, GSR_SORT_THREADS * (big_blocks ? 16u : (uint32_t)GSR_SORT_ITEMS)); }
+static inline uint32_t gsr_sort_group_words(uint32_t n, bool big_blocks, uint32_t NB) { return NB * gsr_div_up(gsr_sort_blocks(n, big_blocks), GSR_SORT_GROUP); }
+static inline size_t gsr_sort_hist_words(uint32_t nblk_1024, uint32_t NB) { return (size_t)NB * nblk_1024 + 2 * (size_t)NB * (nblk_1024 / GSR_SORT_GROUP + 1); }
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
-                         bool* result_in_b, hipStream_t s, bool big_blocks = false);
+                         bool* result_in_b, hipStream_t s, bool big_blocks = false, bool group0_zeroed = false);
+uint32_t gsr_depth_sort_digit_bins();      // 256, or 2048 with GSR_DEPTH_BITS=11 (gsr_binning.hip)

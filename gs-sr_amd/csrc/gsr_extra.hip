@@ -481,7 +481,7 @@ static KnnScratch knn_carve(int P, void* base)
     auto take = [&](size_t bytes) { char* r = p; p += gsr_align(bytes); return r; };
     k.mm = (uint32_t*)take(64); k.keys_a = (uint32_t*)take(n * 4); k.keys_b = (uint32_t*)take(n * 4);
     k.vals_a = (uint32_t*)take(n * 4); k.vals_b = (uint32_t*)take(n * 4);
-    k.hist = (uint32_t*)take(((size_t)256 * nblk + 256) * 4); k.boxes = (float*)take((size_t)nbox * 6 * 4);
+    k.hist = (uint32_t*)take(gsr_sort_hist_words(nblk, 256) * 4); k.boxes = (float*)take((size_t)nbox * 6 * 4);
     k.bytes = (size_t)(p - (char*)base);
     return k;
 }

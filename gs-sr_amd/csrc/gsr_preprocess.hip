@@ -18,6 +18,7 @@ struct PreParams {
     const uint8_t* in_mask;   // FILTER only: optional per-gaussian pre-mask (Octree LOD); masked-out entries get radii 0 without any work
     int scale_stride;         // floats between consecutive scale triples (3, or 6 when fed get_scaling directly)
     int no_cull;           // GSR_NO_CULL=1 (diagnostic): every visible gaussian passes the sub-tile cull -> outputs must not change
+    uint32_t* zero_ptr; uint32_t zero_n;      // first group-histogram buffer of the depth sort that follows (gsr_binning.hip): cleared here
 };
 
 __device__ __forceinline__ void load16(const float* p, float* m)
@@ -40,6 +41,7 @@ __device__ __forceinline__ float two_tau(float o)
 template <bool FILTER_ONLY>
 __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
 {
+    for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.P) return;
     if (FILTER_ONLY && p.in_mask && !p.in_mask[idx]) { p.radii[idx] = 0; return; }
@@ -127,6 +129,7 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
 // SURFEL forward.cu:149-251
 __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
 {
+    for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.P) return;
     float view[16], proj[16];
@@ -258,12 +261,14 @@ static PreParams make_params(const gsr_cfg* cfg, const gsr_inputs* in, GeomView 
     { const char* e = getenv("GSR_NO_CULL"); p.no_cull = (e && atoi(e) != 0) ? 1 : 0; }
     p.in_mask = nullptr; p.scale_stride = 3;
     p.radii = radii; p.g = g;
+    p.zero_ptr = nullptr; p.zero_n = 0;
     return p;
 }
 
 int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s)
 {
     PreParams p = make_params(cfg, in, g, radii);
+    p.zero_ptr = g.hist; p.zero_n = gsr_sort_group_words((uint32_t)cfg->P, false, gsr_depth_sort_digit_bins());
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);
     if (cfg->variant == GSR_SURFEL) hipLaunchKernelGGL(k_preprocess_surfel, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_preprocess_ewa<false>, grid, block, 0, s, p);
