@@ -66,6 +66,24 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, u
     }
 }
 
+// exclusive scan of every row of a [rows x cols] matrix in place, one block per row (coalesced), row totals to tot[].
+// Used on the digit-major histogram hist[d * nblk + blk] of LARGE sorts (more than GSR_SORT_MAX_GROUPS block groups), rows = digits.
+__global__ void __launch_bounds__(256) k_scan_rows(uint32_t* __restrict__ data, uint32_t cols, uint32_t* __restrict__ tot)
+{
+    __shared__ uint32_t lds[17];
+    uint32_t* row = data + (size_t)blockIdx.x * cols;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < cols; c0 += 256) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint32_t v = (i < cols) ? row[i] : 0;
+        uint32_t t;
+        const uint32_t incl = block_incl_scan(v, lds, &t);
+        if (i < cols) row[i] = carry + incl - v;
+        carry += t;
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
+}
+
 // ------------------------------------------------------------------------------------------------ radix sort
 // Digits of up to 11 bits: NB = histogram bins the kernel is built for (256 for <= 8-bit digits, 2048 for 9..11 bits; the wide form is
 // an A/B option of the depth order only, see gsr_launch_depth_order).
@@ -74,7 +92,8 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, u
 // keys in front of its own with ~ groups + GROUP coalesced row reads instead of a separate scan kernel over the whole matrix.
 template <int ITEMS, int NB>
 __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev,
-                                                                 int shift, uint32_t mask, uint32_t* __restrict__ H, uint32_t* __restrict__ GH)
+                                                                 int shift, uint32_t mask, uint32_t* __restrict__ H, uint32_t* __restrict__ GH,
+                                                                 uint32_t digit_major_nblk)
 {
     __shared__ uint32_t h[NB];
     if (n_dev) n = min(n, *n_dev);       // device-side element count (speculative forward): n is then the capacity
@@ -87,6 +106,10 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_hist(const uint32_t*
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
+    if (digit_major_nblk) {              // large sort: digit-major matrix for k_scan_rows
+        for (uint32_t d = threadIdx.x; d <= mask; d += GSR_SORT_THREADS) H[(size_t)d * digit_major_nblk + blockIdx.x] = h[d];
+        return;
+    }
     uint32_t* grow = GH + (size_t)(blockIdx.x / GSR_SORT_GROUP) * NB;
     for (uint32_t d = threadIdx.x; d < NB; d += GSR_SORT_THREADS) {
         const uint32_t c = h[d];
@@ -116,7 +139,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                     uint32_t n, const uint32_t* __restrict__ n_dev, int shift, int bits,
                                                                     const uint32_t* __restrict__ H, const uint32_t* __restrict__ GH, uint32_t ngroups,
-                                                                    uint32_t* __restrict__ GH_next)
+                                                                    uint32_t* __restrict__ GH_next, uint32_t digit_major_nblk)
 {
     constexpr int DPT = NB / GSR_SORT_THREADS;
     if (n_dev) n = min(n, *n_dev);
@@ -133,6 +156,14 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
         uint32_t t[DPT], before[DPT], ex[DPT];
 #pragma unroll
         for (int k = 0; k < DPT; k++) { t[k] = 0; before[k] = 0; }
+        if (digit_major_nblk) {          // large sort: k_scan_rows left the exclusive row prefix in H and the digit totals in GH
+#pragma unroll
+            for (int k = 0; k < DPT; k++) {
+                const uint32_t d = DPT * threadIdx.x + k;
+                if (d <= mask) { t[k] = GH[d]; before[k] = H[(size_t)d * digit_major_nblk + blockIdx.x]; }
+            }
+            ngroups = 0;
+        }
         // rows are requested eight at a time (independent loads in flight): a rolled loop would pay one L2 round trip per row
         for (uint32_t g0 = 0; g0 < ngroups; g0 += 8) {
 #pragma unroll
@@ -145,7 +176,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
                 for (int u = 0; u < 8; u++) { t[k] += c[u]; if (g0 + u < grp) before[k] += c[u]; }
             }
         }
-        {
+        if (!digit_major_nblk) {
             const uint32_t b0 = grp * GSR_SORT_GROUP;
 #pragma unroll
             for (int k = 0; k < DPT; k++) {
@@ -244,7 +275,11 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
     const uint32_t ngroups = gsr_div_up(nblk, GSR_SORT_GROUP);
     uint32_t* GH[2] = { hist, hist + (size_t)NB * ngroups };
     uint32_t* H = hist + 2 * (size_t)NB * ngroups;
-    if (!group0_zeroed) GSR_CHECK(hipMemsetAsync(GH[0], 0, (size_t)NB * ngroups * sizeof(uint32_t), s), "memset group histogram");
+    // Every scatter block reads all group rows: O(nblk^2 / 16) words per pass.  Beyond GSR_SORT_MAX_GROUPS groups (~800k keys at 1024 per block,
+    // ~3 M at 4096) that costs more than the row-scan kernel it replaces (measured: 17 M instances, +0.23 ms per forward), so large sorts keep
+    // the digit-major matrix + k_scan_rows (digit totals in GH[0]).
+    const uint32_t dm = (ngroups > GSR_SORT_MAX_GROUPS) ? nblk : 0u;
+    if (!dm && !group0_zeroed) GSR_CHECK(hipMemsetAsync(GH[0], 0, (size_t)NB * ngroups * sizeof(uint32_t), s), "memset group histogram");
     // identity_vals: the first pass generates value i for element i instead of reading vals_a
     uint32_t *kin = keys_a, *vin = identity_vals ? nullptr : vals_a, *kout = keys_b, *vout = vals_b;
     bool in_b = false;
@@ -256,18 +291,20 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         int bits = (remaining + passes_left - 1) / passes_left;
         uint32_t mask = (1u << bits) - 1u;
         const dim3 g(nblk), b(GSR_SORT_THREADS);
-        uint32_t* gh = GH[pass & 1];
-        uint32_t* gh_next = (passes_left > 1) ? GH[(pass + 1) & 1] : nullptr;
+        uint32_t* gh = dm ? GH[0] : GH[pass & 1];
+        uint32_t* gh_next = (!dm && passes_left > 1) ? GH[(pass + 1) & 1] : nullptr;
         if (wide) {
-            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh);
-            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh);
-            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next);
-            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
+            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
+            if (dm) hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, H, nblk, gh);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
+            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
         } else {
-            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh);
-            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh);
-            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next);
-            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
+            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
+            if (dm) hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, H, nblk, gh);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
+            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
         }
         uint32_t* t;
         t = kin; kin = kout; kout = t;
