@@ -524,3 +524,15 @@ def test_unused_outputs_send_no_gradient_tensor(variant):
         assert d <= 1e-4 * np.linalg.norm(gb[k].astype(np.float64)) + 1e-30, (k, d)
         assert k == "colors_precomp" or np.abs(gb[k]).max() > 0, k          # the colour image is unused: its parameters get exact zeros
     assert np.linalg.norm(ma.astype(np.float64) - mb) <= 1e-4 * np.linalg.norm(mb.astype(np.float64))
+
+
+def test_eleven_bit_depth_sort_kept_switchable():
+    """GSR_DEPTH_BITS=11 (three 2048-bin passes instead of four 256-bin ones, kept for A/B) has to give the same bit-exact lists: the integer
+    checks of the parity cases are re-run in a child process with the switch set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSR_DEPTH_BITS="11")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
