@@ -199,3 +199,27 @@ def test_dense_tile_lists_backward_through_the_chunk_halving_path(variant):
     for a, b in names:
         x, y = res["grads"][a].astype(np.float64), np.asarray(g[b], np.float64).reshape(res["grads"][a].shape)
         assert np.linalg.norm(x - y) <= 1e-3 * np.linalg.norm(y) + 1e-12, (variant, a, np.linalg.norm(x - y) / np.linalg.norm(y))
+
+
+@pytest.mark.parametrize("P", [1, 63, 1023, 1024, 1025, 16384, 16385, 17 * 1024 + 5, 786432, 786433, 787456 + 7])
+def test_sort_block_and_group_boundaries(P):
+    """The radix passes keep one histogram per block of 1024 keys and one per group of 16 blocks; beyond 48 groups the sort switches to
+    the digit-major matrix + row scan.  Counts on both sides of every boundary: the depth order and the per-tile lists stay exact
+    (stable: equal depths keep index order)."""
+    hr = _hr()
+    W, H = 96, 64
+    sc = scenes.make_scene("ewa", P, W, H, seed=P % 97, sigma_px=0.8)
+    if P > 4:
+        sc["means3D"][P // 3] = sc["means3D"][P // 3 - 1]            # a depth tie whose order only stability decides
+    st = hr.run_raw("ewa", sc)
+    assert st["R"] == int(st["tiles_touched"].sum())
+    tk, pl = st["tile_keys"].astype(np.int64)[: st["R"]], st["point_list"].astype(np.int64)[: st["R"]]
+    assert np.all(np.diff(tk) >= 0)
+    assert np.array_equal(np.bincount(pl, minlength=P), st["tiles_touched"])
+    pv = sc["means3D"] @ sc["viewmatrix"][:3, :3] + sc["viewmatrix"][3, :3]
+    db = pv[:, 2].astype(np.float32).view(np.uint32).astype(np.int64)
+    same = np.nonzero(np.diff(tk) == 0)[0]
+    a, b = pl[same], pl[same + 1]
+    assert np.all((db[a] < db[b]) | ((db[a] == db[b]) & (a < b)))
+    counts = np.bincount(tk, minlength=st["ranges"].shape[0])
+    assert np.array_equal(st["ranges"][:, 1] - st["ranges"][:, 0], counts)
