@@ -42,6 +42,9 @@ class Adam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         L = lib()
+        steps = self.__dict__.setdefault("_gsr_step_views", {})
+        if len(steps) > 4 * sum(len(g["params"]) for g in self.param_groups) + 64:      # parameters replaced by densification leave stale ids
+            steps.clear()
         rest = []                                  # (group, params) torch handles itself
         batch = {}                                 # device -> list of table entries (one launch per 24 tensors)
         keep = []                                  # contiguous copies that must outlive the launch call
@@ -63,8 +66,17 @@ class Adam(torch.optim.Adam):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                t = float(st["step"])
+                stp = st["step"]                   # a CPU scalar tensor, as torch keeps it; bumped through a cached numpy view of the same
+                ent = steps.get(id(p))             # memory (a torch op + float() per parameter cost more than the whole kernel launch)
+                if ent is None or ent[0] is not stp:
+                    ent = steps[id(p)] = (stp, stp.numpy()) if (stp.device.type == "cpu" and stp.dtype == torch.float32) else (stp, None)
+                view = ent[1]
+                if view is not None:
+                    view += 1.0
+                    t = float(view)
+                else:
+                    stp += 1
+                    t = float(stp)
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous()):
                     st["exp_avg"], st["exp_avg_sq"] = m, v = m.contiguous(), v.contiguous()
