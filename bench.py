@@ -363,7 +363,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"diff_{ {'ewa':'gaussian','surfel':'surfel','plane':'plane'}[args.variant] }_rasterization forward+backward "
                                    f"({ {'ewa':'3DGS EWA','surfel':'2DGS surfel: the rasterizer of configs[1] scaffold-2dgs','plane':'PGSR plane: the rasterizer of configs[2]'}[args.variant] }) "
-                                   f"+ fused L1/linear image loss + fused Adam on EXPLICIT Gaussians, {'SH deg 3' if args.color_mode == 'sh' else 'colors_precomp'}, "
+                                   f"+ fused L1/linear image loss + fused Adam (gsrast.optim, one HIP kernel) on EXPLICIT Gaussians, {'SH deg 3' if args.color_mode == 'sh' else 'colors_precomp'}, "
                                    f"P={args.P}, {args.W}x{args.H}, synthetic scene SURVEY §8d (seed=rank); the complete methods (decode, SSIM, "
                                    f"regularisers, statistics) are timed in method_iteration",
                        "variant": args.variant, "P": args.P, "W": args.W, "H": args.H, "tile_instances_R": R, "tile_instances_R_after_timed_steps": R_after,
