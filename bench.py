@@ -219,6 +219,7 @@ def method_iteration(device, which, steps=20):
     this repo, with GPU-kernel time (torch.profiler / roctracer: every kernel of the process, C-ABI launches included) beside wall time.
       scaffold-2dgs (configs[1]): prefilter (scaffold_filter) -> neural-Gaussian decode (72k anchors x 10 offsets -> ~320k Gaussians) ->
         diff_surfel_rasterization -> L1+SSIM, normal + distortion regularisers, scaling loss -> backward -> densification statistics -> Adam.
+      octree-2dgs (configs[3] / [4]): the same iteration behind the Octree model's level-of-detail mask + prefilter (87k anchors on 6 levels).
       octree-pgsr (configs[2], after step 7000), for the view AND its neighbour camera: octree level-of-detail mask + prefilter ->
         neural-Gaussian decode (74k anchors x 10 offsets on 6 levels -> ~300k Gaussians) -> per-Gaussian all_map -> diff_plane_rasterization;
         then L1+SSIM + single-view normal loss + multi-view geometric / NCC losses + scaling loss -> backward -> statistics -> Adam.
@@ -227,9 +228,10 @@ def method_iteration(device, which, steps=20):
     import types
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import iter_breakdown
-    if which == "scaffold-2dgs":
+    if which in ("scaffold-2dgs", "octree-2dgs"):
         import bench_pipeline
-        step, st = bench_pipeline.build(types.SimpleNamespace(decode="hip", loss="full-hip", Na=72000), device)
+        lod = which == "octree-2dgs"
+        step, st = bench_pipeline.build(types.SimpleNamespace(decode="hip", loss="full-hip", Na=87000 if lod else 72000, lod=lod), device)
     elif which == "octree-pgsr":
         import bench_pipeline_octree_pgsr
         step, st = bench_pipeline_octree_pgsr.build(types.SimpleNamespace(Na=74000), device)
@@ -387,7 +389,7 @@ def main():
         except Exception:
             pass
         if world == 1 and not args.no_method_iteration and args.variant == "surfel" and (args.W, args.H) == (1920, 1080):
-            out["method_iteration"] = {m: method_iteration(device, m) for m in ("scaffold-2dgs", "octree-pgsr", "pgsr")}
+            out["method_iteration"] = {m: method_iteration(device, m) for m in ("scaffold-2dgs", "octree-2dgs", "octree-pgsr", "pgsr")}
         if world == 1 and not args.no_cpu_baseline:
             og = scenes.random_out_grads(args.variant, args.W, args.H, seed=0)
             out["cpu_baseline"], ref = cpu_baseline(args.variant, sc, og)

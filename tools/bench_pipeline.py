@@ -26,8 +26,11 @@ from gsrast.optim import Adam          # noqa: E402
 
 
 def build(a, dev, seed=0):
-    """-> (step, st): one scaffold-2dgs training iteration on a synthetic anchor scene; a has .decode, .loss, .Na."""
+    """-> (step, st): one scaffold-2dgs training iteration on a synthetic anchor scene; a has .decode, .loss, .Na and optionally .lod
+    (True: octree-2dgs, BASELINE configs[3]/[4] -- OctreeScene's level-of-detail mask + prefilter (gsr_octree_visible) in front of the same
+    decode / surfel rasterizer / losses, anchors on 6 octree levels)."""
     W, H, k, A = 1920, 1080, 10, 32
+    lod = bool(getattr(a, "lod", False))
     sc = scenes.make_scene("surfel", a.Na, W, H, seed=seed, color_mode="precomp")
     t = hiprun.to_dev(sc, dev)
     rs = hiprun.settings("surfel", t)
@@ -56,6 +59,14 @@ def build(a, dev, seed=0):
     wvt, fpt = t["viewmatrix"], t["projmatrix"]
     rm, nr = camera_ray_matrices(wvt, fpt, W, H)
     case = {"k": k, "dist_o": False, "dist_c": False, "dist_k": False}
+    if lod:
+        from gsrast import octree
+        LEVELS, FORK = 6, 2.0
+        level = torch.randint(0, LEVELS, (a.Na, 1), generator=g).to(dev)
+        extra_level = torch.zeros(a.Na, device=dev)
+        dist = (t["means3D"] - t["campos"]).norm(dim=1)
+        standard_dist = float(dist.median()) * FORK ** 3.5     # the median anchor predicts level 3.5: levels 0..3 or 0..4 of 0..5 pass the mask
+        voxel_size = float(ext.median()) * 8.0
     acc = {"opacity_accum": torch.zeros(a.Na, 1, device=dev), "anchor_demon": torch.zeros(a.Na, 1, device=dev),
            "offset_gradient_accum": torch.zeros(a.Na * k, 1, device=dev), "offset_denom": torch.zeros(a.Na * k, 1, device=dev)}
     st = {}
@@ -63,8 +74,12 @@ def build(a, dev, seed=0):
     def step():
         scaling = torch.exp(scaling_log)
         with torch.no_grad():                                 # prefilter_voxel (scaffold_scene.py:122-155)
-            radii = sf.GaussianRasterizer(fs).visible_filter(means3D=anchor, scales=scaling[:, :3], rotations=rot_anchor, cov3D_precomp=None)
-            vmask = radii > 0
+            if lod:                                           # set_anchor_mask + prefilter_voxel of the Octree model in one call, no host sync
+                vmask = octree.octree_visible(fs, anchor, level, scaling, rot_anchor, voxel_size, FORK, standard_dist, LEVELS, dist2level="round",
+                                              extra_level=extra_level)["visible_mask"]
+            else:
+                radii = sf.GaussianRasterizer(fs).visible_filter(means3D=anchor, scales=scaling[:, :3], rotations=rot_anchor, cov3D_precomp=None)
+                vmask = radii > 0
         app = emb.weight[1]
         if a.decode == "hip":
             vis_idx = decode.compact_visible(vmask, padded=True)   # once per iteration, shared by the decode and the statistics; no host sync
@@ -108,6 +123,7 @@ def main():
                     help="bench: L1 + linear aux (bench.py's loss); full-*: the reference's L1+SSIM + normal/dist regularisers + scaling loss, "
                          "fused HIP kernels or the reference's torch formulas")
     ap.add_argument("--Na", type=int, default=72000)
+    ap.add_argument("--lod", action="store_true", help="octree-2dgs: level-of-detail mask + prefilter (use --Na 87000 for ~300k Gaussians)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     a = ap.parse_args()
@@ -118,7 +134,7 @@ def main():
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"pipeline": "scaffold-2dgs", "decode": a.decode, "loss": a.loss, "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps,
+    print(json.dumps({"pipeline": "octree-2dgs" if a.lod else "scaffold-2dgs", "decode": a.decode, "loss": a.loss, "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps,
                       "ms_per_iter": 1e3 * dt / a.steps, "iters_per_s": a.steps / dt}))
 
 

@@ -44,13 +44,14 @@ def measure(step, dev, steps=20, warmup=8, top=14):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--method", default="scaffold-2dgs", choices=["scaffold-2dgs", "pgsr", "octree-pgsr"])
+    ap.add_argument("--method", default="scaffold-2dgs", choices=["scaffold-2dgs", "octree-2dgs", "pgsr", "octree-pgsr"])
     ap.add_argument("--steps", type=int, default=20)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    if a.method == "scaffold-2dgs":
+    if a.method in ("scaffold-2dgs", "octree-2dgs"):
         import bench_pipeline
-        step, st = bench_pipeline.build(types.SimpleNamespace(decode="hip", loss="full-hip", Na=72000), dev)
+        lod = a.method == "octree-2dgs"
+        step, st = bench_pipeline.build(types.SimpleNamespace(decode="hip", loss="full-hip", Na=87000 if lod else 72000, lod=lod), dev)
     elif a.method == "octree-pgsr":
         import bench_pipeline_octree_pgsr
         step, st = bench_pipeline_octree_pgsr.build(types.SimpleNamespace(Na=74000), dev)
