@@ -11,6 +11,14 @@ every gradient path of the backward kernel is live.  Nothing is skipped inside t
 Multi-GPU: VastGaussian tiles are independent sub-scenes -> one tile per GPU, one process per GPU, no
 data-path collective ("weak" scaling); value = all ranks' iterations / max-over-ranks time.
 
+How N > 1 is launched.  Either form gives N ranks, one per GPU, RCCL (backend "nccl") for the barrier / reductions:
+  * `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+    (RANK / LOCAL_RANK / WORLD_SIZE in the environment: this process IS one rank);
+  * `python bench.py --gpus N ...` with no RANK in the environment: this process becomes the launcher and starts the N ranks itself
+    through gsrast.launch_tiles.spawn_ranks (HIP_VISIBLE_DEVICES + NUMA affinity per child, children polled, first failure ends the job).
+    N > torch.cuda.device_count() is an error unless --oversubscribe is given; ranks then share devices and, because RCCL refuses two
+    ranks on one device, the control collectives run over gloo on host tensors (reported as "backend" in the line).
+
 One JSON line on rank 0, with "roofline" (dominant kernel = blend backward, live HIP-event duration from the library's
 stage profiler, algorithmic bytes of SURVEY.md §8d) and "cpu_baseline" (the CPU oracle, kind "port", N=1 only).
 """
@@ -252,9 +260,27 @@ def method_iteration(device, which, steps=20):
     return r
 
 
+def launch_ranks(args, ndev):
+    """`python bench.py --gpus N` with no RANK in the environment: start the N ranks (the job train_split.py:24-38 runs one tile after the
+    other, and train.py:78-80 refuses on more than one GPU) and return the job's exit code; rank 0 prints the JSON line."""
+    from gsrast import launch_tiles
+    if args.gpus > ndev and not args.oversubscribe:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible; pass --oversubscribe to let ranks share devices")
+    shared = args.gpus > ndev
+    env = {"GSR_BENCH_BACKEND": "gloo" if shared else "nccl"}
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    port = int(os.environ.get("MASTER_PORT", "0")) or launch_tiles.free_port()
+    return launch_tiles.spawn_ranks(lambda r: cmd, args.gpus, min(args.gpus, ndev), port, pin_gpus=not args.no_pin, extra_env=env)
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="number of ranks = GPUs (one tile-scene each).  N > 1 without RANK in the environment: bench.py starts the N ranks itself "
+                         "(one pinned process per GPU, RCCL); under torch.distributed.run it is one of them")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow --gpus N > visible devices: ranks share devices (rank r on device r %% devices), control collectives over gloo")
+    ap.add_argument("--no-pin", action="store_true", help="self-launch without HIP_VISIBLE_DEVICES / NUMA pinning (LOCAL_RANK selects the device)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", default="surfel", choices=["ewa", "surfel", "plane"])
@@ -268,25 +294,42 @@ def main():
                     help="skip the extra 'method_iteration' measurement (full scaffold-2dgs iteration incl. decode, real losses, statistics)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
+    ndev = torch.cuda.device_count()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, ndev))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
-    dev_index = local_rank % torch.cuda.device_count()     # one GPU per rank on the 8-GPU node; wraps only in single-GPU dry runs
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N (see --help)")
+    shared_devices = os.environ.get("GSR_BENCH_BACKEND", "nccl") != "nccl"
+    if local_rank >= ndev and not (shared_devices or args.oversubscribe):
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {ndev} visible device(s); pass --oversubscribe to share devices")
+    dev_index = local_rank % ndev                           # one GPU per rank; wraps only when devices are shared on purpose
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1 or "RANK" in os.environ:      # under torch.distributed.run: RCCL for the barrier / max-reduction only
+    backend = None
+    ranks_seen = None
+    if world > 1 or "RANK" in os.environ:      # one of N ranks: RCCL for the barrier / max-reduction only
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")        # "gloo": dry run of the N-rank path on a box with fewer GPUs
+        backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")        # "gloo": ranks share devices (RCCL refuses two ranks on one device)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # what lets a reader check that the communicator really holds N ranks on N devices: every rank's device identity, all-gathered
+        pr = torch.cuda.get_device_properties(device)
+        me = {"rank": rank, "pid": os.getpid(), "visible": os.environ.get("HIP_VISIBLE_DEVICES"), "device_index": dev_index,
+              "uuid": str(getattr(pr, "uuid", "")), "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                                                                getattr(pr, "pci_device_id", 0))}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
 
     import gsrast
     import scenes
@@ -361,6 +404,8 @@ def main():
             "metric": "train iters/sec @300k Gaussians 1080p (rasterize fwd+bwd ms and HBM GB/s vs roofline alongside)",
             "value": round(total_iters / elapsed, 3), "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "backend": backend, "dist_world_size": (dist.get_world_size() if dist is not None else 1), "ranks": ranks_seen,
+            "distinct_devices": (len({(r["uuid"], r["pci"]) for r in ranks_seen}) if ranks_seen else 1),
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"diff_{ {'ewa':'gaussian','surfel':'surfel','plane':'plane'}[args.variant] }_rasterization forward+backward "

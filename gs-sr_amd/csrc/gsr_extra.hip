@@ -350,10 +350,11 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamTable T)
 extern "C" int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor* t, void* stream)
 {
     if (count < 0 || (count > 0 && !t)) { gsr_set_error("adam_step_multi: bad table"); return 1; }
-    for (int32_t i0 = 0; i0 < count; i0 += GSR_ADAM_MAX) {
+    int32_t i = 0;                              // consumed index, carried across launches: empty tensors are skipped without using a table slot,
+    while (i < count) {                         // so a batch may consume more than GSR_ADAM_MAX indices and the next one must start behind them
         AdamTable T; T.count = 0; T.pad = 0;
         uint32_t blocks = 0;
-        for (int32_t i = i0; i < count && T.count < GSR_ADAM_MAX; i++) {
+        for (; i < count && T.count < GSR_ADAM_MAX; i++) {
             const gsr_adam_tensor& a = t[i];
             if (a.n <= 0) continue;
             if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq || !(a.bias_correction2_sqrt > 0.0f)) {

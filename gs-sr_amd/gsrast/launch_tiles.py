@@ -11,6 +11,9 @@ reduction that yields the whole-job it/s.
 `--workers-per-gpu K` starts K workers on every GPU (K * gpus ranks, rank r on GPU r % gpus).  One training iteration at 300k Gaussians /
 1080p leaves the GPU idle between its ~90 dependent launches; two independent tiles interleave on one MI355X at 1081 it/s in total against
 904 it/s for one (profiles/r02_bench_2ranks_one_gpu.json; three or four workers lose again: 823 / 920 it/s), and 288 GB hold many tiles.
+RCCL refuses a communicator in which two ranks sit on the same device ("Duplicate GPU detected"), and the job has no data-path collective
+anyway, so with K > 1 the workers stay on their HIP devices while the control collectives (start/stop barrier, job reduction) run over gloo
+on host tensors: `--backend` names the CONTROL backend, `--device` where the tiles train (default: cuda for nccl, cpu for gloo).
 
 `--entry module:function` names the per-tile trainer: `function(tile_dir, out_paths, device, tile_index) -> iterations_done`.
 For the reference that function is a 5-line shim around `train.main(tile_config)`.
@@ -46,16 +49,22 @@ def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    use_gpu = args.backend == "nccl"
+    use_gpu = worker_device(args) == "cuda"
+    if args.backend == "nccl" and not use_gpu:
+        raise RuntimeError("launch_tiles: backend nccl needs --device cuda")
     if use_gpu:
         if not torch.cuda.is_available():
-            raise RuntimeError("launch_tiles: backend nccl needs a HIP device (use --backend gloo for CPU-only dry runs)")
+            raise RuntimeError("launch_tiles: --device cuda needs a HIP device (use --backend gloo --device cpu for CPU-only dry runs)")
         torch.cuda.set_device(local % torch.cuda.device_count())
         device = torch.device("cuda", torch.cuda.current_device())
     else:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    ctl_dev = device if args.backend == "nccl" else None            # where the control collectives' tensors live
     entry = resolve_entry(args.entry)
     names = tiles.list_tiles(args.data)
     out_names = tile_dirnames(len(names))
@@ -72,11 +81,12 @@ def worker(args):
         done.append(i)
     tiles.barrier(device)
     elapsed = time.perf_counter() - t0
-    t_max, n_sum = tiles.reduce_job(elapsed, iters, device if use_gpu else None)
+    t_max, n_sum = tiles.reduce_job(elapsed, iters, ctl_dev)
     summary = None
     if rank == 0:
         summary = {"tiles": len(names), "workers": world, "elapsed_s": t_max, "iterations": n_sum,
-                   "iters_per_s": (n_sum / t_max) if t_max > 0 else 0.0}
+                   "iters_per_s": (n_sum / t_max) if t_max > 0 else 0.0, "backend": args.backend if world > 1 else None,
+                   "device": device.type}
         print(json.dumps(summary), flush=True)
     if world > 1:
         dist.barrier()
@@ -102,32 +112,46 @@ def gpu_numa_cpus(gpu_index):
         return None
 
 
-def spawn(args):
-    """Parent: start one child per GPU with the torchrun environment contract (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*).
-    Every worker is pinned: HIP_VISIBLE_DEVICES = its GPU (the process sees exactly one device, LOCAL_RANK-independent code paths
-    cannot land on GPU 0 by accident) and, where sysfs tells the GPU's NUMA node, CPU affinity to that node's cores.  The children
-    are polled: when one exits non-zero the others are terminated instead of waiting in a collective until the backend times out."""
-    per = max(1, int(getattr(args, "workers_per_gpu", 1)))
-    n = args.gpus * per                                                            # ranks; rank r works on GPU r % gpus
+def worker_device(args):
+    """'cuda' | 'cpu': where the tiles train.  Follows --device when given, else the control backend (nccl -> cuda, gloo -> cpu)."""
+    d = getattr(args, "device", None)
+    return d if d else ("cuda" if args.backend == "nccl" else "cpu")
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(cmd_of_rank, ranks, gpus, port, pin_gpus=True, affinity=True, extra_env=None, poll_s=0.05):
+    """Start `ranks` child processes with the torchrun environment contract (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*); rank r works on GPU
+    r % gpus.  With `pin_gpus` every child is pinned: HIP_VISIBLE_DEVICES = its GPU (the process sees exactly one device and LOCAL_RANK is
+    0, so LOCAL_RANK-independent code paths cannot land on GPU 0 by accident) and, where sysfs tells the GPU's NUMA node, CPU affinity to
+    that node's cores.  The children are polled: when one exits non-zero the others are terminated instead of waiting in a collective
+    until the backend times out.  Returns the first non-zero exit code, or 0.  Used by the tile launcher and by `bench.py --gpus N`."""
     procs = []
     pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # the directory that holds gsrast/ and the drop-in packages
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if args.backend == "nccl" else str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(args.port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    visible = os.environ.get("HIP_VISIBLE_DEVICES")
+    ids = [v for v in visible.split(",") if v != ""] if visible else [str(i) for i in range(gpus)]
+    for r in range(ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if pin_gpus else str(r), WORLD_SIZE=str(ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-        if args.backend == "nccl":
-            visible = os.environ.get("HIP_VISIBLE_DEVICES")
-            ids = visible.split(",") if visible else [str(i) for i in range(args.gpus)]
-            env["HIP_VISIBLE_DEVICES"] = ids[(r % args.gpus) % len(ids)]
-        cmd = [sys.executable, "-m", "gsrast.launch_tiles", "--data", args.data, "--output", args.output, "--entry", args.entry,
-               "--backend", args.backend, "--gpus", str(args.gpus), "--workers-per-gpu", str(per), "--_child"]
-        cpus = gpu_numa_cpus(r % args.gpus) if (args.backend == "nccl" and not args.no_affinity) else None
+        if extra_env:
+            env.update(extra_env)
+        if pin_gpus:
+            env["HIP_VISIBLE_DEVICES"] = ids[(r % gpus) % len(ids)]
+        cpus = gpu_numa_cpus(r % gpus) if (pin_gpus and affinity) else None
         pre = (lambda c=cpus: os.sched_setaffinity(0, c)) if cpus else None
-        procs.append(subprocess.Popen(cmd, env=env, preexec_fn=pre))
+        procs.append(subprocess.Popen(cmd_of_rank(r), env=env, preexec_fn=pre))
     rc = 0
     alive = list(procs)
     while alive:
-        time.sleep(0.05)
+        time.sleep(poll_s)
         for p in list(alive):
             code = p.poll()
             if code is None:
@@ -140,13 +164,30 @@ def spawn(args):
     return rc
 
 
+def spawn(args):
+    """Parent of the tile job: gpus x workers-per-gpu children through spawn_ranks.  When several workers share a GPU the children get
+    the gloo control backend (RCCL rejects two ranks on one device) and keep --device cuda."""
+    per = max(1, int(getattr(args, "workers_per_gpu", 1)))
+    n = args.gpus * per                                                            # ranks; rank r works on GPU r % gpus
+    device = worker_device(args)
+    backend = args.backend
+    if backend == "nccl" and per > 1:
+        backend = "gloo"
+        print(f"launch_tiles: {per} workers per GPU -> control collectives over gloo (host tensors), tiles stay on the HIP devices", file=sys.stderr)
+    cmd = [sys.executable, "-m", "gsrast.launch_tiles", "--data", args.data, "--output", args.output, "--entry", args.entry,
+           "--backend", backend, "--device", device, "--gpus", str(args.gpus), "--workers-per-gpu", str(per), "--_child"]
+    return spawn_ranks(lambda r: cmd, n, args.gpus, args.port, pin_gpus=(device == "cuda"), affinity=not args.no_affinity)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--data", required=True, help="partitioned scene directory holding tile_* sub-directories")
     ap.add_argument("--output", required=True)
     ap.add_argument("--entry", required=True, help="module:function(tile_dir, out_paths, device, tile_index) -> iterations")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="backend of the CONTROL collectives (barrier, job reduction); nccl = RCCL, one rank per GPU")
+    ap.add_argument("--device", default=None, choices=["cuda", "cpu"], help="where the tiles train (default: cuda for nccl, cpu for gloo)")
     ap.add_argument("--port", type=int, default=29531)
     ap.add_argument("--workers-per-gpu", type=int, default=1, help="concurrent tile workers per GPU (2 fills the launch gaps of one: +20 %% aggregate it/s)")
     ap.add_argument("--no-affinity", action="store_true", help="do not pin workers to the CPUs of their GPU's NUMA node")

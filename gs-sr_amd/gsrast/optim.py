@@ -14,6 +14,7 @@ import ctypes as C
 import math
 
 import torch
+from torch.optim.adam import adam as _torch_adam
 
 from . import check, lib, stream_ptr
 
@@ -94,16 +95,14 @@ class Adam(torch.optim.Adam):
             table = (_AdamTensor * len(entries))(*entries)
             with torch.cuda.device(dev):
                 check(L.gsr_adam_step_multi(len(entries), table, stream_ptr(dev)), "adam_step_multi")
-        if rest:                                   # uncovered parameters: exactly torch's update, on a view of the groups that holds only them
-            saved = [(g, g["params"]) for g, _ in rest]
-            groups = self.param_groups
-            try:
-                for g, ps in rest:
-                    g["params"] = ps
-                self.param_groups = [g for g, _ in rest]
-                super().step()
-            finally:
-                self.param_groups = groups
-                for g, ps in saved:
-                    g["params"] = ps
+        for group, ps in rest:                     # uncovered parameters: exactly torch's update (its functional form on a copy of the group
+            g2 = dict(group, params=ps)            # that holds only them) -- not super().step(), which would fire the step hooks a second time
+            pw, grads, m1, m2, mx, st = [], [], [], [], [], []
+            has_complex = self._init_group(g2, pw, grads, m1, m2, mx, st)
+            b1, b2 = group["betas"]
+            _torch_adam(pw, grads, m1, m2, mx, st, amsgrad=group["amsgrad"], has_complex=has_complex, beta1=b1, beta2=b2, lr=group["lr"],
+                        weight_decay=group["weight_decay"], eps=group["eps"], maximize=group["maximize"], foreach=group["foreach"],
+                        capturable=group["capturable"], differentiable=group["differentiable"], fused=group["fused"],
+                        grad_scale=getattr(self, "grad_scale", None), found_inf=getattr(self, "found_inf", None),
+                        decoupled_weight_decay=group.get("decoupled_weight_decay", False))
         return loss

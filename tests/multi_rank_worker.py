@@ -15,7 +15,7 @@ for p in (os.path.join(ROOT, "gs-sr_amd"), os.path.join(ROOT, "tests")):
 def tile_entry(tile_dir, out_paths, device, tile_index):
     """Records how the launcher pinned this worker; 'trains' 7 iterations."""
     json.dump({"tile": tile_index, "visible": os.environ.get("HIP_VISIBLE_DEVICES"), "device_count": torch.cuda.device_count(),
-               "device": str(device), "affinity": len(os.sched_getaffinity(0))}, open(os.path.join(out_paths["config"], "worker.json"), "w"))
+               "device": str(device), "pid": os.getpid(), "affinity": len(os.sched_getaffinity(0))}, open(os.path.join(out_paths["config"], "worker.json"), "w"))
     x = torch.ones(8, device=device)
     assert float(x.sum()) == 8.0
     return 7

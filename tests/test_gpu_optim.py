@@ -75,3 +75,26 @@ def test_state_surgery_of_densification_and_uncovered_parameters():
     assert float(opt.state[newp]["step"]) == 2.0 and opt.state[newp]["exp_avg"].shape == (120, 3)
     d = before - newp.detach()
     assert torch.all(d > 0) and torch.allclose(d[:100], d[:1].expand(100, 3), atol=1e-7)
+
+
+def test_more_tensors_than_one_table_with_empty_ones():
+    """30 parameter tensors, some with numel() == 0 (features_rest is (N, 0, 3) at sh_degree 0), on one device: more than the 24 slots of
+    one launch table.  ADVICE r2: the batch loop used to restart 24 indices further whatever it had consumed, so an empty tensor inside a
+    batch made the next batch re-apply entries -- a silent double step.  Every tensor must get exactly one torch-identical update."""
+    from gsrast.optim import Adam
+    shapes = [(5000 + 37 * i, 3) if i % 7 != 2 else (11, 0, 3) for i in range(30)]
+    lrs = [1e-3 * (1 + i % 5) for i in range(30)]
+    pa, oa = _models(5, shapes, lrs, Adam)
+    pb, ob = _models(5, shapes, lrs, lambda groups, **kw: torch.optim.Adam(groups, foreach=False, **kw))
+    g = torch.Generator().manual_seed(1)
+    for t in range(1, 4):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for ps in (pa, pb):
+            for p, gr in zip(ps, grads):
+                p.grad = gr.to(DEV)
+        oa.step(); ob.step()
+        for i in range(30):
+            assert float(oa.state[pa[i]]["step"]) == t
+            assert torch.allclose(pa[i], pb[i], rtol=0, atol=1e-4 * lrs[i] + 5e-7), (t, i)
+            assert torch.allclose(oa.state[pa[i]]["exp_avg"], ob.state[pb[i]]["exp_avg"], rtol=1e-5, atol=2e-6), (t, i)
+            assert torch.allclose(oa.state[pa[i]]["exp_avg_sq"], ob.state[pb[i]]["exp_avg_sq"], rtol=1e-5, atol=1e-12), (t, i)

@@ -33,3 +33,30 @@ def test_lr_scale_is_a_per_element_learning_rate():
     a = oracle_optim.adam_step(p, g, z, z, 1, 1.0, lr_scale=np.full(50, 3e-3, np.float32))[0]
     b = oracle_optim.adam_step(p, g, z, z, 1, 3e-3)[0]
     assert np.allclose(a, b, rtol=0, atol=1e-6)
+
+
+def test_uncovered_parameters_take_torchs_update_and_hooks_fire_once():
+    """Host tensors are not covered by the HIP kernel: gsrast.optim.Adam must give them exactly torch.optim.Adam's update through torch's
+    functional form -- and the optimizer's step hooks must fire once per step(), not twice (the fallback used to call
+    super().step() from inside the overridden step())."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gs-sr_amd"))
+    import torch
+    from gsrast.optim import Adam
+    torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))])          # a plain Adam in the process: torch wraps Adam.step with its profile hook
+    g = torch.Generator().manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(7, 3, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g).double())]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa = Adam([{"params": [a[0]], "lr": 1e-2}, {"params": [a[1]], "lr": 3e-3}], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [b[0]], "lr": 1e-2}, {"params": [b[1]], "lr": 3e-3}], lr=0.0, eps=1e-15, foreach=False)
+    fired = []
+    oa.register_step_post_hook(lambda *args: fired.append(1))
+    for t in range(3):
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, generator=g).to(p.dtype)
+            p.grad = gr.clone(); q.grad = gr.clone()
+        oa.step(); ob.step()
+        for p, q in zip(a, b):
+            assert torch.equal(p, q) and torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]) and float(oa.state[p]["step"]) == t + 1
+    assert len(fired) == 3
+    assert len(oa.param_groups) == 2 and oa.param_groups[0]["params"][0] is a[0]
