@@ -18,17 +18,39 @@
 #include <omp.h>
 #endif
 
+/* Arithmetic type.  The default build is float32 (the reference's type); -DGSR_REAL=double builds the SAME statements in float64
+   (libgsr_oracle_f64.so), the truth the float32 evaluations -- this oracle's and the HIP library's -- are measured against.  Literals keep their
+   float suffix, so both builds use bit-identical constants and thresholds. */
+#define RS sizeof(real)
+#if GSR_REAL_IS_DOUBLE
+#define R_sqrt sqrt
+#define R_exp exp
+#define R_fmin fmin
+#define R_fmax fmax
+#define R_ceil ceil
+#define R_fabs fabs
+#define R_floor floor
+#else
+#define R_sqrt sqrtf
+#define R_exp expf
+#define R_fmin fminf
+#define R_fmax fmaxf
+#define R_ceil ceilf
+#define R_fabs fabsf
+#define R_floor floorf
+#endif
+
 #define BLOCK_X 16
 #define BLOCK_Y 16
 
 /* ------------------------------------------------------------------ small linear algebra */
 /* m3 mimics a column-major 3x3 (element c[col][row]) so expressions can be restated index-for-index
    from sources that use that convention. */
-typedef struct { float c[3][3]; } m3;
-typedef struct { float x, y, z; } f3;
-typedef struct { float x, y; } f2;
+typedef struct { real c[3][3]; } m3;
+typedef struct { real x, y, z; } f3;
+typedef struct { real x, y; } f2;
 
-static m3 m3_cols(float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2)
+static m3 m3_cols(real a0, real a1, real a2, real b0, real b1, real b2, real c0, real c1, real c2)
 {
     m3 m; m.c[0][0]=a0; m.c[0][1]=a1; m.c[0][2]=a2; m.c[1][0]=b0; m.c[1][1]=b1; m.c[1][2]=b2;
     m.c[2][0]=c0; m.c[2][1]=c1; m.c[2][2]=c2; return m;
@@ -48,31 +70,31 @@ static m3 m3_t(m3 a)
     for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) r.c[j][i] = a.c[i][j];
     return r;
 }
-static float dot3(const float* a, const float* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+static real dot3(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
 
 /* 3DGS auxiliary.h:58-100 */
-static f3 transformPoint4x3(f3 p, const float* m)
+static f3 transformPoint4x3(f3 p, const real* m)
 {
     f3 t = { m[0]*p.x + m[4]*p.y + m[8]*p.z + m[12],
              m[1]*p.x + m[5]*p.y + m[9]*p.z + m[13],
              m[2]*p.x + m[6]*p.y + m[10]*p.z + m[14] };
     return t;
 }
-static void transformPoint4x4(f3 p, const float* m, float o[4])
+static void transformPoint4x4(f3 p, const real* m, real o[4])
 {
     o[0] = m[0]*p.x + m[4]*p.y + m[8]*p.z + m[12];
     o[1] = m[1]*p.x + m[5]*p.y + m[9]*p.z + m[13];
     o[2] = m[2]*p.x + m[6]*p.y + m[10]*p.z + m[14];
     o[3] = m[3]*p.x + m[7]*p.y + m[11]*p.z + m[15];
 }
-static f3 transformVec4x3(f3 p, const float* m)
+static f3 transformVec4x3(f3 p, const real* m)
 {
     f3 t = { m[0]*p.x + m[4]*p.y + m[8]*p.z,
              m[1]*p.x + m[5]*p.y + m[9]*p.z,
              m[2]*p.x + m[6]*p.y + m[10]*p.z };
     return t;
 }
-static f3 transformVec4x3Transpose(f3 p, const float* m)
+static f3 transformVec4x3Transpose(f3 p, const real* m)
 {
     f3 t = { m[0]*p.x + m[1]*p.y + m[2]*p.z,
              m[4]*p.x + m[5]*p.y + m[6]*p.z,
@@ -80,7 +102,7 @@ static f3 transformVec4x3Transpose(f3 p, const float* m)
     return t;
 }
 /* 3DGS auxiliary.h:41-44 -- NB the literals are double, so this is evaluated in double */
-static float ndc2Pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+static real ndc2Pix(real v, int S) { return (real)(((v + 1.0) * S - 1.0) * 0.5); }
 
 static int imin(int a, int b) { return a < b ? a : b; }
 static int imax(int a, int b) { return a > b ? a : b; }
@@ -95,7 +117,7 @@ static void getRect(f2 p, int max_radius, int gx, int gy, uint32_t rmin[2], uint
 }
 
 /* 3DGS auxiliary.h:139-164 (the prefiltered trap is not restated: it aborts the reference) */
-static int in_frustum(int idx, const float* pts, const float* view, f3* p_view)
+static int in_frustum(int idx, const real* pts, const real* view, f3* p_view)
 {
     f3 p = { pts[3*idx], pts[3*idx+1], pts[3*idx+2] };
     *p_view = transformPoint4x3(p, view);
@@ -103,28 +125,28 @@ static int in_frustum(int idx, const float* pts, const float* view, f3* p_view)
 }
 
 /* ------------------------------------------------------------------ spherical harmonics */
-static const float SH_C0 = 0.28209479177387814f;
-static const float SH_C1 = 0.4886025119029199f;
-static const float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+static const real SH_C0 = 0.28209479177387814f;
+static const real SH_C1 = 0.4886025119029199f;
+static const real SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
                                 -1.0925484305920792f, 0.5462742152960396f };
-static const float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+static const real SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
                                 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                 -0.5900435899266435f };
 
 /* 3DGS forward.cu:20-71 */
-static void computeColorFromSH(int idx, int deg, int M, const float* means, const float* campos,
-                               const float* shs, uint8_t* clamped, float rgb[3])
+static void computeColorFromSH(int idx, int deg, int M, const real* means, const real* campos,
+                               const real* shs, uint8_t* clamped, real rgb[3])
 {
-    float dx = means[3*idx] - campos[0], dy = means[3*idx+1] - campos[1], dz = means[3*idx+2] - campos[2];
-    float len = sqrtf(dx*dx + dy*dy + dz*dz);
-    float x = dx / len, y = dy / len, z = dz / len;
-    const float* sh = shs + (size_t)idx * M * 3;
+    real dx = means[3*idx] - campos[0], dy = means[3*idx+1] - campos[1], dz = means[3*idx+2] - campos[2];
+    real len = R_sqrt(dx*dx + dy*dy + dz*dz);
+    real x = dx / len, y = dy / len, z = dz / len;
+    const real* sh = shs + (size_t)idx * M * 3;
     for (int c = 0; c < 3; c++) {
-        float r = SH_C0 * sh[0*3+c];
+        real r = SH_C0 * sh[0*3+c];
         if (deg > 0) {
             r = r - SH_C1 * y * sh[1*3+c] + SH_C1 * z * sh[2*3+c] - SH_C1 * x * sh[3*3+c];
             if (deg > 1) {
-                float xx = x*x, yy = y*y, zz = z*z, xy = x*y, yz = y*z, xz = x*z;
+                real xx = x*x, yy = y*y, zz = z*z, xy = x*y, yz = y*z, xz = x*z;
                 r = r + SH_C2[0] * xy * sh[4*3+c] + SH_C2[1] * yz * sh[5*3+c]
                       + SH_C2[2] * (2.0f*zz - xx - yy) * sh[6*3+c]
                       + SH_C2[3] * xz * sh[7*3+c] + SH_C2[4] * (xx - yy) * sh[8*3+c];
@@ -148,8 +170,8 @@ static void computeColorFromSH(int idx, int deg, int M, const float* means, cons
 /* 3DGS auxiliary.h:110-120 */
 static f3 dnormvdv(f3 v, f3 dv)
 {
-    float sum2 = v.x*v.x + v.y*v.y + v.z*v.z;
-    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    real sum2 = v.x*v.x + v.y*v.y + v.z*v.z;
+    real invsum32 = 1.0f / R_sqrt(sum2 * sum2 * sum2);
     f3 r;
     r.x = ((+sum2 - v.x*v.x) * dv.x - v.y*v.x*dv.y - v.z*v.x*dv.z) * invsum32;
     r.y = (-v.x*v.y*dv.x + (sum2 - v.y*v.y) * dv.y - v.z*v.y*dv.z) * invsum32;
@@ -158,20 +180,20 @@ static f3 dnormvdv(f3 v, f3 dv)
 }
 
 /* 3DGS backward.cu:20-139 */
-static void computeColorFromSH_bwd(int idx, int deg, int M, const float* means, const float* campos,
-                                   const float* shs, const uint8_t* clamped, const float* dL_dcolor,
-                                   float* dL_dmeans, float* dL_dshs)
+static void computeColorFromSH_bwd(int idx, int deg, int M, const real* means, const real* campos,
+                                   const real* shs, const uint8_t* clamped, const real* dL_dcolor,
+                                   real* dL_dmeans, real* dL_dshs)
 {
     f3 dir_orig = { means[3*idx] - campos[0], means[3*idx+1] - campos[1], means[3*idx+2] - campos[2] };
-    float len = sqrtf(dir_orig.x*dir_orig.x + dir_orig.y*dir_orig.y + dir_orig.z*dir_orig.z);
-    float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-    const float* sh = shs + (size_t)idx * M * 3;
-    float* dL_dsh = dL_dshs + (size_t)idx * M * 3;
-    float dRGB[3];
+    real len = R_sqrt(dir_orig.x*dir_orig.x + dir_orig.y*dir_orig.y + dir_orig.z*dir_orig.z);
+    real x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    const real* sh = shs + (size_t)idx * M * 3;
+    real* dL_dsh = dL_dshs + (size_t)idx * M * 3;
+    real dRGB[3];
     for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[3*idx+c] * (clamped[3*idx+c] ? 0.0f : 1.0f);
 
-    float dRGBdx[3] = {0,0,0}, dRGBdy[3] = {0,0,0}, dRGBdz[3] = {0,0,0};
-#define SHSET(k, coef) do { float cf_ = (coef); for (int c = 0; c < 3; c++) dL_dsh[(k)*3+c] = cf_ * dRGB[c]; } while (0)
+    real dRGBdx[3] = {0,0,0}, dRGBdy[3] = {0,0,0}, dRGBdz[3] = {0,0,0};
+#define SHSET(k, coef) do { real cf_ = (coef); for (int c = 0; c < 3; c++) dL_dsh[(k)*3+c] = cf_ * dRGB[c]; } while (0)
     SHSET(0, SH_C0);
     if (deg > 0) {
         SHSET(1, -SH_C1 * y); SHSET(2, SH_C1 * z); SHSET(3, -SH_C1 * x);
@@ -179,7 +201,7 @@ static void computeColorFromSH_bwd(int idx, int deg, int M, const float* means, 
             dRGBdx[c] = -SH_C1 * sh[3*3+c]; dRGBdy[c] = -SH_C1 * sh[1*3+c]; dRGBdz[c] = SH_C1 * sh[2*3+c];
         }
         if (deg > 1) {
-            float xx = x*x, yy = y*y, zz = z*z, xy = x*y, yz = y*z, xz = x*z;
+            real xx = x*x, yy = y*y, zz = z*z, xy = x*y, yz = y*z, xz = x*z;
             SHSET(4, SH_C2[0] * xy); SHSET(5, SH_C2[1] * yz); SHSET(6, SH_C2[2] * (2.f*zz - xx - yy));
             SHSET(7, SH_C2[3] * xz); SHSET(8, SH_C2[4] * (xx - yy));
             for (int c = 0; c < 3; c++) {
@@ -219,10 +241,10 @@ static void computeColorFromSH_bwd(int idx, int deg, int M, const float* means, 
 
 /* ------------------------------------------------------------------ EWA preprocess helpers */
 /* 3DGS forward.cu:118-152 (quaternion deliberately NOT normalised) */
-static void computeCov3D(const float* scale, float mod, const float* rot, float* cov3D)
+static void computeCov3D(const real* scale, real mod, const real* rot, real* cov3D)
 {
     m3 S = m3_cols(mod*scale[0],0,0, 0,mod*scale[1],0, 0,0,mod*scale[2]);
-    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    real r = rot[0], x = rot[1], y = rot[2], z = rot[3];
     m3 R = m3_cols(1.f - 2.f*(y*y + z*z), 2.f*(x*y - r*z), 2.f*(x*z + r*y),
                    2.f*(x*y + r*z), 1.f - 2.f*(x*x + z*z), 2.f*(y*z - r*x),
                    2.f*(x*z - r*y), 2.f*(y*z + r*x), 1.f - 2.f*(x*x + y*y));
@@ -233,15 +255,15 @@ static void computeCov3D(const float* scale, float mod, const float* rot, float*
 }
 
 /* 3DGS forward.cu:74-113; also returns T for the backward (backward.cu:144-195 recomputes the same) */
-static void computeCov2D(f3 mean, float fx, float fy, float tan_fovx, float tan_fovy, const float* cov3D,
-                         const float* view, float cov[3], m3* T_out, m3* Vrk_out, f3* t_out,
-                         float* xgm, float* ygm)
+static void computeCov2D(f3 mean, real fx, real fy, real tan_fovx, real tan_fovy, const real* cov3D,
+                         const real* view, real cov[3], m3* T_out, m3* Vrk_out, f3* t_out,
+                         real* xgm, real* ygm)
 {
     f3 t = transformPoint4x3(mean, view);
-    const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
-    const float txtz = t.x / t.z, tytz = t.y / t.z;
-    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
-    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    const real limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+    const real txtz = t.x / t.z, tytz = t.y / t.z;
+    t.x = R_fmin(limx, R_fmax(-limx, txtz)) * t.z;
+    t.y = R_fmin(limy, R_fmax(-limy, tytz)) * t.z;
     if (xgm) *xgm = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
     if (ygm) *ygm = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
     m3 J = m3_cols(fx / t.z, 0.0f, -(fx * t.x) / (t.z * t.z),
@@ -261,19 +283,19 @@ static void computeCov2D(f3 mean, float fx, float fy, float tan_fovx, float tan_
 
 /* ------------------------------------------------------------------ surfel preprocess helpers */
 /* SURFEL auxiliary.h:215-238 */
-static m3 quat_to_rotmat(const float* q)
+static m3 quat_to_rotmat(const real* q)
 {
-    float s = 1.0f / sqrtf(q[3]*q[3] + q[0]*q[0] + q[1]*q[1] + q[2]*q[2]);
-    float w = q[0]*s, x = q[1]*s, y = q[2]*s, z = q[3]*s;
+    real s = 1.0f / R_sqrt(q[3]*q[3] + q[0]*q[0] + q[1]*q[1] + q[2]*q[2]);
+    real w = q[0]*s, x = q[1]*s, y = q[2]*s, z = q[3]*s;
     return m3_cols(1.f - 2.f*(y*y + z*z), 2.f*(x*y + w*z), 2.f*(x*z - w*y),
                    2.f*(x*y - w*z), 1.f - 2.f*(x*x + z*z), 2.f*(y*z + w*x),
                    2.f*(x*z + w*y), 2.f*(y*z - w*x), 1.f - 2.f*(x*x + y*y));
 }
 /* SURFEL auxiliary.h:241-284; v_R indexed [col][row] */
-static void quat_to_rotmat_vjp(const float* q, m3 v_R, float out[4])
+static void quat_to_rotmat_vjp(const real* q, m3 v_R, real out[4])
 {
-    float s = 1.0f / sqrtf(q[3]*q[3] + q[0]*q[0] + q[1]*q[1] + q[2]*q[2]);
-    float w = q[0]*s, x = q[1]*s, y = q[2]*s, z = q[3]*s;
+    real s = 1.0f / R_sqrt(q[3]*q[3] + q[0]*q[0] + q[1]*q[1] + q[2]*q[2]);
+    real w = q[0]*s, x = q[1]*s, y = q[2]*s, z = q[3]*s;
     out[0] = 2.f * (x * (v_R.c[1][2] - v_R.c[2][1]) + y * (v_R.c[2][0] - v_R.c[0][2]) + z * (v_R.c[0][1] - v_R.c[1][0]));
     out[1] = 2.f * (-2.f * x * (v_R.c[1][1] + v_R.c[2][2]) + y * (v_R.c[0][1] + v_R.c[1][0]) +
                     z * (v_R.c[0][2] + v_R.c[2][0]) + w * (v_R.c[1][2] - v_R.c[2][1]));
@@ -285,14 +307,14 @@ static void quat_to_rotmat_vjp(const float* q, m3 v_R, float out[4])
 
 /* Pm[k][c] = (world2ndc * ndc2pix) as a 4x3 matrix: column c of the pixel-space homogeneous coordinate.
    SURFEL forward.cu:99-112 / backward.cu:498-513 */
-static void surfel_P(const float* proj, int W, int H, float Pm[4][3])
+static void surfel_P(const real* proj, int W, int H, real Pm[4][3])
 {
-    float n00 = (float)((float)W / 2.0), n03 = (float)((float)(W - 1) / 2.0);
-    float n11 = (float)((float)H / 2.0), n13 = (float)((float)(H - 1) / 2.0);
+    real n00 = (real)((real)W / 2.0), n03 = (real)((real)(W - 1) / 2.0);
+    real n11 = (real)((real)H / 2.0), n13 = (real)((real)(H - 1) / 2.0);
     for (int k = 0; k < 4; k++) {
         /* world2ndc element (row k, col j) = proj[4k + j] */
-        float a0 = proj[4*k+0], a1 = proj[4*k+1], a3 = proj[4*k+3];
-        float a2 = proj[4*k+2];
+        real a0 = proj[4*k+0], a1 = proj[4*k+1], a3 = proj[4*k+3];
+        real a2 = proj[4*k+2];
         Pm[k][0] = a0 * n00 + a1 * 0.0f + a2 * 0.0f + a3 * n03;
         Pm[k][1] = a0 * 0.0f + a1 * n11 + a2 * 0.0f + a3 * n13;
         Pm[k][2] = a0 * 0.0f + a1 * 0.0f + a2 * 0.0f + a3 * 1.0f;
@@ -300,25 +322,25 @@ static void surfel_P(const float* proj, int W, int H, float Pm[4][3])
 }
 
 /* SURFEL forward.cu:75-115.  T stored as three float3: Tu (x coeffs of u,v,1), Tv (y coeffs), Tw (w coeffs) */
-static void compute_transmat(f3 p, const float* scale2, float mod, const float* rot, const float* proj,
-                             const float* view, int W, int H, float T[9], f3* normal)
+static void compute_transmat(f3 p, const real* scale2, real mod, const real* rot, const real* proj,
+                             const real* view, int W, int H, real T[9], f3* normal)
 {
     m3 R = quat_to_rotmat(rot);
-    float sx = mod * scale2[0], sy = mod * scale2[1];
-    float L0[3] = { R.c[0][0]*sx, R.c[0][1]*sx, R.c[0][2]*sx };
-    float L1[3] = { R.c[1][0]*sy, R.c[1][1]*sy, R.c[1][2]*sy };
-    float L2[3] = { R.c[2][0], R.c[2][1], R.c[2][2] };
-    float rows[3][4] = { { L0[0], L0[1], L0[2], 0.0f }, { L1[0], L1[1], L1[2], 0.0f }, { p.x, p.y, p.z, 1.0f } };
+    real sx = mod * scale2[0], sy = mod * scale2[1];
+    real L0[3] = { R.c[0][0]*sx, R.c[0][1]*sx, R.c[0][2]*sx };
+    real L1[3] = { R.c[1][0]*sy, R.c[1][1]*sy, R.c[1][2]*sy };
+    real L2[3] = { R.c[2][0], R.c[2][1], R.c[2][2] };
+    real rows[3][4] = { { L0[0], L0[1], L0[2], 0.0f }, { L1[0], L1[1], L1[2], 0.0f }, { p.x, p.y, p.z, 1.0f } };
     /* (splat2world^T * world2ndc) first, then * ndc2pix -- left-to-right like the source expression */
-    float n00 = (float)((float)W / 2.0), n03 = (float)((float)(W - 1) / 2.0);
-    float n11 = (float)((float)H / 2.0), n13 = (float)((float)(H - 1) / 2.0);
+    real n00 = (real)((real)W / 2.0), n03 = (real)((real)(W - 1) / 2.0);
+    real n11 = (real)((real)H / 2.0), n13 = (real)((real)(H - 1) / 2.0);
     for (int r = 0; r < 3; r++) {
-        float h[4];
+        real h[4];
         for (int j = 0; j < 4; j++)
             h[j] = rows[r][0]*proj[0*4+j] + rows[r][1]*proj[1*4+j] + rows[r][2]*proj[2*4+j] + rows[r][3]*proj[3*4+j];
-        float tx = h[0]*n00 + h[1]*0.0f + h[2]*0.0f + h[3]*n03;
-        float ty = h[0]*0.0f + h[1]*n11 + h[2]*0.0f + h[3]*n13;
-        float tw = h[0]*0.0f + h[1]*0.0f + h[2]*0.0f + h[3]*1.0f;
+        real tx = h[0]*n00 + h[1]*0.0f + h[2]*0.0f + h[3]*n03;
+        real ty = h[0]*0.0f + h[1]*n11 + h[2]*0.0f + h[3]*n13;
+        real tw = h[0]*0.0f + h[1]*0.0f + h[2]*0.0f + h[3]*1.0f;
         T[0 + r] = tx; T[3 + r] = ty; T[6 + r] = tw;
     }
     f3 l2 = { L2[0], L2[1], L2[2] };
@@ -326,23 +348,23 @@ static void compute_transmat(f3 p, const float* scale2, float mod, const float* 
 }
 
 /* SURFEL forward.cu:119-145 */
-static int compute_aabb(const float T[9], float cutoff, f2* point_image, f2* extent)
+static int compute_aabb(const real T[9], real cutoff, f2* point_image, f2* extent)
 {
-    const float* Tu = T; const float* Tv = T + 3; const float* Tw = T + 6;
-    float t[3] = { cutoff*cutoff, cutoff*cutoff, -1.0f };
-    float ww[3] = { Tw[0]*Tw[0], Tw[1]*Tw[1], Tw[2]*Tw[2] };
-    float d = dot3(t, ww);
+    const real* Tu = T; const real* Tv = T + 3; const real* Tw = T + 6;
+    real t[3] = { cutoff*cutoff, cutoff*cutoff, -1.0f };
+    real ww[3] = { Tw[0]*Tw[0], Tw[1]*Tw[1], Tw[2]*Tw[2] };
+    real d = dot3(t, ww);
     if (d == 0.0f) return 0;
-    float inv = 1 / d;
-    float f[3] = { inv*t[0], inv*t[1], inv*t[2] };
-    float uw[3] = { Tu[0]*Tw[0], Tu[1]*Tw[1], Tu[2]*Tw[2] };
-    float vw[3] = { Tv[0]*Tw[0], Tv[1]*Tw[1], Tv[2]*Tw[2] };
-    float uu[3] = { Tu[0]*Tu[0], Tu[1]*Tu[1], Tu[2]*Tu[2] };
-    float vv[3] = { Tv[0]*Tv[0], Tv[1]*Tv[1], Tv[2]*Tv[2] };
-    float px = dot3(f, uw), py = dot3(f, vw);
-    float h0x = px*px - dot3(f, uu), h0y = py*py - dot3(f, vv);
+    real inv = 1 / d;
+    real f[3] = { inv*t[0], inv*t[1], inv*t[2] };
+    real uw[3] = { Tu[0]*Tw[0], Tu[1]*Tw[1], Tu[2]*Tw[2] };
+    real vw[3] = { Tv[0]*Tw[0], Tv[1]*Tw[1], Tv[2]*Tw[2] };
+    real uu[3] = { Tu[0]*Tu[0], Tu[1]*Tu[1], Tu[2]*Tu[2] };
+    real vv[3] = { Tv[0]*Tv[0], Tv[1]*Tv[1], Tv[2]*Tv[2] };
+    real px = dot3(f, uw), py = dot3(f, vw);
+    real h0x = px*px - dot3(f, uu), h0y = py*py - dot3(f, vv);
     point_image->x = px; point_image->y = py;
-    extent->x = sqrtf(fmaxf(1e-4f, h0x)); extent->y = sqrtf(fmaxf(1e-4f, h0y));
+    extent->x = R_sqrt(R_fmax(1e-4f, h0x)); extent->y = R_sqrt(R_fmax(1e-4f, h0y));
     return 1;
 }
 
@@ -350,14 +372,15 @@ static int compute_aabb(const float T[9], float cutoff, f2* point_image, f2* ext
 struct ref_state {
     int variant, P, W, H, gx, gy, T, N, R;
     /* geometry state (3DGS rasterizer_impl.cu:155-170, SURFEL :162-163) */
-    float* depths; uint8_t* clamped; float* means2D; float* cov3D /* or transMat (9) */;
-    float* conic_opacity /* or normal_opacity */; float* rgb; uint32_t* tiles_touched; uint32_t* point_offsets;
+    real* depths; uint8_t* clamped; real* means2D; real* cov3D /* or transMat (9) */;
+    real* conic_opacity /* or normal_opacity */; real* rgb; uint32_t* tiles_touched; uint32_t* point_offsets;
     int32_t* radii;
     /* binning */
     uint64_t* keys; uint32_t* point_list;
     /* image */
-    float* final_T; uint32_t* n_contrib; uint32_t* ranges;
-    float* out_all_map; /* PLANE: kept for backward (all_map_pixels) */
+    real* final_T; uint32_t* n_contrib; uint32_t* ranges;
+    real* out_all_map; /* PLANE: kept for backward (all_map_pixels) */
+    real* kappa;       /* truth runs: conditioning of the per-gaussian quantities (EWA/PLANE: (ac + b^2)/det of the 2D covariance) */
 };
 
 static void* xcalloc(size_t n, size_t s) { void* p = calloc(n ? n : 1, s); if (!p) { fprintf(stderr, "oracle: OOM\n"); abort(); } return p; }
@@ -368,7 +391,7 @@ void ref_free(ref_state* st)
     free(st->depths); free(st->clamped); free(st->means2D); free(st->cov3D); free(st->conic_opacity);
     free(st->rgb); free(st->tiles_touched); free(st->point_offsets); free(st->radii);
     free(st->keys); free(st->point_list); free(st->final_T); free(st->n_contrib); free(st->ranges);
-    free(st->out_all_map);
+    free(st->out_all_map); free(st->kappa);
     free(st);
 }
 
@@ -405,40 +428,44 @@ static void radix_sort_pairs(uint64_t* keys, uint32_t* vals, size_t n, int end_b
 /* ------------------------------------------------------------------ forward */
 /* per-gaussian preprocess: EWA = 3DGS forward.cu:156-256 (PLANE forward.cu:156-268 identical);
    SURFEL = forward.cu:149-251 */
-static void preprocess_one(ref_state* st, const ref_inputs* in, int idx, float fx, float fy)
+static void preprocess_one(ref_state* st, const ref_inputs* in, int idx, real fx, real fy)
 {
     const int W = in->W, H = in->H;
     st->radii[idx] = 0; st->tiles_touched[idx] = 0;
+    /* truth runs: the culling decisions and the radius come from the float32 run (in->ov_radii); own gates are not applied */
+    const int ov = in->ov_radii != NULL;
+    if (ov && in->ov_radii[idx] <= 0) return;
     f3 p_view;
-    if (!in_frustum(idx, in->means3D, in->viewmatrix, &p_view)) return;
+    if (!in_frustum(idx, in->means3D, in->viewmatrix, &p_view) && !ov) return;
     f3 p_orig = { in->means3D[3*idx], in->means3D[3*idx+1], in->means3D[3*idx+2] };
 
-    f2 point_image; float my_radius;
+    f2 point_image; real my_radius;
     uint32_t rmin[2], rmax[2];
     if (st->variant != REF_SURFEL) {
-        float ph[4]; transformPoint4x4(p_orig, in->projmatrix, ph);
-        float p_w = 1.0f / (ph[3] + 0.0000001f);
-        float projx = ph[0] * p_w, projy = ph[1] * p_w;
-        const float* cov3D;
+        real ph[4]; transformPoint4x4(p_orig, in->projmatrix, ph);
+        real p_w = 1.0f / (ph[3] + 0.0000001f);
+        real projx = ph[0] * p_w, projy = ph[1] * p_w;
+        const real* cov3D;
         if (in->cov3D_precomp) cov3D = in->cov3D_precomp + 6*idx;
         else { computeCov3D(in->scales + 3*idx, in->scale_modifier, in->rotations + 4*idx, st->cov3D + 6*idx); cov3D = st->cov3D + 6*idx; }
-        float cov[3];
+        real cov[3];
         computeCov2D(p_orig, fx, fy, in->tanfovx, in->tanfovy, cov3D, in->viewmatrix, cov, NULL, NULL, NULL, NULL, NULL);
-        float det = (cov[0] * cov[2] - cov[1] * cov[1]);
-        if (det == 0.0f) return;
-        float det_inv = 1.f / det;
-        float conic[3] = { cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv };
-        float mid = 0.5f * (cov[0] + cov[2]);
-        float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-        float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-        my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        real det = (cov[0] * cov[2] - cov[1] * cov[1]);
+        if (det == 0.0f && !ov) return;
+        if (st->kappa) st->kappa[idx] = (cov[0] * cov[2] + cov[1] * cov[1]) / R_fabs(det);
+        real det_inv = 1.f / det;
+        real conic[3] = { cov[2] * det_inv, -cov[1] * det_inv, cov[0] * det_inv };
+        real mid = 0.5f * (cov[0] + cov[2]);
+        real lambda1 = mid + R_sqrt(R_fmax(0.1f, mid * mid - det));
+        real lambda2 = mid - R_sqrt(R_fmax(0.1f, mid * mid - det));
+        my_radius = R_ceil(3.f * R_sqrt(R_fmax(lambda1, lambda2)));
         point_image.x = ndc2Pix(projx, W); point_image.y = ndc2Pix(projy, H);
         getRect(point_image, (int)my_radius, st->gx, st->gy, rmin, rmax);
-        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) return;
+        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0 && !ov) return;
         st->conic_opacity[4*idx+0] = conic[0]; st->conic_opacity[4*idx+1] = conic[1];
         st->conic_opacity[4*idx+2] = conic[2]; st->conic_opacity[4*idx+3] = in->opacities[idx];
     } else {
-        float T[9]; f3 normal;
+        real T[9]; f3 normal;
         if (!in->cov3D_precomp) {
             compute_transmat(p_orig, in->scales + 2*idx, in->scale_modifier, in->rotations + 4*idx,
                              in->projmatrix, in->viewmatrix, W, H, T, &normal);
@@ -448,92 +475,158 @@ static void preprocess_one(ref_state* st, const ref_inputs* in, int idx, float f
             normal.x = 0.0f; normal.y = 0.0f; normal.z = 1.0f;
         }
         /* DUAL_VISIABLE, SURFEL forward.cu:209-214 */
-        float cosv = -(p_view.x*normal.x + p_view.y*normal.y + p_view.z*normal.z);
-        if (cosv == 0) return;
-        float mult = cosv > 0 ? 1.f : -1.f;
+        real cosv = -(p_view.x*normal.x + p_view.y*normal.y + p_view.z*normal.z);
+        if (cosv == 0 && !ov) return;
+        real mult = cosv > 0 ? 1.f : -1.f;
         normal.x = mult*normal.x; normal.y = mult*normal.y; normal.z = mult*normal.z;
-        const float cutoff = 3.0f;
-        f2 extent;
-        if (!compute_aabb(T, cutoff, &point_image, &extent)) return;
-        my_radius = ceilf(fmaxf(fmaxf(extent.x, extent.y), cutoff * 0.707106f));
+        const real cutoff = 3.0f;
+        f2 extent = { 0, 0 };
+        point_image.x = 0; point_image.y = 0;
+        if (!compute_aabb(T, cutoff, &point_image, &extent) && !ov) return;
+        my_radius = R_ceil(R_fmax(R_fmax(extent.x, extent.y), cutoff * 0.707106f));
         getRect(point_image, (int)my_radius, st->gx, st->gy, rmin, rmax);
-        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0) return;
+        if ((rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) == 0 && !ov) return;
         st->conic_opacity[4*idx+0] = normal.x; st->conic_opacity[4*idx+1] = normal.y;
         st->conic_opacity[4*idx+2] = normal.z; st->conic_opacity[4*idx+3] = in->opacities[idx];
     }
     if (!in->colors_precomp) {
-        float rgb[3];
+        real rgb[3];
         computeColorFromSH(idx, in->D, in->M, in->means3D, in->campos, in->shs, st->clamped, rgb);
         st->rgb[3*idx] = rgb[0]; st->rgb[3*idx+1] = rgb[1]; st->rgb[3*idx+2] = rgb[2];
     }
     st->depths[idx] = p_view.z;
-    st->radii[idx] = (int)my_radius;
+    st->radii[idx] = ov ? in->ov_radii[idx] : (int)my_radius;
     st->means2D[2*idx] = point_image.x; st->means2D[2*idx+1] = point_image.y;
     st->tiles_touched[idx] = (rmax[1] - rmin[1]) * (rmax[0] - rmin[0]);
 }
 
-static const float near_n = 0.2f, far_n = 100.0f, FilterInvSquare = 2.0f;
+/* lock-free max into a non-negative real (bit patterns of non-negative IEEE numbers order like unsigned integers) */
+static void atomic_max_real(real* p, real v)
+{
+#if GSR_REAL_IS_DOUBLE
+    uint64_t* q = (uint64_t*)p; uint64_t nv; memcpy(&nv, &v, 8);
+    uint64_t cur = __atomic_load_n(q, __ATOMIC_RELAXED);
+    while (cur < nv && !__atomic_compare_exchange_n(q, &cur, nv, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+#else
+    uint32_t* q = (uint32_t*)p; uint32_t nv; memcpy(&nv, &v, 4);
+    uint32_t cur = __atomic_load_n(q, __ATOMIC_RELAXED);
+    while (cur < nv && !__atomic_compare_exchange_n(q, &cur, nv, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+#endif
+}
+
+static const real near_n = 0.2f, far_n = 100.0f, FilterInvSquare = 2.0f;
+/* truth runs: float32 unit roundoff and the safety factor on the first-order error bounds of the gate bookkeeping */
+static const real U32 = 5.9604644775390625e-08f, GATE_SAFETY = 4.0f;
 
 /* blend forward for one pixel of one tile.  EWA: 3DGS forward.cu:261-374.  PLANE: forward.cu:273-407.
    SURFEL: forward.cu:256-448. */
-static void blend_pixel_fwd(const ref_state* st, const ref_inputs* in, const float* feat, float fx, float fy,
+static void blend_pixel_fwd(const ref_state* st, const ref_inputs* in, const real* feat, real fx, real fy,
                             uint32_t px, uint32_t py, uint32_t r0, uint32_t r1,
-                            float* out_color, float* out_others, int32_t* out_observe,
-                            float* out_all_map, float* out_plane_depth)
+                            real* out_color, real* out_others, int32_t* out_observe,
+                            real* out_all_map, real* out_plane_depth)
 {
     const int W = st->W, H = st->H; const size_t HW = (size_t)H * W;
     const uint32_t pix_id = (uint32_t)W * py + px;
-    const float pixfx = (float)px, pixfy = (float)py;
-    float T = 1.0f; uint32_t contributor = 0, last_contributor = 0;
-    float C[3] = {0,0,0};
+    const real pixfx = (real)px, pixfy = (real)py;
+    real T = 1.0f; uint32_t contributor = 0, last_contributor = 0;
+    real C[3] = {0,0,0};
     /* surfel aux */
-    float Nn[3] = {0,0,0}, Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0, median_contributor = -1;
-    int surf_idx = -1; float median_normal[3] = {0,0,0};
+    real Nn[3] = {0,0,0}, Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0, median_contributor = -1;
+    int surf_idx = -1; real median_normal[3] = {0,0,0};
     /* plane aux */
-    float All_map[5] = {0,0,0,0,0};
-    const float rayx = (pixfx - (float)(W * 0.5f)) / fx, rayy = (pixfy - (float)(H * 0.5f)) / fy;
+    real All_map[5] = {0,0,0,0,0};
+    const real rayx = (pixfx - (real)(W * 0.5f)) / fx, rayy = (pixfy - (real)(H * 0.5f)) / fy;
 
+    /* gate bookkeeping of truth runs (in->gate_margin != NULL), see gsr_oracle.h: GM = smallest margin / bound so far */
+    const int gates = in->gate_margin != NULL;
+    real GM = 1e30f, nT = 0; int GI = REF_GATE_NONE, GS = -1;
+#define GATE(which, value, thr, bound) do { if (gates) { const real m_ = R_fabs((value) - (thr)) / ((bound) + 1e-300); \
+        if (m_ < GM) { GM = m_; GI = (which); GS = (int)id; } } } while (0)
     for (uint32_t k = r0; k < r1; k++) {
         const uint32_t id = st->point_list[k];
         contributor++;
-        float alpha, depth = 0; const float* nor_o = st->conic_opacity + 4*id;
+        real alpha, depth = 0; const real* nor_o = st->conic_opacity + 4*id;
+        real e_pow = 0;     /* first-order bound of the float32 error of `power` (absolute) = of alpha (relative) */
         if (st->variant != REF_SURFEL) {
-            float dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
-            const float* con_o = nor_o;
-            float power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+            real dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
+            const real* con_o = nor_o;
+            real power = -0.5f * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+            if (gates) {
+                /* conic entries carry eta_c = 4 U32 kappa (inverse of an elongated 2D covariance), the projected centre eta_m = 2 U32
+                   relative to its pixel coordinate; the arithmetic of `power` itself 4 roundings of its terms */
+                const real S = 0.5f * (R_fabs(con_o[0]) * dx * dx + R_fabs(con_o[2]) * dy * dy) + R_fabs(con_o[1] * dx * dy);
+                const real eta_c = U32 * 4 * st->kappa[id], eta_m = U32 * 2;
+                e_pow = GATE_SAFETY * ((eta_c + 2 * U32) * S + eta_m * (R_fabs(con_o[0] * dx + con_o[1] * dy) * R_fabs(st->means2D[2*id])
+                                                                   + R_fabs(con_o[2] * dy + con_o[1] * dx) * R_fabs(st->means2D[2*id+1])));
+                GATE(REF_GATE_POWER, power, 0, e_pow);
+            }
             if (power > 0.0f) continue;
-            alpha = fminf(0.99f, con_o[3] * expf(power));
+            alpha = R_fmin(0.99f, con_o[3] * R_exp(power));
         } else {
-            const float* Tm = (in->cov3D_precomp ? in->cov3D_precomp : st->cov3D) + 9*id;
-            const float* Tu = Tm; const float* Tv = Tm + 3; const float* Tw = Tm + 6;
-            float kx = pixfx*Tw[0] - Tu[0], ky = pixfx*Tw[1] - Tu[1], kz = pixfx*Tw[2] - Tu[2];
-            float lx = pixfy*Tw[0] - Tv[0], ly = pixfy*Tw[1] - Tv[1], lz = pixfy*Tw[2] - Tv[2];
-            float ppx = ky*lz - kz*ly, ppy = kz*lx - kx*lz, ppz = kx*ly - ky*lx;
+            const real* Tm = (in->cov3D_precomp ? in->cov3D_precomp : st->cov3D) + 9*id;
+            const real* Tu = Tm; const real* Tv = Tm + 3; const real* Tw = Tm + 6;
+            real kx = pixfx*Tw[0] - Tu[0], ky = pixfx*Tw[1] - Tu[1], kz = pixfx*Tw[2] - Tu[2];
+            real lx = pixfy*Tw[0] - Tv[0], ly = pixfy*Tw[1] - Tv[1], lz = pixfy*Tw[2] - Tv[2];
+            real ppx = ky*lz - kz*ly, ppy = kz*lx - kx*lz, ppz = kx*ly - ky*lx;
             if (ppz == 0.0f) continue;
-            float sx = ppx / ppz, sy = ppy / ppz;
-            float rho3d = (sx*sx + sy*sy);
-            float dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
-            float rho2d = FilterInvSquare * (dx*dx + dy*dy);
-            float rho = fminf(rho3d, rho2d);
+            real sx = ppx / ppz, sy = ppy / ppz;
+            real rho3d = (sx*sx + sy*sy);
+            real dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
+            real rho2d = FilterInvSquare * (dx*dx + dy*dy);
+            real rho = R_fmin(rho3d, rho2d);
             depth = (rho3d <= rho2d) ? (sx*Tw[0] + sy*Tw[1]) + Tw[2] : Tw[2];
+            if (gates) {
+                /* running error of the ray-splat intersection: T entries carry eta_T = 2 U32 (products of three matrices), then
+                   k = px Tw - Tu, l = py Tw - Tv, p = k x l, s = p.xy / p.z -- the amplifier is 1 / |p.z| for edge-on splats */
+                const real eta_T = U32 * 2;
+                const real ek[3] = { eta_T * (R_fabs(pixfx*Tw[0]) + R_fabs(Tu[0])), eta_T * (R_fabs(pixfx*Tw[1]) + R_fabs(Tu[1])), eta_T * (R_fabs(pixfx*Tw[2]) + R_fabs(Tu[2])) };
+                const real el[3] = { eta_T * (R_fabs(pixfy*Tw[0]) + R_fabs(Tv[0])), eta_T * (R_fabs(pixfy*Tw[1]) + R_fabs(Tv[1])), eta_T * (R_fabs(pixfy*Tw[2]) + R_fabs(Tv[2])) };
+                const real epx = ek[1]*R_fabs(lz) + ek[2]*R_fabs(ly) + R_fabs(ky)*el[2] + R_fabs(kz)*el[1] + 2*U32*(R_fabs(ky*lz) + R_fabs(kz*ly));
+                const real epy = ek[2]*R_fabs(lx) + ek[0]*R_fabs(lz) + R_fabs(kz)*el[0] + R_fabs(kx)*el[2] + 2*U32*(R_fabs(kz*lx) + R_fabs(kx*lz));
+                const real epz = ek[0]*R_fabs(ly) + ek[1]*R_fabs(lx) + R_fabs(kx)*el[1] + R_fabs(ky)*el[0] + 2*U32*(R_fabs(kx*ly) + R_fabs(ky*lx));
+                const real apz = R_fabs(ppz);
+                const real esx = (epx + R_fabs(sx) * epz) / apz + 2*U32*R_fabs(sx), esy = (epy + R_fabs(sy) * epz) / apz + 2*U32*R_fabs(sy);
+                const real e3 = GATE_SAFETY * (2 * (R_fabs(sx) * esx + R_fabs(sy) * esy) + 2*U32*rho3d);
+                const real e2 = GATE_SAFETY * (2 * FilterInvSquare * U32 * 2 * (R_fabs(dx) * R_fabs(st->means2D[2*id]) + R_fabs(dy) * R_fabs(st->means2D[2*id+1])) + 2*U32*rho2d);
+                GATE(REF_GATE_RHO, rho3d, rho2d, e3 + e2);
+                const real ed = (rho3d <= rho2d) ? GATE_SAFETY * (esx * R_fabs(Tw[0]) + esy * R_fabs(Tw[1]) + (eta_T + 2*U32) * (R_fabs(sx*Tw[0]) + R_fabs(sy*Tw[1]) + R_fabs(Tw[2])))
+                                                 : GATE_SAFETY * eta_T * R_fabs(Tw[2]);
+                GATE(REF_GATE_NEAR, depth, near_n, ed);
+                e_pow = 0.5f * ((rho3d <= rho2d) ? e3 : e2);
+                GATE(REF_GATE_POWER, -0.5f * rho, 0, e_pow);
+            }
             if (depth < near_n) continue;
-            float power = -0.5f * rho;
+            real power = -0.5f * rho;
             if (power > 0.0f) continue;
-            alpha = fminf(0.99f, nor_o[3] * expf(power));
+            alpha = R_fmin(0.99f, nor_o[3] * R_exp(power));
+        }
+        real e_alpha = 0;       /* absolute float32 error bound of alpha */
+        if (gates) {
+            e_alpha = (alpha < 0.99f) ? alpha * (e_pow + GATE_SAFETY * 2 * U32) : 0;
+            GATE(REF_GATE_ALPHA, alpha, 1.0f / 255.0f, e_alpha);
+            if (in->splat_noise && alpha >= 0.5f / 255.0f) {
+                const real rel = e_pow + GATE_SAFETY * 2 * U32;
+                atomic_max_real(&in->splat_noise[id], rel);
+            }
         }
         if (alpha < 1.0f / 255.0f) continue;
-        float test_T = T * (1 - alpha);
+        real test_T = T * (1 - alpha);
+        if (gates) {
+            GATE(REF_GATE_TERMINATE, test_T, 0.0001f, test_T * (nT + e_alpha / (1 - alpha) + GATE_SAFETY * 2 * U32));
+            if (st->variant != REF_EWA && test_T >= 0.0001f) GATE(REF_GATE_HALF, T, 0.5f, T * (nT + GATE_SAFETY * U32));
+        }
         if (test_T < 0.0001f) break;   /* done = true: nothing after this can contribute */
-        float w = alpha * T;
+        nT += e_alpha / (1 - alpha) + GATE_SAFETY * 2 * U32;
+        real w = alpha * T;
         if (st->variant == REF_SURFEL) {
-            float A = 1 - T;
-            float m = far_n / (far_n - near_n) * (1 - near_n / depth);
+            real A = 1 - T;
+            real m = far_n / (far_n - near_n) * (1 - near_n / depth);
             distortion += (m * m * A + M2 - 2 * m * M1) * w;
             Dd += depth * w; M1 += m * w; M2 += m * m * w;
             if (T > 0.5f) {
                 median_depth = depth; surf_idx = (int)id;
                 for (int ch = 0; ch < 3; ch++) median_normal[ch] = nor_o[ch];
-                median_contributor = (float)contributor;
+                median_contributor = (real)contributor;
             }
             for (int ch = 0; ch < 3; ch++) Nn[ch] += nor_o[ch] * w;
         }
@@ -551,11 +644,13 @@ static void blend_pixel_fwd(const ref_state* st, const ref_inputs* in, const flo
         T = test_T;
         last_contributor = contributor;
     }
+#undef GATE
+    if (gates) { in->gate_margin[pix_id] = GM; in->gate_id[pix_id] = GI; in->gate_splat[pix_id] = GS; }
     st->final_T[pix_id] = T;
     st->n_contrib[pix_id] = last_contributor;
     for (int ch = 0; ch < 3; ch++) out_color[ch*HW + pix_id] = C[ch] + T * in->bg[ch];
     if (st->variant == REF_SURFEL) {
-        /* float -> uint32 conversion of -1 saturates to 0 on the GPU; restated explicitly */
+        /* real -> uint32 conversion of -1 saturates to 0 on the GPU; restated explicitly */
         st->n_contrib[pix_id + HW] = median_contributor < 0 ? 0u : (uint32_t)median_contributor;
         st->final_T[pix_id + HW] = M1;
         st->final_T[pix_id + 2*HW] = M2;
@@ -564,17 +659,17 @@ static void blend_pixel_fwd(const ref_state* st, const ref_inputs* in, const flo
         for (int ch = 0; ch < 3; ch++) out_others[pix_id + (2+ch)*HW] = Nn[ch];
         out_others[pix_id + 5*HW] = median_depth;
         out_others[pix_id + 6*HW] = distortion;
-        out_others[pix_id + 7*HW] = (float)surf_idx;
+        out_others[pix_id + 7*HW] = (real)surf_idx;
         for (int ch = 0; ch < 3; ch++) out_others[pix_id + (8+ch)*HW] = median_normal[ch];
     }
     if (st->variant == REF_PLANE && in->render_geo) {
         for (int ch = 0; ch < 5; ch++) out_all_map[ch*HW + pix_id] = All_map[ch];
-        out_plane_depth[pix_id] = (float)(All_map[4] / -(All_map[0] * rayx + All_map[1] * rayy + All_map[2] + 1.0e-8));
+        out_plane_depth[pix_id] = (real)(All_map[4] / -(All_map[0] * rayx + All_map[1] * rayy + All_map[2] + 1.0e-8));
     }
 }
 
-ref_state* ref_forward(int variant, const ref_inputs* in, float* out_color, int32_t* radii, float* out_others,
-                       int32_t* out_observe, float* out_all_map, float* out_plane_depth)
+ref_state* ref_forward(int variant, const ref_inputs* in, real* out_color, int32_t* radii, real* out_others,
+                       int32_t* out_observe, real* out_all_map, real* out_plane_depth)
 {
     ref_state* st = (ref_state*)xcalloc(1, sizeof(ref_state));
     const int P = in->P, W = in->W, H = in->H;
@@ -583,22 +678,23 @@ ref_state* ref_forward(int variant, const ref_inputs* in, float* out_color, int3
     st->T = st->gx * st->gy; st->N = W * H;
     const size_t HW = (size_t)W * H;
     const int tm = (variant == REF_SURFEL) ? 9 : 6;
-    st->depths = (float*)xcalloc(P, 4); st->clamped = (uint8_t*)xcalloc((size_t)P*3, 1);
-    st->means2D = (float*)xcalloc((size_t)P*2, 4); st->cov3D = (float*)xcalloc((size_t)P*tm, 4);
-    st->conic_opacity = (float*)xcalloc((size_t)P*4, 4); st->rgb = (float*)xcalloc((size_t)P*3, 4);
+    st->depths = (real*)xcalloc(P, RS); st->clamped = (uint8_t*)xcalloc((size_t)P*3, 1);
+    st->means2D = (real*)xcalloc((size_t)P*2, RS); st->cov3D = (real*)xcalloc((size_t)P*tm, RS);
+    st->conic_opacity = (real*)xcalloc((size_t)P*4, RS); st->rgb = (real*)xcalloc((size_t)P*3, RS);
     st->tiles_touched = (uint32_t*)xcalloc(P, 4); st->point_offsets = (uint32_t*)xcalloc(P, 4);
     st->radii = (int32_t*)xcalloc(P, 4);
-    st->final_T = (float*)xcalloc(HW * (variant == REF_SURFEL ? 3 : 1), 4);
+    st->final_T = (real*)xcalloc(HW * (variant == REF_SURFEL ? 3 : 1), RS);
     st->n_contrib = (uint32_t*)xcalloc(HW * (variant == REF_SURFEL ? 2 : 1), 4);
     st->ranges = (uint32_t*)xcalloc((size_t)st->T * 2, 4);
+    if (in->gate_margin) st->kappa = (real*)xcalloc(P, RS);
 
     /* 3DGS rasterizer_impl.cu:220-221 */
-    const float focal_y = H / (2.0f * in->tanfovy);
-    const float focal_x = W / (2.0f * in->tanfovx);
+    const real focal_y = H / (2.0f * in->tanfovy);
+    const real focal_x = W / (2.0f * in->tanfovx);
 
-    memset(out_color, 0, HW * 3 * 4);
-    if (variant == REF_SURFEL) memset(out_others, 0, HW * 11 * 4);
-    if (variant == REF_PLANE) { memset(out_observe, 0, (size_t)P * 4); memset(out_all_map, 0, HW * 5 * 4); memset(out_plane_depth, 0, HW * 4); }
+    memset(out_color, 0, HW * 3 * RS);
+    if (variant == REF_SURFEL) memset(out_others, 0, HW * 11 * RS);
+    if (variant == REF_PLANE) { memset(out_observe, 0, (size_t)P * 4); memset(out_all_map, 0, HW * 5 * RS); memset(out_plane_depth, 0, HW * RS); }
 
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
@@ -606,6 +702,14 @@ ref_state* ref_forward(int variant, const ref_inputs* in, float* out_color, int3
     for (int i = 0; i < P; i++) preprocess_one(st, in, i, focal_x, focal_y);
     if (radii) memcpy(radii, st->radii, (size_t)P * 4);
 
+    if (in->ov_radii) {
+        /* truth run: sorted instance list and tile ranges of the float32 run */
+        st->R = in->ov_R;
+        st->point_list = (uint32_t*)xcalloc(st->R, 4);
+        memcpy(st->point_list, in->ov_point_list, (size_t)st->R * 4);
+        memcpy(st->ranges, in->ov_ranges, (size_t)st->T * 8);
+        goto blend;
+    }
     /* inclusive scan, 3DGS rasterizer_impl.cu:277-281 */
     uint32_t acc = 0;
     for (int i = 0; i < P; i++) { acc += st->tiles_touched[i]; st->point_offsets[i] = acc; }
@@ -622,7 +726,7 @@ ref_state* ref_forward(int variant, const ref_inputs* in, float* out_color, int3
             uint32_t rmin[2], rmax[2];
             f2 pxy = { st->means2D[2*i], st->means2D[2*i+1] };
             getRect(pxy, st->radii[i], st->gx, st->gy, rmin, rmax);
-            uint32_t dbits; memcpy(&dbits, &st->depths[i], 4);
+            const float d32 = (float)st->depths[i]; uint32_t dbits; memcpy(&dbits, &d32, 4);   /* the key is the FLOAT32 bit pattern of the depth */
             for (uint32_t y = rmin[1]; y < rmax[1]; y++)
                 for (uint32_t x = rmin[0]; x < rmax[0]; x++) {
                     uint64_t key = (uint64_t)(y * (uint32_t)st->gx + x);
@@ -648,7 +752,9 @@ ref_state* ref_forward(int variant, const ref_inputs* in, float* out_color, int3
         if (i == st->R - 1) st->ranges[2*cur+1] = (uint32_t)st->R;
     }
 
-    const float* feat = in->colors_precomp ? in->colors_precomp : st->rgb;
+blend:;
+    const real* feat = in->colors_precomp ? in->colors_precomp : st->rgb;
+    if (in->splat_noise) memset(in->splat_noise, 0, (size_t)P * RS);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4)
 #endif
@@ -664,14 +770,14 @@ ref_state* ref_forward(int variant, const ref_inputs* in, float* out_color, int3
             }
     }
     if (variant == REF_PLANE) {
-        st->out_all_map = (float*)xcalloc(HW * 5, 4);
-        memcpy(st->out_all_map, out_all_map, HW * 5 * 4);
+        st->out_all_map = (real*)xcalloc(HW * 5, RS);
+        memcpy(st->out_all_map, out_all_map, HW * 5 * RS);
     }
     return st;
 }
 
 /* ------------------------------------------------------------------ backward */
-static void atomic_addf(float* p, float v)
+static void atomic_addf(real* p, real v)
 {
 #ifdef _OPENMP
 #pragma omp atomic
@@ -681,50 +787,50 @@ static void atomic_addf(float* p, float v)
 
 /* blend backward, one pixel.  EWA: 3DGS backward.cu:399-557.  PLANE: backward.cu:399-614.
    SURFEL: backward.cu:143-447. */
-static void blend_pixel_bwd(const ref_state* st, const ref_inputs* in, const float* colors, float fx, float fy,
+static void blend_pixel_bwd(const ref_state* st, const ref_inputs* in, const real* colors, real fx, real fy,
                             uint32_t px, uint32_t py, uint32_t r0, uint32_t r1, const ref_out_grads* og,
-                            float* dL_dmean2D /*[P,3]*/, float* dL_dmean2D_abs, float* dL_dconic /*[P,4]*/,
-                            float* dL_dnormal3D /*[P,3]*/, float* dL_dtransMat /*[P,9]*/, float* dL_dopacity,
-                            float* dL_dcolors, float* dL_dall_map)
+                            real* dL_dmean2D /*[P,3]*/, real* dL_dmean2D_abs, real* dL_dconic /*[P,4]*/,
+                            real* dL_dnormal3D /*[P,3]*/, real* dL_dtransMat /*[P,9]*/, real* dL_dopacity,
+                            real* dL_dcolors, real* dL_dall_map)
 {
     const int W = st->W, H = st->H; const size_t HW = (size_t)H * W;
     const uint32_t pix_id = (uint32_t)W * py + px;
-    const float pixfx = (float)px, pixfy = (float)py;
+    const real pixfx = (real)px, pixfy = (real)py;
     const int toDo = (int)(r1 - r0);
-    const float T_final = st->final_T[pix_id];
-    float T = T_final;
+    const real T_final = st->final_T[pix_id];
+    real T = T_final;
     uint32_t contributor = (uint32_t)toDo;
     const int last_contributor = (int)st->n_contrib[pix_id];
-    float accum_rec[3] = {0,0,0}, dL_dpixel[3], last_color[3] = {0,0,0};
+    real accum_rec[3] = {0,0,0}, dL_dpixel[3], last_color[3] = {0,0,0};
     for (int i = 0; i < 3; i++) dL_dpixel[i] = og->dL_dcolor ? og->dL_dcolor[i*HW + pix_id] : 0.0f;
-    float last_alpha = 0;
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    real last_alpha = 0;
+    const real ddelx_dx = (real)(0.5 * W), ddely_dy = (real)(0.5 * H);
 
     /* PLANE extras, backward.cu:433,460-490 */
-    float accum_all_map[5] = {0,0,0,0,0}, last_all_map[5] = {0,0,0,0,0}, dL_dout_all_map[5] = {0,0,0,0,0};
+    real accum_all_map[5] = {0,0,0,0,0}, last_all_map[5] = {0,0,0,0,0}, dL_dout_all_map[5] = {0,0,0,0,0};
     const int geo = (st->variant == REF_PLANE) && in->render_geo;
     if (geo) {
-        const float rayx = (float)((pixfx - W * 0.5) / fx), rayy = (float)((pixfy - H * 0.5) / fy);
+        const real rayx = (real)((pixfx - W * 0.5) / fx), rayy = (real)((pixfy - H * 0.5) / fy);
         for (int i = 0; i < 5; i++) dL_dout_all_map[i] = og->dL_dout_all_map ? og->dL_dout_all_map[i*HW + pix_id] : 0.0f;
-        const float nx = st->out_all_map[pix_id], ny = st->out_all_map[HW + pix_id], nz = st->out_all_map[2*HW + pix_id];
-        const float distance = st->out_all_map[4*HW + pix_id];
-        const float tmp = (float)(nx * rayx + ny * rayy + nz + 1.0e-8);
-        const float dpd = og->dL_dplane_depth ? og->dL_dplane_depth[pix_id] : 0.0f;
+        const real nx = st->out_all_map[pix_id], ny = st->out_all_map[HW + pix_id], nz = st->out_all_map[2*HW + pix_id];
+        const real distance = st->out_all_map[4*HW + pix_id];
+        const real tmp = (real)(nx * rayx + ny * rayy + nz + 1.0e-8);
+        const real dpd = og->dL_dplane_depth ? og->dL_dplane_depth[pix_id] : 0.0f;
         dL_dout_all_map[4] += (-dpd / tmp);
         dL_dout_all_map[0] += dpd * (distance / (tmp * tmp) * rayx);
         dL_dout_all_map[1] += dpd * (distance / (tmp * tmp) * rayy);
         dL_dout_all_map[2] += dpd * (distance / (tmp * tmp));
     }
     /* SURFEL extras, backward.cu:205-243 */
-    float dL_dreg = 0, dL_ddepth = 0, dL_daccum = 0, dL_dnormal2D[3] = {0,0,0}, dL_dmedian_depth = 0;
-    float dL_dmedian_normal2D[3] = {0,0,0};
+    real dL_dreg = 0, dL_ddepth = 0, dL_daccum = 0, dL_dnormal2D[3] = {0,0,0}, dL_dmedian_depth = 0;
+    real dL_dmedian_normal2D[3] = {0,0,0};
     int median_contributor = 0;
-    float last_depth = 0, last_normal[3] = {0,0,0}, accum_depth_rec = 0, accum_alpha_rec = 0, accum_normal_rec[3] = {0,0,0};
-    float final_D = 0, final_D2 = 0, final_A = 0, last_dL_dT = 0;
+    real last_depth = 0, last_normal[3] = {0,0,0}, accum_depth_rec = 0, accum_alpha_rec = 0, accum_normal_rec[3] = {0,0,0};
+    real final_D = 0, final_D2 = 0, final_A = 0, last_dL_dT = 0;
     if (st->variant == REF_SURFEL) {
         median_contributor = (int)st->n_contrib[pix_id + HW];
         if (og->dL_dothers) {
-            const float* g = og->dL_dothers;
+            const real* g = og->dL_dothers;
             dL_ddepth = g[0*HW + pix_id]; dL_daccum = g[1*HW + pix_id]; dL_dreg = g[6*HW + pix_id];
             for (int i = 0; i < 3; i++) dL_dnormal2D[i] = g[(2+i)*HW + pix_id];
             dL_dmedian_depth = g[5*HW + pix_id];
@@ -737,71 +843,71 @@ static void blend_pixel_bwd(const ref_state* st, const ref_inputs* in, const flo
         const uint32_t id = st->point_list[r1 - 1 - (uint32_t)j];
         contributor--;
         if ((int)contributor >= last_contributor) continue;   /* uint32 vs int compare in the source: both non-negative */
-        const float* nor_o = st->conic_opacity + 4*id;
-        const float dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
-        float G, alpha;
+        const real* nor_o = st->conic_opacity + 4*id;
+        const real dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
+        real G, alpha;
         /* surfel intersection temporaries */
-        float kx=0,ky=0,kz=0,lx=0,ly=0,lz=0,ppz=0,sx=0,sy=0,rho3d=0,rho2d=0,c_d=0; const float* Tw = NULL;
+        real kx=0,ky=0,kz=0,lx=0,ly=0,lz=0,ppz=0,sx=0,sy=0,rho3d=0,rho2d=0,c_d=0; const real* Tw = NULL;
         if (st->variant != REF_SURFEL) {
-            const float power = -0.5f * (nor_o[0] * dx * dx + nor_o[2] * dy * dy) - nor_o[1] * dx * dy;
+            const real power = -0.5f * (nor_o[0] * dx * dx + nor_o[2] * dy * dy) - nor_o[1] * dx * dy;
             if (power > 0.0f) continue;
-            G = expf(power);
+            G = R_exp(power);
         } else {
-            const float* Tm = (in->cov3D_precomp ? in->cov3D_precomp : st->cov3D) + 9*id;
-            const float* Tu = Tm; const float* Tv = Tm + 3; Tw = Tm + 6;
+            const real* Tm = (in->cov3D_precomp ? in->cov3D_precomp : st->cov3D) + 9*id;
+            const real* Tu = Tm; const real* Tv = Tm + 3; Tw = Tm + 6;
             kx = pixfx*Tw[0] - Tu[0]; ky = pixfx*Tw[1] - Tu[1]; kz = pixfx*Tw[2] - Tu[2];
             lx = pixfy*Tw[0] - Tv[0]; ly = pixfy*Tw[1] - Tv[1]; lz = pixfy*Tw[2] - Tv[2];
-            float ppx = ky*lz - kz*ly, ppy = kz*lx - kx*lz; ppz = kx*ly - ky*lx;
+            real ppx = ky*lz - kz*ly, ppy = kz*lx - kx*lz; ppz = kx*ly - ky*lx;
             if (ppz == 0.0f) continue;
             sx = ppx / ppz; sy = ppy / ppz;
             rho3d = (sx*sx + sy*sy);
             rho2d = FilterInvSquare * (dx*dx + dy*dy);
-            float rho = fminf(rho3d, rho2d);
+            real rho = R_fmin(rho3d, rho2d);
             c_d = (rho3d <= rho2d) ? (sx*Tw[0] + sy*Tw[1]) + Tw[2] : Tw[2];
             if (c_d < near_n) continue;
-            float power = -0.5f * rho;
+            real power = -0.5f * rho;
             if (power > 0.0f) continue;
-            G = expf(power);
+            G = R_exp(power);
         }
-        alpha = fminf(0.99f, nor_o[3] * G);
+        alpha = R_fmin(0.99f, nor_o[3] * G);
         if (alpha < 1.0f / 255.0f) continue;
 
         T = T / (1.f - alpha);
-        const float dchannel_dcolor = alpha * T;
-        float dL_dalpha = 0.0f;
+        const real dchannel_dcolor = alpha * T;
+        real dL_dalpha = 0.0f;
         for (int ch = 0; ch < 3; ch++) {
-            const float c = colors[3*id + ch];
+            const real c = colors[3*id + ch];
             accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
             last_color[ch] = c;
-            const float dL_dchannel = dL_dpixel[ch];
+            const real dL_dchannel = dL_dpixel[ch];
             dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
             atomic_addf(&dL_dcolors[3*id + ch], dchannel_dcolor * dL_dchannel);
         }
         if (geo) {
             for (int ch = 0; ch < 5; ch++) {
-                const float c = in->all_map[5*id + ch];
+                const real c = in->all_map[5*id + ch];
                 accum_all_map[ch] = last_alpha * last_all_map[ch] + (1.f - last_alpha) * accum_all_map[ch];
                 last_all_map[ch] = c;
-                const float dL_dchannel = dL_dout_all_map[ch];
+                const real dL_dchannel = dL_dout_all_map[ch];
                 dL_dalpha += (c - accum_all_map[ch]) * dL_dchannel;
                 atomic_addf(&dL_dall_map[5*id + ch], dchannel_dcolor * dL_dchannel);
             }
         }
-        float dL_dz = 0.0f;
+        real dL_dz = 0.0f;
         if (st->variant == REF_SURFEL) {
-            float dL_dweight = 0;
-            const float m_d = far_n / (far_n - near_n) * (1 - near_n / c_d);
-            const float dmd_dd = (far_n * near_n) / ((far_n - near_n) * c_d * c_d);
+            real dL_dweight = 0;
+            const real m_d = far_n / (far_n - near_n) * (1 - near_n / c_d);
+            const real dmd_dd = (far_n * near_n) / ((far_n - near_n) * c_d * c_d);
             if ((int)contributor == median_contributor - 1) dL_dz += dL_dmedian_depth;
             dL_dweight += (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
             dL_dalpha += dL_dweight - last_dL_dT;
             last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
-            const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+            const real dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
             dL_dz += dL_dmd * dmd_dd;
             accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
             last_depth = c_d;
             dL_dalpha += (c_d - accum_depth_rec) * dL_ddepth;
-            accum_alpha_rec = (float)(last_alpha * 1.0 + (1.f - last_alpha) * accum_alpha_rec);
+            accum_alpha_rec = (real)(last_alpha * 1.0 + (1.f - last_alpha) * accum_alpha_rec);
             dL_dalpha += (1 - accum_alpha_rec) * dL_daccum;
             for (int ch = 0; ch < 3; ch++) {
                 accum_normal_rec[ch] = last_alpha * last_normal[ch] + (1.f - last_alpha) * accum_normal_rec[ch];
@@ -814,20 +920,20 @@ static void blend_pixel_bwd(const ref_state* st, const ref_inputs* in, const flo
         }
         dL_dalpha *= T;
         last_alpha = alpha;
-        float bg_dot_dpixel = 0;
+        real bg_dot_dpixel = 0;
         for (int i = 0; i < 3; i++) bg_dot_dpixel += in->bg[i] * dL_dpixel[i];
         dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-        const float dL_dG = nor_o[3] * dL_dalpha;
+        const real dL_dG = nor_o[3] * dL_dalpha;
 
         if (st->variant != REF_SURFEL) {
-            const float gdx = G * dx, gdy = G * dy;
-            const float dG_ddelx = -gdx * nor_o[0] - gdy * nor_o[1];
-            const float dG_ddely = -gdy * nor_o[2] - gdx * nor_o[1];
+            const real gdx = G * dx, gdy = G * dy;
+            const real dG_ddelx = -gdx * nor_o[0] - gdy * nor_o[1];
+            const real dG_ddely = -gdy * nor_o[2] - gdx * nor_o[1];
             atomic_addf(&dL_dmean2D[3*id + 0], dL_dG * dG_ddelx * ddelx_dx);
             atomic_addf(&dL_dmean2D[3*id + 1], dL_dG * dG_ddely * ddely_dy);
             if (st->variant == REF_PLANE) {
-                atomic_addf(&dL_dmean2D_abs[3*id + 0], fabsf(dL_dG * dG_ddelx * ddelx_dx));
-                atomic_addf(&dL_dmean2D_abs[3*id + 1], fabsf(dL_dG * dG_ddely * ddely_dy));
+                atomic_addf(&dL_dmean2D_abs[3*id + 0], R_fabs(dL_dG * dG_ddelx * ddelx_dx));
+                atomic_addf(&dL_dmean2D_abs[3*id + 1], R_fabs(dL_dG * dG_ddely * ddely_dy));
             }
             atomic_addf(&dL_dconic[4*id + 0], -0.5f * gdx * dx * dL_dG);
             atomic_addf(&dL_dconic[4*id + 1], -0.5f * gdx * dy * dL_dG);
@@ -835,22 +941,22 @@ static void blend_pixel_bwd(const ref_state* st, const ref_inputs* in, const flo
         } else {
             dL_dz += alpha * T * dL_ddepth;
             if (rho3d <= rho2d) {
-                const float dL_dsx = dL_dG * -G * sx + dL_dz * Tw[0];
-                const float dL_dsy = dL_dG * -G * sy + dL_dz * Tw[1];
-                const float dsx_pz = dL_dsx / ppz, dsy_pz = dL_dsy / ppz;
-                const float dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * sx + dsy_pz * sy);
+                const real dL_dsx = dL_dG * -G * sx + dL_dz * Tw[0];
+                const real dL_dsy = dL_dG * -G * sy + dL_dz * Tw[1];
+                const real dsx_pz = dL_dsx / ppz, dsy_pz = dL_dsy / ppz;
+                const real dpx = dsx_pz, dpy = dsy_pz, dpz = -(dsx_pz * sx + dsy_pz * sy);
                 /* dL_dk = cross(l, dL_dp); dL_dl = cross(dL_dp, k) */
-                const float dkx = ly*dpz - lz*dpy, dky = lz*dpx - lx*dpz, dkz = lx*dpy - ly*dpx;
-                const float dlx = dpy*kz - dpz*ky, dly = dpz*kx - dpx*kz, dlz = dpx*ky - dpy*kx;
-                float* g = dL_dtransMat + 9*id;
+                const real dkx = ly*dpz - lz*dpy, dky = lz*dpx - lx*dpz, dkz = lx*dpy - ly*dpx;
+                const real dlx = dpy*kz - dpz*ky, dly = dpz*kx - dpx*kz, dlz = dpx*ky - dpy*kx;
+                real* g = dL_dtransMat + 9*id;
                 atomic_addf(&g[0], -dkx); atomic_addf(&g[1], -dky); atomic_addf(&g[2], -dkz);
                 atomic_addf(&g[3], -dlx); atomic_addf(&g[4], -dly); atomic_addf(&g[5], -dlz);
                 atomic_addf(&g[6], pixfx * dkx + pixfy * dlx + dL_dz * sx);
                 atomic_addf(&g[7], pixfx * dky + pixfy * dly + dL_dz * sy);
                 atomic_addf(&g[8], pixfx * dkz + pixfy * dlz + dL_dz * 1.0f);
             } else {
-                const float dG_ddelx = -G * FilterInvSquare * dx;
-                const float dG_ddely = -G * FilterInvSquare * dy;
+                const real dG_ddelx = -G * FilterInvSquare * dx;
+                const real dG_ddely = -G * FilterInvSquare * dy;
                 atomic_addf(&dL_dmean2D[3*id + 0], dL_dG * dG_ddelx);
                 atomic_addf(&dL_dmean2D[3*id + 1], dL_dG * dG_ddely);
                 atomic_addf(&dL_dtransMat[9*id + 8], dL_dz);
@@ -861,20 +967,20 @@ static void blend_pixel_bwd(const ref_state* st, const ref_inputs* in, const flo
 }
 
 /* 3DGS backward.cu:144-274 */
-static void computeCov2D_bwd(const ref_inputs* in, int idx, const float* cov3Ds, float h_x, float h_y,
-                             const float* dL_dconics, float* dL_dmeans, float* dL_dcov)
+static void computeCov2D_bwd(const ref_inputs* in, int idx, const real* cov3Ds, real h_x, real h_y,
+                             const real* dL_dconics, real* dL_dmeans, real* dL_dcov)
 {
-    const float* cov3D = cov3Ds + 6*idx;
+    const real* cov3D = cov3Ds + 6*idx;
     f3 mean = { in->means3D[3*idx], in->means3D[3*idx+1], in->means3D[3*idx+2] };
-    float dcx = dL_dconics[4*idx], dcy = dL_dconics[4*idx+1], dcz = dL_dconics[4*idx+3];
-    float cov[3]; m3 T, Vrk; f3 t; float x_grad_mul, y_grad_mul;
+    real dcx = dL_dconics[4*idx], dcy = dL_dconics[4*idx+1], dcz = dL_dconics[4*idx+3];
+    real cov[3]; m3 T, Vrk; f3 t; real x_grad_mul, y_grad_mul;
     computeCov2D(mean, h_x, h_y, in->tanfovx, in->tanfovy, cov3D, in->viewmatrix, cov, &T, &Vrk, &t, &x_grad_mul, &y_grad_mul);
-    const float* vm = in->viewmatrix;
+    const real* vm = in->viewmatrix;
     m3 Wm = m3_cols(vm[0], vm[4], vm[8], vm[1], vm[5], vm[9], vm[2], vm[6], vm[10]);
-    float a = cov[0], b = cov[1], c = cov[2];
-    float denom = a * c - b * b;
-    float dL_da = 0, dL_db = 0, dL_dc = 0;
-    float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    real a = cov[0], b = cov[1], c = cov[2];
+    real denom = a * c - b * b;
+    real dL_da = 0, dL_db = 0, dL_dc = 0;
+    real denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
     if (denom2inv != 0) {
         dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
         dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
@@ -888,37 +994,37 @@ static void computeCov2D_bwd(const ref_inputs* in, int idx, const float* cov3Ds,
     } else {
         for (int i = 0; i < 6; i++) dL_dcov[6*idx+i] = 0;
     }
-    float dL_dT00 = 2*(T.c[0][0]*Vrk.c[0][0] + T.c[0][1]*Vrk.c[0][1] + T.c[0][2]*Vrk.c[0][2])*dL_da + (T.c[1][0]*Vrk.c[0][0] + T.c[1][1]*Vrk.c[0][1] + T.c[1][2]*Vrk.c[0][2])*dL_db;
-    float dL_dT01 = 2*(T.c[0][0]*Vrk.c[1][0] + T.c[0][1]*Vrk.c[1][1] + T.c[0][2]*Vrk.c[1][2])*dL_da + (T.c[1][0]*Vrk.c[1][0] + T.c[1][1]*Vrk.c[1][1] + T.c[1][2]*Vrk.c[1][2])*dL_db;
-    float dL_dT02 = 2*(T.c[0][0]*Vrk.c[2][0] + T.c[0][1]*Vrk.c[2][1] + T.c[0][2]*Vrk.c[2][2])*dL_da + (T.c[1][0]*Vrk.c[2][0] + T.c[1][1]*Vrk.c[2][1] + T.c[1][2]*Vrk.c[2][2])*dL_db;
-    float dL_dT10 = 2*(T.c[1][0]*Vrk.c[0][0] + T.c[1][1]*Vrk.c[0][1] + T.c[1][2]*Vrk.c[0][2])*dL_dc + (T.c[0][0]*Vrk.c[0][0] + T.c[0][1]*Vrk.c[0][1] + T.c[0][2]*Vrk.c[0][2])*dL_db;
-    float dL_dT11 = 2*(T.c[1][0]*Vrk.c[1][0] + T.c[1][1]*Vrk.c[1][1] + T.c[1][2]*Vrk.c[1][2])*dL_dc + (T.c[0][0]*Vrk.c[1][0] + T.c[0][1]*Vrk.c[1][1] + T.c[0][2]*Vrk.c[1][2])*dL_db;
-    float dL_dT12 = 2*(T.c[1][0]*Vrk.c[2][0] + T.c[1][1]*Vrk.c[2][1] + T.c[1][2]*Vrk.c[2][2])*dL_dc + (T.c[0][0]*Vrk.c[2][0] + T.c[0][1]*Vrk.c[2][1] + T.c[0][2]*Vrk.c[2][2])*dL_db;
-    float dL_dJ00 = Wm.c[0][0]*dL_dT00 + Wm.c[0][1]*dL_dT01 + Wm.c[0][2]*dL_dT02;
-    float dL_dJ02 = Wm.c[2][0]*dL_dT00 + Wm.c[2][1]*dL_dT01 + Wm.c[2][2]*dL_dT02;
-    float dL_dJ11 = Wm.c[1][0]*dL_dT10 + Wm.c[1][1]*dL_dT11 + Wm.c[1][2]*dL_dT12;
-    float dL_dJ12 = Wm.c[2][0]*dL_dT10 + Wm.c[2][1]*dL_dT11 + Wm.c[2][2]*dL_dT12;
-    float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
-    float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-    float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-    float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+    real dL_dT00 = 2*(T.c[0][0]*Vrk.c[0][0] + T.c[0][1]*Vrk.c[0][1] + T.c[0][2]*Vrk.c[0][2])*dL_da + (T.c[1][0]*Vrk.c[0][0] + T.c[1][1]*Vrk.c[0][1] + T.c[1][2]*Vrk.c[0][2])*dL_db;
+    real dL_dT01 = 2*(T.c[0][0]*Vrk.c[1][0] + T.c[0][1]*Vrk.c[1][1] + T.c[0][2]*Vrk.c[1][2])*dL_da + (T.c[1][0]*Vrk.c[1][0] + T.c[1][1]*Vrk.c[1][1] + T.c[1][2]*Vrk.c[1][2])*dL_db;
+    real dL_dT02 = 2*(T.c[0][0]*Vrk.c[2][0] + T.c[0][1]*Vrk.c[2][1] + T.c[0][2]*Vrk.c[2][2])*dL_da + (T.c[1][0]*Vrk.c[2][0] + T.c[1][1]*Vrk.c[2][1] + T.c[1][2]*Vrk.c[2][2])*dL_db;
+    real dL_dT10 = 2*(T.c[1][0]*Vrk.c[0][0] + T.c[1][1]*Vrk.c[0][1] + T.c[1][2]*Vrk.c[0][2])*dL_dc + (T.c[0][0]*Vrk.c[0][0] + T.c[0][1]*Vrk.c[0][1] + T.c[0][2]*Vrk.c[0][2])*dL_db;
+    real dL_dT11 = 2*(T.c[1][0]*Vrk.c[1][0] + T.c[1][1]*Vrk.c[1][1] + T.c[1][2]*Vrk.c[1][2])*dL_dc + (T.c[0][0]*Vrk.c[1][0] + T.c[0][1]*Vrk.c[1][1] + T.c[0][2]*Vrk.c[1][2])*dL_db;
+    real dL_dT12 = 2*(T.c[1][0]*Vrk.c[2][0] + T.c[1][1]*Vrk.c[2][1] + T.c[1][2]*Vrk.c[2][2])*dL_dc + (T.c[0][0]*Vrk.c[2][0] + T.c[0][1]*Vrk.c[2][1] + T.c[0][2]*Vrk.c[2][2])*dL_db;
+    real dL_dJ00 = Wm.c[0][0]*dL_dT00 + Wm.c[0][1]*dL_dT01 + Wm.c[0][2]*dL_dT02;
+    real dL_dJ02 = Wm.c[2][0]*dL_dT00 + Wm.c[2][1]*dL_dT01 + Wm.c[2][2]*dL_dT02;
+    real dL_dJ11 = Wm.c[1][0]*dL_dT10 + Wm.c[1][1]*dL_dT11 + Wm.c[1][2]*dL_dT12;
+    real dL_dJ12 = Wm.c[2][0]*dL_dT10 + Wm.c[2][1]*dL_dT11 + Wm.c[2][2]*dL_dT12;
+    real tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    real dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    real dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    real dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
     f3 dt = { dL_dtx, dL_dty, dL_dtz };
     f3 dm = transformVec4x3Transpose(dt, vm);
     dL_dmeans[3*idx] = dm.x; dL_dmeans[3*idx+1] = dm.y; dL_dmeans[3*idx+2] = dm.z;   /* assignment */
 }
 
 /* 3DGS backward.cu:278-341 (no quaternion-normalisation Jacobian) */
-static void computeCov3D_bwd(int idx, const float* scale, float mod, const float* rot, const float* dL_dcov3Ds,
-                             float* dL_dscales, float* dL_drots)
+static void computeCov3D_bwd(int idx, const real* scale, real mod, const real* rot, const real* dL_dcov3Ds,
+                             real* dL_dscales, real* dL_drots)
 {
-    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    real r = rot[0], x = rot[1], y = rot[2], z = rot[3];
     m3 R = m3_cols(1.f - 2.f*(y*y + z*z), 2.f*(x*y - r*z), 2.f*(x*z + r*y),
                    2.f*(x*y + r*z), 1.f - 2.f*(x*x + z*z), 2.f*(y*z - r*x),
                    2.f*(x*z - r*y), 2.f*(y*z + r*x), 1.f - 2.f*(x*x + y*y));
-    float s[3] = { mod*scale[0], mod*scale[1], mod*scale[2] };
+    real s[3] = { mod*scale[0], mod*scale[1], mod*scale[2] };
     m3 S = m3_cols(s[0],0,0, 0,s[1],0, 0,0,s[2]);
     m3 Mm = m3_mul(S, R);
-    const float* g = dL_dcov3Ds + 6*idx;
+    const real* g = dL_dcov3Ds + 6*idx;
     m3 dL_dSigma = m3_cols(g[0], 0.5f*g[1], 0.5f*g[2], 0.5f*g[1], g[3], 0.5f*g[4], 0.5f*g[2], 0.5f*g[4], g[5]);
     m3 M2 = Mm; for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) M2.c[j][i] = 2.0f * Mm.c[j][i];
     m3 dL_dM = m3_mul(M2, dL_dSigma);
@@ -927,7 +1033,7 @@ static void computeCov3D_bwd(int idx, const float* scale, float mod, const float
     dL_dscales[3*idx+1] = dot3(Rt.c[1], dL_dMt.c[1]);
     dL_dscales[3*idx+2] = dot3(Rt.c[2], dL_dMt.c[2]);
     for (int i = 0; i < 3; i++) { dL_dMt.c[0][i] *= s[0]; dL_dMt.c[1][i] *= s[1]; dL_dMt.c[2][i] *= s[2]; }
-    float* q = dL_drots + 4*idx;
+    real* q = dL_drots + 4*idx;
     q[0] = 2*z*(dL_dMt.c[0][1] - dL_dMt.c[1][0]) + 2*y*(dL_dMt.c[2][0] - dL_dMt.c[0][2]) + 2*x*(dL_dMt.c[1][2] - dL_dMt.c[2][1]);
     q[1] = 2*y*(dL_dMt.c[1][0] + dL_dMt.c[0][1]) + 2*z*(dL_dMt.c[2][0] + dL_dMt.c[0][2]) + 2*r*(dL_dMt.c[1][2] - dL_dMt.c[2][1]) - 4*x*(dL_dMt.c[2][2] + dL_dMt.c[1][1]);
     q[2] = 2*x*(dL_dMt.c[1][0] + dL_dMt.c[0][1]) + 2*r*(dL_dMt.c[2][0] - dL_dMt.c[0][2]) + 2*z*(dL_dMt.c[1][2] + dL_dMt.c[2][1]) - 4*y*(dL_dMt.c[2][2] + dL_dMt.c[0][0]);
@@ -936,12 +1042,12 @@ static void computeCov3D_bwd(int idx, const float* scale, float mod, const float
 
 /* SURFEL backward.cu:450-580 */
 static void compute_transmat_aabb_bwd(const ref_state* st, const ref_inputs* in, int idx, int W, int H,
-                                      const float* dL_dnormals, const float* dL_dmean2Ds, float* dL_dTs,
-                                      float* dL_dmeans, float* dL_dscales, float* dL_drots)
+                                      const real* dL_dnormals, const real* dL_dmean2Ds, real* dL_dTs,
+                                      real* dL_dmeans, real* dL_dscales, real* dL_drots)
 {
     const int precomp = (in->scales == NULL);
-    float T[9]; f3 normal = {0,0,0}; float Pm[4][3]; m3 R; f3 p_orig = {0,0,0};
-    const float* rot = NULL; const float* scale = NULL;
+    real T[9]; f3 normal = {0,0,0}; real Pm[4][3]; m3 R; f3 p_orig = {0,0,0};
+    const real* rot = NULL; const real* scale = NULL;
     if (precomp) {
         memcpy(T, in->cov3D_precomp + 9*idx, sizeof(T));
     } else {
@@ -953,26 +1059,26 @@ static void compute_transmat_aabb_bwd(const ref_state* st, const ref_inputs* in,
         surfel_P(in->projmatrix, W, H, Pm);
     }
     (void)st;
-    float dT[3][3];   /* dT[j] = dL/d(T_j), j: 0=Tu 1=Tv 2=Tw */
+    real dT[3][3];   /* dT[j] = dL/d(T_j), j: 0=Tu 1=Tv 2=Tw */
     for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) dT[j][i] = dL_dTs[9*idx + 3*j + i];
-    const float gmx = dL_dmean2Ds[3*idx], gmy = dL_dmean2Ds[3*idx+1];
+    const real gmx = dL_dmean2Ds[3*idx], gmy = dL_dmean2Ds[3*idx+1];
     if (gmx != 0 || gmy != 0) {
-        const float* Tu = T; const float* Tv = T + 3; const float* Tw = T + 6;
-        float tv[3] = { 9.0f, 9.0f, -1.0f };
-        float ww[3] = { Tw[0]*Tw[0], Tw[1]*Tw[1], Tw[2]*Tw[2] };
-        float d = dot3(tv, ww);
-        float inv = 1.0f / d;
-        float f[3] = { tv[0]*inv, tv[1]*inv, tv[2]*inv };
-        float dT0[3], dT1[3], dT3[3], dL_df[3];
+        const real* Tu = T; const real* Tv = T + 3; const real* Tw = T + 6;
+        real tv[3] = { 9.0f, 9.0f, -1.0f };
+        real ww[3] = { Tw[0]*Tw[0], Tw[1]*Tw[1], Tw[2]*Tw[2] };
+        real d = dot3(tv, ww);
+        real inv = 1.0f / d;
+        real f[3] = { tv[0]*inv, tv[1]*inv, tv[2]*inv };
+        real dT0[3], dT1[3], dT3[3], dL_df[3];
         for (int i = 0; i < 3; i++) {
             dT0[i] = gmx * f[i] * Tw[i];
             dT1[i] = gmy * f[i] * Tw[i];
             dT3[i] = gmx * f[i] * Tu[i] + gmy * f[i] * Tv[i];
             dL_df[i] = gmx * Tu[i] * Tw[i] + gmy * Tv[i] * Tw[i];
         }
-        float dL_dd = (float)(dot3(dL_df, f) * (-1.0 / d));
+        real dL_dd = (real)(dot3(dL_df, f) * (-1.0 / d));
         for (int i = 0; i < 3; i++) {
-            float dd_dT3 = tv[i] * Tw[i] * 2.0f;
+            real dd_dT3 = tv[i] * Tw[i] * 2.0f;
             dT3[i] += dL_dd * dd_dT3;
             dT[0][i] += dT0[i]; dT[1][i] += dT1[i]; dT[2][i] += dT3[i];
         }
@@ -983,15 +1089,15 @@ static void compute_transmat_aabb_bwd(const ref_state* st, const ref_inputs* in,
     }
     if (precomp) return;
     /* dL_dM = P * transpose(dL_dT): dM[j][k] = sum_c Pm[k][c] * dT[c][j]   (j: 0=L0 row,1=L1 row,2=centre row) */
-    float dM[3][4];
+    real dM[3][4];
     for (int j = 0; j < 3; j++)
         for (int k = 0; k < 4; k++)
             dM[j][k] = Pm[k][0]*dT[0][j] + Pm[k][1]*dT[1][j] + Pm[k][2]*dT[2][j];
     f3 dn = { dL_dnormals[3*idx], dL_dnormals[3*idx+1], dL_dnormals[3*idx+2] };
     f3 dL_dtn = transformVec4x3Transpose(dn, in->viewmatrix);
     f3 p_view = transformPoint4x3(p_orig, in->viewmatrix);
-    float cosv = -(p_view.x*normal.x + p_view.y*normal.y + p_view.z*normal.z);
-    float mult = cosv > 0 ? 1.f : -1.f;
+    real cosv = -(p_view.x*normal.x + p_view.y*normal.y + p_view.z*normal.z);
+    real mult = cosv > 0 ? 1.f : -1.f;
     dL_dtn.x *= mult; dL_dtn.y *= mult; dL_dtn.z *= mult;
     m3 dL_dRS = m3_cols(dM[0][0], dM[0][1], dM[0][2], dM[1][0], dM[1][1], dM[1][2], dL_dtn.x, dL_dtn.y, dL_dtn.z);
     m3 dL_dR = m3_cols(dL_dRS.c[0][0]*scale[0], dL_dRS.c[0][1]*scale[0], dL_dRS.c[0][2]*scale[0],
@@ -1008,18 +1114,18 @@ void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, 
     const int P = st->P, W = st->W, H = st->H, M = in->M;
     const int surf = st->variant == REF_SURFEL;
     const int tm = surf ? 9 : 6;
-    memset(ig->dL_dmeans3D, 0, (size_t)P*3*4); memset(ig->dL_dmeans2D, 0, (size_t)P*3*4);
-    if (ig->dL_dmeans2D_abs) memset(ig->dL_dmeans2D_abs, 0, (size_t)P*3*4);
-    memset(ig->dL_dcolors, 0, (size_t)P*3*4); memset(ig->dL_dopacity, 0, (size_t)P*4);
-    memset(ig->dL_dcov3D, 0, (size_t)P*tm*4);
-    if (ig->dL_dsh && M > 0) memset(ig->dL_dsh, 0, (size_t)P*M*3*4);
-    memset(ig->dL_dscales, 0, (size_t)P*(surf ? 2 : 3)*4); memset(ig->dL_drotations, 0, (size_t)P*4*4);
-    if (ig->dL_dall_map) memset(ig->dL_dall_map, 0, (size_t)P*5*4);
-    memset(ig->dL_dconic, 0, (size_t)P*(surf ? 3 : 4)*4);
+    memset(ig->dL_dmeans3D, 0, (size_t)P*3*RS); memset(ig->dL_dmeans2D, 0, (size_t)P*3*RS);
+    if (ig->dL_dmeans2D_abs) memset(ig->dL_dmeans2D_abs, 0, (size_t)P*3*RS);
+    memset(ig->dL_dcolors, 0, (size_t)P*3*RS); memset(ig->dL_dopacity, 0, (size_t)P*RS);
+    memset(ig->dL_dcov3D, 0, (size_t)P*tm*RS);
+    if (ig->dL_dsh && M > 0) memset(ig->dL_dsh, 0, (size_t)P*M*3*RS);
+    memset(ig->dL_dscales, 0, (size_t)P*(surf ? 2 : 3)*RS); memset(ig->dL_drotations, 0, (size_t)P*4*RS);
+    if (ig->dL_dall_map) memset(ig->dL_dall_map, 0, (size_t)P*5*RS);
+    memset(ig->dL_dconic, 0, (size_t)P*(surf ? 3 : 4)*RS);
 
-    const float focal_y = H / (2.0f * in->tanfovy);
-    const float focal_x = W / (2.0f * in->tanfovx);
-    const float* colors = in->colors_precomp ? in->colors_precomp : st->rgb;
+    const real focal_y = H / (2.0f * in->tanfovy);
+    const real focal_x = W / (2.0f * in->tanfovx);
+    const real* colors = in->colors_precomp ? in->colors_precomp : st->rgb;
 
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4)
@@ -1040,7 +1146,7 @@ void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, 
 
     if (!surf) {
         /* BACKWARD::preprocess, 3DGS backward.cu:559-625 */
-        const float* cov3D_ptr = in->cov3D_precomp ? in->cov3D_precomp : st->cov3D;
+        const real* cov3D_ptr = in->cov3D_precomp ? in->cov3D_precomp : st->cov3D;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -1049,15 +1155,15 @@ void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, 
             computeCov2D_bwd(in, idx, cov3D_ptr, focal_x, focal_y, ig->dL_dconic, ig->dL_dmeans3D, ig->dL_dcov3D);
             /* preprocessCUDA bwd, 3DGS backward.cu:346-396 */
             f3 m = { in->means3D[3*idx], in->means3D[3*idx+1], in->means3D[3*idx+2] };
-            const float* proj = in->projmatrix;
-            float mh[4]; transformPoint4x4(m, proj, mh);
-            float m_w = 1.0f / (mh[3] + 0.0000001f);
-            float mul1 = (proj[0]*m.x + proj[4]*m.y + proj[8]*m.z + proj[12]) * m_w * m_w;
-            float mul2 = (proj[1]*m.x + proj[5]*m.y + proj[9]*m.z + proj[13]) * m_w * m_w;
-            const float gx_ = ig->dL_dmeans2D[3*idx], gy_ = ig->dL_dmeans2D[3*idx+1];
-            float dmx = (proj[0]*m_w - proj[3]*mul1) * gx_ + (proj[1]*m_w - proj[3]*mul2) * gy_;
-            float dmy = (proj[4]*m_w - proj[7]*mul1) * gx_ + (proj[5]*m_w - proj[7]*mul2) * gy_;
-            float dmz = (proj[8]*m_w - proj[11]*mul1) * gx_ + (proj[9]*m_w - proj[11]*mul2) * gy_;
+            const real* proj = in->projmatrix;
+            real mh[4]; transformPoint4x4(m, proj, mh);
+            real m_w = 1.0f / (mh[3] + 0.0000001f);
+            real mul1 = (proj[0]*m.x + proj[4]*m.y + proj[8]*m.z + proj[12]) * m_w * m_w;
+            real mul2 = (proj[1]*m.x + proj[5]*m.y + proj[9]*m.z + proj[13]) * m_w * m_w;
+            const real gx_ = ig->dL_dmeans2D[3*idx], gy_ = ig->dL_dmeans2D[3*idx+1];
+            real dmx = (proj[0]*m_w - proj[3]*mul1) * gx_ + (proj[1]*m_w - proj[3]*mul2) * gy_;
+            real dmy = (proj[4]*m_w - proj[7]*mul1) * gx_ + (proj[5]*m_w - proj[7]*mul2) * gy_;
+            real dmz = (proj[8]*m_w - proj[11]*mul1) * gx_ + (proj[9]*m_w - proj[11]*mul2) * gy_;
             ig->dL_dmeans3D[3*idx] += dmx; ig->dL_dmeans3D[3*idx+1] += dmy; ig->dL_dmeans3D[3*idx+2] += dmz;
             if (in->shs)
                 computeColorFromSH_bwd(idx, in->D, M, in->means3D, in->campos, in->shs, st->clamped,
@@ -1070,7 +1176,7 @@ void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, 
         /* SURFEL backward.cu:582-637.  fork quirk: W,H are re-derived from focal*tan*2 in float32 */
         const int Wb = (int)(focal_x * in->tanfovx * 2);
         const int Hb = (int)(focal_y * in->tanfovy * 2);
-        const float* transMats = in->cov3D_precomp ? in->cov3D_precomp : st->cov3D;
+        const real* transMats = in->cov3D_precomp ? in->cov3D_precomp : st->cov3D;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -1082,9 +1188,9 @@ void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, 
                 computeColorFromSH_bwd(idx, in->D, M, in->means3D, in->campos, in->shs, st->clamped,
                                        ig->dL_dcolors, ig->dL_dmeans3D, ig->dL_dsh);
             /* densification proxy overwrites dL_dmean2D, SURFEL backward.cu:633-636 */
-            float depth = transMats[9*idx + 8];
-            ig->dL_dmeans2D[3*idx+0] = (float)(ig->dL_dcov3D[9*idx + 2] * depth * 0.5 * (float)Wb);
-            ig->dL_dmeans2D[3*idx+1] = (float)(ig->dL_dcov3D[9*idx + 5] * depth * 0.5 * (float)Hb);
+            real depth = transMats[9*idx + 8];
+            ig->dL_dmeans2D[3*idx+0] = (real)(ig->dL_dcov3D[9*idx + 2] * depth * 0.5 * (real)Wb);
+            ig->dL_dmeans2D[3*idx+1] = (real)(ig->dL_dcov3D[9*idx + 5] * depth * 0.5 * (real)Hb);
         }
     }
 }
@@ -1096,19 +1202,19 @@ void ref_get_point_list(const ref_state* st, uint32_t* out) { memcpy(out, st->po
 void ref_get_keys(const ref_state* st, uint64_t* out) { memcpy(out, st->keys, (size_t)st->R * 8); }
 void ref_get_ranges(const ref_state* st, uint32_t* out) { memcpy(out, st->ranges, (size_t)st->T * 8); }
 void ref_get_tiles_touched(const ref_state* st, uint32_t* out) { memcpy(out, st->tiles_touched, (size_t)st->P * 4); }
-void ref_get_geom(const ref_state* st, float* depths, float* means2D, float* conic_opacity, float* rgb, float* cov)
+void ref_get_geom(const ref_state* st, real* depths, real* means2D, real* conic_opacity, real* rgb, real* cov)
 {
     size_t P = (size_t)st->P;
-    if (depths) memcpy(depths, st->depths, P*4);
-    if (means2D) memcpy(means2D, st->means2D, P*8);
-    if (conic_opacity) memcpy(conic_opacity, st->conic_opacity, P*16);
-    if (rgb) memcpy(rgb, st->rgb, P*12);
-    if (cov) memcpy(cov, st->cov3D, P*(st->variant == REF_SURFEL ? 9 : 6)*4);
+    if (depths) memcpy(depths, st->depths, P*RS);
+    if (means2D) memcpy(means2D, st->means2D, P*2*RS);
+    if (conic_opacity) memcpy(conic_opacity, st->conic_opacity, P*4*RS);
+    if (rgb) memcpy(rgb, st->rgb, P*3*RS);
+    if (cov) memcpy(cov, st->cov3D, P*(st->variant == REF_SURFEL ? 9 : 6)*RS);
 }
-void ref_get_image_state(const ref_state* st, float* final_T, uint32_t* n_contrib)
+void ref_get_image_state(const ref_state* st, real* final_T, uint32_t* n_contrib)
 {
     size_t N = (size_t)st->N;
-    if (final_T) memcpy(final_T, st->final_T, N * (st->variant == REF_SURFEL ? 3 : 1) * 4);
+    if (final_T) memcpy(final_T, st->final_T, N * (st->variant == REF_SURFEL ? 3 : 1) * RS);
     if (n_contrib) memcpy(n_contrib, st->n_contrib, N * (st->variant == REF_SURFEL ? 2 : 1) * 4);
 }
 
@@ -1118,8 +1224,8 @@ void ref_visible_filter(const ref_inputs* in, int32_t* radii)
 {
     const int P = in->P, W = in->W, H = in->H;
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
-    const float focal_y = H / (2.0f * in->tanfovy);
-    const float focal_x = W / (2.0f * in->tanfovx);
+    const real focal_y = H / (2.0f * in->tanfovy);
+    const real focal_x = W / (2.0f * in->tanfovx);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -1128,19 +1234,19 @@ void ref_visible_filter(const ref_inputs* in, int32_t* radii)
         f3 p_view;
         if (!in_frustum(idx, in->means3D, in->viewmatrix, &p_view)) continue;
         f3 p_orig = { in->means3D[3*idx], in->means3D[3*idx+1], in->means3D[3*idx+2] };
-        float ph[4]; transformPoint4x4(p_orig, in->projmatrix, ph);
-        float p_w = 1.0f / (ph[3] + 0.0000001f);
-        float cov3Dl[6]; const float* cov3D;
+        real ph[4]; transformPoint4x4(p_orig, in->projmatrix, ph);
+        real p_w = 1.0f / (ph[3] + 0.0000001f);
+        real cov3Dl[6]; const real* cov3D;
         if (in->cov3D_precomp) cov3D = in->cov3D_precomp + 6*idx;
         else { computeCov3D(in->scales + 3*idx, in->scale_modifier, in->rotations + 4*idx, cov3Dl); cov3D = cov3Dl; }
-        float cov[3];
+        real cov[3];
         computeCov2D(p_orig, focal_x, focal_y, in->tanfovx, in->tanfovy, cov3D, in->viewmatrix, cov, NULL, NULL, NULL, NULL, NULL);
-        float det = (cov[0] * cov[2] - cov[1] * cov[1]);
+        real det = (cov[0] * cov[2] - cov[1] * cov[1]);
         if (det == 0.0f) continue;
-        float mid = 0.5f * (cov[0] + cov[2]);
-        float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-        float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-        float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        real mid = 0.5f * (cov[0] + cov[2]);
+        real lambda1 = mid + R_sqrt(R_fmax(0.1f, mid * mid - det));
+        real lambda2 = mid - R_sqrt(R_fmax(0.1f, mid * mid - det));
+        real my_radius = R_ceil(3.f * R_sqrt(R_fmax(lambda1, lambda2)));
         f2 pi = { ndc2Pix(ph[0] * p_w, W), ndc2Pix(ph[1] * p_w, H) };
         uint32_t rmin[2], rmax[2];
         getRect(pi, (int)my_radius, gx, gy, rmin, rmax);
@@ -1150,7 +1256,7 @@ void ref_visible_filter(const ref_inputs* in, int32_t* radii)
 }
 
 /* 3DGS rasterizer_impl.cu:54-66,141-153 */
-void ref_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
+void ref_mark_visible(int32_t P, const real* means3D, const real* viewmatrix, const real* projmatrix, uint8_t* present)
 {
     (void)projmatrix;
     for (int i = 0; i < P; i++) { f3 pv; present[i] = (uint8_t)in_frustum(i, means3D, viewmatrix, &pv); }

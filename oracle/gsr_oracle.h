@@ -24,58 +24,88 @@
 extern "C" {
 #endif
 
+/* arithmetic type of the rasterizer entry points: float (default build, libgsr_oracle.so / _fma.so) or double
+   (-DGSR_REAL_IS_DOUBLE=1, libgsr_oracle_f64.so: every `real` array below is then float64) */
+#if GSR_REAL_IS_DOUBLE
+typedef double real;
+#else
+typedef float real;
+#endif
+
 enum { REF_EWA = 0, REF_SURFEL = 1, REF_PLANE = 2 };
 
 typedef struct ref_inputs {
     int32_t P, D, M;          /* #gaussians, active SH degree, SH coefficients per gaussian (0 = none) */
     int32_t W, H;
-    float tanfovx, tanfovy;
-    float scale_modifier;
+    real tanfovx, tanfovy;
+    real scale_modifier;
     int32_t prefiltered;
     int32_t render_geo;       /* PLANE only */
-    const float* bg;          /* [3] */
-    const float* viewmatrix;  /* [16] row-vector convention (p_view = [p 1] * V) */
-    const float* projmatrix;  /* [16] */
-    const float* campos;      /* [3] */
-    const float* means3D;     /* [P,3] */
-    const float* shs;         /* [P,M,3] or NULL */
-    const float* colors_precomp; /* [P,3] or NULL */
-    const float* opacities;   /* [P] */
-    const float* scales;      /* [P,3] (SURFEL [P,2]) or NULL */
-    const float* rotations;   /* [P,4] wxyz or NULL */
-    const float* cov3D_precomp; /* [P,6] (SURFEL: transMat [P,9]) or NULL */
-    const float* all_map;     /* PLANE [P,5] or NULL */
+    const real* bg;          /* [3] */
+    const real* viewmatrix;  /* [16] row-vector convention (p_view = [p 1] * V) */
+    const real* projmatrix;  /* [16] */
+    const real* campos;      /* [3] */
+    const real* means3D;     /* [P,3] */
+    const real* shs;         /* [P,M,3] or NULL */
+    const real* colors_precomp; /* [P,3] or NULL */
+    const real* opacities;   /* [P] */
+    const real* scales;      /* [P,3] (SURFEL [P,2]) or NULL */
+    const real* rotations;   /* [P,4] wxyz or NULL */
+    const real* cov3D_precomp; /* [P,6] (SURFEL: transMat [P,9]) or NULL */
+    const real* all_map;     /* PLANE [P,5] or NULL */
+    /* ---- truth-run controls; all NULL / 0 in ordinary runs --------------------------------------------------------------------
+       Integer stages taken from another (float32) run, so that the float64 build walks the SAME culling decisions, radii, sorted
+       instance list and tile ranges and its images / gradients are comparable element by element: */
+    const int32_t* ov_radii;         /* [P]   culling + radii */
+    const uint32_t* ov_point_list;   /* [R]   sorted instance list */
+    const uint32_t* ov_ranges;       /* [T,2] tile ranges */
+    int32_t ov_R;
+    /* Gate robustness of every pixel (outputs): a running first-order float32 rounding-error bound is carried beside every quantity
+       that feeds a discrete decision of the blend loop; gate_margin = min over the pixel's decisions of |value - threshold| / bound.
+       > 1: every correct float32 evaluation of the reference's formulas takes the same decisions at this pixel (robust);
+       <= 1: a 1-ulp-level difference may flip the decision named by gate_id on splat gate_splat (fragile). */
+    real* gate_margin;               /* [H*W] or NULL */
+    int32_t* gate_id;                /* [H*W] REF_GATE_* */
+    int32_t* gate_splat;             /* [H*W] */
+    real* splat_noise;               /* [P] or NULL: max over the splat's evaluated pairs of the relative float32 error bound of alpha */
 } ref_inputs;
 
+enum { REF_GATE_NONE = 0, REF_GATE_POWER = 1,   /* power > 0 */
+       REF_GATE_ALPHA = 2,                      /* alpha < 1/255 */
+       REF_GATE_TERMINATE = 3,                  /* T (1 - alpha) < 1e-4 */
+       REF_GATE_HALF = 4,                       /* T > 0.5 (median depth / observe count) */
+       REF_GATE_RHO = 5,                        /* SURFEL rho3d <= rho2d */
+       REF_GATE_NEAR = 6 };                     /* SURFEL depth < near */
+
 typedef struct ref_out_grads {      /* dL/d(outputs); NULL pointers are treated as zeros */
-    const float* dL_dcolor;         /* [3,H,W] */
-    const float* dL_dothers;        /* SURFEL [11,H,W] */
-    const float* dL_dout_all_map;   /* PLANE [5,H,W] */
-    const float* dL_dplane_depth;   /* PLANE [1,H,W] */
+    const real* dL_dcolor;         /* [3,H,W] */
+    const real* dL_dothers;        /* SURFEL [11,H,W] */
+    const real* dL_dout_all_map;   /* PLANE [5,H,W] */
+    const real* dL_dplane_depth;   /* PLANE [1,H,W] */
 } ref_out_grads;
 
 typedef struct ref_in_grads {       /* all caller-allocated, zero-filled by the callee first */
-    float* dL_dmeans3D;     /* [P,3] */
-    float* dL_dmeans2D;     /* [P,3] */
-    float* dL_dmeans2D_abs; /* PLANE [P,3] or NULL */
-    float* dL_dcolors;      /* [P,3] */
-    float* dL_dopacity;     /* [P] */
-    float* dL_dcov3D;       /* [P,6]  (SURFEL: dL_dtransMat [P,9]) */
-    float* dL_dsh;          /* [P,M,3] or NULL when M==0 */
-    float* dL_dscales;      /* [P,3] (SURFEL [P,2]) */
-    float* dL_drotations;   /* [P,4] */
-    float* dL_dall_map;     /* PLANE [P,5] or NULL */
-    float* dL_dconic;       /* EWA/PLANE [P,4]; SURFEL: dL_dnormal [P,3] -- intermediate, exposed for tests */
+    real* dL_dmeans3D;     /* [P,3] */
+    real* dL_dmeans2D;     /* [P,3] */
+    real* dL_dmeans2D_abs; /* PLANE [P,3] or NULL */
+    real* dL_dcolors;      /* [P,3] */
+    real* dL_dopacity;     /* [P] */
+    real* dL_dcov3D;       /* [P,6]  (SURFEL: dL_dtransMat [P,9]) */
+    real* dL_dsh;          /* [P,M,3] or NULL when M==0 */
+    real* dL_dscales;      /* [P,3] (SURFEL [P,2]) */
+    real* dL_drotations;   /* [P,4] */
+    real* dL_dall_map;     /* PLANE [P,5] or NULL */
+    real* dL_dconic;       /* EWA/PLANE [P,4]; SURFEL: dL_dnormal [P,3] -- intermediate, exposed for tests */
 } ref_in_grads;
 
 typedef struct ref_state ref_state;
 
 /* forward: returns an opaque state (owned by the oracle; free with ref_free) holding geometry/binning/image state */
 ref_state* ref_forward(int variant, const ref_inputs* in,
-                       float* out_color /*[3,H,W]*/, int32_t* radii /*[P]*/,
-                       float* out_others /*SURFEL [11,H,W]*/,
-                       int32_t* out_observe /*PLANE [P]*/, float* out_all_map /*PLANE [5,H,W]*/,
-                       float* out_plane_depth /*PLANE [1,H,W]*/);
+                       real* out_color /*[3,H,W]*/, int32_t* radii /*[P]*/,
+                       real* out_others /*SURFEL [11,H,W]*/,
+                       int32_t* out_observe /*PLANE [P]*/, real* out_all_map /*PLANE [5,H,W]*/,
+                       real* out_plane_depth /*PLANE [1,H,W]*/);
 void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, ref_in_grads* ig);
 void ref_free(ref_state* st);
 
@@ -86,14 +116,14 @@ void     ref_get_point_list(const ref_state* st, uint32_t* out /*[R]*/);
 void     ref_get_keys(const ref_state* st, uint64_t* out /*[R] sorted keys*/);
 void     ref_get_ranges(const ref_state* st, uint32_t* out /*[T,2]*/);
 void     ref_get_tiles_touched(const ref_state* st, uint32_t* out /*[P]*/);
-void     ref_get_geom(const ref_state* st, float* depths /*[P]*/, float* means2D /*[P,2]*/,
-                      float* conic_opacity /*[P,4] (SURFEL normal_opacity)*/, float* rgb /*[P,3]*/,
-                      float* cov3D_or_transmat /*[P,6] or [P,9]*/);
-void     ref_get_image_state(const ref_state* st, float* final_T /*[N] (SURFEL [3N])*/,
+void     ref_get_geom(const ref_state* st, real* depths /*[P]*/, real* means2D /*[P,2]*/,
+                      real* conic_opacity /*[P,4] (SURFEL normal_opacity)*/, real* rgb /*[P,3]*/,
+                      real* cov3D_or_transmat /*[P,6] or [P,9]*/);
+void     ref_get_image_state(const ref_state* st, real* final_T /*[N] (SURFEL [3N])*/,
                              uint32_t* n_contrib /*[N] (SURFEL [2N])*/);
 
 void ref_visible_filter(const ref_inputs* in, int32_t* radii);   /* scaffold-filter */
-void ref_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+void ref_mark_visible(int32_t P, const real* means3D, const real* viewmatrix, const real* projmatrix,
                       uint8_t* present);
 
 /* in-repo TSDF definition (gssr/utils/mesh_utils.py:195-246), one frame, updates tsdf/weight/rgb in place */

@@ -16,31 +16,43 @@ EWA, SURFEL, PLANE = 0, 1, 2
 VARIANT_ID = {"ewa": EWA, "surfel": SURFEL, "plane": PLANE}
 
 _fp = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+GATE_NAMES = {0: "none", 1: "power>0", 2: "alpha<1/255", 3: "T(1-alpha)<1e-4", 4: "T>0.5", 5: "rho3d<=rho2d", 6: "depth<near"}     # gsr_oracle.h REF_GATE_*
 
 
-class RefInputs(C.Structure):
-    _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
-                ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
-                ("prefiltered", C.c_int32), ("render_geo", C.c_int32),
-                ("bg", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp), ("means3D", _fp),
-                ("shs", _fp), ("colors_precomp", _fp), ("opacities", _fp), ("scales", _fp), ("rotations", _fp),
-                ("cov3D_precomp", _fp), ("all_map", _fp)]
+def _structs(ct):
+    """ctypes mirrors of gsr_oracle.h for the arithmetic type `real` = ct (c_float: libgsr_oracle.so / _fma.so, c_double: _f64.so)."""
+    rp = C.POINTER(ct)
+
+    class RefInputs(C.Structure):
+        _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+                    ("tanfovx", ct), ("tanfovy", ct), ("scale_modifier", ct),
+                    ("prefiltered", C.c_int32), ("render_geo", C.c_int32),
+                    ("bg", rp), ("viewmatrix", rp), ("projmatrix", rp), ("campos", rp), ("means3D", rp),
+                    ("shs", rp), ("colors_precomp", rp), ("opacities", rp), ("scales", rp), ("rotations", rp),
+                    ("cov3D_precomp", rp), ("all_map", rp),
+                    ("ov_radii", _i32p), ("ov_point_list", _u32p), ("ov_ranges", _u32p), ("ov_R", C.c_int32),
+                    ("gate_margin", rp), ("gate_id", _i32p), ("gate_splat", _i32p), ("splat_noise", rp)]
+
+    class RefOutGrads(C.Structure):
+        _fields_ = [("dL_dcolor", rp), ("dL_dothers", rp), ("dL_dout_all_map", rp), ("dL_dplane_depth", rp)]
+
+    class RefInGrads(C.Structure):
+        _fields_ = [(n, rp) for n in ("dL_dmeans3D", "dL_dmeans2D", "dL_dmeans2D_abs", "dL_dcolors", "dL_dopacity",
+                                      "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dall_map", "dL_dconic")]
+    return RefInputs, RefOutGrads, RefInGrads
 
 
-class RefOutGrads(C.Structure):
-    _fields_ = [("dL_dcolor", _fp), ("dL_dothers", _fp), ("dL_dout_all_map", _fp), ("dL_dplane_depth", _fp)]
-
-
-class RefInGrads(C.Structure):
-    _fields_ = [(n, _fp) for n in ("dL_dmeans3D", "dL_dmeans2D", "dL_dmeans2D_abs", "dL_dcolors", "dL_dopacity",
-                                   "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dall_map", "dL_dconic")]
+RefInputs, RefOutGrads, RefInGrads = _structs(C.c_float)
+RefInputs64, RefOutGrads64, RefInGrads64 = _structs(C.c_double)
 
 
 def build(force=False):
     so = os.path.join(ORACLE_DIR, "libgsr_oracle.so")
-    so2 = os.path.join(ORACLE_DIR, "libgsr_oracle_fma.so")
+    others = [os.path.join(ORACLE_DIR, f) for f in ("libgsr_oracle_fma.so", "libgsr_oracle_f64.so")]
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
-    if force or not os.path.exists(so) or not os.path.exists(so2) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+    if force or not all(os.path.exists(q) for q in [so] + others) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so
 
@@ -61,6 +73,29 @@ class fma_twin:
     def __exit__(self, *a):
         global _LIB, _FMA
         _LIB, _FMA = self.saved
+
+
+_LIB64 = None
+
+
+def lib64():
+    """libgsr_oracle_f64.so: the same sources with the rasterizer's arithmetic in double (the truth of the parity tests)."""
+    global _LIB64
+    if _LIB64 is None:
+        build()
+        L = C.CDLL(os.path.join(ORACLE_DIR, "libgsr_oracle_f64.so"))
+        dp = C.POINTER(C.c_double)
+        L.ref_forward.restype = C.c_void_p
+        L.ref_forward.argtypes = [C.c_int, C.POINTER(RefInputs64), dp, _i32p, dp, _i32p, dp, dp]
+        L.ref_backward.restype = None
+        L.ref_backward.argtypes = [C.c_void_p, C.POINTER(RefInputs64), C.POINTER(RefOutGrads64), C.POINTER(RefInGrads64)]
+        L.ref_free.argtypes = [C.c_void_p]
+        L.ref_num_rendered.argtypes = [C.c_void_p]; L.ref_num_rendered.restype = C.c_int32
+        L.ref_num_tiles.argtypes = [C.c_void_p]; L.ref_num_tiles.restype = C.c_int32
+        L.ref_get_image_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_get_geom.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        _LIB64 = L
+    return _LIB64
 
 
 def lib():
@@ -102,35 +137,44 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _f64(a):
+    """float32 VALUES widened to float64: the truth run starts from exactly the numbers the float32 implementations get."""
+    a = _f32(a)
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
 def _p(a):
-    return a.ctypes.data_as(_fp) if a is not None else None
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(C.c_double) if a.dtype == np.float64 else _fp)
 
 
 class _Keep:
     """Holds numpy arrays alive next to the ctypes struct that points into them."""
 
-    def __init__(self):
+    def __init__(self, wide=False):
         self.arrs = []
+        self.wide = wide
 
     def f(self, a):
-        a = _f32(a)
+        a = _f64(a) if self.wide else _f32(a)
         if a is not None:
             self.arrs.append(a)
         return _p(a)
 
 
-def make_inputs(scene, variant):
-    """scene: dict with the keyword tensors of the reference rasterizer call (see tests/scenes.py)."""
-    k = _Keep()
-    ri = RefInputs()
+def make_inputs(scene, variant, wide=False):
+    """scene: dict with the keyword tensors of the reference rasterizer call (see tests/scenes.py).  wide: the float64 build's struct."""
+    k = _Keep(wide)
+    ri = RefInputs64() if wide else RefInputs()
     means3D = _f32(scene["means3D"])
     ri.P = means3D.shape[0]
     shs = scene.get("shs")
     ri.M = 0 if shs is None else int(np.asarray(shs).shape[1])
     ri.D = int(scene.get("sh_degree", 0))
     ri.W = int(scene["W"]); ri.H = int(scene["H"])
-    ri.tanfovx = float(scene["tanfovx"]); ri.tanfovy = float(scene["tanfovy"])
-    ri.scale_modifier = float(scene.get("scale_modifier", 1.0))
+    ri.tanfovx = float(np.float32(scene["tanfovx"])); ri.tanfovy = float(np.float32(scene["tanfovy"]))     # the float32 values in both builds
+    ri.scale_modifier = float(np.float32(scene.get("scale_modifier", 1.0)))
     ri.prefiltered = 0
     ri.render_geo = int(bool(scene.get("render_geo", True)))
     ri.bg = k.f(scene["bg"]); ri.viewmatrix = k.f(scene["viewmatrix"]); ri.projmatrix = k.f(scene["projmatrix"])
@@ -215,6 +259,82 @@ class Forward:
     def close(self):
         if self.st:
             lib().ref_free(self.st); self.st = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Truth:
+    """The float64 build of the same oracle sources on the same inputs, walking the INTEGER stages of a float32 run `f32` (an oracle.Forward:
+    culling decisions, radii, sorted instance list, tile ranges), so that every image / gradient element is the float64 value of exactly the
+    computation the float32 implementations perform.  Besides the outputs it reports how robust the discrete gate decisions of every pixel
+    are against float32 rounding (gsr_oracle.h ref_inputs.gate_margin):
+        margin  [H,W]  min over the pixel's gate decisions of |value - threshold| / (first-order float32 error bound); > 1 = robust
+        gate    [H,W]  which decision is the closest one (GATE_NAMES), splat [H,W] the Gaussian it concerns
+        splat_noise [P] max over a Gaussian's evaluated pairs of the relative float32 error bound of its alpha (conditioning of the splat)"""
+
+    def __init__(self, scene, variant, f32):
+        if isinstance(variant, str):
+            variant = VARIANT_ID[variant]
+        L = lib64()
+        self.variant = variant
+        self.ri = ri = make_inputs(scene, variant, wide=True)
+        P, W, H = ri.P, ri.W, ri.H
+        self.P, self.W, self.H = P, W, H
+        self._ov = (np.ascontiguousarray(f32.radii, np.int32), np.ascontiguousarray(f32.point_list(), np.uint32), np.ascontiguousarray(f32.ranges(), np.uint32))
+        ri.ov_radii = self._ov[0].ctypes.data_as(_i32p); ri.ov_point_list = self._ov[1].ctypes.data_as(_u32p)
+        ri.ov_ranges = self._ov[2].ctypes.data_as(_u32p); ri.ov_R = int(self._ov[1].shape[0])
+        self.margin = np.zeros((H, W), np.float64); self.gate = np.zeros((H, W), np.int32); self.splat = np.zeros((H, W), np.int32)
+        self.splat_noise = np.zeros((P,), np.float64)
+        ri.gate_margin = _p(self.margin); ri.gate_id = self.gate.ctypes.data_as(_i32p); ri.gate_splat = self.splat.ctypes.data_as(_i32p)
+        ri.splat_noise = _p(self.splat_noise)
+        self.color = np.zeros((3, H, W), np.float64)
+        self.radii = np.zeros((P,), np.int32)
+        self.others = np.zeros((11, H, W), np.float64) if variant == SURFEL else None
+        self.observe = np.zeros((P,), np.int32) if variant == PLANE else None
+        self.out_all_map = np.zeros((5, H, W), np.float64) if variant == PLANE else None
+        self.plane_depth = np.zeros((1, H, W), np.float64) if variant == PLANE else None
+        self.st = L.ref_forward(variant, C.byref(ri), _p(self.color), self.radii.ctypes.data_as(_i32p), _p(self.others),
+                                self.observe.ctypes.data_as(_i32p) if self.observe is not None else None, _p(self.out_all_map), _p(self.plane_depth))
+
+    def image_state(self):
+        k = 3 if self.variant == SURFEL else 1
+        k2 = 2 if self.variant == SURFEL else 1
+        ft = np.zeros((k, self.H, self.W), np.float64); nc = np.zeros((k2, self.H, self.W), np.uint32)
+        lib64().ref_get_image_state(self.st, ft.ctypes.data, nc.ctypes.data)
+        return ft, nc
+
+    def backward(self, dL_dcolor=None, dL_dothers=None, dL_dout_all_map=None, dL_dplane_depth=None):
+        P, M = self.P, self.ri.M
+        surf = self.variant == SURFEL
+        k = _Keep(True)
+        og = RefOutGrads64(k.f(dL_dcolor), k.f(dL_dothers), k.f(dL_dout_all_map), k.f(dL_dplane_depth))
+        z = lambda *shape: np.zeros(shape, np.float64)
+        g = dict(dL_dmeans3D=z(P, 3), dL_dmeans2D=z(P, 3), dL_dmeans2D_abs=z(P, 3), dL_dcolors=z(P, 3), dL_dopacity=z(P, 1),
+                 dL_dcov3D=z(P, 9 if surf else 6), dL_dsh=z(P, max(M, 1), 3), dL_dscales=z(P, 2 if surf else 3), dL_drotations=z(P, 4),
+                 dL_dall_map=z(P, 5), dL_dconic=z(P, 3 if surf else 4))
+        ig = RefInGrads64(*[_p(g[n]) for n, _ in RefInGrads64._fields_])
+        lib64().ref_backward(self.st, C.byref(self.ri), C.byref(og), C.byref(ig))
+        if M == 0:
+            g["dL_dsh"] = z(P, 0, 3)
+        return g
+
+    def fragile(self):
+        """[H,W] bool: pixels where some gate decision is within its float32 error bound of flipping."""
+        return self.margin <= 1.0
+
+    def close(self):
+        if self.st:
+            lib64().ref_free(self.st); self.st = None
 
     def __enter__(self):
         return self

@@ -421,54 +421,52 @@ FULL_CASES = [
 ]
 
 
+def _hip_outputs(hr, variant, sc, og):
+    """The HIP library's results in the layout tests/parity_truth.py compares (integer stages included)."""
+    st = hr.run_raw(variant, sc)
+    res = hr.run(variant, sc, og)
+    cand = dict(color=st["color"], final_T=st["final_T"], n_contrib=st["n_contrib"], grads=res["grads"])
+    if variant == "surfel":
+        cand["others"] = st["others"]
+    if variant == "plane":
+        cand.update(all_map=st["all_map"], plane_depth=st["plane_depth"], observe=st["observe"])
+    return st, cand
+
+
+def _check_against_truth(hr, variant, cm, sc, og):
+    """Integer stages bit-exact against the float32 oracle; everything else against the FLOAT64 truth (tests/parity_truth.py): exact indices and
+    the nominal 1e-4 on every pixel whose gate decisions are robust under float32 rounding, every other mismatch attributed to a named gate,
+    gradients within max(1e-3, 2 x the float32 oracle's own error vs the truth)."""
+    import parity_truth as pt
+    f32, fma, truth, ints = pt.run_oracles(sc, variant, og)
+    st, cand = _hip_outputs(hr, variant, sc, og)
+    assert st["R"] == ints["R"]
+    assert np.array_equal(st["radii"], ints["radii"])
+    assert np.array_equal(st["tiles_touched"], ints["tiles_touched"])
+    assert np.array_equal(st["point_list"], ints["point_list"])
+    rr = ints["ranges"]; touched = rr[:, 1] > rr[:, 0]
+    assert np.array_equal(st["ranges"][touched], rr[touched])
+    return pt.check_case(variant, cm, cand, f32, fma, truth)
+
+
 @pytest.mark.parametrize("variant,cm,seed,pose", FULL_CASES)
 def test_full_size_oracle_parity(variant, cm, seed, pose):
-    """Integer stages bit-exact; images <= 1e-4 and gradients <= 1e-3 against the oracle, each bar relaxed at most to 1.5 x the
-    oracle's own FMA-contraction self-difference measured on the same case (the noise floor of the reference's formulas in fp32)."""
+    """BASELINE size (P = 300 000, 1920x1080).  Round 3: the bars are no longer relaxed to the oracle's FMA self-difference -- the candidate is
+    compared with a float64 evaluation of the same computation, see _check_against_truth."""
     hr = _hiprun()
     P, W, H = 300000, 1920, 1080
     sc = scenes.make_scene(variant, P, W, H, seed=seed, color_mode=cm, pose=pose, bg=(0.1, 0.3, 0.2) if seed else (0.0, 0.0, 0.0))
     og = scenes.random_out_grads(variant, W, H, seed=seed)           # SURVEY 8d: N(0,1)/N
-    with oracle.fma_twin():
-        with oracle.Forward(sc, variant) as f2:
-            g2 = f2.backward(**og)
-            fl = dict(color=f2.color.copy(), others=None if f2.others is None else f2.others.copy(),
-                      all_map=None if f2.out_all_map is None else f2.out_all_map.copy(),
-                      plane_depth=None if f2.plane_depth is None else f2.plane_depth.copy(), final_T=f2.image_state()[0])
-    with oracle.Forward(sc, variant) as f:
-        g = f.backward(**og)
-        st = hr.run_raw(variant, sc)
-        assert st["R"] == f.R
-        assert np.array_equal(st["radii"], f.radii)
-        assert np.array_equal(st["tiles_touched"], f.tiles_touched())
-        assert np.array_equal(st["point_list"], f.point_list())
-        rr = f.ranges(); touched = rr[:, 1] > rr[:, 0]
-        assert np.array_equal(st["ranges"][touched], rr[touched])
-        ft, nc = f.image_state()
-        _ncontrib_close(st["n_contrib"][0], nc[0], st["final_T"][0], ft[0])
-        _img_close(st["color"], f.color, floor=fl["color"])
-        _img_close(st["final_T"][0], ft[0], floor=fl["final_T"][0])
-        if variant == "surfel":
-            for ch in (0, 1, 2, 3, 4, 6):
-                _img_close(st["others"][ch], f.others[ch], floor=fl["others"][ch])
-            # median depth / index / normal sit behind the T > 0.5 gate: equal wherever the median splat agrees
-            same = st["others"][7] == f.others[7]
-            assert same.mean() >= 1 - max(1e-4, 1.5 * float((fl["others"][7] != f.others[7]).mean()))
-            for ch in (5, 8, 9, 10):
-                assert (np.abs(st["others"][ch] - f.others[ch])[same] > 1e-4 * max(1.0, np.abs(f.others[ch]).max())).mean() <= 1e-5
-        if variant == "plane":
-            _counts_close(st["observe"], f.observe)
-            _img_close(st["all_map"], f.out_all_map, floor=fl["all_map"])
-            _img_close(st["plane_depth"], f.plane_depth, frac=1e-3, floor=fl["plane_depth"])
-        res = hr.run(variant, sc, og)
-    gg = res["grads"]
-    pairs = [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"),
-             ("dL_dopacities", "dL_dopacity"), ("dL_dmeans2D", "dL_dmeans2D")]
-    pairs.append(("dL_dshs", "dL_dsh") if cm == "sh" else ("dL_dcolors_precomp", "dL_dcolors"))
-    if variant == "plane":
-        pairs += [("dL_dall_map", "dL_dall_map"), ("dL_dmeans2D_abs", "dL_dmeans2D_abs")]
-    for a, b in pairs:
-        _grad_close(gg[a], g[b], floor=g2[b])
+    rep = _check_against_truth(hr, variant, cm, sc, og)
+    assert rep["robust_pixel_fraction"] > 0.95
+
+
+@pytest.mark.parametrize("variant,cm,P,W,H,pose", CASES)
+def test_small_cases_against_the_float64_truth(variant, cm, P, W, H, pose):
+    hr = _hiprun()
+    sc = scenes.make_scene(variant, P, W, H, seed=11, color_mode=cm, bg=(0.2, 0.4, 0.6), pose=pose)
+    og = scenes.random_out_grads(variant, W, H, seed=11, scale=1.0)
+    _check_against_truth(hr, variant, cm, sc, og)
 
 
 def test_pixel_parallel_backward_kept_switchable():
