@@ -38,7 +38,7 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug)
 #include <vector>
 struct ProfRec { int label; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
-static std::atomic<bool> g_prof_on{false};
+static std::atomic<uint32_t> g_prof_on{0};      // bit i: stage i is timed
 static std::vector<ProfRec> g_prof;
 static std::vector<ProfRec> g_prof_free;
 static double g_prof_ms[GSR_PROF_LABELS];
@@ -57,7 +57,7 @@ static void prof_drain()      // caller holds g_prof_mu
 }
 struct ProfScope {
     ProfRec r; bool on; hipStream_t s;
-    ProfScope(int label, hipStream_t s_) : on(g_prof_on.load(std::memory_order_relaxed)), s(s_)
+    ProfScope(int label, hipStream_t s_) : on((g_prof_on.load(std::memory_order_relaxed) >> label) & 1u), s(s_)
     {
         if (!on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -79,7 +79,10 @@ extern "C" int gsr_profile_enable(int32_t enable)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     prof_drain();
-    g_prof_on = enable != 0;
+    // enable: 0 = off, 1 = every stage (the original meaning), otherwise bit (8 + i) selects stage i alone -- an event pair costs ~10 us of
+    // stream idle time per stage boundary (profiles/r03_timeline.json), so a caller that wants ONE kernel's duration inside a timed
+    // region enables only that stage
+    g_prof_on = enable == 0 ? 0u : (enable == 1 ? 0xFFu : (((uint32_t)enable >> 8) & 0xFFu));
     for (int i = 0; i < GSR_PROF_LABELS; i++) { g_prof_ms[i] = 0; g_prof_n[i] = 0; }
     return 0;
 }
@@ -323,12 +326,43 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
     return 0;
 }
 
+// No host synchronisation, no host-visible state: every call is a fixed sequence of launches on `stream` whose shapes depend only on cfg and the
+// arena capacities -- the form a HIP graph can record and replay.
+__global__ void k_forward_status(const uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ status)
+{
+    const uint32_t R = counters[0];
+    status[0] = R;
+    if (R > cap) status[1] = 1u;
+}
+extern "C" int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                                 void* binning, size_t binning_bytes, void* img, size_t img_bytes, int32_t* radii,
+                                 const gsr_outputs* out, uint32_t* status_dev, void* stream)
+{
+    if (check_cfg(cfg, in)) return 1;
+    if (!status_dev) { gsr_set_error("gsr_forward_async: status_dev must be provided"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (cfg->P == 0) { GSR_CHECK(hipMemsetAsync(status_dev, 0, sizeof(uint32_t), s), "status"); return 0; }
+    GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
+    if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
+    const uint32_t cap = gsr_binning_capacity(cfg->variant, binning_bytes, cfg->W, cfg->H);
+    if (cap == 0) { gsr_set_error("binning buffer too small"); return 1; }
+    BinView b = gsr_carve_bin(cfg->variant, cap, cfg->W, cfg->H, binning);
+    ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, img);
+    if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
+    if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1;
+    if (gsr_launch_depth_order(cfg, g, nullptr, s)) return 1;
+    hipLaunchKernelGGL(k_forward_status, dim3(1), dim3(1), 0, s, g.counters, cap, status_dev);
+    if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s)) return 1;
+    if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ backward
-extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii,
-                            const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
-                            const void* img, size_t img_bytes, uint32_t num_rendered,
-                            void* scratch, size_t scratch_bytes,
-                            const gsr_out_grads* og, const gsr_in_grads* ig, void* stream)
+extern "C" int gsr_backward_ex(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii,
+                               const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                               const void* img, size_t img_bytes, uint32_t num_rendered,
+                               void* scratch, size_t scratch_bytes,
+                               const gsr_out_grads* og, const gsr_in_grads* ig, uint32_t flags, void* stream)
 {
     if (check_cfg(cfg, in)) return 1;
     (void)geom_bytes; (void)img_bytes;
@@ -342,13 +376,22 @@ extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int3
                               const_cast<void*>(binning));
     ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img));
     float* acc = reinterpret_cast<float*>(scratch);
-    { ProfScope ps(GSR_PROF_BWD_MEMSET, s); GSR_CHECK(hipMemsetAsync(acc, 0, need, s), "memset acc"); }
+    if (!(flags & GSR_BWD_SCRATCH_IS_ZERO)) { ProfScope ps(GSR_PROF_BWD_MEMSET, s); GSR_CHECK(hipMemsetAsync(acc, 0, need, s), "memset acc"); }
     if (num_rendered > 0) {
         ProfScope ps(GSR_PROF_BLEND_BWD, s);
         if (gsr_launch_blend_bwd(cfg, in, g, b, im, og, acc, s)) return 1;
     }
-    { ProfScope ps(GSR_PROF_PREPROCESS_BWD, s); if (gsr_launch_preprocess_bwd(cfg, in, radii, g, acc, ig, s)) return 1; }
+    { ProfScope ps(GSR_PROF_PREPROCESS_BWD, s); if (gsr_launch_preprocess_bwd(cfg, in, radii, g, acc, ig, (flags & GSR_BWD_LEAVE_ZERO) != 0, s)) return 1; }
     return 0;
+}
+
+extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii,
+                            const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                            const void* img, size_t img_bytes, uint32_t num_rendered,
+                            void* scratch, size_t scratch_bytes,
+                            const gsr_out_grads* og, const gsr_in_grads* ig, void* stream)
+{
+    return gsr_backward_ex(cfg, in, radii, geom, geom_bytes, binning, binning_bytes, img, img_bytes, num_rendered, scratch, scratch_bytes, og, ig, 0u, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ debug reads

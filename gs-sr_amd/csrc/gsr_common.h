@@ -92,7 +92,7 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
 int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_out_grads* og, float* acc, hipStream_t s);
 int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,
-                              const float* acc, const gsr_in_grads* ig, hipStream_t s);
+                              float* acc, const gsr_in_grads* ig, bool leave_zero, hipStream_t s);
 
 // generic device-wide primitives (gsr_binning.hip)
 // Histogram scratch of the sort: [2 group-histogram buffers of NB * groups words][block histograms NB * nblk], groups = ceil(nblk / 16).

@@ -364,8 +364,16 @@ struct PreBwdParams {
     const uint32_t* clamped;
     const float4* rec;
     const float* acc;
+    float* acc_clear;       // == acc when the accumulator rows are to be left zeroed (gsr_backward_ex GSR_BWD_LEAVE_ZERO), else nullptr
     gsr_in_grads ig;
 };
+// zero one accumulator row (AS floats, 16-byte aligned: AS is a multiple of 4) after the thread has read it
+template <int AS4> __device__ __forceinline__ void clear_acc_row(float* acc_clear, int idx)
+{
+    float4* r = reinterpret_cast<float4*>(acc_clear + (size_t)idx * (AS4 * 4));
+#pragma unroll
+    for (int k = 0; k < AS4; k++) r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 
 // SH backward, 3DGS backward.cu:20-139.  Writes dL_dsh[idx] and returns the view-direction term of dL/dmean.
 __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* sh, float3 mean, float3 campos, uint32_t clamped,
@@ -531,6 +539,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_ewa(PreBwdParams p)
     for (int i = 0; i < 6; i++) ig.dL_dcov3D[6 * idx + i] = dcov[i];
     for (int i = 0; i < 3; i++) ig.dL_dscales[3 * idx + i] = dsc[i];
     for (int i = 0; i < 4; i++) ig.dL_drotations[4 * idx + i] = drot[i];
+    if (p.acc_clear) { if (p.variant == GSR_PLANE) clear_acc_row<GSR_ACC_PLANE / 4>(p.acc_clear, idx); else clear_acc_row<GSR_ACC_EWA / 4>(p.acc_clear, idx); }
 }
 
 // SURFEL backward.cu:450-637
@@ -647,10 +656,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_surfel(PreBwdParams p)
     for (int i = 0; i < 9; i++) ig.dL_dcov3D[9 * idx + i] = dTout[i];
     ig.dL_dscales[2 * idx] = dsc[0]; ig.dL_dscales[2 * idx + 1] = dsc[1];
     for (int i = 0; i < 4; i++) ig.dL_drotations[4 * idx + i] = drot[i];
+    if (p.acc_clear) clear_acc_row<GSR_ACC_SURFEL / 4>(p.acc_clear, idx);
 }
 
 int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,
-                              const float* acc, const gsr_in_grads* ig, hipStream_t s)
+                              float* acc, const gsr_in_grads* ig, bool leave_zero, hipStream_t s)
 {
     PreBwdParams p;
     p.P = cfg->P; p.D = cfg->D; p.M = cfg->M; p.W = cfg->W; p.H = cfg->H; p.variant = cfg->variant;
@@ -660,7 +670,7 @@ int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const in
     p.mod = cfg->scale_modifier;
     p.means3D = in->means3D; p.shs = in->shs; p.scales = in->scales; p.rots = in->rotations; p.cov3D_pre = in->cov3D_precomp;
     p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
-    p.radii = radii; p.clamped = g.clamped; p.rec = g.rec; p.acc = acc; p.ig = *ig;
+    p.radii = radii; p.clamped = g.clamped; p.rec = g.rec; p.acc = acc; p.acc_clear = leave_zero ? acc : nullptr; p.ig = *ig;
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);
     if (cfg->variant == GSR_SURFEL) hipLaunchKernelGGL(k_preprocess_bwd_surfel, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_preprocess_bwd_ewa, grid, block, 0, s, p);

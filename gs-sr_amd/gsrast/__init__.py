@@ -64,7 +64,7 @@ class LodCfg(C.Structure):
 
 
 EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward_scratch_bytes",
-           "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_mark_visible", "gsr_visible_filter",
+           "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_ex", "gsr_forward_async", "gsr_mark_visible", "gsr_visible_filter",
            "gsr_tsdf_integrate", "gsr_tsdf_integrate_dense", "gsr_tsdf_sparse_integrate", "gsr_tsdf_sparse_merge", "gsr_loss_l1_linear", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
            "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward",
            "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_octree_visible",
@@ -101,6 +101,11 @@ def lib():
     L.gsr_backward.restype = C.c_int
     L.gsr_backward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, _vp, sz, _vp, sz, _vp, sz, C.c_uint32, _vp, sz,
                                C.POINTER(OutGrads), C.POINTER(InGrads), _vp]
+    L.gsr_backward_ex.restype = C.c_int
+    L.gsr_backward_ex.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, _vp, sz, _vp, sz, _vp, sz, C.c_uint32, _vp, sz,
+                                  C.POINTER(OutGrads), C.POINTER(InGrads), C.c_uint32, _vp]
+    L.gsr_forward_async.restype = C.c_int
+    L.gsr_forward_async.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, sz, _vp, sz, _vp, C.POINTER(Outputs), _vp, _vp]
     L.gsr_mark_visible.restype = C.c_int
     L.gsr_mark_visible.argtypes = [C.c_int32, _vp, _vp, _vp, _vp, _vp]
     L.gsr_visible_filter.restype = C.c_int
@@ -161,8 +166,15 @@ def lib():
     return L
 
 
-def profile_enable(on=True):
-    lib().gsr_profile_enable(1 if on else 0)
+def profile_enable(on=True, stages=None):
+    """Starts (and resets) / stops the stage profiler.  stages: names out of PROF_LABELS to time only those (each timed stage costs ~10 us
+    of stream idle time per launch: two HIP event records)."""
+    if not on:
+        lib().gsr_profile_enable(0)
+    elif stages is None:
+        lib().gsr_profile_enable(1)
+    else:
+        lib().gsr_profile_enable(sum(1 << PROF_LABELS.index(n) for n in stages) << 8)
 
 
 def profile_read():

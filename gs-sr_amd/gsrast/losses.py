@@ -4,6 +4,22 @@ import torch
 from . import lib, check, ptr, stream_ptr, dev_f32
 
 
+# Zero-initialised scalars for kernels that accumulate a loss value with atomics: one torch.zeros(1024) serves 1024 calls (a fill kernel per
+# call costs ~4 us + a launch gap on a 1 ms iteration).  Every scalar is handed out once; a spent block stays alive through its views.
+_ZEROS = {}
+
+
+def zero_scalar(device):
+    if torch.cuda.is_current_stream_capturing():          # inside a graph the fill has to be part of the graph: replays re-zero it
+        return torch.zeros((), dtype=torch.float32, device=device)
+    ent = _ZEROS.get(device)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = _ZEROS[device] = [torch.zeros(1024, dtype=torch.float32, device=device), 0]
+    v = ent[0][ent[1]]
+    ent[1] += 1
+    return v
+
+
 class _L1PlusLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, color, gt, aux, waux, root=False):
@@ -14,7 +30,7 @@ class _L1PlusLinear(torch.autograd.Function):
         if (a is None) != (w is None) or (a is not None and a.numel() != w.numel()):
             raise RuntimeError("aux and waux must both be given and have the same number of elements")
         dcol = torch.empty_like(c)
-        loss = torch.zeros((), dtype=torch.float32, device=c.device)
+        loss = zero_scalar(c.device)
         check(lib().gsr_loss_l1_linear(c.numel(), ptr(c), ptr(g), ptr(dcol), a.numel() if a is not None else 0, ptr(a), ptr(w),
                                        ptr(loss), stream_ptr(c.device)), "loss_l1_linear")
         ctx.save_for_backward(dcol, w if w is not None else torch.empty(0, device=c.device))

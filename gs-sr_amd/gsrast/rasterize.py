@@ -35,6 +35,65 @@ def _bytes(n, device):
     return torch.empty((max(int(n), 1),), dtype=torch.uint8, device=device)
 
 
+# ---- forward without any host synchronisation (gsr_forward_async): the form a HIP graph can record.  Selected inside `static_capacity(...)`
+# and automatically while the current stream is being captured (torch.cuda.graph).  The binning arena has a FIXED capacity -- the argument, or
+# 1.25 x the running-max hint of earlier (eager) calls -- and the host never learns num_rendered: every such call appends (status, capacity)
+# to a registry the caller inspects whenever it synchronises anyway: status[0] = instances of the last run, status[1] != 0 = a run
+# overflowed the capacity (outputs of that run were incomplete -> raise the capacity and re-run / re-capture; gsrast.graphs does that).
+_ASYNC = threading.local()
+_ASYNC_STATUS = []            # [(status int32[2] tensor, capacity)] of the async forwards issued since async_status_reset()
+
+
+class static_capacity:
+    """with static_capacity(cap=None): rasterizer forwards inside run sync-free against a binning arena of `cap` tile instances."""
+
+    def __init__(self, cap=None):
+        self.cap = cap
+
+    def __enter__(self):
+        self.prev = getattr(_ASYNC, "cap", False)
+        _ASYNC.cap = self.cap if self.cap is not None else True
+        return self
+
+    def __exit__(self, *a):
+        _ASYNC.cap = self.prev
+
+
+def async_status(reset=False):
+    """-> list of (num_rendered, overflowed, capacity) for the sync-free forwards recorded so far (reads the device words: synchronises)."""
+    out = [(int(st[0]), bool(st[1]), cap) for st, cap in ((t.cpu(), c) for t, c in _ASYNC_STATUS)]
+    if reset:
+        _ASYNC_STATUS.clear()
+    return out
+
+
+def async_status_reset():
+    _ASYNC_STATUS.clear()
+
+
+# ---- gradient-accumulator scratch of the backward, kept per (device, stream, variant, P) and left zeroed by the preprocess backward
+# (gsr_backward_ex GSR_BWD_SCRATCH_IS_ZERO | GSR_BWD_LEAVE_ZERO): no 24 MB memset + launch gap per iteration.  GSR_ACC_REUSE=0 disables.
+_ACC_REUSE = os.environ.get("GSR_ACC_REUSE", "1") != "0"
+_ACC_CACHE = {}
+_ACC_LOCK = threading.Lock()
+
+
+def _acc_scratch(L, variant, P, dev):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, variant, P)
+    with _ACC_LOCK:
+        t = _ACC_CACHE.pop(key, None)          # taken out while in use: a concurrent backward on the same key gets its own buffer
+    if t is None:
+        t = torch.zeros((max(int(L.gsr_backward_scratch_bytes(variant, P)), 1),), dtype=torch.uint8, device=dev)
+    return key, t
+
+
+def _acc_release(key, t):
+    with _ACC_LOCK:
+        if len(_ACC_CACHE) >= 8:                # densification changes P every few hundred iterations: drop the oldest sizes
+            _ACC_CACHE.pop(next(iter(_ACC_CACHE)))
+        _ACC_CACHE[key] = t
+
+
 def _prepare(variant, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, all_map, settings):
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -96,6 +155,24 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
             else:
                 hint = capacity_hint if capacity_hint is not None else _R_HINT.get(key)
     overflowed = False
+    acap = getattr(_ASYNC, "cap", False)
+    if (acap is False) and torch.cuda.is_current_stream_capturing():
+        acap = True
+    if acap is not False and not cfg.debug:
+        if acap is True:
+            with _HINT_LOCK:
+                h = capacity_hint if capacity_hint is not None else _R_HINT.get(key)
+            if h is None:
+                raise RuntimeError("gsrast: a sync-free forward needs a capacity: pass static_capacity(cap) or run the call once eagerly first")
+            acap = int(h * 1.25) + 16384
+        binning = _bytes(L.gsr_binning_bytes(variant, int(acap), W, H), dev)
+        status = torch.zeros((2,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(L.gsr_forward_async(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(), ptr(img),
+                                      img.numel(), ptr(radii), C.byref(o), ptr(status), s), "forward_async")
+        cap = int(L.gsr_binning_capacity(variant, binning.numel(), W, H))
+        _ASYNC_STATUS.append((status, cap))
+        return cap, outs, radii, geom, binning, img
     with torch.cuda.device(dev):
         if hint is not None:
             # steady state: one call, no GPU idle gap at the sync (arena sized from the previous call + 25 % head-room)
@@ -157,12 +234,20 @@ def backward(variant, num_rendered, settings, radii, means3D, sh, colors_precomp
     ig = InGrads(ptr(g["dL_dmeans3D"]), ptr(g["dL_dmeans2D"]), ptr(g.get("dL_dmeans2D_abs")), ptr(g["dL_dcolors"]),
                  ptr(g["dL_dopacity"]), ptr(g["dL_dcov3D"]), ptr(g["dL_dsh"]) if M > 0 else None, ptr(g["dL_dscales"]),
                  ptr(g["dL_drotations"]), ptr(g.get("dL_dall_map")))
-    scratch = _bytes(L.gsr_backward_scratch_bytes(variant, P), dev)
     radii_c = radii.contiguous()
-    with torch.cuda.device(dev):
-        check(L.gsr_backward(C.byref(cfg), C.byref(inp), ptr(radii_c), ptr(geom), geom.numel(), ptr(binning),
-                             binning.numel(), ptr(img), img.numel(), int(num_rendered), ptr(scratch), scratch.numel(),
-                             C.byref(og), C.byref(ig), stream_ptr(dev)), "backward")
+    if _ACC_REUSE:
+        akey, scratch = _acc_scratch(L, variant, P, dev)
+        with torch.cuda.device(dev):
+            check(L.gsr_backward_ex(C.byref(cfg), C.byref(inp), ptr(radii_c), ptr(geom), geom.numel(), ptr(binning),
+                                    binning.numel(), ptr(img), img.numel(), int(num_rendered), ptr(scratch), scratch.numel(),
+                                    C.byref(og), C.byref(ig), 3, stream_ptr(dev)), "backward")      # 3 = SCRATCH_IS_ZERO | LEAVE_ZERO
+        _acc_release(akey, scratch)             # only after a successful enqueue: a failed call may have left it dirty
+    else:
+        scratch = _bytes(L.gsr_backward_scratch_bytes(variant, P), dev)
+        with torch.cuda.device(dev):
+            check(L.gsr_backward(C.byref(cfg), C.byref(inp), ptr(radii_c), ptr(geom), geom.numel(), ptr(binning),
+                                 binning.numel(), ptr(img), img.numel(), int(num_rendered), ptr(scratch), scratch.numel(),
+                                 C.byref(og), C.byref(ig), stream_ptr(dev)), "backward")
     if sh is None or sh.numel() == 0 or M == 0:
         g["dL_dsh"] = torch.zeros((P, M, 3), **f32)
     return g

@@ -145,6 +145,29 @@ int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii,
                  void* scratch, size_t scratch_bytes,
                  const gsr_out_grads* og, const gsr_in_grads* ig, void* stream);
 
+/* gsr_backward with flags (round 3).  The gradient accumulators in `scratch` are what the blend backward adds into and the preprocess backward
+ * reads exactly once:
+ *   GSR_BWD_SCRATCH_IS_ZERO  the caller guarantees scratch holds only zeros (e.g. left so by the previous call): the 24 MB memset
+ *                            (+ its launch gap) in front of the blend backward is skipped;
+ *   GSR_BWD_LEAVE_ZERO       the preprocess backward writes zeros back over every accumulator row after reading it, so the SAME scratch can be
+ *                            passed with GSR_BWD_SCRATCH_IS_ZERO next time (a training loop keeps one scratch per model: ~11 us per iteration).
+ * flags = 0 is gsr_backward. */
+enum { GSR_BWD_SCRATCH_IS_ZERO = 1, GSR_BWD_LEAVE_ZERO = 2 };
+int gsr_backward_ex(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii,
+                    const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                    const void* img, size_t img_bytes, uint32_t num_rendered,
+                    void* scratch, size_t scratch_bytes,
+                    const gsr_out_grads* og, const gsr_in_grads* ig, uint32_t flags, void* stream);
+
+/* ---- forward with NO host synchronisation at all (round 3): the form that can be recorded into a HIP graph (hipStreamBeginCapture /
+ * torch.cuda.graph) and replayed.  Like gsr_forward it runs against a binning arena of fixed capacity and the kernels read the instance
+ * count on the device; unlike gsr_forward the host never learns it: status_dev[0] <- num_rendered, status_dev[1] <- 1 if it exceeded the
+ * capacity (outputs then incomplete; status_dev[1] is sticky: the library only ever sets it, the caller clears it), both DEVICE words the
+ * caller reads whenever it synchronises anyway.  gsr_backward[_ex] of such a call takes num_rendered = the capacity. */
+int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                      void* binning, size_t binning_bytes, void* img, size_t img_bytes, int32_t* radii /*[P]*/,
+                      const gsr_outputs* out, uint32_t* status_dev /*[2]*/, void* stream);
+
 /* ---- helpers of the same extensions */
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present /*[P] bool*/, void* stream);
@@ -345,7 +368,8 @@ int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const vo
                    const void* img, uint32_t num_rendered, void* dst, void* stream);
 
 /* ---- optional stage profiler: HIP events recorded on the launch stream around every stage.
- * gsr_profile_enable(1) resets and starts, gsr_profile_read returns total milliseconds and launch counts per label. */
+ * gsr_profile_enable(1) resets and starts every stage, gsr_profile_enable(mask << 8) only the stages whose bit is set in mask (an event pair
+ * costs ~10 us of stream idle time per stage boundary), 0 stops; gsr_profile_read returns total milliseconds and launch counts per label. */
 enum gsr_prof_label {
     GSR_PROF_PREPROCESS = 0, GSR_PROF_DEPTH_ORDER = 1, GSR_PROF_BINNING = 2, GSR_PROF_BLEND_FWD = 3,
     GSR_PROF_BWD_MEMSET = 4, GSR_PROF_BLEND_BWD = 5, GSR_PROF_PREPROCESS_BWD = 6, GSR_PROF_LABELS = 8
