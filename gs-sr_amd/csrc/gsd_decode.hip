@@ -976,6 +976,41 @@ extern "C" int gsd_forward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_p
     return gsr_check_launch("gsd_forward", s, false);
 }
 
+// Static-shape forward (round 3): no host synchronisation, so the call can be recorded into a HIP graph and replayed.  The outputs keep their
+// worst-case Nv*k rows; the rows behind the P emitted ones are PARKED at the camera centre with zero opacity, so that any rasterizer of this
+// library culls them in its preprocess (view depth 0 <= 0.2; radii 0, no tile instance, zero gradients) -- the caller passes all Nv*k rows on
+// and never learns P on the host.  *count_dev (DEVICE, optional) <- P.
+__global__ void __launch_bounds__(256) k_park_tail(const uint32_t* __restrict__ total, uint32_t cap, const float* __restrict__ campos,
+                                                   float* __restrict__ xyz, float* __restrict__ color, float* __restrict__ opacity,
+                                                   float* __restrict__ scaling, float* __restrict__ rot, uint32_t* __restrict__ count_dev)
+{
+    const uint32_t P = *total;
+    if (count_dev && blockIdx.x == 0 && threadIdx.x == 0) *count_dev = P;
+    const float cx = campos[0], cy = campos[1], cz = campos[2];
+    for (uint32_t i = P + blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
+        xyz[3 * i] = cx; xyz[3 * i + 1] = cy; xyz[3 * i + 2] = cz;
+        color[3 * i] = 0.f; color[3 * i + 1] = 0.f; color[3 * i + 2] = 0.f;
+        opacity[i] = 0.f;
+        scaling[3 * i] = 0.f; scaling[3 * i + 1] = 0.f; scaling[3 * i + 2] = 0.f;
+        rot[4 * i] = 1.f; rot[4 * i + 1] = 0.f; rot[4 * i + 2] = 0.f; rot[4 * i + 3] = 0.f;
+    }
+}
+extern "C" int gsd_forward_static(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask,
+                                  uint32_t* row_offset, const gsd_outputs* out, uint32_t* count_dev, void* scratch, size_t scratch_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (fwd_checks(cfg, in, p, scratch, scratch_bytes, "gsd_forward_static")) return 1;
+    if (cfg->Nv && (!neural_opacity || !mask || !row_offset)) { gsr_set_error("gsd_forward_static: null output"); return 1; }
+    if (cfg->Nv && check_outputs(out, "gsd_forward_static")) return 1;
+    enqueue_stage1(cfg, in, p, neural_opacity, mask, row_offset, scratch, s);
+    if (cfg->Nv == 0) { if (count_dev) GSR_CHECK(hipMemsetAsync(count_dev, 0, sizeof(uint32_t), s), "count"); return gsr_check_launch("gsd_forward_static", s, false); }
+    enqueue_stage2(cfg, in, neural_opacity, row_offset, out, scratch, s);
+    const uint32_t cap = (uint32_t)cfg->Nv * (uint32_t)cfg->k;
+    hipLaunchKernelGGL(k_park_tail, dim3(gsr_div_up(cap, 256u * 8u) + 1u), dim3(256), 0, s, fwd_total(scratch), cap, in->campos, out->xyz, out->color,
+                       out->opacity, out->scaling, out->rot, count_dev);
+    return gsr_check_launch("gsd_forward_static", s, false);
+}
+
 // backward scratch: [weight image][feature-major columns SC_COLS x ld][tile partials][bias partials]
 static size_t bwd_ld(const gsd_cfg* c) { return (size_t)gsr_div_up((uint32_t)(c->Nv > 0 ? c->Nv : 1), GSD_BLOCK) * GSD_BLOCK; }
 extern "C" size_t gsd_backward_scratch_bytes(const gsd_cfg* cfg)

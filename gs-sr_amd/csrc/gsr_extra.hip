@@ -306,9 +306,10 @@ extern "C" int gsr_adam_step(int64_t n, float* param, const float* grad, float* 
 #define GSR_ADAM_MAX 24
 #define GSR_ADAM_CHUNK 4096
 struct AdamEntry { float* p; const float* g; float* m; float* v; const float* sc; int64_t n; float step_size, w1, b2, w2, inv_bc2_sqrt, eps; uint32_t first_block, vec; };
-struct AdamTable { int32_t count; int32_t pad; AdamEntry e[GSR_ADAM_MAX]; };
+struct AdamTable { int32_t count; int32_t first; const float* hyper; AdamEntry e[GSR_ADAM_MAX]; };      // hyper: device [total][2] or null; first: caller index of e[0]
+struct AdamIdx { int32_t idx[GSR_ADAM_MAX]; };
 
-__global__ void __launch_bounds__(256) k_adam_multi(AdamTable T)
+__global__ void __launch_bounds__(256) k_adam_multi(AdamTable T, AdamIdx X)
 {
     int k = 0;
 #pragma unroll 1
@@ -316,7 +317,9 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamTable T)
     const AdamEntry& E = T.e[k];
     const int64_t base = (int64_t)(blockIdx.x - E.first_block) * GSR_ADAM_CHUNK;
     const int64_t end = min(E.n, base + GSR_ADAM_CHUNK);
-    const float step_size = E.step_size, w1 = E.w1, b2 = E.b2, w2 = E.w2, ibc = E.inv_bc2_sqrt, eps = E.eps;
+    float step_size = E.step_size, ibc = E.inv_bc2_sqrt;
+    const float w1 = E.w1, b2 = E.b2, w2 = E.w2, eps = E.eps;
+    if (T.hyper) { step_size = T.hyper[2 * X.idx[k]]; ibc = 1.0f / T.hyper[2 * X.idx[k] + 1]; }      // per-step scalars from device memory (graph replay)
     auto upd = [&](float& pp, float gg, float& mm, float& vv, float sc) {
         mm = mm + (gg - mm) * w1;
         vv = vv * b2 + gg * gg * w2;
@@ -347,19 +350,28 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamTable T)
     }
 }
 
-extern "C" int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor* t, void* stream)
+static int adam_multi(int32_t count, const gsr_adam_tensor* t, const float* hyper_dev, void* stream);
+extern "C" int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor* t, void* stream) { return adam_multi(count, t, nullptr, stream); }
+extern "C" int gsr_adam_step_multi_dev(int32_t count, const gsr_adam_tensor* t, const float* hyper_dev, void* stream)
+{
+    if (!hyper_dev) { gsr_set_error("adam_step_multi_dev: hyper_dev is NULL"); return 1; }
+    return adam_multi(count, t, hyper_dev, stream);
+}
+static int adam_multi(int32_t count, const gsr_adam_tensor* t, const float* hyper_dev, void* stream)
 {
     if (count < 0 || (count > 0 && !t)) { gsr_set_error("adam_step_multi: bad table"); return 1; }
     int32_t i = 0;                              // consumed index, carried across launches: empty tensors are skipped without using a table slot,
     while (i < count) {                         // so a batch may consume more than GSR_ADAM_MAX indices and the next one must start behind them
-        AdamTable T; T.count = 0; T.pad = 0;
+        AdamTable T; T.count = 0; T.first = i; T.hyper = hyper_dev;
+        AdamIdx X;
         uint32_t blocks = 0;
         for (; i < count && T.count < GSR_ADAM_MAX; i++) {
             const gsr_adam_tensor& a = t[i];
             if (a.n <= 0) continue;
-            if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq || !(a.bias_correction2_sqrt > 0.0f)) {
+            if (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq || (!hyper_dev && !(a.bias_correction2_sqrt > 0.0f))) {
                 gsr_set_error("adam_step_multi: tensor %d: null pointer or bias_correction2_sqrt <= 0", i); return 1;
             }
+            X.idx[T.count] = i;
             AdamEntry& E = T.e[T.count++];
             E.p = a.param; E.g = a.grad; E.m = a.exp_avg; E.v = a.exp_avg_sq; E.sc = a.lr_scale; E.n = a.n;
             E.step_size = a.step_size; E.w1 = (float)(1.0 - a.beta1); E.b2 = (float)a.beta2; E.w2 = (float)(1.0 - a.beta2);
@@ -368,7 +380,7 @@ extern "C" int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor* t, void
             E.vec = ((((uintptr_t)a.param | (uintptr_t)a.grad | (uintptr_t)a.exp_avg | (uintptr_t)a.exp_avg_sq | (uintptr_t)a.lr_scale) & 15) == 0) ? 1u : 0u;
             blocks += (uint32_t)((a.n + GSR_ADAM_CHUNK - 1) / GSR_ADAM_CHUNK);
         }
-        if (blocks) hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T);
+        if (blocks) hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T, X);
     }
     return gsr_check_launch("adam_step_multi", (hipStream_t)stream, false);
 }

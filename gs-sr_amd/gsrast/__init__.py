@@ -69,7 +69,7 @@ EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward
            "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward",
            "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_octree_visible",
            "gsr_loss_plane_mv_scratch_bytes", "gsr_loss_plane_mv_geo", "gsr_loss_plane_mv_ncc",
-           "gsr_plane_allmap", "gsr_plane_allmap_backward", "gsr_sample_mask_scratch_bytes", "gsr_sample_mask", "gsr_densify_stats", "gsr_adam_step", "gsr_adam_step_multi"]
+           "gsr_plane_allmap", "gsr_plane_allmap_backward", "gsr_sample_mask_scratch_bytes", "gsr_sample_mask", "gsr_densify_stats", "gsr_adam_step", "gsr_adam_step_multi", "gsr_adam_step_multi_dev"]
 PROF_LABELS = ["preprocess", "depth_order", "binning", "blend_fwd", "bwd_memset", "blend_bwd", "preprocess_bwd", "_"]
 
 _lib = None
@@ -122,6 +122,8 @@ def lib():
     L.gsr_tsdf_sparse_merge.argtypes = [C.POINTER(TsdfSparse), C.c_int32, _vp, _vp, _vp, _vp, _vp]
     L.gsr_adam_step_multi.restype = C.c_int
     L.gsr_adam_step_multi.argtypes = [C.c_int32, _vp, _vp]
+    L.gsr_adam_step_multi_dev.restype = C.c_int
+    L.gsr_adam_step_multi_dev.argtypes = [C.c_int32, _vp, _vp, _vp]
     L.gsr_adam_step.restype = C.c_int
     L.gsr_adam_step.argtypes = [C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, _vp, _vp]
     L.gsr_loss_l1_linear.restype = C.c_int

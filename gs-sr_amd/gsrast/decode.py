@@ -14,7 +14,7 @@ from . import check, dev_f32, lib, ptr, stream_ptr
 _vp = C.c_void_p
 PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app")
 EXPORTS = ["gsd_compact_scratch_bytes", "gsd_compact_visible", "gsd_compact_visible_padded", "gsd_forward_scratch_bytes", "gsd_forward_stage1", "gsd_forward_stage2",
-           "gsd_forward", "gsd_backward_scratch_bytes", "gsd_backward", "gsd_training_stats_scratch_bytes", "gsd_training_stats"]
+           "gsd_forward", "gsd_forward_static", "gsd_backward_scratch_bytes", "gsd_backward", "gsd_training_stats_scratch_bytes", "gsd_training_stats"]
 
 
 class Cfg(C.Structure):
@@ -62,6 +62,8 @@ def _lib():
         L.gsd_forward.restype = C.c_int
         L.gsd_forward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, _vp, C.POINTER(Outputs),
                                   C.POINTER(C.c_uint32), _vp, sz, _vp]
+        L.gsd_forward_static.restype = C.c_int
+        L.gsd_forward_static.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, _vp, C.POINTER(Outputs), _vp, _vp, sz, _vp]
         L.gsd_backward_scratch_bytes.restype = sz; L.gsd_backward_scratch_bytes.argtypes = [C.POINTER(Cfg)]
         L.gsd_backward.restype = C.c_int
         L.gsd_backward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, C.c_uint32, C.POINTER(OutGrads),
@@ -107,6 +109,8 @@ class _NeuralDecode(torch.autograd.Function):
     def forward(ctx, flags, vis_idx, campos, level, opacity_scale, anchor, feat, offset, scaling, *params):
         L = _lib()
         dev = anchor.device
+        static_rows = len(flags) > 6 and bool(flags[6])
+        flags = tuple(flags[:6])
         k = flags[0]
         t = {"anchor": dev_f32(anchor, "anchor", False), "feat": dev_f32(feat, "feat", False), "offset": dev_f32(offset, "offset", False),
              "scaling": dev_f32(scaling, "scaling", False), "level": dev_f32(level, "level"), "opacity_scale": dev_f32(opacity_scale, "opacity_scale"),
@@ -126,20 +130,30 @@ class _NeuralDecode(torch.autograd.Function):
         opacity = torch.empty(cap, 1, dtype=torch.float32, device=dev); scl = torch.empty(cap, 3, dtype=torch.float32, device=dev)
         rot = torch.empty(cap, 4, dtype=torch.float32, device=dev)
         out = Outputs(ptr(xyz), ptr(color), ptr(opacity), ptr(scl), ptr(rot))
-        check(L.gsd_forward(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(mask), ptr(row_offset), C.byref(out), C.byref(P),
-                            ptr(scratch), scratch.numel(), stream_ptr(dev)), "decode forward")
-        n = P.value
-        xyz, color, opacity, scl, rot = xyz[:n], color[:n], opacity[:n], scl[:n], rot[:n]
+        count = None
+        if static_rows:         # no host synchronisation: all Nv*k rows are returned, the rows behind the emitted ones parked at the camera centre
+            count = torch.empty(1, dtype=torch.int32, device=dev)
+            check(L.gsd_forward_static(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(mask), ptr(row_offset), C.byref(out), ptr(count),
+                                       ptr(scratch), scratch.numel(), stream_ptr(dev)), "decode forward (static rows)")
+            n = cap
+        else:
+            check(L.gsd_forward(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(mask), ptr(row_offset), C.byref(out), C.byref(P),
+                                ptr(scratch), scratch.numel(), stream_ptr(dev)), "decode forward")
+            n = P.value
+            xyz, color, opacity, scl, rot = xyz[:n], color[:n], opacity[:n], scl[:n], rot[:n]
         ctx.flags, ctx.n = flags, n
         ctx.save_for_backward(t["anchor"], t["feat"], t["offset"], t["scaling"], t["level"], t["opacity_scale"], t["vis_idx"], t["campos"],
                               nop, row_offset, scratch, *[prm[nm] for nm in PARAM_NAMES])
         mask_b = mask.view(torch.bool)
-        ctx.mark_non_differentiable(nop, mask_b)
         ctx.set_materialize_grads(False)     # no zero-filled (Nv*k) gradient tensors for nop / mask (or an unused output) on every backward
+        if static_rows:
+            ctx.mark_non_differentiable(nop, mask_b, count)
+            return xyz, color, opacity, scl, rot, nop, mask_b, count
+        ctx.mark_non_differentiable(nop, mask_b)
         return xyz, color, opacity, scl, rot, nop, mask_b
 
     @staticmethod
-    def backward(ctx, g_xyz, g_color, g_opacity, g_scaling, g_rot, _g_nop, _g_mask):
+    def backward(ctx, g_xyz, g_color, g_opacity, g_scaling, g_rot, _g_nop, _g_mask, _g_count=None):
         L = _lib()
         sv = ctx.saved_tensors
         names = ("anchor", "feat", "offset", "scaling", "level", "opacity_scale", "vis_idx", "campos")
@@ -194,7 +208,7 @@ def feature_bank_blend(anchor, feat, vis_idx, campos, mlp_feature_bank):
 
 def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_color, campos, visible_mask=None, vis_idx=None,
                      appearance=None, level=None, opacity_scale=None, add_opacity_dist=False, add_cov_dist=False, add_color_dist=False,
-                     use_feat_bank=False, mlp_feature_bank=None, padded=False):
+                     use_feat_bank=False, mlp_feature_bank=None, padded=False, static_rows=False):
     """-> (xyz, color, opacity, scaling, rot, neural_opacity, mask), the `is_training=True` tuple of the reference.
 
     anchor (Na,3), feat (Na,32), offset (Na,k,3), scaling (Na,6) = get_scaling; `appearance` = embedding_appearance row of this camera
@@ -202,7 +216,11 @@ def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_co
     Octree progressive ratio with prog[~transition_mask] = 1.  `visible_mask` (bool, Na) or `vis_idx` (int32 indices) selects the anchors.
     `use_feat_bank=True` (+ `mlp_feature_bank`) = the reference's view-adaptive feature branch, see feature_bank_blend.
     `padded=True` (or a `vis_idx` from compact_visible(mask, padded=True)): no host synchronisation for the visible-anchor count; the returned
-    `neural_opacity` / `mask` then have Na * k rows (zeros behind the visible anchors' rows) -- what training_stats_ accepts as is."""
+    `neural_opacity` / `mask` then have Na * k rows (zeros behind the visible anchors' rows) -- what training_stats_ accepts as is.
+    `static_rows=True` (round 3; implies a padded visible list): NO host synchronisation at all and STATIC output shapes -- the form a HIP graph can
+    record.  The five Gaussian tensors keep all Nv * k rows: the P emitted Gaussians first, the rest parked at the camera centre with zero opacity
+    (every rasterizer of this library culls them: radii 0, no tile instance, zero gradients), and an eighth value `count` (int32 device tensor,
+    shape (1,)) = P is returned for consumers that average over the Gaussians (the reference's scaling loss: use sum() / count)."""
     if use_feat_bank and mlp_feature_bank is None:
         raise RuntimeError("gsrast.decode: use_feat_bank=True needs mlp_feature_bank (get_featurebank_mlp of the gaussian model)")
     if feat.shape[1] != 32:
@@ -218,7 +236,7 @@ def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_co
     A = 0 if appearance is None else appearance.numel()
     lvl = None if level is None else level.reshape(-1)
     osc = None if opacity_scale is None else opacity_scale.reshape(-1)
-    flags = (int(k), int(A), bool(add_opacity_dist), bool(add_cov_dist), bool(add_color_dist), lvl is not None)
+    flags = (int(k), int(A), bool(add_opacity_dist), bool(add_cov_dist), bool(add_color_dist), lvl is not None, bool(static_rows))
     app = None if appearance is None else appearance.reshape(-1)
     return _NeuralDecode.apply(flags, vis_idx, campos, lvl, osc, anchor, feat, offset, scaling, *heads, app)
 

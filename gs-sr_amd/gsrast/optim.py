@@ -9,7 +9,12 @@ only `step()` differs: every float32 HIP parameter is updated by ONE streaming k
 op-by-op update.  Parameters the kernel does not cover (other dtypes / devices, sparse gradients) and the options it does not implement
 (amsgrad, weight_decay, maximize, capturable, differentiable) go through torch's own implementation.
 A param group may carry `lr_scale` (float32 tensor shaped like its parameter): a per-element multiplier of the group's learning rate, for
-models that keep all their parameters in one flat tensor (bench.py)."""
+models that keep all their parameters in one flat tensor (bench.py).
+
+HIP graphs (round 3): a `step()` issued while the current stream is being captured (torch.cuda.graph) records ONE launch whose per-step scalars
+(step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t)) are read from a small device buffer instead of being baked into the kernel arguments
+(gsr_adam_step_multi_dev).  `prepare_replay()` -- call it before every `graph.replay()`; gsrast.graphs.GraphedStep does -- bumps the step counters,
+re-reads every group's `lr` (schedulers keep working) and refreshes that buffer with one small asynchronous copy."""
 import ctypes as C
 import math
 
@@ -43,6 +48,8 @@ class Adam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         L = lib()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        captured = []                              # capture: (param, group) in table order, for prepare_replay
         steps = self.__dict__.setdefault("_gsr_step_views", {})
         if len(steps) > 4 * sum(len(g["params"]) for g in self.param_groups) + 64:      # parameters replaced by densification leave stale ids
             steps.clear()
@@ -72,7 +79,10 @@ class Adam(torch.optim.Adam):
                 if ent is None or ent[0] is not stp:
                     ent = steps[id(p)] = (stp, stp.numpy()) if (stp.device.type == "cpu" and stp.dtype == torch.float32) else (stp, None)
                 view = ent[1]
-                if view is not None:
+                if capturing:                      # nothing runs during capture: the counter moves in prepare_replay()
+                    t = max(float(stp), 1.0)
+                    captured.append((p, group))
+                elif view is not None:
                     view += 1.0
                     t = float(view)
                 else:
@@ -91,10 +101,22 @@ class Adam(torch.optim.Adam):
                      lr / (1.0 - beta1 ** t), math.sqrt(1.0 - beta2 ** t), group["eps"], 0.0))
             if other:
                 rest.append((group, other))
+        if capturing:
+            if rest or len(batch) > 1:
+                raise RuntimeError("gsrast.optim.Adam: a captured step() needs every parameter covered by the HIP kernel, on one device")
+            self._gsr_graph = []
         for dev, entries in batch.items():
             table = (_AdamTensor * len(entries))(*entries)
             with torch.cuda.device(dev):
-                check(L.gsr_adam_step_multi(len(entries), table, stream_ptr(dev)), "adam_step_multi")
+                if capturing:
+                    hyper = torch.empty(len(entries), 2, dtype=torch.float32, device=dev)      # from the graph's pool: lives as long as the graph
+                    host = torch.empty(len(entries), 2, dtype=torch.float32).pin_memory()
+                    self._gsr_graph.append((captured, hyper, host))
+                    check(L.gsr_adam_step_multi_dev(len(entries), table, hyper.data_ptr(), stream_ptr(dev)), "adam_step_multi_dev")
+                else:
+                    check(L.gsr_adam_step_multi(len(entries), table, stream_ptr(dev)), "adam_step_multi")
+        if capturing:
+            return loss
         for group, ps in rest:                     # uncovered parameters: exactly torch's update (its functional form on a copy of the group
             g2 = dict(group, params=ps)            # that holds only them) -- not super().step(), which would fire the step hooks a second time
             pw, grads, m1, m2, mx, st = [], [], [], [], [], []
@@ -106,3 +128,19 @@ class Adam(torch.optim.Adam):
                         grad_scale=getattr(self, "grad_scale", None), found_inf=getattr(self, "found_inf", None),
                         decoupled_weight_decay=group.get("decoupled_weight_decay", False))
         return loss
+
+    @torch.no_grad()
+    def prepare_replay(self):
+        """Before every replay of a graph that holds this optimizer's step(): one more step for every captured parameter -- counters bumped,
+        the groups' current learning rates and the bias corrections written to the device buffer the captured launch reads."""
+        for captured, hyper, host in getattr(self, "_gsr_graph", ()):
+            h = host.numpy()
+            for i, (p, group) in enumerate(captured):
+                st = self.state[p]
+                st["step"] += 1
+                t = float(st["step"])
+                beta1, beta2 = group["betas"]
+                lr = group["lr"]
+                h[i, 0] = float(lr) / (1.0 - beta1 ** t)
+                h[i, 1] = math.sqrt(1.0 - beta2 ** t)
+            hyper.copy_(host, non_blocking=True)

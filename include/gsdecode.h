@@ -108,6 +108,13 @@ int gsd_forward_stage2(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_param
 int gsd_forward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask, uint32_t* row_offset,
                 const gsd_outputs* out, uint32_t* P_host, void* scratch, size_t scratch_bytes, void* stream);
 
+/* static-shape forward (round 3): gsd_forward without its host synchronisation -- recordable into a HIP graph.  `out` keeps all Nv*k rows: the P
+   emitted Gaussians first, the remaining rows PARKED at the camera centre (xyz = campos, opacity 0, scaling 0, rot identity, colour 0) so that the
+   rasterizers of this library cull them in preprocess (radii 0, no tile instance, zero gradients); the caller hands all Nv*k rows on.
+   *count_dev (DEVICE word, may be NULL) <- P.  gsd_backward is unchanged: it never reads rows behind P. */
+int gsd_forward_static(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask, uint32_t* row_offset,
+                       const gsd_outputs* out, uint32_t* count_dev, void* scratch, size_t scratch_bytes, void* stream);
+
 /* backward: recomputes the heads, writes the per-anchor gradients, and contracts the weight gradients over the anchors with MFMA.
    scratch >= gsd_backward_scratch_bytes(cfg).  fwd_scratch: the forward's scratch buffer if the caller kept it and the parameters are
    unchanged since (its repacked weights are reused), else NULL. */

@@ -245,6 +245,10 @@ typedef struct gsr_adam_tensor {
     float eps, pad_;
 } gsr_adam_tensor;
 int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor* t, void* stream);
+/* The same with the two per-step scalars of every tensor read from DEVICE memory at run time -- hyper_dev[2 * i] = step_size,
+ * hyper_dev[2 * i + 1] = bias_correction2_sqrt of entry i (the fields of t[i] are ignored) -- so that the launch can sit in a HIP graph: the caller
+ * refreshes the small buffer (learning-rate schedule, bias correction of the current step) before every replay. */
+int gsr_adam_step_multi_dev(int32_t count, const gsr_adam_tensor* t, const float* hyper_dev /*[count,2]*/, void* stream);
 /* Octree-GS level-of-detail mask fused with the prefilter (OctreeGaussianModel.set_anchor_mask / map_to_int_level,
  * gssr/gaussian/octree_gaussian.py:184-203,255-267; OctreeScene.prefilter_voxel, gssr/scene/octree_scene.py:136-172):
  *   dist = |anchor + (voxel_size/2)/fork^level - campos| * resolution_scale;  pred = log2(standard_dist/dist)/log2(fork) + extra_level

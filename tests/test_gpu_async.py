@@ -127,3 +127,69 @@ def test_iteration_replays_from_a_hip_graph():
     for k in names:
         d = (got[k] - ref[k]).norm().item(); n = ref[k].norm().item()
         assert d <= 2e-5 * n + 1e-30, (k, d, n)
+
+
+def test_decode_static_rows_parks_the_tail_and_keeps_gradients():
+    """static_rows=True: same first P rows / same gradients as the exact path, the remaining Nv*k - P rows parked at the camera centre with zero
+    opacity, count = P, and a surfel rasterizer fed all rows renders the same image (the parked rows are culled: radii 0)."""
+    import decode_cases
+    import hiprun as hr
+    from gsrast import decode
+    case = decode_cases.make_case(Na=3000, seed=2)
+    dev = "cuda"
+    t = lambda a: None if a is None else torch.tensor(a, device=dev)
+    par = {n: t(v) for n, v in case["params"].items()}
+    heads = ((par["W1o"], par["b1o"], par["W2o"], par["b2o"]), (par["W1c"], par["b1c"], par["W2c"], par["b2c"]), (par["W1k"], par["b1k"], par["W2k"], par["b2k"]))
+    vis = torch.tensor(case["vis_idx"], dtype=torch.int32, device=dev)
+    campos = t(case["campos"])
+
+    def run(static):
+        leaves = [t(case[k]).requires_grad_(True) for k in ("anchor", "feat", "offset", "scaling")]
+        out = decode.neural_gaussians(leaves[0], leaves[1], leaves[2], leaves[3], heads[0], heads[1], heads[2], campos, vis_idx=vis,
+                                      appearance=par["app"], static_rows=static)
+        P = int(out[7][0]) if static else out[0].shape[0]
+        g = torch.Generator().manual_seed(0)
+        w = [torch.randn(P, c, generator=g).to(dev) for c in (3, 3, 1, 3, 4)]
+        loss = sum((o[:P] * ww).sum() for o, ww in zip(out[:5], w))
+        loss.backward()
+        return out, P, [l.grad.clone() for l in leaves]
+
+    oe, Pe, ge = run(False)
+    os_, Ps, gs = run(True)
+    k = case["offset"].shape[1]
+    assert Ps == Pe and os_[0].shape[0] == vis.numel() * k
+    for a, b in zip(oe[:5], os_[:5]):
+        assert torch.equal(a, b[:Pe])
+    assert torch.equal(os_[0][Pe:], campos.expand(os_[0].shape[0] - Pe, 3)) and not bool(os_[2][Pe:].any())
+    for a, b in zip(ge, gs):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_scaffold_iteration_replayed_from_a_graph_tracks_the_eager_one():
+    """The complete scaffold-2dgs iteration (prefilter, decode, surfel rasterizer, L1+SSIM + normal / distortion + scaling losses, backward,
+    densification statistics, fused Adam) recorded once with gsrast.graphs.GraphedStep and replayed: parameters and statistics after the same
+    number of iterations agree with the eager, reference-shaped iteration (differences: float-atomic order only)."""
+    import os
+    import sys
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_pipeline
+    from gsrast.graphs import GraphedStep
+    dev = torch.device("cuda:0")
+    n_warm, n_run = 3, 4
+    e_step, e_st = bench_pipeline.build(types.SimpleNamespace(decode="hip", loss="full-hip", Na=9000), dev)
+    for _ in range(n_warm + n_run):
+        e_step()
+    g_step, g_st = bench_pipeline.build(types.SimpleNamespace(decode="hip", loss="full-hip", Na=9000, static=True), dev)
+    it = GraphedStep(g_step, optimizers=g_st["optimizers"], warmup=n_warm)
+    for _ in range(n_run):
+        it()
+    st = it.check()
+    assert len(st) == 1 and st[0][1] is False and st[0][0] > 0
+    pe = [p for g in e_st["optimizers"][0].param_groups for p in g["params"]]
+    pg = [p for g in g_st["optimizers"][0].param_groups for p in g["params"]]
+    assert e_st["P"] == g_st["P"] and g_st["rows"] >= g_st["P"]
+    for a, b in zip(pe, pg):
+        assert float(e_st["optimizers"][0].state[a]["step"]) == float(g_st["optimizers"][0].state[b]["step"]) == n_warm + n_run
+        d = (a.detach() - b.detach()).norm().item(); n = a.detach().norm().item()
+        assert d <= 2e-3 * n + 1e-6, (tuple(a.shape), d, n)

@@ -26,11 +26,14 @@ from gsrast.optim import Adam          # noqa: E402
 
 
 def build(a, dev, seed=0):
-    """-> (step, st): one scaffold-2dgs training iteration on a synthetic anchor scene; a has .decode, .loss, .Na and optionally .lod
+    """-> (step, st): one scaffold-2dgs training iteration on a synthetic anchor scene; a has .decode, .loss, .Na and optionally .static
+    (True: the sync-free, static-shape form of the same iteration -- decode with static_rows, so that it can be recorded into a HIP graph,
+    gsrast.graphs.GraphedStep) and .lod
     (True: octree-2dgs, BASELINE configs[3]/[4] -- OctreeScene's level-of-detail mask + prefilter (gsr_octree_visible) in front of the same
     decode / surfel rasterizer / losses, anchors on 6 octree levels)."""
     W, H, k, A = 1920, 1080, 10, 32
     lod = bool(getattr(a, "lod", False))
+    static = bool(getattr(a, "static", False))
     sc = scenes.make_scene("surfel", a.Na, W, H, seed=seed, color_mode="precomp")
     t = hiprun.to_dev(sc, dev)
     rs = hiprun.settings("surfel", t)
@@ -83,8 +86,13 @@ def build(a, dev, seed=0):
         app = emb.weight[1]
         if a.decode == "hip":
             vis_idx = decode.compact_visible(vmask, padded=True)   # once per iteration, shared by the decode and the statistics; no host sync
-            xyz, color, opacity, scl, rot, nop, mask = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos,
-                                                                              vis_idx=vis_idx, appearance=app)
+            count = None
+            if static:
+                xyz, color, opacity, scl, rot, nop, mask, count = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos,
+                                                                                         vis_idx=vis_idx, appearance=app, static_rows=True)
+            else:
+                xyz, color, opacity, scl, rot, nop, mask = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos,
+                                                                                  vis_idx=vis_idx, appearance=app)
         else:
             vis = torch.nonzero(vmask).view(-1)
             leaves = {"anchor": anchor, "feat": feat, "offset": offset, "scaling": scaling}
@@ -96,7 +104,10 @@ def build(a, dev, seed=0):
         means2D = torch.zeros_like(xyz, requires_grad=True)
         img, rad, allmap = dsr.GaussianRasterizer(rs)(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color,
                                                       scales=scl[:, :2].contiguous(), rotations=rot)
-        reg = 0.01 * scl[:, :2].prod(dim=1).mean()                                              # scaling_loss (scaffold_2dgs_scene.py:26)
+        if static and a.decode == "hip":        # mean over the P emitted Gaussians: the parked rows have scale 0 and only the divisor differs
+            reg = 0.01 * scl[:, :2].prod(dim=1).sum() / count.to(torch.float32)[0]
+        else:
+            reg = 0.01 * scl[:, :2].prod(dim=1).mean()                                          # scaling_loss (scaffold_2dgs_scene.py:26)
         if a.loss == "bench":
             loss = l1_plus_linear(img, gt, allmap, wmap) + reg
         elif a.loss == "full-hip":
@@ -111,7 +122,13 @@ def build(a, dev, seed=0):
             else:
                 ref_decode_torch.training_statis(acc, k, means2D.grad, o["neural_opacity"].view(-1, 1), rad > 0, o["mask"], vmask)
         opt.step(); opt.zero_grad(set_to_none=True)
-        st["P"] = xyz.shape[0]; st["Nv"] = int(vmask.sum()) if "Nv" not in st else st["Nv"]
+        if "Nv" not in st:                       # once (first eager call): host reads for the report
+            st["Nv"] = int(vmask.sum())
+            st["P"] = int(count[0]) if (static and a.decode == "hip") else xyz.shape[0]
+        st["rows"] = xyz.shape[0]
+        return loss
+
+    st["optimizers"] = [opt]
 
     return step, st
 
@@ -124,17 +141,27 @@ def main():
                          "fused HIP kernels or the reference's torch formulas")
     ap.add_argument("--Na", type=int, default=72000)
     ap.add_argument("--lod", action="store_true", help="octree-2dgs: level-of-detail mask + prefilter (use --Na 87000 for ~300k Gaussians)")
+    ap.add_argument("--static", action="store_true", help="sync-free static-shape iteration (decode static_rows)")
+    ap.add_argument("--graph", action="store_true", help="record the (static) iteration into a HIP graph and replay it (gsrast.graphs.GraphedStep)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     a = ap.parse_args()
+    if a.graph:
+        a.static = True
     step, st = build(a, torch.device("cuda:0"))
+    if a.graph:
+        from gsrast.graphs import GraphedStep
+        step = GraphedStep(step, optimizers=st["optimizers"], warmup=max(3, a.warmup))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps({"pipeline": "octree-2dgs" if a.lod else "scaffold-2dgs", "decode": a.decode, "loss": a.loss, "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps,
+    if a.graph:
+        st["async_status"] = step.check()
+    print(json.dumps({"pipeline": "octree-2dgs" if a.lod else "scaffold-2dgs", "mode": "graph" if a.graph else ("static" if a.static else "eager"),
+                      "rows": st.get("rows"), "async_status": st.get("async_status"), "decode": a.decode, "loss": a.loss, "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps,
                       "ms_per_iter": 1e3 * dt / a.steps, "iters_per_s": a.steps / dt}))
 
 
