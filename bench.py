@@ -283,7 +283,29 @@ def method_iteration(device, which, steps=20):
             step()
         torch.cuda.synchronize(device)
         r = {"wall_ms": round(1e3 * (time.perf_counter() - t0) / steps, 4), "kernel_ms": None, "profiler_error": str(e)[:80]}
-    r.update(method=which, gaussians=int(st["P"]), iters_per_s=round(1e3 / r["wall_ms"], 2))
+    r.update(method=which, gaussians=int(st["P"]), iters_per_s=round(1e3 / r["wall_ms"], 2), mode="eager, reference-shaped (exact row counts, one host sync per decode)")
+    del step, st
+    # the same iteration in its static-shape form, recorded once into a HIP graph and replayed (gsrast.graphs.GraphedStep)
+    try:
+        from gsrast.graphs import GraphedStep
+        if which in ("scaffold-2dgs", "octree-2dgs"):
+            gstep, gst = bench_pipeline.build(types.SimpleNamespace(decode="hip", loss="full-hip", Na=87000 if lod else 72000, lod=lod, static=True), device)
+        elif which == "octree-pgsr":
+            gstep, gst = bench_pipeline_octree_pgsr.build(types.SimpleNamespace(Na=74000, static=True), device)
+        else:
+            gstep, gst = bench_pipeline_pgsr.build(types.SimpleNamespace(glue="hip", P=300000), device)
+        it = GraphedStep(gstep, optimizers=gst["optimizers"], warmup=5)
+        for _ in range(5):
+            it()
+        torch.cuda.synchronize(device); t0 = time.perf_counter()
+        for _ in range(3 * steps):
+            it()
+        torch.cuda.synchronize(device)
+        wall = 1e3 * (time.perf_counter() - t0) / (3 * steps)
+        r["graph_replay"] = {"wall_ms": round(wall, 4), "iters_per_s": round(1e3 / wall, 2), "rasterizer_forwards": [list(x) for x in it.check()],
+                             "what": "static-shape iteration (decode static_rows, sync-free rasterizer forward, Adam scalars from device memory) replayed from one HIP graph"}
+    except Exception as e:
+        r["graph_replay"] = {"error": str(e)[:200]}
     return r
 
 

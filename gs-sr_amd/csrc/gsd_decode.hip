@@ -883,7 +883,7 @@ extern "C" int gsd_compact_visible_padded(const uint8_t* mask, int32_t Na, int32
     uint32_t* total = (uint32_t*)scratch;
     uint32_t* pos = (uint32_t*)((char*)scratch + 256);
     uint32_t* sums = (uint32_t*)((char*)pos + gsr_align((size_t)Na * sizeof(uint32_t)));
-    GSR_CHECK(hipMemsetAsync(vis_idx, 0xFF, (size_t)Na * sizeof(int32_t), s), "gsd_compact_visible_padded: fill");
+    if (gsr_memset_async(vis_idx, 0xFF, (size_t)Na * sizeof(int32_t), s)) { gsr_set_error("gsd_compact_visible_padded: fill"); return 1; };
     hipLaunchKernelGGL(k_flags, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos);
     launch_scan(pos, (uint32_t)Na, sums, total, s);
     hipLaunchKernelGGL(k_scatter_idx, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos, vis_idx);
@@ -1003,7 +1003,7 @@ extern "C" int gsd_forward_static(const gsd_cfg* cfg, const gsd_inputs* in, cons
     if (cfg->Nv && (!neural_opacity || !mask || !row_offset)) { gsr_set_error("gsd_forward_static: null output"); return 1; }
     if (cfg->Nv && check_outputs(out, "gsd_forward_static")) return 1;
     enqueue_stage1(cfg, in, p, neural_opacity, mask, row_offset, scratch, s);
-    if (cfg->Nv == 0) { if (count_dev) GSR_CHECK(hipMemsetAsync(count_dev, 0, sizeof(uint32_t), s), "count"); return gsr_check_launch("gsd_forward_static", s, false); }
+    if (cfg->Nv == 0) { if (count_dev) if (gsr_memset_async(count_dev, 0, sizeof(uint32_t), s)) { gsr_set_error("count"); return 1; }; return gsr_check_launch("gsd_forward_static", s, false); }
     enqueue_stage2(cfg, in, neural_opacity, row_offset, out, scratch, s);
     const uint32_t cap = (uint32_t)cfg->Nv * (uint32_t)cfg->k;
     hipLaunchKernelGGL(k_park_tail, dim3(gsr_div_up(cap, 256u * 8u) + 1u), dim3(256), 0, s, fwd_total(scratch), cap, in->campos, out->xyz, out->color,
@@ -1035,13 +1035,13 @@ extern "C" int gsd_backward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_
     const int k = cfg->k;
     if (cfg->Nv == 0) {       // no anchors: all parameter gradients are zero
         const int lv = cfg->level ? 1 : 0;
-        (void)hipMemsetAsync(g.W1o, 0, sizeof(float) * 32 * (35 + (cfg->dist_o ? 1 : 0) + lv), s); (void)hipMemsetAsync(g.b1o, 0, sizeof(float) * 32, s);
-        (void)hipMemsetAsync(g.W1c, 0, sizeof(float) * 32 * (35 + (cfg->dist_c ? 1 : 0) + lv), s); (void)hipMemsetAsync(g.b1c, 0, sizeof(float) * 32, s);
-        (void)hipMemsetAsync(g.W1k, 0, sizeof(float) * 32 * (35 + (cfg->dist_k ? 1 : 0) + lv + cfg->A), s); (void)hipMemsetAsync(g.b1k, 0, sizeof(float) * 32, s);
-        (void)hipMemsetAsync(g.W2o, 0, sizeof(float) * 32 * k, s); (void)hipMemsetAsync(g.b2o, 0, sizeof(float) * k, s);
-        (void)hipMemsetAsync(g.W2c, 0, sizeof(float) * 32 * 7 * k, s); (void)hipMemsetAsync(g.b2c, 0, sizeof(float) * 7 * k, s);
-        (void)hipMemsetAsync(g.W2k, 0, sizeof(float) * 32 * 3 * k, s); (void)hipMemsetAsync(g.b2k, 0, sizeof(float) * 3 * k, s);
-        if (cfg->A) (void)hipMemsetAsync(g.app, 0, sizeof(float) * cfg->A, s);
+        (void)gsr_memset_async(g.W1o, 0, sizeof(float) * 32 * (35 + (cfg->dist_o ? 1 : 0) + lv), s); (void)gsr_memset_async(g.b1o, 0, sizeof(float) * 32, s);
+        (void)gsr_memset_async(g.W1c, 0, sizeof(float) * 32 * (35 + (cfg->dist_c ? 1 : 0) + lv), s); (void)gsr_memset_async(g.b1c, 0, sizeof(float) * 32, s);
+        (void)gsr_memset_async(g.W1k, 0, sizeof(float) * 32 * (35 + (cfg->dist_k ? 1 : 0) + lv + cfg->A), s); (void)gsr_memset_async(g.b1k, 0, sizeof(float) * 32, s);
+        (void)gsr_memset_async(g.W2o, 0, sizeof(float) * 32 * k, s); (void)gsr_memset_async(g.b2o, 0, sizeof(float) * k, s);
+        (void)gsr_memset_async(g.W2c, 0, sizeof(float) * 32 * 7 * k, s); (void)gsr_memset_async(g.b2c, 0, sizeof(float) * 7 * k, s);
+        (void)gsr_memset_async(g.W2k, 0, sizeof(float) * 32 * 3 * k, s); (void)gsr_memset_async(g.b2k, 0, sizeof(float) * 3 * k, s);
+        if (cfg->A) (void)gsr_memset_async(g.app, 0, sizeof(float) * cfg->A, s);
         return gsr_check_launch("gsd_backward", s, false);
     }
     if (!og || !og->xyz || !og->color || !og->opacity || !og->scaling || !og->rot || !ig->anchor || !ig->feat || !ig->offset || !ig->scaling ||

@@ -31,11 +31,30 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug)
     return 0;
 }
 
+__global__ void __launch_bounds__(256) k_fill_words(uint32_t* __restrict__ p, uint32_t v, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int gsr_memset_async(void* p, int byte_value, size_t nbytes, hipStream_t s)
+{
+    if (nbytes == 0) return 0;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive && (nbytes & 3) == 0 && (((uintptr_t)p) & 3) == 0) {
+        const uint32_t b = (uint32_t)(byte_value & 0xFF), w = b | (b << 8) | (b << 16) | (b << 24);
+        const size_t n = nbytes / 4;
+        const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_fill_words, dim3(blocks), dim3(256), 0, s, (uint32_t*)p, w, n);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
+    return hipMemsetAsync(p, byte_value, nbytes, s) == hipSuccess ? 0 : 1;
+}
+
 // ------------------------------------------------------------------------------------------------ stage profiler
 // Optional: HIP events recorded on the launch stream around every stage; read back with gsr_profile_read.
 // Used by bench.py for the live kernel durations behind the roofline figure.  One mutex guards the record lists, so concurrent
 // forwards from several host threads / streams only serialise on the bookkeeping (a few hundred ns), never on the GPU work.
 #include <vector>
+#include <algorithm>
 struct ProfRec { int label; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static std::atomic<uint32_t> g_prof_on{0};      // bit i: stage i is timed
@@ -341,7 +360,7 @@ extern "C" int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void*
     if (check_cfg(cfg, in)) return 1;
     if (!status_dev) { gsr_set_error("gsr_forward_async: status_dev must be provided"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    if (cfg->P == 0) { GSR_CHECK(hipMemsetAsync(status_dev, 0, sizeof(uint32_t), s), "status"); return 0; }
+    if (cfg->P == 0) { if (gsr_memset_async(status_dev, 0, sizeof(uint32_t), s)) { gsr_set_error("status"); return 1; }; return 0; }
     GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
     if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
     const uint32_t cap = gsr_binning_capacity(cfg->variant, binning_bytes, cfg->W, cfg->H);
@@ -376,7 +395,7 @@ extern "C" int gsr_backward_ex(const gsr_cfg* cfg, const gsr_inputs* in, const i
                               const_cast<void*>(binning));
     ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img));
     float* acc = reinterpret_cast<float*>(scratch);
-    if (!(flags & GSR_BWD_SCRATCH_IS_ZERO)) { ProfScope ps(GSR_PROF_BWD_MEMSET, s); GSR_CHECK(hipMemsetAsync(acc, 0, need, s), "memset acc"); }
+    if (!(flags & GSR_BWD_SCRATCH_IS_ZERO)) { ProfScope ps(GSR_PROF_BWD_MEMSET, s); if (gsr_memset_async(acc, 0, need, s)) { gsr_set_error("memset acc"); return 1; }; }
     if (num_rendered > 0) {
         ProfScope ps(GSR_PROF_BLEND_BWD, s);
         if (gsr_launch_blend_bwd(cfg, in, g, b, im, og, acc, s)) return 1;

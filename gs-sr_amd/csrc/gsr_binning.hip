@@ -279,7 +279,7 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
     // ~3 M at 4096) that costs more than the row-scan kernel it replaces (measured: 17 M instances, +0.23 ms per forward), so large sorts keep
     // the digit-major matrix + k_scan_rows (digit totals in GH[0]).
     const uint32_t dm = (ngroups > GSR_SORT_MAX_GROUPS) ? nblk : 0u;
-    if (!dm && !group0_zeroed) GSR_CHECK(hipMemsetAsync(GH[0], 0, (size_t)NB * ngroups * sizeof(uint32_t), s), "memset group histogram");
+    if (!dm && !group0_zeroed) if (gsr_memset_async(GH[0], 0, (size_t)NB * ngroups * sizeof(uint32_t), s)) { gsr_set_error("memset group histogram"); return 1; };
     // identity_vals: the first pass generates value i for element i instead of reading vals_a
     uint32_t *kin = keys_a, *vin = identity_vals ? nullptr : vals_a, *kout = keys_b, *vout = vals_b;
     bool in_b = false;
@@ -443,7 +443,7 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
 {
     const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     const int T = gx * gy;
-    if (R == 0) { GSR_CHECK(hipMemsetAsync(im.ranges, 0, (size_t)T * sizeof(uint2), s), "memset ranges"); return 0; }
+    if (R == 0) { if (gsr_memset_async(im.ranges, 0, (size_t)T * sizeof(uint2), s)) { gsr_set_error("memset ranges"); return 1; }; return 0; }
     // unsorted instances go to the buffer from which an integral number of passes lands in (tile_keys, point_list)
     const int passes = gsr_tile_sort_passes(T);
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;

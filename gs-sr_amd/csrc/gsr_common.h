@@ -91,6 +91,10 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
                          const gsr_outputs* out, hipStream_t s);
 int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_out_grads* og, float* acc, hipStream_t s);
+// hipMemsetAsync that is safe to record into a HIP graph: on ROCm 7.2 a memset NODE replays with a corrupted fill value from the second replay
+// on (measured round 3: vis_idx filled with 0x5A5A5A5A instead of 0xFF...), so while `s` is being captured the fill is a kernel; eagerly it is
+// the runtime's memset.  nbytes must be a multiple of 4.
+int gsr_memset_async(void* p, int byte_value, size_t nbytes, hipStream_t s);
 int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,
                               float* acc, const gsr_in_grads* ig, bool leave_zero, hipStream_t s);
 

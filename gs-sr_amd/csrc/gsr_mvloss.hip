@@ -428,8 +428,8 @@ extern "C" int gsr_sample_mask(int64_t n, const uint8_t* mask, int32_t num, uint
     uint2* blockcnt = (uint2*)q;
     const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
     const int64_t slots = n < (int64_t)num ? n : (int64_t)num;
-    (void)hipMemsetAsync(hist, 0, 2 * 4096 * sizeof(uint32_t), s);
-    (void)hipMemsetAsync(idx_out, 0xFF, sizeof(int32_t) * (size_t)slots, s);
+    (void)gsr_memset_async(hist, 0, 2 * 4096 * sizeof(uint32_t), s);
+    (void)gsr_memset_async(idx_out, 0xFF, sizeof(int32_t) * (size_t)slots, s);
     hipLaunchKernelGGL(k_sm_hist<0>, dim3(nblk), dim3(256), 0, s, n, mask, s0, s1, (const SmSel*)sel, hist);
     hipLaunchKernelGGL(k_sm_pick<0>, dim3(1), dim3(1024), 0, s, (const uint32_t*)hist, (uint32_t)num, sel);
     hipLaunchKernelGGL(k_sm_hist<1>, dim3(nblk), dim3(256), 0, s, n, mask, s0, s1, (const SmSel*)sel, hist + 4096);
@@ -463,7 +463,7 @@ extern "C" int gsr_loss_plane_mv_geo(const gsr_mv_cfg* cfg, const float* plane_d
         gsr_set_error("loss_plane_mv_geo: null pointer or scratch too small"); return 1;
     }
     const dim3 grid(gsr_div_up(cfg->W, 32), gsr_div_up(cfg->H, 8));
-    (void)hipMemsetAsync(g_near, 0, sizeof(float) * (size_t)cfg->Wn * cfg->Hn, s);
+    (void)gsr_memset_async(g_near, 0, sizeof(float) * (size_t)cfg->Wn * cfg->Hn, s);
     hipLaunchKernelGGL(k_mv_geo, grid, dim3(256), 0, s, *cfg, plane_depth, near_plane_depth, noise, d_mask, weight, g_depth, g_near, (float2*)scratch);
     hipLaunchKernelGGL(k_mv_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, (int)(grid.x * grid.y), stats);
     return gsr_check_launch("loss_plane_mv_geo", s, false);
@@ -480,8 +480,8 @@ extern "C" int gsr_loss_plane_mv_ncc(const gsr_mv_cfg* cfg, int32_t n_samples, c
         gsr_set_error("loss_plane_mv_ncc: null pointer or scratch too small"); return 1;
     }
     const size_t HW = (size_t)cfg->W * cfg->H;
-    (void)hipMemsetAsync(g_normal, 0, sizeof(float) * 3 * HW, s);
-    (void)hipMemsetAsync(g_distance, 0, sizeof(float) * HW, s);
+    (void)gsr_memset_async(g_normal, 0, sizeof(float) * 3 * HW, s);
+    (void)gsr_memset_async(g_distance, 0, sizeof(float) * HW, s);
     const int blocks = gsr_div_up(n_samples > 0 ? n_samples : 1, 16);
     const int ntap = (2 * cfg->patch + 1) * (2 * cfg->patch + 1);
     if (ntap <= 64)

@@ -222,7 +222,7 @@ extern "C" int gsr_tsdf_sparse_integrate(const gsr_tsdf_sparse* s, int32_t W, in
     t.trunc = s->sdf_trunc; t.dtrunc = depth_trunc; t.unit_len = s->voxel_length * TS_RES; t.inv_unit = 1.0f / t.unit_len;
     for (int k = 0; k < 12; k++) t.P[k] = pose[k];
     const int n = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
-    GSR_CHECK(hipMemsetAsync(v.counters + 1, 0, sizeof(int32_t), st), "tsdf_sparse: reset list");
+    if (gsr_memset_async(v.counters + 1, 0, sizeof(int32_t), st)) { gsr_set_error("tsdf_sparse: reset list"); return 1; };
     hipLaunchKernelGGL(k_ts_touch_insert, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n);
     hipLaunchKernelGGL(k_ts_touch_stamp, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n, frame);
     int32_t c[3] = { 0, 0, 0 };

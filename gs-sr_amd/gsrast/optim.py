@@ -109,11 +109,19 @@ class Adam(torch.optim.Adam):
             table = (_AdamTensor * len(entries))(*entries)
             with torch.cuda.device(dev):
                 if capturing:
-                    hyper = torch.empty(len(entries), 2, dtype=torch.float32, device=dev)      # from the graph's pool: lives as long as the graph
-                    host = torch.empty(len(entries), 2, dtype=torch.float32).pin_memory()
-                    self._gsr_graph.append((captured, hyper, host))
+                    # The buffer the recorded launch reads its per-step scalars from must NOT come from the graph's private pool: a block of that
+                    # pool may have held a temporary earlier in the recorded iteration, whose recorded writes would then overwrite, on every
+                    # replay, what prepare_replay() copied in beforehand (measured: step_size read back as 0).  It is created by the eager
+                    # step() calls that precede every capture (torch.cuda.graph needs warm-up iterations anyway).
+                    hyper = self.__dict__.get("_gsr_hyper", {}).get(dev)
+                    if hyper is None or hyper.shape[0] < len(entries):
+                        raise RuntimeError("gsrast.optim.Adam: run at least one eager step() before recording step() into a graph")
+                    self._gsr_graph.append([captured, hyper, [], 0])
                     check(L.gsr_adam_step_multi_dev(len(entries), table, hyper.data_ptr(), stream_ptr(dev)), "adam_step_multi_dev")
                 else:
+                    hy = self.__dict__.setdefault("_gsr_hyper", {})
+                    if dev not in hy or hy[dev].shape[0] < len(entries):
+                        hy[dev] = torch.zeros(len(entries) + 8, 2, dtype=torch.float32, device=dev)
                     check(L.gsr_adam_step_multi(len(entries), table, stream_ptr(dev)), "adam_step_multi")
         if capturing:
             return loss
@@ -132,15 +140,26 @@ class Adam(torch.optim.Adam):
     @torch.no_grad()
     def prepare_replay(self):
         """Before every replay of a graph that holds this optimizer's step(): one more step for every captured parameter -- counters bumped,
-        the groups' current learning rates and the bias corrections written to the device buffer the captured launch reads."""
-        for captured, hyper, host in getattr(self, "_gsr_graph", ()):
-            h = host.numpy()
+        the groups' current learning rates and the bias corrections written to the device buffer the captured launch reads (one small
+        asynchronous copy from a ring of pinned host buffers: the host may run several replays ahead of the device)."""
+        for ent in getattr(self, "_gsr_graph", ()):
+            captured, hyper, ring, pos = ent
+            if len(ring) < 16:
+                ring.append([torch.empty(len(captured), 2, dtype=torch.float32).pin_memory(), None])
+                slot = ring[-1]
+            else:
+                slot = ring[pos % 16]
+                slot[1].synchronize()              # the copy that last used this pinned buffer has completed (16 replays ago: normally no wait)
+            ent[3] = pos + 1
+            h = slot[0].numpy()
             for i, (p, group) in enumerate(captured):
                 st = self.state[p]
                 st["step"] += 1
                 t = float(st["step"])
                 beta1, beta2 = group["betas"]
-                lr = group["lr"]
-                h[i, 0] = float(lr) / (1.0 - beta1 ** t)
+                h[i, 0] = float(group["lr"]) / (1.0 - beta1 ** t)
                 h[i, 1] = math.sqrt(1.0 - beta2 ** t)
-            hyper.copy_(host, non_blocking=True)
+            hyper[: len(captured)].copy_(slot[0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            slot[1] = ev

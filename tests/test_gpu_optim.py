@@ -98,3 +98,37 @@ def test_more_tensors_than_one_table_with_empty_ones():
             assert torch.allclose(pa[i], pb[i], rtol=0, atol=1e-4 * lrs[i] + 5e-7), (t, i)
             assert torch.allclose(oa.state[pa[i]]["exp_avg"], ob.state[pb[i]]["exp_avg"], rtol=1e-5, atol=2e-6), (t, i)
             assert torch.allclose(oa.state[pa[i]]["exp_avg_sq"], ob.state[pb[i]]["exp_avg_sq"], rtol=1e-5, atol=1e-12), (t, i)
+
+
+def test_step_recorded_in_a_hip_graph_matches_torch():
+    """step() issued during stream capture records ONE launch that reads step_size / bias correction from a device buffer; prepare_replay()
+    refreshes it (and honours a learning-rate rewrite) before every replay.  Six replays == six steps of torch.optim.Adam on the same gradients."""
+    from gsrast.optim import Adam
+    shapes = [(20001, 3), (20001, 1), (7,), (513, 4)]
+    lrs = [1.6e-4, 5e-2, 1e-3, 2e-3]
+    pa, oa = _models(7, shapes, lrs, Adam)
+    pb, ob = _models(7, shapes, lrs, lambda groups, **kw: torch.optim.Adam(groups, foreach=False, **kw))
+    gen = torch.Generator().manual_seed(3)
+    static_g = [torch.zeros(s, device=DEV) for s in shapes]
+    for p, g in zip(pa, static_g):
+        p.grad = g                                   # static gradient slots, as a recorded backward leaves them
+    def feed():
+        gs = [torch.randn(s, generator=gen) for s in shapes]
+        for sg, g, q in zip(static_g, gs, pb):
+            sg.copy_(g.to(DEV)); q.grad = g.to(DEV)
+    feed(); oa.step(); ob.step()                     # one eager step creates the state
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        oa.step()
+    for t in range(2, 8):
+        if t == 5:
+            oa.param_groups[0]["lr"] = 3e-5; ob.param_groups[0]["lr"] = 3e-5
+        feed()
+        oa.prepare_replay(); graph.replay(); ob.step()
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert float(oa.state[a]["step"]) == t
+            lr = oa.param_groups[i]["lr"]
+            assert torch.allclose(a, b, rtol=0, atol=1e-4 * lr + 5e-7), (t, i, (a - b).abs().max().item())

@@ -74,6 +74,8 @@ def build(a, dev, seed=0):
            "offset_gradient_accum": torch.zeros(a.Na * k, 1, device=dev), "offset_denom": torch.zeros(a.Na * k, 1, device=dev)}
     st = {}
 
+    stop = getattr(a, "stop_after", None)        # debugging aid (tools/debug_graph.py): return the intermediates of a prefix of the iteration
+
     def step():
         scaling = torch.exp(scaling_log)
         with torch.no_grad():                                 # prefilter_voxel (scaffold_scene.py:122-155)
@@ -84,6 +86,8 @@ def build(a, dev, seed=0):
                 radii = sf.GaussianRasterizer(fs).visible_filter(means3D=anchor, scales=scaling[:, :3], rotations=rot_anchor, cov3D_precomp=None)
                 vmask = radii > 0
         app = emb.weight[1]
+        if stop == "prefilter":
+            return [vmask.clone(), decode.compact_visible(vmask, padded=True).clone()]
         if a.decode == "hip":
             vis_idx = decode.compact_visible(vmask, padded=True)   # once per iteration, shared by the decode and the statistics; no host sync
             count = None
@@ -101,27 +105,45 @@ def build(a, dev, seed=0):
                    "W1k": mlp_k[0].weight, "b1k": mlp_k[0].bias, "W2k": mlp_k[2].weight, "b2k": mlp_k[2].bias, "app": app}
             o, _ = ref_decode_torch.decode_live(case, leaves, par, vis, campos)
             xyz, color, opacity, scl, rot = o["xyz"], o["color"], o["opacity"].view(-1, 1), o["scaling"], o["rot"]
+        if stop == "decode":
+            return [xyz.clone(), opacity.clone(), scl.clone(), rot.clone(), color.clone()] + ([count.clone()] if static else [])
         means2D = torch.zeros_like(xyz, requires_grad=True)
         img, rad, allmap = dsr.GaussianRasterizer(rs)(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color,
                                                       scales=scl[:, :2].contiguous(), rotations=rot)
+        if stop == "raster":
+            return [img.clone(), rad.clone(), allmap.clone()]
         if static and a.decode == "hip":        # mean over the P emitted Gaussians: the parked rows have scale 0 and only the divisor differs
-            reg = 0.01 * scl[:, :2].prod(dim=1).sum() / count.to(torch.float32)[0]
+            reg = 0.01 * (scl[:, 0] * scl[:, 1]).sum() / count.to(torch.float32)[0]
         else:
-            reg = 0.01 * scl[:, :2].prod(dim=1).mean()                                          # scaling_loss (scaffold_2dgs_scene.py:26)
+            reg = 0.01 * (scl[:, 0] * scl[:, 1]).mean()      # scaling_loss (scaffold_2dgs_scene.py:26); x*y, not prod(): prod's backward synchronises when an entry is 0
         if a.loss == "bench":
             loss = l1_plus_linear(img, gt, allmap, wmap) + reg
         elif a.loss == "full-hip":
             loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + surfel_geo_loss(allmap, rm, nr, 0.0, 0.05, 100.0, unit_upstream=True)[0] + reg
         else:
             loss = ref_loss_torch.loss(img.unsqueeze(0), gt.unsqueeze(0), 0.2)[0] + ref_geo_torch.geo_loss(allmap, wvt, fpt, 0.0, 0.05, 100.0)[0] + reg
+        if stop == "loss":
+            return [loss.detach().clone()]
         loss.backward()
+        if stop == "backward":
+            out = [p.grad.clone() for p in params if p.grad is not None] + [means2D.grad.clone()]
+            opt.zero_grad(set_to_none=True)
+            return out
         if a.loss != "bench":                                    # densify(): training_statis every iteration (scaffold_gaussian.py:707-712)
             if a.decode == "hip":
                 decode.training_stats_(acc["opacity_accum"], acc["anchor_demon"], acc["offset_gradient_accum"], acc["offset_denom"], means2D.grad,
                                        nop, rad > 0, mask, vis_idx=vis_idx)
             else:
                 ref_decode_torch.training_statis(acc, k, means2D.grad, o["neural_opacity"].view(-1, 1), rad > 0, o["mask"], vmask)
-        opt.step(); opt.zero_grad(set_to_none=True)
+        if stop == "stats":
+            opt.zero_grad(set_to_none=True)
+            return [acc["opacity_accum"].clone()]
+        opt.step()
+        if stop == "step":
+            out = [p.detach().clone() for p in params]
+            opt.zero_grad(set_to_none=True)
+            return out
+        opt.zero_grad(set_to_none=True)
         if "Nv" not in st:                       # once (first eager call): host reads for the report
             st["Nv"] = int(vmask.sum())
             st["P"] = int(count[0]) if (static and a.decode == "hip") else xyz.shape[0]

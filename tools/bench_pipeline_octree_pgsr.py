@@ -28,7 +28,9 @@ from gsrast.optim import Adam          # noqa: E402
 
 
 def build(a, dev, seed=0):
-    """-> (step, st): one octree-pgsr training iteration (step > 7000); a has .Na."""
+    """-> (step, st): one octree-pgsr training iteration (step > 7000); a has .Na and optionally .static (the sync-free static-shape form:
+    decode with static_rows, recordable into a HIP graph -- gsrast.graphs.GraphedStep)."""
+    static = bool(getattr(a, "static", False))
     W, H, k, A, LEVELS, FORK = 1920, 1080, 10, 32, 6, 2.0
     sc = scenes.make_scene("plane", a.Na, W, H, seed=seed, color_mode="precomp")
     t = hiprun.to_dev(sc, dev)
@@ -72,19 +74,23 @@ def build(a, dev, seed=0):
         vis = octree.octree_visible(fs, anchor, level, scaling, rot_anchor, voxel_size, FORK, standard_dist, LEVELS, dist2level="round",
                                     extra_level=extra_level)   # set_anchor_mask + prefilter_voxel, no host sync
         vis_idx = decode.compact_visible(vis["visible_mask"], padded=True)
-        xyz, color, opacity, scl, rot, nop, mask = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, tt["campos"],
-                                                                          vis_idx=vis_idx, appearance=emb.weight[cam_id])
+        out = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, tt["campos"], vis_idx=vis_idx, appearance=emb.weight[cam_id],
+                                      static_rows=static)
+        xyz, color, opacity, scl, rot, nop, mask = out[:7]
+        count = out[7] if static else None
         am = plane_input_all_map(xyz, rot, scl, tt["viewmatrix"], tt["campos"])
         m2 = torch.zeros_like(xyz, requires_grad=True); m2a = torch.zeros_like(xyz, requires_grad=True)
         img, radii, obs, oam, pd = dpr.GaussianRasterizer(rs)(means3D=xyz, means2D=m2, means2D_abs=m2a, opacities=opacity, colors_precomp=color,
                                                              scales=scl, rotations=rot, all_map=am)
-        return img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vis["visible_mask"]
+        return img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vis["visible_mask"], count
 
     def step():
         scaling = torch.exp(scaling_log)
-        img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask = render(views[0], 1, scaling)
-        _, _, _, pd2, _, _, _, _, _, _ = render(views[1], 2, scaling)
-        loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + plane_geo_loss(pd, oam, rm1, weight, 0.015, unit_upstream=True)[0] + 0.01 * scl.prod(dim=1).mean()
+        img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask, count = render(views[0], 1, scaling)
+        pd2 = render(views[1], 2, scaling)[3]
+        vol = scl[:, 0] * scl[:, 1] * scl[:, 2]          # x*y*z, not prod(dim=1): prod's backward synchronises (nonzero) when an entry is 0
+        reg = 0.01 * (vol.sum() / count.to(torch.float32)[0] if static else vol.mean())
+        loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + plane_geo_loss(pd, oam, rm1, weight, 0.015, unit_upstream=True)[0] + reg
         geo, ncc = plane_multiview_loss(pd, pd2, None, None, gray1, gray2, mcfg, 0.03, 0.15, out_all_map=oam)
         (loss + geo + ncc).backward()
         decode.training_stats_(acc["opacity_accum"], acc["anchor_demon"], acc["offset_gradient_accum"], acc["offset_denom"], m2.grad, nop, radii > 0,
@@ -93,16 +99,24 @@ def build(a, dev, seed=0):
         if "P" not in st:
             st["P"] = int(mask.sum()); st["Nv"] = int(vmask.sum())
 
+    st["optimizers"] = [opt]
     return step, st
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--static", action="store_true", help="sync-free static-shape iteration (decode static_rows)")
+    ap.add_argument("--graph", action="store_true", help="record the (static) iteration into a HIP graph and replay it")
     ap.add_argument("--Na", type=int, default=74000)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     a = ap.parse_args()
+    if a.graph:
+        a.static = True
     step, st = build(a, torch.device("cuda:0"))
+    if a.graph:
+        from gsrast.graphs import GraphedStep
+        step = GraphedStep(step, optimizers=st["optimizers"], warmup=max(3, a.warmup))
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -110,7 +124,7 @@ def main():
         step()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(json.dumps({"pipeline": "octree-pgsr (step > 7000: LOD mask + prefilter + decode + plane render, twice; single-view + multi-view losses)",
-                      "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps, "ms_per_iter": round(1e3 * dt / a.steps, 3),
+                      "mode": "graph" if a.graph else ("static" if a.static else "eager"), "Na": a.Na, "Nv": st["Nv"], "P": st["P"], "steps": a.steps, "ms_per_iter": round(1e3 * dt / a.steps, 3),
                       "iters_per_s": round(a.steps / dt, 1)}))
 
 

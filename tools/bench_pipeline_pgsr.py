@@ -99,6 +99,7 @@ def build(a, dev):
         (loss + geo + ncc).backward()
         opt.step(); opt.zero_grad(set_to_none=True)
 
+    st["optimizers"] = [opt]
     if a.glue == "torch":                                                 # a fixed sample set of the reference's size
         with torch.no_grad():
             st["idx"] = torch.randperm(W * H, device=dev)[:102400]
