@@ -174,15 +174,18 @@ def make_step(variant, sc, device):
 
 
 def cpu_baseline(variant, sc, og, budget_s=25.0):
-    """Times the CPU oracle (plain-C restatement, OpenMP over all host threads) on the SAME scene: raster fwd+bwd.
-    Also returns the last run's outputs so that the caller can state full-size parity in the same line (the oracle as the checker)."""
+    """Times the CPU oracle (plain-C restatement of the reference's rasterizer, OpenMP) on the SAME scene, as BASELINE.md section 3 asks:
+      * all host threads: rasterizer forward+backward (`value`), and one complete TRAIN STEP = that + the L1 image loss / its gradient + Adam on
+        the explicit parameters, the latter two as torch CPU ops (`train_step_ms`);
+      * one thread: a bounded sample -- every 32nd tile in the blend loops -- extrapolated to the whole image (`one_thread`).
+    Also returns workload statistics of the forward (evaluated / contributing (pixel, splat) pairs)."""
     import oracle
     keep = {}
 
     def once():
         with oracle.Forward(sc, variant) as f:
-            g = f.backward(**og)
-            keep.update(color=f.color.copy(), radii=f.radii.copy(), point_list=f.point_list(), grads=g)
+            f.backward(**og)
+            keep["pairs"] = f.pair_counts()
     t0 = time.time()
     once()
     first = time.time() - t0
@@ -193,10 +196,40 @@ def cpu_baseline(variant, sc, og, budget_s=25.0):
         tot += time.time() - t0
         n += 1
     per = (tot / n) if n else first
-    return {"value": round(1.0 / per, 4), "unit": "rasterize fwd+bwd iters/s", "cores": oracle.omp_threads(), "kind": "port",
+    # loss + optimizer of the train step on the host (torch CPU, all threads): L1 against a target + its gradient, Adam on every parameter tensor
+    P, W, H = sc["means3D"].shape[0], int(sc["W"]), int(sc["H"])
+    img = torch.rand(3, H, W); gt = torch.rand(3, H, W)
+    prm = [torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(sc[k], np.float32)).reshape(P, -1).clone())
+           for k in ("means3D", "scales", "rotations", "opacities", "shs" if sc.get("shs") is not None else "colors_precomp")]
+    opt = torch.optim.Adam(prm, lr=1e-4, eps=1e-15)
+    for q in prm:
+        q.grad = torch.randn_like(q)
+    t0 = time.time()
+    for _ in range(3):
+        x = img.clone().requires_grad_(True)
+        (x - gt).abs().mean().backward()
+        opt.step()
+    extra = (time.time() - t0) / 3
+    # one thread, every 32nd tile; the per-Gaussian stages (preprocess, scan, duplicate, sort) are measured with no tile at all and not scaled
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    threads = oracle.omp_threads()
+    oracle.set_threads(1)
+    try:
+        oracle.set_tile_stride(T + 1); t0 = time.time(); once(); t_fixed = time.time() - t0
+        oracle.set_tile_stride(32); t0 = time.time(); once(); t_s = time.time() - t0
+    finally:
+        oracle.set_tile_stride(1); oracle.set_threads(threads)
+    one = t_fixed + 32.0 * max(t_s - t_fixed, 0.0)
+    return {"value": round(1.0 / per, 4), "unit": "rasterize fwd+bwd iters/s", "cores": threads, "kind": "port",
             "ms_per_iter": round(per * 1e3, 1),
+            "train_step_ms": round((per + extra) * 1e3, 1), "train_step_iters_per_s": round(1.0 / (per + extra), 4),
+            "train_step_what": f"rasterizer fwd+bwd ({per * 1e3:.0f} ms, oracle, {threads} threads) + L1 loss and gradient + Adam on {sum(q.numel() for q in prm)} "
+                               f"parameters ({extra * 1e3:.1f} ms, torch CPU)",
+            "one_thread": {"ms_per_iter_extrapolated": round(one * 1e3, 0), "iters_per_s": round(1.0 / one, 5),
+                           "sample": f"1 OpenMP thread; per-Gaussian stages in full ({t_fixed:.2f} s) + every 32nd tile of the blend forward+backward "
+                                     f"({t_s - t_fixed:.2f} s) x 32"},
             "sample": f"{max(n, 1)} x full workload ({variant}, same scene as the GPU run), oracle/gsr_oracle.c with OpenMP; "
-                      f"rasterizer forward+backward only (no loss/optimizer)"}, keep
+                      f"rasterizer forward+backward only (no loss/optimizer) for `value`"}, keep
 
 
 def parity_full_size(variant, sc, og, device, color_mode):
@@ -480,7 +513,11 @@ def main():
                                    f"P={args.P}, {args.W}x{args.H}, synthetic scene SURVEY §8d (seed=rank); the complete methods (decode, SSIM, "
                                    f"regularisers, statistics) are timed in method_iteration",
                        "variant": args.variant, "P": args.P, "W": args.W, "H": args.H, "tile_instances_R": R, "tile_instances_R_after_timed_steps": R_after,
-                       "visible": int((st["radii"] > 0).sum()), "parallelism": f"{world} independent tile(s), 1 per GPU, no collective"},
+                       "visible": int((st["radii"] > 0).sum()),
+                       "tiles": T, "tiles_touched": int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()),
+                       "gaussians_per_tile_mean": round(R / max(int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()), 1), 1),
+                       "gaussians_per_tile_max": int((st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0].astype(np.int64)).max()),
+                       "parallelism": f"{world} independent tile(s), 1 per GPU, no collective"},
             "rasterize_fwd_ms": round(raster_fwd, 4), "rasterize_bwd_ms": round(raster_bwd, 4),
             "rasterize_fwd_bwd_ms": round(raster_fwd + raster_bwd, 4),
             "stage_ms": {k: round(v, 4) for k, v in ms.items()},
@@ -506,7 +543,10 @@ def main():
             out["method_iteration"] = {m: method_iteration(device, m) for m in ("scaffold-2dgs", "octree-2dgs", "octree-pgsr", "pgsr")}
         if world == 1 and not args.no_cpu_baseline:
             og = scenes.random_out_grads(args.variant, args.W, args.H, seed=0)
-            out["cpu_baseline"], _ = cpu_baseline(args.variant, sc, og)
+            out["cpu_baseline"], kept = cpu_baseline(args.variant, sc, og)
+            ev, co = kept["pairs"]
+            out["config"].update(pairs_evaluated_by_the_reference_loop=ev, contributing_pairs_C=co,
+                                 contributing_pairs_per_tile_instance=round(co / max(R, 1), 2))
             out["parity_full_size"] = parity_full_size(args.variant, sc, og, device, args.color_mode)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -82,7 +82,7 @@ struct TouchParams {
     float fx, fy, cx, cy, rfx, rfy, trunc, dtrunc, unit_len, inv_unit;
     float P[12];       // camera -> world (inverse extrinsic), row-major 3x4
 };
-__device__ __forceinline__ bool ts_pixel_range(const TouchParams& t, const float* __restrict__ depth, int i, int* lo, int* hi)
+__device__ __forceinline__ bool ts_pixel_range(const TouchParams& t, const float* __restrict__ depth, int i, int* lo, int* hi, int* oor)
 {
     const int nu = (t.W + t.stride - 1) / t.stride;
     const int u = (i % nu) * t.stride, v = (i / nu) * t.stride;
@@ -96,7 +96,9 @@ __device__ __forceinline__ bool ts_pixel_range(const TouchParams& t, const float
     for (int a = 0; a < 3; a++) {
         lo[a] = (int)floorf((p[a] - t.trunc) * t.inv_unit);
         hi[a] = (int)floorf((p[a] + t.trunc) * t.inv_unit);
-        if (lo[a] < -(1 << 20) + 1 || hi[a] > (1 << 20) - 2 || hi[a] - lo[a] > 3) return false;      // outside the key range / degenerate
+        // outside the 21-bit key range (or a box wider than the 4 units check_vol admits): the sample cannot be stored -> raise the volume's
+        // "out of range" flag instead of dropping it silently (the host turns it into an error after the launch)
+        if (lo[a] < -(1 << 20) + 1 || hi[a] > (1 << 20) - 2 || hi[a] - lo[a] > 3) { *oor = 1; return false; }
     }
     return true;
 }
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(256) k_ts_touch_insert(SparseTsdf v, TouchPara
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int lo[3], hi[3];
-    if (!ts_pixel_range(t, depth, i, lo, hi)) return;
+    if (!ts_pixel_range(t, depth, i, lo, hi, &v.counters[3])) return;
     for (int x = lo[0]; x <= hi[0]; x++)
         for (int y = lo[1]; y <= hi[1]; y++)
             for (int z = lo[2]; z <= hi[2]; z++) (void)ts_insert(v, x, y, z);
@@ -115,7 +117,8 @@ __global__ void __launch_bounds__(256) k_ts_touch_stamp(SparseTsdf v, TouchParam
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int lo[3], hi[3];
-    if (!ts_pixel_range(t, depth, i, lo, hi)) return;
+    int scratch_flag = 0;
+    if (!ts_pixel_range(t, depth, i, lo, hi, &scratch_flag)) return;
     for (int x = lo[0]; x <= hi[0]; x++)
         for (int y = lo[1]; y <= hi[1]; y++)
             for (int z = lo[2]; z <= hi[2]; z++) {
@@ -206,6 +209,11 @@ static int check_vol(const gsr_tsdf_sparse* s)
         gsr_set_error("tsdf_sparse: hash table must hold at least twice the unit capacity"); return 1;
     }
     if (!(s->voxel_length > 0.f) || !(s->sdf_trunc > 0.f)) { gsr_set_error("tsdf_sparse: voxel_length / sdf_trunc must be positive"); return 1; }
+    // a depth sample opens the units its +-sdf_trunc box overlaps, at most 4 per axis: a wider band would be dropped sample by sample
+    if (2.0f * s->sdf_trunc > 3.0f * TS_RES * s->voxel_length) {
+        gsr_set_error("tsdf_sparse: sdf_trunc %g exceeds 1.5 units (%g = 24 voxels): the truncation band must fit in 4 units per axis", s->sdf_trunc,
+                      1.5f * TS_RES * s->voxel_length); return 1;
+    }
     return 0;
 }
 
@@ -225,10 +233,15 @@ extern "C" int gsr_tsdf_sparse_integrate(const gsr_tsdf_sparse* s, int32_t W, in
     if (gsr_memset_async(v.counters + 1, 0, sizeof(int32_t), st)) { gsr_set_error("tsdf_sparse: reset list"); return 1; };
     hipLaunchKernelGGL(k_ts_touch_insert, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n);
     hipLaunchKernelGGL(k_ts_touch_stamp, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n, frame);
-    int32_t c[3] = { 0, 0, 0 };
+    int32_t c[4] = { 0, 0, 0, 0 };
     GSR_CHECK(hipMemcpyAsync(c, v.counters, sizeof(c), hipMemcpyDeviceToHost, st), "tsdf_sparse: read counters");
     GSR_CHECK(hipStreamSynchronize(st), "tsdf_sparse: sync");
     if (c[2]) { gsr_set_error("tsdf_sparse: capacity exhausted (%u units); allocate a larger volume", s->cap_blocks); return 1; }
+    if (c[3]) {
+        (void)gsr_memset_async(v.counters + 3, 0, sizeof(int32_t), st);
+        gsr_set_error("tsdf_sparse: a depth sample lies outside the addressable volume (|unit coordinate| >= 2^20, i.e. %g scene units from the origin)",
+                      (double)(1 << 20) * s->voxel_length * TS_RES); return 1;
+    }
     if (n_touched_host) *n_touched_host = (uint32_t)c[1];
     if (c[1] > 0) {
         IntParams p;

@@ -2,7 +2,7 @@
 compute_unbounded_tsdf (gssr/utils/mesh_utils.py:195-246) as one streaming kernel."""
 import torch
 
-from . import lib, check, ptr, stream_ptr, dev_f32, TsdfSparse
+from . import last_error, lib, check, ptr, stream_ptr, dev_f32, TsdfSparse
 
 
 def tsdf_integrate_(points, full_proj_transform, depthmap, rgbmap, sdf_trunc, tsdfs, rgbs, weights):
@@ -55,6 +55,8 @@ class DenseTSDFVolume:
         c = dev_f32(rgb, "rgb", allow_empty=False)
         if quantize_rgb8:        # mesh_utils.py:170 converts colours to uint8 before fusion
             c = (torch.clamp(c, 0.0, 1.0) * 255).to(torch.uint8).to(torch.float32).contiguous()
+        else:                    # same 0..255 scale without the rounding, so that volumes built either way can be merged
+            c = (torch.clamp(c, 0.0, 1.0) * 255).contiguous()
         H, W = int(d.shape[-2]), int(d.shape[-1])
         E = (C.c_float * 16)(*[float(v) for v in torch.as_tensor(extrinsic, dtype=torch.float32).reshape(-1).tolist()])
         o = (C.c_float * 3)(*self.origin)
@@ -94,15 +96,20 @@ class ScalableTSDFVolume:
     csrc/gsr_tsdf_sparse.hip); tests pin the HIP volume against a plain-C restatement on the CPU and, unit by unit, against
     DenseTSDFVolume.
 
-    capacity_units bounds the number of 16^3 units (80 KB each: tsdf + weight + 3 colour floats per voxel); exceeding it raises.
+    capacity_units is the INITIAL number of 16^3 units (80 KB each: tsdf + weight + 3 colour floats per voxel); a frame that needs more doubles
+    the pool (a fresh volume, the existing units merged in on the device) unless auto_grow=False, in which case it raises.
+    Colours are stored on the 0..255 scale whether or not they are quantised to integers first (quantize_rgb8).
     Multi-GPU (extract_mesh_split.py:54-128): every rank integrates its own tile's frames, `merge_()` fuses the volumes of all ranks
     (weighted running averages are associative), `merge_from(other)` fuses two volumes on one device."""
 
     RES = 16
 
-    def __init__(self, voxel_length, sdf_trunc, capacity_units=16384, device="cuda", depth_sampling_stride=4):
+    def __init__(self, voxel_length, sdf_trunc, capacity_units=16384, device="cuda", depth_sampling_stride=4, auto_grow=True):
         self.voxel_length = float(voxel_length)
         self.sdf_trunc = float(sdf_trunc)
+        self.auto_grow = bool(auto_grow)
+        if 2.0 * self.sdf_trunc > 3.0 * self.RES * self.voxel_length:
+            raise RuntimeError(f"ScalableTSDFVolume: sdf_trunc {self.sdf_trunc} exceeds 1.5 units = {1.5 * self.RES * self.voxel_length} (24 voxels)")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("ScalableTSDFVolume lives on a HIP device; there is no CPU path")
@@ -135,6 +142,8 @@ class ScalableTSDFVolume:
         c = dev_f32(rgb, "rgb", allow_empty=False)
         if quantize_rgb8:        # mesh_utils.py:170 converts colours to uint8 before fusion
             c = (torch.clamp(c, 0.0, 1.0) * 255).to(torch.uint8).to(torch.float32).contiguous()
+        else:                    # same 0..255 scale without the rounding, so that volumes built either way can be merged
+            c = (torch.clamp(c, 0.0, 1.0) * 255).contiguous()
         H, W = int(d.shape[-2]), int(d.shape[-1])
         E = torch.as_tensor(extrinsic, dtype=torch.float64).reshape(4, 4).cpu()
         Pm = torch.linalg.inv(E)
@@ -142,13 +151,29 @@ class ScalableTSDFVolume:
         Pa = (C.c_float * 12)(*[float(v) for v in Pm[:3].reshape(-1).tolist()])
         self.frame += 1
         n = C.c_uint32(0)
-        st = self._struct()
-        with torch.cuda.device(self.device):
-            check(lib().gsr_tsdf_sparse_integrate(C.byref(st), W, H, ptr(d), ptr(c), float(fx), float(fy), float(cx), float(cy), Ea, Pa,
-                                                  float(min(depth_trunc, 3.0e38)), self.stride, self.frame, C.byref(n), stream_ptr(self.device)),
-                  "tsdf_sparse_integrate")
+        while True:
+            st = self._struct()
+            with torch.cuda.device(self.device):
+                rc = lib().gsr_tsdf_sparse_integrate(C.byref(st), W, H, ptr(d), ptr(c), float(fx), float(fy), float(cx), float(cy), Ea, Pa,
+                                                     float(min(depth_trunc, 3.0e38)), self.stride, self.frame, C.byref(n), stream_ptr(self.device))
+            if rc != 0 and self.auto_grow and "capacity exhausted" in last_error() and self.cap < (1 << 27):
+                self._grow()              # the touch pass ran out of pool slots before any voxel was updated: double the pool, integrate again
+                continue
+            check(rc, "tsdf_sparse_integrate")
+            break
         self.last_touched = int(n.value)
         return self
+
+    def _grow(self):
+        """Doubles the unit pool: a fresh volume of twice the capacity receives the units allocated so far (one device-side merge)."""
+        n = min(int(self.counters[0].item()), self.cap)
+        fresh = ScalableTSDFVolume(self.voxel_length, self.sdf_trunc, 2 * self.cap, self.device, self.stride, self.auto_grow)
+        if n:
+            R = self.RES
+            fresh.merge_units_(self.coord[:n], self.tsdf[:n].view(n, R, R, R), self.weight[:n].view(n, R, R, R), self.color[:n].view(n, R, R, R, 3),
+                               assume_unique=True)
+        fresh.frame = self.frame
+        self.__dict__.update(fresh.__dict__)
 
     @property
     def num_units(self):
@@ -160,12 +185,18 @@ class ScalableTSDFVolume:
         n, R = self.num_units, self.RES
         return self.coord[:n], self.tsdf[:n].view(n, R, R, R), self.weight[:n].view(n, R, R, R), self.color[:n].view(n, R, R, R, 3)
 
-    def merge_units_(self, coords, tsdf, weight, color):
-        """self <- weighted merge with the given units (tensors shaped like `units()`, on this device)."""
+    def merge_units_(self, coords, tsdf, weight, color, assume_unique=False):
+        """self <- weighted merge with the given units (tensors shaped like `units()`, on this device).  The merge kernel runs one workgroup per
+        listed unit, so a coordinate must not appear twice in one list: unless `assume_unique` the list is first fused with itself
+        (merge_unit_lists: sort-unique + index_add)."""
         import ctypes as C
         n = int(coords.shape[0])
         if n == 0:
             return self
+        if not assume_unique:
+            V = self.RES ** 3
+            coords, tsdf, weight, color = merge_unit_lists(coords, tsdf.reshape(n, V), weight.reshape(n, V), color.reshape(n, V, 3))
+            n = int(coords.shape[0])
         co = coords.to(torch.int32).contiguous()
         t, w, c = (x.to(torch.float32).contiguous() for x in (tsdf, weight, color))
         st = self._struct()
@@ -178,7 +209,7 @@ class ScalableTSDFVolume:
         if abs(other.voxel_length - self.voxel_length) > 0 or abs(other.sdf_trunc - self.sdf_trunc) > 0:
             raise RuntimeError("merge_from: volumes must share voxel_length and sdf_trunc")
         co, t, w, c = other.units()
-        return self.merge_units_(co.to(self.device), t.to(self.device), w.to(self.device), c.to(self.device))
+        return self.merge_units_(co.to(self.device), t.to(self.device), w.to(self.device), c.to(self.device), assume_unique=True)
 
     def merge_(self, group=None):
         """Fuses the volumes of all ranks; afterwards every rank holds the same fused volume (unit numbering may differ between ranks).
@@ -189,7 +220,7 @@ class ScalableTSDFVolume:
         co, t, w, c = self.units()
         merged = merge_unit_lists(*gather_unit_lists(co, t.reshape(len(co), -1), w.reshape(len(co), -1), c.reshape(len(co), -1, 3), group))
         fresh = ScalableTSDFVolume(self.voxel_length, self.sdf_trunc, max(self.cap, int(merged[0].shape[0])), self.device, self.stride)
-        fresh.merge_units_(*merged)
+        fresh.merge_units_(*merged, assume_unique=True)
         fresh.frame = self.frame
         self.__dict__.update(fresh.__dict__)
         return self
@@ -197,17 +228,18 @@ class ScalableTSDFVolume:
     def to_dense(self, origin_unit, dims_units):
         """Dense (tsdf, weight, color) arrays over a box of units [origin_unit, origin_unit + dims_units): test / export helper."""
         R = self.RES
-        ox, oy, oz = (int(v) for v in origin_unit); nx, ny, nz = (int(v) for v in dims_units)
-        T = torch.zeros((nx * R, ny * R, nz * R), dtype=torch.float32, device=self.device)
-        Wt = torch.zeros_like(T); Cc = torch.zeros((nx * R, ny * R, nz * R, 3), dtype=torch.float32, device=self.device)
+        nx, ny, nz = (int(v) for v in dims_units)
+        org = torch.tensor([int(v) for v in origin_unit], dtype=torch.int32, device=self.device)
         co, t, w, c = self.units()
-        for k in range(co.shape[0]):
-            x, y, z = (int(v) for v in co[k].tolist())
-            x -= ox; y -= oy; z -= oz
-            if 0 <= x < nx and 0 <= y < ny and 0 <= z < nz:
-                sl = (slice(x * R, (x + 1) * R), slice(y * R, (y + 1) * R), slice(z * R, (z + 1) * R))
-                T[sl] = t[k]; Wt[sl] = w[k]; Cc[sl] = c[k]
-        return T, Wt, Cc
+        rel = co - org
+        ins = ((rel >= 0) & (rel < torch.tensor([nx, ny, nz], dtype=torch.int32, device=self.device))).all(dim=1)
+        idx = rel[ins].long()
+        # (nx, ny, nz, R, R, R) unit-major scratch: every selected unit is one indexed assignment, then the axes are interleaved
+        T = torch.zeros((nx, ny, nz, R, R, R), dtype=torch.float32, device=self.device)
+        Wt = torch.zeros_like(T); Cc = torch.zeros((nx, ny, nz, R, R, R, 3), dtype=torch.float32, device=self.device)
+        T[idx[:, 0], idx[:, 1], idx[:, 2]] = t[ins]; Wt[idx[:, 0], idx[:, 1], idx[:, 2]] = w[ins]; Cc[idx[:, 0], idx[:, 1], idx[:, 2]] = c[ins]
+        dense = lambda a: a.permute(0, 3, 1, 4, 2, 5, *range(6, a.dim())).reshape(nx * R, ny * R, nz * R, *a.shape[6:])
+        return dense(T), dense(Wt), dense(Cc)
 
 
 def gather_unit_lists(coords, tsdf, weight, color, group=None):

@@ -368,6 +368,9 @@ static int compute_aabb(const real T[9], real cutoff, f2* point_image, f2* exten
     return 1;
 }
 
+/* every stride-th tile only in the blend loops (forward and backward): the bounded 1-thread sample of bench.py's cpu_baseline */
+static int g_tile_stride = 1;
+
 /* ------------------------------------------------------------------ state */
 struct ref_state {
     int variant, P, W, H, gx, gy, T, N, R;
@@ -380,6 +383,7 @@ struct ref_state {
     /* image */
     real* final_T; uint32_t* n_contrib; uint32_t* ranges;
     real* out_all_map; /* PLANE: kept for backward (all_map_pixels) */
+    uint64_t pairs_evaluated, pairs_contributing;   /* workload statistics of the blend forward ("contributing pairs C") */
     real* kappa;       /* truth runs: conditioning of the per-gaussian quantities (EWA/PLANE: (ac + b^2)/det of the 2D covariance) */
 };
 
@@ -540,11 +544,12 @@ static void blend_pixel_fwd(const ref_state* st, const ref_inputs* in, const rea
     /* gate bookkeeping of truth runs (in->gate_margin != NULL), see gsr_oracle.h: GM = smallest margin / bound so far */
     const int gates = in->gate_margin != NULL;
     real GM = 1e30f, nT = 0; int GI = REF_GATE_NONE, GS = -1;
+    uint32_t n_eval = 0, n_contrib_pairs = 0;
 #define GATE(which, value, thr, bound) do { if (gates) { const real m_ = R_fabs((value) - (thr)) / ((bound) + 1e-300); \
         if (m_ < GM) { GM = m_; GI = (which); GS = (int)id; } } } while (0)
     for (uint32_t k = r0; k < r1; k++) {
         const uint32_t id = st->point_list[k];
-        contributor++;
+        contributor++; n_eval++;
         real alpha, depth = 0; const real* nor_o = st->conic_opacity + 4*id;
         real e_pow = 0;     /* first-order bound of the float32 error of `power` (absolute) = of alpha (relative) */
         if (st->variant != REF_SURFEL) {
@@ -616,6 +621,7 @@ static void blend_pixel_fwd(const ref_state* st, const ref_inputs* in, const rea
             if (st->variant != REF_EWA && test_T >= 0.0001f) GATE(REF_GATE_HALF, T, 0.5f, T * (nT + GATE_SAFETY * U32));
         }
         if (test_T < 0.0001f) break;   /* done = true: nothing after this can contribute */
+        n_contrib_pairs++;
         nT += e_alpha / (1 - alpha) + GATE_SAFETY * 2 * U32;
         real w = alpha * T;
         if (st->variant == REF_SURFEL) {
@@ -645,6 +651,8 @@ static void blend_pixel_fwd(const ref_state* st, const ref_inputs* in, const rea
         last_contributor = contributor;
     }
 #undef GATE
+    __atomic_fetch_add(&((ref_state*)st)->pairs_evaluated, (uint64_t)n_eval, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&((ref_state*)st)->pairs_contributing, (uint64_t)n_contrib_pairs, __ATOMIC_RELAXED);
     if (gates) { in->gate_margin[pix_id] = GM; in->gate_id[pix_id] = GI; in->gate_splat[pix_id] = GS; }
     st->final_T[pix_id] = T;
     st->n_contrib[pix_id] = last_contributor;
@@ -753,12 +761,14 @@ ref_state* ref_forward(int variant, const ref_inputs* in, real* out_color, int32
     }
 
 blend:;
+    const int tile_stride = g_tile_stride;
     const real* feat = in->colors_precomp ? in->colors_precomp : st->rgb;
     if (in->splat_noise) memset(in->splat_noise, 0, (size_t)P * RS);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4)
 #endif
     for (int tile = 0; tile < st->T; tile++) {
+        if (tile % tile_stride) continue;
         uint32_t tx = (uint32_t)(tile % st->gx), ty = (uint32_t)(tile / st->gx);
         uint32_t r0 = st->ranges[2*tile], r1 = st->ranges[2*tile+1];
         for (uint32_t ly = 0; ly < BLOCK_Y; ly++)
@@ -1131,6 +1141,7 @@ void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, 
 #pragma omp parallel for schedule(dynamic, 4)
 #endif
     for (int tile = 0; tile < st->T; tile++) {
+        if (tile % g_tile_stride) continue;
         uint32_t tx = (uint32_t)(tile % st->gx), ty = (uint32_t)(tile / st->gx);
         uint32_t r0 = st->ranges[2*tile], r1 = st->ranges[2*tile+1];
         for (uint32_t ly = 0; ly < BLOCK_Y; ly++)
@@ -1198,6 +1209,16 @@ void ref_backward(ref_state* st, const ref_inputs* in, const ref_out_grads* og, 
 /* ------------------------------------------------------------------ introspection */
 int32_t ref_num_rendered(const ref_state* st) { return st->R; }
 int32_t ref_num_tiles(const ref_state* st) { return st->T; }
+void ref_get_pair_counts(const ref_state* st, uint64_t* evaluated, uint64_t* contributing) { *evaluated = st->pairs_evaluated; *contributing = st->pairs_contributing; }
+void ref_set_tile_stride(int32_t n) { g_tile_stride = n > 0 ? n : 1; }
+void ref_set_threads(int32_t n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 void ref_get_point_list(const ref_state* st, uint32_t* out) { memcpy(out, st->point_list, (size_t)st->R * 4); }
 void ref_get_keys(const ref_state* st, uint64_t* out) { memcpy(out, st->keys, (size_t)st->R * 8); }
 void ref_get_ranges(const ref_state* st, uint32_t* out) { memcpy(out, st->ranges, (size_t)st->T * 8); }

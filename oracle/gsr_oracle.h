@@ -112,6 +112,11 @@ void ref_free(ref_state* st);
 /* introspection of intermediate (integer, bit-exact comparable) stages */
 int32_t  ref_num_rendered(const ref_state* st);
 int32_t  ref_num_tiles(const ref_state* st);
+/* workload statistics of the forward: (pixel, splat) pairs evaluated before termination / passing every gate (the "contributing pairs C" of SURVEY 8d) */
+void     ref_get_pair_counts(const ref_state* st, uint64_t* evaluated, uint64_t* contributing);
+/* measurement controls of bench.py's cpu_baseline leg: OpenMP thread count, and "every n-th tile only" in the blend loops */
+void     ref_set_threads(int32_t n);
+void     ref_set_tile_stride(int32_t n);
 void     ref_get_point_list(const ref_state* st, uint32_t* out /*[R]*/);
 void     ref_get_keys(const ref_state* st, uint64_t* out /*[R] sorted keys*/);
 void     ref_get_ranges(const ref_state* st, uint32_t* out /*[T,2]*/);

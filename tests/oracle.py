@@ -214,6 +214,13 @@ class Forward:
     def point_list(self):
         out = np.zeros((self.R,), np.uint32); lib().ref_get_point_list(self.st, out.ctypes.data); return out
 
+    def pair_counts(self):
+        """-> (evaluated, contributing) (pixel, splat) pairs of the forward."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        f = lib().ref_get_pair_counts; f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]; f.restype = None
+        f(self.st, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def keys(self):
         out = np.zeros((self.R,), np.uint64); lib().ref_get_keys(self.st, out.ctypes.data); return out
 
@@ -389,6 +396,14 @@ def dist2(points):
 
 def omp_threads():
     return int(lib().ref_omp_threads())
+
+
+def set_threads(n):
+    lib().ref_set_threads(C.c_int32(int(n)))
+
+
+def set_tile_stride(n):
+    lib().ref_set_tile_stride(C.c_int32(int(n)))
 
 
 def loss_l1_ssim(img, gt, lam):

@@ -109,12 +109,61 @@ def test_two_tile_volumes_merge_to_the_joint_volume():
             dist.destroy_process_group()
 
 
-def test_capacity_overflow_raises():
+def test_capacity_overflow_raises_or_grows():
+    """auto_grow=False: a frame that needs more units than the pool holds raises; the default doubles the pool until the frame fits and then
+    holds exactly the volume a large-enough pool would have built."""
     from gsrast.tsdf import ScalableTSDFVolume
     f = tsdf_cases.frames(1)[0]
-    vol = ScalableTSDFVolume(VL, TR, capacity_units=16)
+    args = (torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda(), f["fx"], f["fy"], f["cx"], f["cy"], f["E"])
+    vol = ScalableTSDFVolume(VL, TR, capacity_units=16, auto_grow=False)
     with pytest.raises(RuntimeError, match="capacity exhausted"):
-        vol.integrate(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda(), f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT)
+        vol.integrate(*args, depth_trunc=DT)
+    small = ScalableTSDFVolume(VL, TR, capacity_units=16)
+    small.integrate(*args, depth_trunc=DT)
+    big = ScalableTSDFVolume(VL, TR, capacity_units=8192)
+    big.integrate(*args, depth_trunc=DT)
+    assert small.cap > 16 and small.num_units == big.num_units
+    key = lambda v: {tuple(k): i for i, k in enumerate(v.units()[0].tolist())}
+    ks, kb = key(small), key(big)
+    assert set(ks) == set(kb)
+    order = torch.tensor([ks[k] for k in kb], device="cuda")
+    for a, b in zip(small.units()[1:], big.units()[1:]):
+        assert torch.equal(a[order], b)
+
+
+def test_rejects_a_truncation_band_wider_than_four_units_and_samples_out_of_range():
+    """a depth sample whose +-sdf_trunc box spans more than 4 units per axis, or whose unit coordinate leaves the 21-bit key range,
+    used to be dropped silently (a volume with no units and no error)."""
+    from gsrast.tsdf import ScalableTSDFVolume
+    with pytest.raises(RuntimeError, match="1.5 units"):
+        ScalableTSDFVolume(0.01, 0.3)                                      # 30 voxels > 24
+    vol = ScalableTSDFVolume(1e-4, 5e-4, capacity_units=64)
+    depth = torch.full((1, 8, 8), 2000.0, device="cuda"); rgb = torch.zeros(3, 8, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="outside the addressable volume"):          # 2000 / (16 * 1e-4) > 2^20 units from the origin
+        vol.integrate(rgb, depth, 10.0, 10.0, 4.0, 4.0, np.eye(4, dtype=np.float32), depth_trunc=1e9)
+
+
+def test_merge_units_fuses_duplicate_coordinates_and_colour_scales_agree():
+    """merge_units_ with a caller-supplied list that names a unit twice (the merge kernel runs one workgroup per listed unit: duplicates would
+    race) gives the weighted fusion; quantize_rgb8=False stores colours on the same 0..255 scale as the default."""
+    from gsrast.tsdf import ScalableTSDFVolume
+    g = torch.Generator().manual_seed(0)
+    co = torch.tensor([[1, 2, 3], [0, 0, 0], [1, 2, 3]], dtype=torch.int32).cuda()
+    t = torch.rand(3, 16, 16, 16, generator=g).cuda(); w = torch.randint(1, 4, (3, 16, 16, 16), generator=g).float().cuda()
+    c = torch.rand(3, 16, 16, 16, 3, generator=g).cuda()
+    vol = ScalableTSDFVolume(VL, TR, capacity_units=64)
+    vol.merge_units_(co, t, w, c)
+    uc, ut, uw, _ = vol.units()
+    assert vol.num_units == 2
+    k = [tuple(x) for x in uc.tolist()].index((1, 2, 3))
+    assert torch.equal(uw[k], w[0] + w[2]) and torch.allclose(ut[k], (t[0] * w[0] + t[2] * w[2]) / (w[0] + w[2]), atol=1e-6)
+    f = tsdf_cases.frames(1)[0]
+    rgb = torch.from_numpy(f["rgb"]).cuda(); depth = torch.from_numpy(f["depth"]).cuda()
+    a = ScalableTSDFVolume(VL, TR, capacity_units=8192); b = ScalableTSDFVolume(VL, TR, capacity_units=8192)
+    a.integrate(rgb, depth, f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT)
+    b.integrate(rgb, depth, f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT, quantize_rgb8=False)
+    ca, cb = a.units()[3], b.units()[3]
+    assert ca.max().item() > 1.5 and (ca - cb).abs().max().item() <= 1.0          # same scale, differing by the rounding to integers only
 
 
 def test_reference_default_resolution_runs_without_a_dense_grid():

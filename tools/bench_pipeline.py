@@ -112,10 +112,13 @@ def build(a, dev, seed=0):
                                                       scales=scl[:, :2].contiguous(), rotations=rot)
         if stop == "raster":
             return [img.clone(), rad.clone(), allmap.clone()]
+        # scaling_loss (scaffold_2dgs_scene.py:26) as x*y on unbound columns: prod(dim=1)'s backward synchronises the host (nonzero) when an entry
+        # is 0, and scl[:, i] slices cost one zero-filled (P,3) gradient each; unbind's backward is one stack
+        sx, sy, _sz = scl.unbind(dim=1)
         if static and a.decode == "hip":        # mean over the P emitted Gaussians: the parked rows have scale 0 and only the divisor differs
-            reg = 0.01 * (scl[:, 0] * scl[:, 1]).sum() / count.to(torch.float32)[0]
+            reg = 0.01 * (sx * sy).sum() / count.to(torch.float32)[0]
         else:
-            reg = 0.01 * (scl[:, 0] * scl[:, 1]).mean()      # scaling_loss (scaffold_2dgs_scene.py:26); x*y, not prod(): prod's backward synchronises when an entry is 0
+            reg = 0.01 * (sx * sy).mean()
         if a.loss == "bench":
             loss = l1_plus_linear(img, gt, allmap, wmap) + reg
         elif a.loss == "full-hip":

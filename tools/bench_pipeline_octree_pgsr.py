@@ -88,7 +88,8 @@ def build(a, dev, seed=0):
         scaling = torch.exp(scaling_log)
         img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask, count = render(views[0], 1, scaling)
         pd2 = render(views[1], 2, scaling)[3]
-        vol = scl[:, 0] * scl[:, 1] * scl[:, 2]          # x*y*z, not prod(dim=1): prod's backward synchronises (nonzero) when an entry is 0
+        sx, sy, sz = scl.unbind(dim=1)                    # x*y*z on unbound columns (backward = ONE stack), not prod(dim=1): prod's backward
+        vol = sx * sy * sz                                # synchronises (nonzero) when an entry is 0, and not scl[:, i]: one zero-filled (P,3) per slice
         reg = 0.01 * (vol.sum() / count.to(torch.float32)[0] if static else vol.mean())
         loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + plane_geo_loss(pd, oam, rm1, weight, 0.015, unit_upstream=True)[0] + reg
         geo, ncc = plane_multiview_loss(pd, pd2, None, None, gray1, gray2, mcfg, 0.03, 0.15, out_all_map=oam)
