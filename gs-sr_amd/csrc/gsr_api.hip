@@ -172,6 +172,7 @@ ImgView gsr_carve_img(int variant, int W, int H, void* base)
     im.final_T = take<float>(p, N * (variant == GSR_SURFEL ? 3 : 1));
     im.n_contrib = take<uint32_t>(p, N * (variant == GSR_SURFEL ? 2 : 1));
     im.ranges = take<uint2>(p, (size_t)gx * gy);
+    im.tile_order = take<uint32_t>(p, (size_t)gx * gy);
     im.bytes = (size_t)(p - reinterpret_cast<char*>(base));
     return im;
 }

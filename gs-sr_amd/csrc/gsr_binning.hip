@@ -429,6 +429,63 @@ __global__ void __launch_bounds__(256) k_tile_ranges(uint32_t R, const uint32_t*
     if (i == R - 1) ranges[cur].y = R;
 }
 
+// Launch order of the blend kernels: tiles by DESCENDING list length (eight power-of-two classes, raster order inside a class so that
+// neighbouring tiles -- which share most of their splats -- still run close together).  The blend kernels run one workgroup per tile and a
+// tile's time is proportional to its list; in raster order the launch ends on whichever long tiles happen to come late, with this order the
+// long ones start first and the short ones fill the tail.  Stable counting sort by one workgroup (T is 8160 at 1080p).
+__global__ void __launch_bounds__(1024) k_tile_order(const uint2* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ order)
+{
+    constexpr int NB = 8;
+    __shared__ uint32_t cnt[NB * 1024];
+    __shared__ uint32_t lds[17];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (T + 1023u) / 1024u, b0 = min(T, tid * per), e0 = min(T, b0 + per);
+    auto cls = [](uint2 r) -> int {
+        const uint32_t len = r.y > r.x ? r.y - r.x : 0u;
+        if (len == 0) return NB - 1;
+        const int l2 = 31 - __builtin_clz(len);
+        return (NB - 2) - min(max(l2 - 4, 0), NB - 2);          // >= 1024 -> 0, 512.. -> 1, ... 32..63 -> 5, 1..31 -> 6
+    };
+    uint32_t c[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) c[k] = 0;
+    for (uint32_t t = b0; t < e0; t++) {
+        const int k = cls(ranges[t]);
+#pragma unroll
+        for (int q = 0; q < NB; q++) c[q] += (q == k) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) cnt[k * 1024 + tid] = c[k];
+    __syncthreads();
+    // exclusive prefix over the class-major array (class 0 of every thread, then class 1, ...): thread t owns entries [8t, 8t + 8)
+    uint32_t v[NB], sum = 0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) { v[k] = cnt[NB * tid + k]; sum += v[k]; }
+    uint32_t tot;
+    const uint32_t incl = block_incl_scan(sum, lds, &tot);
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < NB; k++) { cnt[NB * tid + k] = run; run += v[k]; }
+    __syncthreads();
+    uint32_t pos[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) pos[k] = cnt[k * 1024 + tid];
+    for (uint32_t t = b0; t < e0; t++) {
+        const int k = cls(ranges[t]);
+        uint32_t dst = 0;
+#pragma unroll
+        for (int q = 0; q < NB; q++) if (q == k) { dst = pos[q]; pos[q]++; }
+        order[dst] = t;
+    }
+}
+
+bool gsr_tile_order_enabled()
+{
+    static int order = -1;
+    if (order < 0) { const char* e = getenv("GSR_TILE_ORDER"); order = (e && atoi(e) != 0) ? 1 : 0; }
+    return order != 0;
+}
+
 static int tile_bits(int T)
 {
     int b = 1;
@@ -443,7 +500,11 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
 {
     const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     const int T = gx * gy;
-    if (R == 0) { if (gsr_memset_async(im.ranges, 0, (size_t)T * sizeof(uint2), s)) { gsr_set_error("memset ranges"); return 1; }; return 0; }
+    if (R == 0) {
+        if (gsr_memset_async(im.ranges, 0, (size_t)T * sizeof(uint2), s)) { gsr_set_error("memset ranges"); return 1; }
+        if (gsr_tile_order_enabled()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
+        return 0;
+    }
     // unsorted instances go to the buffer from which an integral number of passes lands in (tile_keys, point_list)
     const int passes = gsr_tile_sort_passes(T);
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
@@ -453,5 +514,6 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     bool in_b = false;
     gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true);
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
+    if (gsr_tile_order_enabled()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
     return gsr_check_launch("binning", s, cfg->debug);
 }

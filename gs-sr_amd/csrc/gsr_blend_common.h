@@ -8,6 +8,7 @@ struct BlendParams {
     int W, H, gx, gy, variant, render_geo, xcd_remap;
     float fx, fy;
     const uint2* ranges;
+    const uint32_t* tile_order;      // or nullptr: blockIdx -> tile through tile_of_block
     const uint32_t* point_list;
     const float4* cull;
     const float4* rec;
@@ -24,8 +25,9 @@ struct BlendParams {
 
 // Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md); give each XCD a contiguous band of tiles so that
 // neighbouring tiles -- which share most of their splats -- hit the same 4 MiB L2.  Bijective for any T; speed only.
-__device__ __forceinline__ int tile_of_block(int b, int T, int remap)
+__device__ __forceinline__ int tile_of_block(int b, int T, int remap, const uint32_t* __restrict__ order = nullptr)
 {
+    if (order) return (int)order[b];      // longest tile lists first: the launch does not end on a few long tiles (k_tile_order)
     if (!remap) return b;
     const int q = T >> 3, r = T & 7, xcd = b & 7, idx = b >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;

@@ -71,27 +71,30 @@ def async_status_reset():
     _ASYNC_STATUS.clear()
 
 
-# ---- gradient-accumulator scratch of the backward, kept per (device, stream, variant, P) and left zeroed by the preprocess backward
-# (gsr_backward_ex GSR_BWD_SCRATCH_IS_ZERO | GSR_BWD_LEAVE_ZERO): no 24 MB memset + launch gap per iteration.  GSR_ACC_REUSE=0 disables.
+# ---- gradient-accumulator scratch of the backward, kept per (device, stream, variant) and left zeroed by the preprocess backward
+# (gsr_backward_ex GSR_BWD_SCRATCH_IS_ZERO | GSR_BWD_LEAVE_ZERO): no 24 MB memset + launch gap per iteration.  One buffer serves every P up to
+# its size (a call touches -- and clears -- rows [0, P) only; the decode's output row count changes from iteration to iteration), it is replaced
+# by a larger one when P outgrows it.  GSR_ACC_REUSE=0 disables.
 _ACC_REUSE = os.environ.get("GSR_ACC_REUSE", "1") != "0"
 _ACC_CACHE = {}
 _ACC_LOCK = threading.Lock()
 
 
 def _acc_scratch(L, variant, P, dev):
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, variant, P)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, variant)
+    need = max(int(L.gsr_backward_scratch_bytes(variant, P)), 1)
     with _ACC_LOCK:
         t = _ACC_CACHE.pop(key, None)          # taken out while in use: a concurrent backward on the same key gets its own buffer
-    if t is None:
-        t = torch.zeros((max(int(L.gsr_backward_scratch_bytes(variant, P)), 1),), dtype=torch.uint8, device=dev)
+    if t is None or t.numel() < need:
+        t = torch.zeros((need + need // 4,), dtype=torch.uint8, device=dev)      # 25 % head-room: P drifts a little every iteration
     return key, t
 
 
 def _acc_release(key, t):
     with _ACC_LOCK:
-        if len(_ACC_CACHE) >= 8:                # densification changes P every few hundred iterations: drop the oldest sizes
-            _ACC_CACHE.pop(next(iter(_ACC_CACHE)))
-        _ACC_CACHE[key] = t
+        old = _ACC_CACHE.get(key)
+        if old is None or old.numel() <= t.numel():
+            _ACC_CACHE[key] = t
 
 
 def _prepare(variant, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, all_map, settings):

@@ -162,7 +162,9 @@ def test_merge_units_fuses_duplicate_coordinates_and_colour_scales_agree():
     a = ScalableTSDFVolume(VL, TR, capacity_units=8192); b = ScalableTSDFVolume(VL, TR, capacity_units=8192)
     a.integrate(rgb, depth, f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT)
     b.integrate(rgb, depth, f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT, quantize_rgb8=False)
-    ca, cb = a.units()[3], b.units()[3]
+    ka = {tuple(k): i for i, k in enumerate(a.units()[0].tolist())}
+    order = torch.tensor([ka[tuple(k)] for k in b.units()[0].tolist()], device="cuda")          # the two pools number their units independently
+    ca, cb = a.units()[3][order], b.units()[3]
     assert ca.max().item() > 1.5 and (ca - cb).abs().max().item() <= 1.0          # same scale, differing by the rounding to integers only
 
 
