@@ -139,7 +139,7 @@ GeomView gsr_carve_geom(int variant, int P, void* base)
     g.keys_b = take<uint32_t>(p, n);
     g.vals_b = take<uint32_t>(p, n);
     g.sorted_idx = g.vals_a;                 // four sort passes: identity -> vals_b -> vals_a -> vals_b -> vals_a (gsr_launch_depth_order)
-    g.hist = take<uint32_t>(p, gsr_sort_hist_words(nblk, 2048));   // sized for 11-bit digits (GSR_DEPTH_BITS=11)
+    g.hist = take<uint32_t>(p, gsr_sort_hist_words(nblk, gsr_depth_sort_digit_bins()));   // 256-bin digits (2048 only under GSR_DEPTH_BITS=11: the size query and the carve run in one process, after the environment is read)
     g.scan_tmp = take<uint32_t>(p, gsr_div_up((uint32_t)n, GSR_SCAN_BLOCK) + 64);
     g.counters = take<uint32_t>(p, 64);
     g.bytes = (size_t)(p - reinterpret_cast<char*>(base));
@@ -148,7 +148,7 @@ GeomView gsr_carve_geom(int variant, int P, void* base)
 
 BinView gsr_carve_bin(int variant, uint32_t R, int W, int H, void* base)
 {
-    (void)variant; (void)W; (void)H;
+    (void)variant;
     BinView b;
     char* p = reinterpret_cast<char*>(base);
     const size_t n = R > 0 ? R : 1;
@@ -159,6 +159,10 @@ BinView gsr_carve_bin(int variant, uint32_t R, int W, int H, void* base)
     b.vals_b = take<uint32_t>(p, n);
     b.hist = take<uint32_t>(p, gsr_sort_hist_words(nblk, 256));
     b.scan_tmp = take<uint32_t>(p, 64);
+    {
+        const size_t T = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * ((H + GSR_TILE - 1) / GSR_TILE);
+        b.qmask = take<unsigned long long>(p, ((n >> 6) + T + 2) * 4);
+    }
     b.bytes = (size_t)(p - reinterpret_cast<char*>(base));
     return b;
 }

@@ -347,7 +347,7 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
     // digit-major histogram matrix is written / scanned / read with a block-count stride), so 2048 bins cost more than the pass saved.
     const int depth_bits = gsr_depth_sort_digit_bins() == 2048 ? 11 : 8;
     // the preprocess kernel cleared the first group-histogram buffer (gsr_preprocess.hip: PreParams::zero_ptr)
-    gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, depth_bits, true, g.hist, &in_b, s, false, true);
+    if (gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, depth_bits, true, g.hist, &in_b, s, false, true)) return 1;
     if (depth_bits == 11)      // odd pass count: the ids ended in vals_b, bring them to sorted_idx (= vals_a)
         GSR_CHECK(hipMemcpyAsync(g.sorted_idx, g.vals_b, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, s), "copy sorted ids");
     const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
@@ -512,7 +512,7 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P, g.sorted_idx, g.offsets, g.scan_tmp,
                        g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256));
     bool in_b = false;
-    gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true);
+    if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true)) return 1;
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
     if (gsr_tile_order_enabled()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
     return gsr_check_launch("binning", s, cfg->debug);

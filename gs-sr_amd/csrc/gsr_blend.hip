@@ -52,6 +52,8 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         const uint32_t id = v ? p.point_list[i] : 0u;
         const bool hit = v && cull_hit<V>(p.cull, id, (float)ox, (float)oy);
         uint64_t m = __ballot(hit);
+        // the ballot is what the splat-parallel backward needs to know about this (batch, quadrant): keep it (8 bytes per 64 entries)
+        if (p.qmask && lane == 0) p.qmask[(((size_t)(range.x >> 6) + (size_t)tile + ((base - range.x) >> 6)) << 2) + wave] = m;
         // Every lane whose candidate survives the cull stages that candidate's packed record in the wave's LDS slots: one burst of vector
         // loads per 64 candidates instead of a scalar-load round trip per pair.  The pair loop reads the record back through a wave-uniform
         // LDS address (broadcast ds_read_b128), so the blend maths runs on VGPR operands only -- on gfx950 a VALU instruction with an SGPR
@@ -413,6 +415,12 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
         // BASELINE scene (uniform density, round 3): blend fwd 0.2016 vs 0.2010 ms, bwd 0.4840 vs 0.4838 -- no tail to remove -- while the
         // ordering kernel costs 11 us; off by default, kept for scenes with a few very long tiles.
         p.tile_order = gsr_tile_order_enabled() ? im.tile_order : nullptr;
+    }
+    {
+        // GSR_CULL_REUSE=0: the backward re-tests every entry against the four 8x8 quadrants (round 2) instead of reading the forward's ballots
+        static int reuse = -1;
+        if (reuse < 0) { const char* e = getenv("GSR_CULL_REUSE"); reuse = e ? (atoi(e) != 0) : 1; }
+        p.qmask = reuse ? b.qmask : nullptr;
     }
     p.ranges = im.ranges; p.point_list = b.point_list; p.cull = g.cull; p.rec = g.rec; p.bg = cfg->bg;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib;

@@ -10,6 +10,7 @@ struct BlendParams {
     const uint2* ranges;
     const uint32_t* tile_order;      // or nullptr: blockIdx -> tile through tile_of_block
     const uint32_t* point_list;
+    unsigned long long* qmask;       // BinView::qmask, or nullptr (GSR_CULL_REUSE=0)
     const float4* cull;
     const float4* rec;
     const float* bg;

@@ -19,9 +19,13 @@
 //     next through a per-pixel carry (T, S) held, again, by lane j of the row.  No forward-side checkpoints are needed: the chain starts at the stored
 //     final T / last contributor exactly like the reference's replay.
 //   * each lane accumulates its splat's 9 / 16 / 18 gradient components in REGISTERS over the 16 pixels -- no cross-lane
-//     reduction at all -- and adds them once per load into a per-tile LDS table indexed by the tile-list entry (ds_add_f32);
-//     the table is flushed once per tile with one 16-lane atomic per list entry that received anything (37 % of the tile
-//     instances contribute to no pixel and cost nothing): 0.87 M accumulator line-operations per launch instead of 1.92 M.
+//     reduction at all -- and merges them once per load into its WAVE's private LDS table (one row per tile-list entry that
+//     reaches the wave's quadrant): the four rows of a load go one after the other as plain read-add-write (a splat can sit in
+//     several rows of a load, never twice in one row; DS operations of a wave execute in order), no LDS float atomics.  After
+//     a barrier the four waves' tables are combined and flushed with one 16-lane global atomic per entry that received anything
+//     (37 % of the tile instances reach no pixel and cost nothing): 1.64 M accumulator atomics per launch (profiles/r02_pmc_summary.json)
+//     against 2.02 M for the pixel-parallel kernel.  (The first table version used ds_add_f32: ~2 cycles per LANE, a third of the
+//     kernel in the LDS pipe.)
 // Reference semantics: 3DGS backward.cu:399-557, SURFEL backward.cu:143-447, PLANE backward.cu:399-614 (gates, thresholds, the
 // median-normal quirk, no gradient through the 0.99 clamp test); see DESIGN.md "splat-parallel backward".
 #include "gsr_blend_common.h"
@@ -365,11 +369,20 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             if (t < n) {
                 const uint32_t id = p.point_list[range.x + cbase + t];
                 s_ids[t] = id;
-                const float4 ca = p.cull[2 * (size_t)id], cb = p.cull[2 * (size_t)id + 1];
                 uint32_t m = 0;
+                if (p.qmask) {
+                    // the forward kept its per-(batch, quadrant) cull ballots: same test, same inputs -- no second evaluation, no cull-record gather
+                    // (valid for every entry a quadrant's wave can use: the forward wave tested all batches up to its last contributor)
+                    const uint32_t ei = cbase + t;
+                    const unsigned long long* q = p.qmask + (((size_t)(range.x >> 6) + (size_t)tile + (ei >> 6)) << 2);
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (cull_hit_rec<V>(ca, cb, (float)(tx * GSR_TILE + (q & 1) * GSR_SUB), (float)(ty * GSR_TILE + (q >> 1) * GSR_SUB), 7.f)) m |= 1u << q;
+                    for (int w4 = 0; w4 < 4; w4++) m |= (uint32_t)((q[w4] >> (ei & 63u)) & 1ull) << w4;
+                } else {
+                    const float4 ca = p.cull[2 * (size_t)id], cb = p.cull[2 * (size_t)id + 1];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (cull_hit_rec<V>(ca, cb, (float)(tx * GSR_TILE + (q & 1) * GSR_SUB), (float)(ty * GSR_TILE + (q >> 1) * GSR_SUB), 7.f)) m |= 1u << q;
+                }
                 s_mask[t] = (uint16_t)m;
             }
         }

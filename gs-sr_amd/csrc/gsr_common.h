@@ -45,7 +45,7 @@ struct GeomView {
     float4* rec;              // [P * stride] packed blend record
     uint32_t* clamped;        // [P]  3 bits: SH colour clamped to 0 per channel
     uint32_t* sorted_idx;     // [P]  gaussian ids in (depth, id) order
-    uint32_t* offsets;        // [P]  inclusive prefix sum of tiles_touched in sorted order
+    uint32_t* offsets;        // [P]  BLOCK-LOCAL inclusive prefix of tiles_touched in depth order (k_offsets_local); the global prefix is offsets[i] + scan_tmp[i / GSR_SCAN_BLOCK]
     uint32_t* keys_b;         // [P]  sort ping-pong
     uint32_t* vals_a;         // [P]
     uint32_t* vals_b;         // [P]
@@ -61,6 +61,9 @@ struct BinView {
     uint32_t* vals_b;         // [R]
     uint32_t* hist;           // [128 * nblk(R)]
     uint32_t* scan_tmp;
+    // per (tile, 64-entry batch of its list, 8x8 quadrant): the forward's sub-tile cull ballot, reused by the splat-parallel backward instead of
+    // re-testing every entry against the four quadrants.  Word index ((range.x >> 6) + tile + batch) * 4 + quadrant (unique per tile and batch).
+    unsigned long long* qmask;
     size_t bytes;
 };
 struct ImgView {

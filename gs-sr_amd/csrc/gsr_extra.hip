@@ -510,7 +510,7 @@ extern "C" int gsr_dist2(int32_t P, const float* points, float* out, void* scrat
     hipLaunchKernelGGL(k_knn_minmax, dim3(min(1024u, gsr_div_up((uint32_t)P, 256))), dim3(256), 0, s, P, points, k.mm);
     hipLaunchKernelGGL(k_knn_morton, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, points, k.mm, k.keys_a);
     bool in_b = false;
-    gsr_radix_sort_pairs(k.keys_a, k.vals_a, k.keys_b, k.vals_b, (uint32_t)P, nullptr, 0, 30, 8, true, k.hist, &in_b, s);
+    if (gsr_radix_sort_pairs(k.keys_a, k.vals_a, k.keys_b, k.vals_b, (uint32_t)P, nullptr, 0, 30, 8, true, k.hist, &in_b, s)) return 1;
     const uint32_t* order = in_b ? k.vals_b : k.vals_a;
     hipLaunchKernelGGL(k_knn_boxes, dim3(nbox), dim3(GSR_KNN_BOX), 0, s, P, points, order, k.boxes);
     hipLaunchKernelGGL(k_knn_dist, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, points, order, k.boxes, nbox, out);
