@@ -157,7 +157,6 @@ def make_step(variant, sc, device):
         means2D.grad = None
         if m2a is not None:
             m2a.grad = None
-        state["loss"] = loss
         state["vis"] = radii
         return loss
 
@@ -344,6 +343,12 @@ def method_iteration(device, which, steps=20):
     return r
 
 
+def child_env():
+    """Environment of the single-process helper children: no torchrun variables (they must not join or shadow the parent's process group)."""
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                             "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+
+
 def launch_ranks(args, ndev):
     """`python bench.py --gpus N` with no RANK in the environment: start the N ranks (the job train_split.py:24-38 runs one tile after the
     other, and train.py:78-80 refuses on more than one GPU) and return the job's exit code; rank 0 prints the JSON line."""
@@ -375,6 +380,8 @@ def main():
                     help="precomp = scaffold/octree path (configs 2-5, default); sh = vanilla path with degree-3 SH (config 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph-replay", action="store_true", help="skip the informational HIP-graph replay of the same step")
+    ap.add_argument("--graph-replay-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--method-iteration-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--stage-steps", type=int, default=20, help="untimed iterations after the timed region in which EVERY stage carries HIP events (stage_ms)")
     ap.add_argument("--profile-all-stages-in-timed-region", action="store_true",
                     help="round-1/2 behaviour: all seven stages timed with HIP events inside the timed region (costs ~6 %% of the step in event gaps)")
@@ -422,6 +429,25 @@ def main():
     import gsrast
     import scenes
     gsrast.lib()
+    if args.method_iteration_child:
+        print(json.dumps(method_iteration(device, args.method_iteration_child, steps=40)), flush=True)
+        return
+    if args.graph_replay_child:
+        sc = scenes.make_scene(args.variant, args.P, args.W, args.H, seed=0, color_mode=args.color_mode)
+        step, state = make_step(args.variant, sc, device)
+        from gsrast.graphs import GraphedStep
+        it = GraphedStep(step, optimizers=[state["optimizer"]], warmup=max(3, args.warmup))
+        for _ in range(5):
+            it()
+        torch.cuda.synchronize(device); tg = time.perf_counter()
+        for _ in range(args.steps):
+            it()
+        torch.cuda.synchronize(device)
+        tg = time.perf_counter() - tg
+        print(json.dumps({"iters_per_s": round(args.steps / tg, 3), "ms_per_step": round(1e3 * tg / args.steps, 4), "steps": args.steps,
+                          "rasterizer_forwards": [list(x) for x in it.check()],
+                          "what": "the step of `value` (same scene, seed 0), recorded into one HIP graph and replayed; separate process"}), flush=True)
+        return
     # one independent tile-scene per rank (train_split.py trains tiles independently; seed = tile index)
     sc = scenes.make_scene(args.variant, args.P, args.W, args.H, seed=rank, color_mode=args.color_mode)
     step, state = make_step(args.variant, sc, device)
@@ -459,24 +485,17 @@ def main():
     graph_info = None
     if rank == 0 and world == 1 and not args.no_graph_replay:
         # informational: the SAME step recorded once into a HIP graph (sync-free rasterizer forward, Adam scalars from device memory) and replayed;
-        # `value` above stays the eagerly launched loop, whose dominant kernel is timed live with HIP events as the contract asks
+        # `value` above stays the eagerly launched loop, whose dominant kernel is timed live with HIP events as the contract asks.  Run in a child
+        # process: nothing that happens while recording / replaying a graph can take the headline line down with it.
+        import subprocess
         try:
-            from gsrast.graphs import GraphedStep
-            it = GraphedStep(step, optimizers=[state["optimizer"]], warmup=3)
-            for _ in range(5):
-                it()
-            torch.cuda.synchronize(device); tg = time.perf_counter()
-            for _ in range(args.steps):
-                it()
-            torch.cuda.synchronize(device)
-            tg = time.perf_counter() - tg
-            stt = it.check()
-            graph_info = {"iters_per_s": round(args.steps / tg, 3), "ms_per_step": round(1e3 * tg / args.steps, 4), "steps": args.steps,
-                          "rasterizer_forwards": [list(x) for x in stt], "what": "the step of `value`, recorded into one HIP graph and replayed"}
-            del it
+            cmd = [sys.executable, os.path.abspath(__file__), "--graph-replay-child", "--variant", args.variant, "--P", str(args.P), "--W", str(args.W),
+                   "--H", str(args.H), "--color-mode", args.color_mode, "--steps", str(args.steps), "--warmup", str(args.warmup)]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=child_env())
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            graph_info = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": f"child rc={r.returncode}: {r.stderr[-200:]}"}
         except Exception as e:
             graph_info = {"error": str(e)[:200]}
-
     if rank == 0:
         import hiprun
         st = hiprun.run_raw(args.variant, sc, device=device)
@@ -565,7 +584,17 @@ def main():
         if graph_info is not None:
             out["graph_replay"] = graph_info
         if world == 1 and not args.no_method_iteration and args.variant == "surfel" and (args.W, args.H) == (1920, 1080):
-            out["method_iteration"] = {m: method_iteration(device, m) for m in ("scaffold-2dgs", "octree-2dgs", "octree-pgsr", "pgsr")}
+            # every method in its own child process (its pipelines, profiler session and graph capture cannot disturb the headline line)
+            import subprocess
+            out["method_iteration"] = {}
+            for m in ("scaffold-2dgs", "octree-2dgs", "octree-pgsr", "pgsr"):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--method-iteration-child", m], capture_output=True, text=True, timeout=600,
+                                       env=child_env())
+                    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                    out["method_iteration"][m] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": f"child rc={r.returncode}: {r.stderr[-200:]}"}
+                except Exception as e:
+                    out["method_iteration"][m] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             og = scenes.random_out_grads(args.variant, args.W, args.H, seed=0)
             out["cpu_baseline"], kept = cpu_baseline(args.variant, sc, og)
