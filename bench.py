@@ -197,6 +197,7 @@ def cpu_baseline(variant, sc, og, budget_s=25.0):
         tot += time.time() - t0
         n += 1
     per = (tot / n) if n else first
+    full_pairs = keep["pairs"]                 # of a full run (the one-thread sample below overwrites keep)
     # loss + optimizer of the train step on the host (torch CPU, all threads): L1 against a target + its gradient, Adam on every parameter tensor
     P, W, H = sc["means3D"].shape[0], int(sc["W"]), int(sc["H"])
     img = torch.rand(3, H, W); gt = torch.rand(3, H, W)
@@ -230,7 +231,7 @@ def cpu_baseline(variant, sc, og, budget_s=25.0):
                            "sample": f"1 OpenMP thread; per-Gaussian stages in full ({t_fixed:.2f} s) + every 32nd tile of the blend forward+backward "
                                      f"({t_s - t_fixed:.2f} s) x 32"},
             "sample": f"{max(n, 1)} x full workload ({variant}, same scene as the GPU run), oracle/gsr_oracle.c with OpenMP; "
-                      f"rasterizer forward+backward only (no loss/optimizer) for `value`"}, keep
+                      f"rasterizer forward+backward only (no loss/optimizer) for `value`"}, {"pairs": full_pairs}
 
 
 def parity_full_size(variant, sc, og, device, color_mode):
@@ -308,7 +309,7 @@ def method_iteration(device, which, steps=20):
         import bench_pipeline_pgsr
         step, st = bench_pipeline_pgsr.build(types.SimpleNamespace(glue="hip", P=300000), device)
     try:
-        r = iter_breakdown.measure(step, device, steps=steps, warmup=8, top=8)
+        r = iter_breakdown.measure(step, device, steps=steps, warmup=25, top=8)
     except Exception as e:       # profiler unavailable: wall time only
         for _ in range(8):
             step()
@@ -430,7 +431,7 @@ def main():
     import scenes
     gsrast.lib()
     if args.method_iteration_child:
-        print(json.dumps(method_iteration(device, args.method_iteration_child, steps=40)), flush=True)
+        print(json.dumps(method_iteration(device, args.method_iteration_child, steps=60)), flush=True)
         return
     if args.graph_replay_child:
         sc = scenes.make_scene(args.variant, args.P, args.W, args.H, seed=0, color_mode=args.color_mode)
@@ -528,17 +529,19 @@ def main():
         # measures the ceilings by operand kind: only VGPR-only fma / mul / add reach ~890 G/s; any DPP form, any SGPR operand and
         # v_min / v_max issue at ~575 G/s, transcendentals at ~300 G/s -- the instruction mix of these kernels caps them well below 1228.8.
         valu = None
-        pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_summary.json", "r01_pmc_summary.json")) if os.path.exists(q)), "")
+        pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")) if os.path.exists(q)), "")
         vidx = {"ewa": 0, "surfel": 1, "plane": 2}[args.variant]
         if os.path.exists(pj) and args.P == 300000 and (args.W, args.H) == (1920, 1080) and args.color_mode == "precomp":
             try:
                 kname = (f"k_blend_bwd_sp<{vidx}>" if bwd_sp else f"k_blend_bwd<{vidx}>") if dom == "blend_bwd" else f"k_blend_fwd<{vidx}>"
-                insts = json.load(open(pj)).get(kname, {}).get("SQ_INSTS_VALU")
+                pmc = json.load(open(pj))
+                insts = pmc.get(kname, {}).get("SQ_INSTS_VALU")
                 if insts:
                     rate = insts / (ms[dom] * 1e-3)
                     valu = {"wave_insts_per_launch": int(insts), "achieved_Ginst_s": round(rate / 1e9, 1), "peak_Ginst_s": 1228.8,
                             "frac": round(rate / 1228.8e9, 4),
-                            "measured_ceilings_Ginst_s": {"vgpr_only_fma": 890, "dpp_or_sgpr_operand": 575, "transcendental": 300}, "source": f"profiles/{os.path.basename(pj)} SQ_INSTS_VALU / live avg_launch_ms"}
+                            "measured_ceilings_Ginst_s": {"vgpr_only_fma": 890, "dpp_or_sgpr_operand": 575, "transcendental": 300}, "source": f"profiles/{os.path.basename(pj)} SQ_INSTS_VALU (PMC pass of git revision "
+                                      f"{pmc.get('_meta', {}).get('git_revision_of_the_measured_library', 'unrecorded')}) / live avg_launch_ms"}
             except Exception:
                 valu = None
         out = {
