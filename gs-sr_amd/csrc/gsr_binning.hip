@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_local(const uint32_t
 {
     __shared__ uint32_t lds[17];
     const uint32_t i = blockIdx.x * GSR_SCAN_BLOCK + threadIdx.x;
-    uint32_t v = (i < P) ? tiles_touched[sorted_idx[i]] : 0;
+    uint32_t v = (i < P) ? tiles_touched[sorted_idx ? sorted_idx[i] : i] : 0;      // sorted_idx == nullptr: gaussians in id order
     uint32_t tot;
     uint32_t incl = block_incl_scan(v, lds, &tot);
     if (i < P) offsets[i] = incl;
@@ -337,9 +337,29 @@ uint32_t gsr_depth_sort_digit_bins()
     return depth_bits == 11 ? 2048u : 256u;
 }
 
+// Where the depth order of a tile's list comes from.
+//   "tile" (default, round 3): no global depth sort.  Instances are emitted in ID order, the stable tile sort bins them, and k_tile_depth_sort
+//           orders every tile's list by (depth bits, id) in LDS -- one launch over R instances instead of the eight launches of a 4-pass radix
+//           sort over P keys, each of which costs its ~5-10 us latency floor whatever P is (profiles/r03_timeline_surfel.json).
+//   "global" (GSR_DEPTH_ORDER=global, rounds 1-2): stable LSD sort of the P gaussians by depth bits first, instances emitted in that order.
+// Both give the reference's order: by tile, then depth bits, then gaussian id (3DGS rasterizer_impl.cu:70-111, 300-308).
+bool gsr_depth_order_is_global()
+{
+    static int global_sort = -1;
+    if (global_sort < 0) { const char* e = getenv("GSR_DEPTH_ORDER"); global_sort = (e && e[0] == 'g') ? 1 : 0; }
+    return global_sort != 0;
+}
+
 int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s)
 {
     const uint32_t P = (uint32_t)cfg->P;
+    if (!gsr_depth_order_is_global()) {
+        // id order: only the prefix sum of tiles_touched (block-local + block sums; k_duplicate adds the two) and num_rendered
+        const uint32_t nb = gsr_div_up(P, GSR_SCAN_BLOCK);
+        hipLaunchKernelGGL(k_offsets_local, dim3(nb), dim3(GSR_SCAN_BLOCK), 0, s, (const uint32_t*)nullptr, g.tiles_touched, P, g.offsets, g.scan_tmp);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nb, g.counters, host_word_dev);
+        return gsr_check_launch("depth_order", s, cfg->debug);
+    }
     bool in_b = false;
     // Four 8-bit passes: keys depth_key (A) <-> keys_b end in A, ids: identity -> vals_b -> vals_a -> vals_b -> vals_a (= sorted_idx).
     // GSR_DEPTH_BITS=11 selects three 11-bit passes instead (33 >= 32 bits, bit-identical result, kept for A/B): MEASURED SLOWER on
@@ -375,7 +395,7 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
     if (i < T) ranges[i] = make_uint2(0u, 0u);                           // the cudaMemset of rasterizer_impl.cu:310, folded in (k_tile_ranges runs later)
     for (uint32_t z = i; z < zero_n; z += gridDim.x * blockDim.x) zero_ptr[z] = 0u;      // first group-histogram buffer of the tile sort that follows
     const bool v = i < P;
-    const uint32_t g = v ? sorted_idx[i] : 0u;
+    const uint32_t g = v ? (sorted_idx ? sorted_idx[i] : i) : 0u;
     const uint32_t cnt = v ? tiles_touched[g] : 0u;
     // inclusive prefix of tiles_touched in depth order = block-local prefix (k_offsets_local) + exclusive prefix of the block sums
     const uint32_t incl = v ? offsets[i] + block_prefix[i / GSR_SCAN_BLOCK] : 0u;
@@ -486,6 +506,135 @@ bool gsr_tile_order_enabled()
     return order != 0;
 }
 
+// ------------------------------------------------------------------------------------------------ per-tile depth order
+// One wave per tile: the tile's list (ids in id order after the stable tile sort) is loaded together with the gaussians' depth bits, sorted as
+// 64-bit (depth << 32 | id) words by a bitonic network in the wave's private LDS slice (no barriers: DS operations of a wave execute in order),
+// and the ids are written back.  Lists longer than TDS_WAVE_CAP are left to the end of the workgroup's life, where its four waves sort them
+// together (up to TDS_WG_CAP, block-level network with barriers); anything longer goes through a stable 4-pass LSD radix sort in global
+// memory by the workgroup (scratch: the free ping-pong half of the binning arena) -- slow, correct, and only reached by tiles with > 4096 entries.
+#define TDS_WAVE_CAP 1024u
+#define TDS_WG_CAP 4096u
+__device__ __forceinline__ void tds_cmpx(unsigned long long* s, uint32_t t, uint32_t j, uint32_t k)
+{
+    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), q = i | j;
+    const unsigned long long a = s[i], b = s[q];
+    const bool up = (i & k) == 0u;
+    if ((a > b) == up) { s[i] = b; s[q] = a; }
+}
+__device__ void tds_global_radix(uint32_t* __restrict__ ids_a, uint32_t* __restrict__ keys_a, uint32_t* __restrict__ ids_b, uint32_t* __restrict__ keys_b,
+                                 uint32_t n, uint32_t* hist /*LDS [256]*/, uint32_t* cnt /*LDS [4][256]*/, uint32_t* lds17)
+{
+    // stable LSD radix sort of (keys_a, ids_a)[0, n) by key, 8 bits per pass, ping-ponging with (keys_b, ids_b); four passes end in the a arrays
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint64_t lt = lanemask_lt();
+    for (int pass = 0; pass < 4; pass++) {
+        const uint32_t* ki = (pass & 1) ? keys_b : keys_a; const uint32_t* vi = (pass & 1) ? ids_b : ids_a;
+        uint32_t* ko = (pass & 1) ? keys_a : keys_b; uint32_t* vo = (pass & 1) ? ids_a : ids_b;
+        const int shift = 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t e = tid; e < n; e += 256u) atomicAdd(&hist[(ki[e] >> shift) & 255u], 1u);
+        __syncthreads();
+        {
+            const uint32_t v = hist[tid];
+            uint32_t tot;
+            const uint32_t incl = block_incl_scan(v, lds17, &tot);
+            hist[tid] = incl - v;                    // start of digit tid's run
+        }
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += 256u) {
+            cnt[tid] = 0; cnt[256 + tid] = 0; cnt[512 + tid] = 0; cnt[768 + tid] = 0;
+            __syncthreads();
+            const uint32_t e = c0 + tid;
+            const bool valid = e < n;
+            const uint32_t key = valid ? ki[e] : 0u, val = valid ? vi[e] : 0u;
+            const uint32_t d = (key >> shift) & 255u;
+            uint64_t peers = __ballot(valid);
+            if (!valid) peers = ~peers;
+            for (int b = 0; b < 8; b++) { const bool bit = (d >> b) & 1u; const uint64_t m = __ballot(bit); peers &= bit ? m : ~m; }
+            const uint32_t before = (uint32_t)__popcll(peers & lt);
+            if (valid && before == 0) cnt[wave * 256 + d] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            uint32_t pos = 0;
+            if (valid) { pos = hist[d] + before; for (uint32_t w = 0; w < wave; w++) pos += cnt[w * 256 + d]; }
+            __syncthreads();
+            hist[tid] += cnt[tid] + cnt[256 + tid] + cnt[512 + tid] + cnt[768 + tid];
+            if (valid) { ko[pos] = key; vo[pos] = val; }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t T, uint32_t cap, const uint32_t* __restrict__ depth_key,
+                                                         uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
+                                                         uint32_t* __restrict__ scratch_keys, uint32_t* __restrict__ scratch_ids)
+{
+    __shared__ unsigned long long s_all[TDS_WG_CAP];        // four wave slices of TDS_WAVE_CAP words, or one block-level buffer
+    __shared__ uint32_t s_hist[256], s_cnt[4 * 256], s_lds[17];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * 4u + wave;
+    uint2 r = make_uint2(0u, 0u);
+    if (tile < T) r = ranges[tile];
+    r.y = min(r.y, cap);                                     // a speculative forward that overflowed its arena is redone by the caller; stay in bounds
+    const uint32_t n = r.y > r.x ? r.y - r.x : 0u;
+    if (n > 1u && n <= TDS_WAVE_CAP) {
+        unsigned long long* sl = s_all + wave * TDS_WAVE_CAP;
+        uint32_t m = 2u;
+        while (m < n) m <<= 1;
+        for (uint32_t e = lane; e < m; e += 64u) {
+            unsigned long long w = ~0ull;                    // padding sorts behind every real entry
+            if (e < n) { const uint32_t id = point_list[r.x + e]; w = ((unsigned long long)depth_key[id] << 32) | id; }
+            sl[e] = w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = 2u; k <= m; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                for (uint32_t t = lane; t < (m >> 1); t += 64u) tds_cmpx(sl, t, j, k);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        for (uint32_t e = lane; e < n; e += 64u) point_list[r.x + e] = (uint32_t)sl[e];
+    }
+    // lists too long for one wave: the workgroup's four waves take them one after the other (block-uniform loop over the four tiles)
+    __shared__ uint32_t s_big[4];
+    if (lane == 0) s_big[wave] = (n > TDS_WAVE_CAP) ? 1u : 0u;
+    __syncthreads();
+    for (uint32_t w4 = 0; w4 < 4u; w4++) {
+        if (!s_big[w4]) continue;                            // block-uniform
+        const uint32_t t4 = blockIdx.x * 4u + w4;
+        uint2 rr = ranges[t4];
+        rr.y = min(rr.y, cap);
+        const uint32_t nn = rr.y - rr.x;
+        __syncthreads();
+        if (nn <= TDS_WG_CAP) {
+            uint32_t m = 2u;
+            while (m < nn) m <<= 1;
+            for (uint32_t e = threadIdx.x; e < m; e += 256u) {
+                unsigned long long w = ~0ull;
+                if (e < nn) { const uint32_t id = point_list[rr.x + e]; w = ((unsigned long long)depth_key[id] << 32) | id; }
+                s_all[e] = w;
+            }
+            __syncthreads();
+            for (uint32_t k = 2u; k <= m; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                    for (uint32_t t = threadIdx.x; t < (m >> 1); t += 256u) tds_cmpx(s_all, t, j, k);
+                    __syncthreads();
+                }
+            for (uint32_t e = threadIdx.x; e < nn; e += 256u) point_list[rr.x + e] = (uint32_t)s_all[e];
+            __syncthreads();
+        } else {
+            // (keys, ids) = (scratch_keys, point_list) <-> (tile_keys, scratch_ids); tile_keys of this tile is rewritten afterwards (constant = tile id)
+            for (uint32_t e = threadIdx.x; e < nn; e += 256u) scratch_keys[rr.x + e] = depth_key[point_list[rr.x + e]];
+            __threadfence_block();
+            __syncthreads();
+            tds_global_radix(point_list + rr.x, scratch_keys + rr.x, scratch_ids + rr.x, tile_keys + rr.x, nn, s_hist, s_cnt, s_lds);
+            for (uint32_t e = threadIdx.x; e < nn; e += 256u) tile_keys[rr.x + e] = t4;
+            __syncthreads();
+        }
+    }
+}
+
 static int tile_bits(int T)
 {
     int b = 1;
@@ -509,11 +658,16 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     const int passes = gsr_tile_sort_passes(T);
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
-    hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P, g.sorted_idx, g.offsets, g.scan_tmp,
+    const bool global_order = gsr_depth_order_is_global();
+    hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P,
+                       global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
                        g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256));
     bool in_b = false;
     if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true)) return 1;
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
+    if (!global_order)
+        hipLaunchKernelGGL(k_tile_depth_sort, dim3(gsr_div_up((uint32_t)T, 4u)), dim3(256), 0, s, im.ranges, (uint32_t)T, R, g.depth_key, b.point_list, b.tile_keys,
+                           b.keys_b, b.vals_b);
     if (gsr_tile_order_enabled()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
     return gsr_check_launch("binning", s, cfg->debug);
 }

@@ -524,12 +524,45 @@ def test_unused_outputs_send_no_gradient_tensor(variant):
     assert np.linalg.norm(ma.astype(np.float64) - mb) <= 1e-4 * np.linalg.norm(mb.astype(np.float64))
 
 
+def test_global_depth_sort_kept_switchable():
+    """GSR_DEPTH_ORDER=global selects rounds 1-2's ordering (stable LSD sort of the P gaussians by depth bits, instances emitted in that order) instead
+    of the per-tile depth sort; the bit-exact list checks of the parity cases are re-run in a child process with it set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSR_DEPTH_ORDER="global")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity or test_long_tile_lists",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("variant,P", [("ewa", 700), ("surfel", 5000), ("plane", 9000), ("ewa", 40000), ("surfel", 24000)])
+def test_long_tile_lists_sort_paths(variant, P):
+    """A 48x32 image (6 tiles) with thousands of gaussians per tile: the per-tile depth sort's three paths -- one wave (<= 1024 entries), the
+    workgroup's block-level network (<= 4096) and the global-memory radix fallback (longer) -- give the oracle's list bit for bit, and the
+    tile keys survive the fallback's use of their array as scratch."""
+    hr = _hiprun()
+    W, H = 48, 32
+    sc = scenes.make_scene(variant, P, W, H, seed=21)
+    with oracle.Forward(sc, variant) as f:
+        st = hr.run_raw(variant, sc)
+        assert st["R"] == f.R
+        assert np.array_equal(st["point_list"], f.point_list())
+        assert np.array_equal(st["tile_keys"], (f.keys() >> np.uint64(32)).astype(np.uint32))
+        rr = f.ranges(); touched = rr[:, 1] > rr[:, 0]
+        assert np.array_equal(st["ranges"][touched], rr[touched])
+        lens = (rr[:, 1] - rr[:, 0])[touched]
+        ft, nc = f.image_state()
+        _ncontrib_close(st["n_contrib"][0], nc[0], st["final_T"][0], ft[0])
+    return int(lens.max())
+
+
 def test_eleven_bit_depth_sort_kept_switchable():
     """GSR_DEPTH_BITS=11 (three 2048-bin passes instead of four 256-bin ones, kept for A/B) has to give the same bit-exact lists: the integer
     checks of the parity cases are re-run in a child process with the switch set."""
     import subprocess
     import sys
-    env = dict(os.environ, GSR_DEPTH_BITS="11")
+    env = dict(os.environ, GSR_DEPTH_BITS="11", GSR_DEPTH_ORDER="global")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
