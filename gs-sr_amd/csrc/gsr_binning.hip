@@ -343,17 +343,24 @@ uint32_t gsr_depth_sort_digit_bins()
 //           sort over P keys, each of which costs its ~5-10 us latency floor whatever P is (profiles/r03_timeline_surfel.json).
 //   "global" (GSR_DEPTH_ORDER=global, rounds 1-2): stable LSD sort of the P gaussians by depth bits first, instances emitted in that order.
 // Both give the reference's order: by tile, then depth bits, then gaussian id (3DGS rasterizer_impl.cu:70-111, 300-308).
-bool gsr_depth_order_is_global()
+// Measured (MI355X, 1080p, surfel; profiles/r03_depth_order_ab.txt), ordering chain = depth_order + binning stages, tile / global:
+//   P = 100k (57 entries per tile)  85 / 118 us;   300k (169)  116 / 144 us;   600k (337)  172 / 180 us;   1M (562)  296 / 267 us;   3M (1690)  773 / 658 us
+// -- the per-tile sort is O(n^2 / 64) per list up to 256 entries and a bitonic network above, so the global sort wins again on long lists:
+// "auto" (default) takes the per-tile path while P <= 96 tiles' worth of gaussians (about 780k at 1080p).
+bool gsr_depth_order_is_global(int P, int T)
 {
-    static int global_sort = -1;
-    if (global_sort < 0) { const char* e = getenv("GSR_DEPTH_ORDER"); global_sort = (e && e[0] == 'g') ? 1 : 0; }
-    return global_sort != 0;
+    static int mode = -1;                       // 0 auto, 1 global, 2 tile
+    if (mode < 0) { const char* e = getenv("GSR_DEPTH_ORDER"); mode = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 't' ? 2 : 0)); }
+    if (mode == 1) return true;
+    if (mode == 2) return false;
+    return (long long)P > 96ll * (long long)T;
 }
 
 int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s)
 {
     const uint32_t P = (uint32_t)cfg->P;
-    if (!gsr_depth_order_is_global()) {
+    const int T_tiles = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
+    if (!gsr_depth_order_is_global(cfg->P, T_tiles)) {
         // id order: only the prefix sum of tiles_touched (block-local + block sums; k_duplicate adds the two) and num_rendered
         const uint32_t nb = gsr_div_up(P, GSR_SCAN_BLOCK);
         hipLaunchKernelGGL(k_offsets_local, dim3(nb), dim3(GSR_SCAN_BLOCK), 0, s, (const uint32_t*)nullptr, g.tiles_touched, P, g.offsets, g.scan_tmp);
@@ -512,6 +519,7 @@ bool gsr_tile_order_enabled()
 // and the ids are written back.  Lists longer than TDS_WAVE_CAP are left to the end of the workgroup's life, where its four waves sort them
 // together (up to TDS_WG_CAP, block-level network with barriers); anything longer goes through a stable 4-pass LSD radix sort in global
 // memory by the workgroup (scratch: the free ping-pong half of the binning arena) -- slow, correct, and only reached by tiles with > 4096 entries.
+#define TDS_RANK_CAP 256u
 #define TDS_WAVE_CAP 1024u
 #define TDS_WG_CAP 4096u
 __device__ __forceinline__ void tds_cmpx(unsigned long long* s, uint32_t t, uint32_t j, uint32_t k)
@@ -578,7 +586,33 @@ __global__ void __launch_bounds__(256) k_tile_depth_sort(const uint2* __restrict
     if (tile < T) r = ranges[tile];
     r.y = min(r.y, cap);                                     // a speculative forward that overflowed its arena is redone by the caller; stay in bounds
     const uint32_t n = r.y > r.x ? r.y - r.x : 0u;
-    if (n > 1u && n <= TDS_WAVE_CAP) {
+    if (n > 1u && n <= TDS_RANK_CAP) {
+        // short lists (the common case: ~170 entries at 300k gaussians / 1080p): rank by counting.  Every lane holds up to four entries and counts,
+        // over ALL entries of the list (broadcast LDS reads, no dependency between iterations), how many sort in front of each -- the words are
+        // distinct (the id is part of them), so the ranks are a permutation and each id is written straight to its place.  A bitonic network of the
+        // same size is a chain of 36 dependent LDS round trips per wave; this is ~n/2 independent ones.
+        unsigned long long* sl = s_all + wave * TDS_WAVE_CAP;
+        unsigned long long w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t e = lane + 64u * q;
+            w[q] = ~0ull;
+            if (e < n) { const uint32_t id = point_list[r.x + e]; w[q] = ((unsigned long long)depth_key[id] << 32) | id; }
+            sl[e] = w[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t rank[4] = { 0u, 0u, 0u, 0u };
+        const uint32_t n2 = (n + 1u) & ~1u;                  // sl[n] is a padding word (~0) when n is odd: never smaller than a real entry
+        for (uint32_t e = 0; e < n2; e += 2u) {
+            const unsigned long long a = sl[e], b = sl[e + 1u];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rank[q] += (a < w[q] ? 1u : 0u) + (b < w[q] ? 1u : 0u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (lane + 64u * q < n) point_list[r.x + rank[q]] = (uint32_t)w[q];
+    } else if (n > TDS_RANK_CAP && n <= TDS_WAVE_CAP) {
         unsigned long long* sl = s_all + wave * TDS_WAVE_CAP;
         uint32_t m = 2u;
         while (m < n) m <<= 1;
@@ -658,7 +692,7 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     const int passes = gsr_tile_sort_passes(T);
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
-    const bool global_order = gsr_depth_order_is_global();
+    const bool global_order = gsr_depth_order_is_global(cfg->P, T);
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P,
                        global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
                        g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256));

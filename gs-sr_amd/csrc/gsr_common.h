@@ -98,7 +98,7 @@ int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
 // hipMemsetAsync that is safe to record into a HIP graph: on ROCm 7.2 a memset NODE replays with a corrupted fill value from the second replay
 // on (measured round 3: vis_idx filled with 0x5A5A5A5A instead of 0xFF...), so while `s` is being captured the fill is a kernel; eagerly it is
 // the runtime's memset.  nbytes must be a multiple of 4.
-bool gsr_depth_order_is_global();     // GSR_DEPTH_ORDER=global: rounds 1-2 global depth sort instead of the per-tile sort (gsr_binning.hip)
+bool gsr_depth_order_is_global(int P, int T);     // per-tile depth sort or the global one (GSR_DEPTH_ORDER=tile|global|auto; gsr_binning.hip)
 bool gsr_tile_order_enabled();        // GSR_TILE_ORDER=1 (gsr_binning.hip)
 int gsr_memset_async(void* p, int byte_value, size_t nbytes, hipStream_t s);
 int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,

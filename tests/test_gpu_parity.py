@@ -524,6 +524,17 @@ def test_unused_outputs_send_no_gradient_tensor(variant):
     assert np.linalg.norm(ma.astype(np.float64) - mb) <= 1e-4 * np.linalg.norm(mb.astype(np.float64))
 
 
+def test_per_tile_depth_sort_forced():
+    """The long-list cases above with GSR_DEPTH_ORDER=tile, in a child process (the switch is read once per process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSR_DEPTH_ORDER="tile")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_long_tile_lists or test_forward_backward_parity",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout and "skipped" not in r.stdout.splitlines()[-1]
+
+
 def test_global_depth_sort_kept_switchable():
     """GSR_DEPTH_ORDER=global selects rounds 1-2's ordering (stable LSD sort of the P gaussians by depth bits, instances emitted in that order) instead
     of the per-tile depth sort; the bit-exact list checks of the parity cases are re-run in a child process with it set."""
@@ -537,11 +548,13 @@ def test_global_depth_sort_kept_switchable():
 
 
 @pytest.mark.parametrize("variant,P", [("ewa", 700), ("surfel", 5000), ("plane", 9000), ("ewa", 40000), ("surfel", 24000)])
-def test_long_tile_lists_sort_paths(variant, P):
-    """A 48x32 image (6 tiles) with thousands of gaussians per tile: the per-tile depth sort's three paths -- one wave (<= 1024 entries), the
+def test_long_tile_lists_sort_paths(variant, P, monkeypatch):
+    """(GSR_DEPTH_ORDER=tile unless the environment already chose: "auto" would send these gaussian counts to the global sort.)  A 48x32 image (6 tiles) with thousands of gaussians per tile: the per-tile depth sort's three paths -- one wave (<= 1024 entries), the
     workgroup's block-level network (<= 4096) and the global-memory radix fallback (longer) -- give the oracle's list bit for bit, and the
     tile keys survive the fallback's use of their array as scratch."""
     hr = _hiprun()
+    if "GSR_DEPTH_ORDER" not in os.environ:
+        pytest.skip("run by test_per_tile_depth_sort_forced (the library reads GSR_DEPTH_ORDER once per process)")
     W, H = 48, 32
     sc = scenes.make_scene(variant, P, W, H, seed=21)
     with oracle.Forward(sc, variant) as f:
