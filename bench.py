@@ -50,9 +50,15 @@ def algorithmic_bytes(variant, R, N, T):
     return fwd, bwd
 
 
+def depth_order_is_global(P, T):
+    """The library's choice (gsr_binning.hip gsr_depth_order_is_global): per-tile depth sort while P <= 96 T unless GSR_DEPTH_ORDER says otherwise."""
+    e = os.environ.get("GSR_DEPTH_ORDER", "")
+    return True if e[:1] == "g" else (False if e[:1] == "t" else P > 96 * T)
+
+
 def stage_bytes(variant, color_mode, P, R, N, T):
-    """Algorithmic bytes per launch of every stage (sort passes as implemented here:
-    4 depth passes over P (key+value, read+write) and ceil(log2 T / 8) tile passes over R)."""
+    """Algorithmic bytes per launch of every stage (SURVEY.md §8d table; sort passes as implemented here: ceil(log2 T / 8) tile passes over R;
+    depth order either 4 radix passes over P (key+value, read+write) or, per-tile mode, one pass over R: id + depth-key gather read, id written)."""
     sh = 192 if color_mode == "sh" else 12
     fwd_b, bwd_b = algorithmic_bytes(variant, R, N, T)
     pre = P * ((12 + 8 + 16 + 4 + sh) + (4 + 8 + 4 + 36 + 16 + 4)) if variant == "surfel" else \
@@ -61,7 +67,9 @@ def stage_bytes(variant, color_mode, P, R, N, T):
     tile_passes = (tile_bits + 7) // 8
     acc = {"ewa": 48, "plane": 64, "surfel": 80}[variant]
     pre_bwd = P * (acc + 12 + 16 + 8 + (2 * 192 if color_mode == "sh" else 0) + 12 + 12 + 12 + 4 + 36 + 8 + 16)
-    return {"preprocess": pre, "depth_order": 4 * 16 * P + 8 * P, "binning": 20 * P + 8 * R + tile_passes * 16 * R + 4 * R + 8 * T,
+    glob = depth_order_is_global(P, T)
+    return {"preprocess": pre, "depth_order": (4 * 16 * P + 8 * P) if glob else 8 * P,
+            "binning": 20 * P + 8 * R + tile_passes * 16 * R + 4 * R + 8 * T + (0 if glob else 12 * R),
             "blend_fwd": fwd_b, "bwd_memset": P * acc, "blend_bwd": bwd_b, "preprocess_bwd": pre_bwd}
 
 
@@ -559,6 +567,7 @@ def main():
                                    f"regularisers, statistics) are timed in method_iteration",
                        "variant": args.variant, "P": args.P, "W": args.W, "H": args.H, "tile_instances_R": R, "tile_instances_R_after_timed_steps": R_after,
                        "visible": int((st["radii"] > 0).sum()),
+                       "depth_order": "global 4-pass radix sort of the gaussians" if depth_order_is_global(args.P, T) else "per-tile sort of the binned lists (k_tile_depth_sort)",
                        "tiles": T, "tiles_touched": int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()),
                        "gaussians_per_tile_mean": round(R / max(int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()), 1), 1),
                        "gaussians_per_tile_max": int((st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0].astype(np.int64)).max()),
