@@ -529,6 +529,34 @@ __device__ __forceinline__ void tds_cmpx(unsigned long long* s, uint32_t t, uint
     const bool up = (i & k) == 0u;
     if ((a > b) == up) { s[i] = b; s[q] = a; }
 }
+// rank-by-counting sort of a list of n <= 64 NQ entries by one wave (see k_tile_depth_sort); sl: the wave's LDS slice, >= 64 NQ + 2 words
+template <int NQ>
+__device__ __forceinline__ void tds_rank_sort(unsigned long long* sl, uint32_t* __restrict__ list, const uint32_t* __restrict__ depth_key, uint32_t n, uint32_t lane)
+{
+    unsigned long long w[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint32_t e = lane + 64u * q;
+        w[q] = ~0ull;
+        if (e < n) { const uint32_t id = list[e]; w[q] = ((unsigned long long)depth_key[id] << 32) | id; }
+        sl[e] = w[q];
+    }
+    if (lane < 2u) sl[64u * NQ + lane] = ~0ull;              // padding read by the last (odd) iteration
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t rank[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) rank[q] = 0u;
+    const uint32_t n2 = (n + 1u) & ~1u;                      // a padding word (~0) is never smaller than a real entry
+    for (uint32_t e = 0; e < n2; e += 2u) {
+        const unsigned long long a = sl[e], b = sl[e + 1u];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) rank[q] += (a < w[q] ? 1u : 0u) + (b < w[q] ? 1u : 0u);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        if (lane + 64u * q < n) list[rank[q]] = (uint32_t)w[q];
+}
 __device__ void tds_global_radix(uint32_t* __restrict__ ids_a, uint32_t* __restrict__ keys_a, uint32_t* __restrict__ ids_b, uint32_t* __restrict__ keys_b,
                                  uint32_t n, uint32_t* hist /*LDS [256]*/, uint32_t* cnt /*LDS [4][256]*/, uint32_t* lds17)
 {
@@ -592,26 +620,11 @@ __global__ void __launch_bounds__(256) k_tile_depth_sort(const uint2* __restrict
         // distinct (the id is part of them), so the ranks are a permutation and each id is written straight to its place.  A bitonic network of the
         // same size is a chain of 36 dependent LDS round trips per wave; this is ~n/2 independent ones.
         unsigned long long* sl = s_all + wave * TDS_WAVE_CAP;
-        unsigned long long w[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t e = lane + 64u * q;
-            w[q] = ~0ull;
-            if (e < n) { const uint32_t id = point_list[r.x + e]; w[q] = ((unsigned long long)depth_key[id] << 32) | id; }
-            sl[e] = w[q];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t rank[4] = { 0u, 0u, 0u, 0u };
-        const uint32_t n2 = (n + 1u) & ~1u;                  // sl[n] is a padding word (~0) when n is odd: never smaller than a real entry
-        for (uint32_t e = 0; e < n2; e += 2u) {
-            const unsigned long long a = sl[e], b = sl[e + 1u];
-#pragma unroll
-            for (int q = 0; q < 4; q++) rank[q] += (a < w[q] ? 1u : 0u) + (b < w[q] ? 1u : 0u);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (lane + 64u * q < n) point_list[r.x + rank[q]] = (uint32_t)w[q];
+        const uint32_t nq = (n + 63u) >> 6;                  // entries per lane actually in use (wave-uniform): 3 for the typical 170-entry list
+        if (nq == 1u) tds_rank_sort<1>(sl, point_list + r.x, depth_key, n, lane);
+        else if (nq == 2u) tds_rank_sort<2>(sl, point_list + r.x, depth_key, n, lane);
+        else if (nq == 3u) tds_rank_sort<3>(sl, point_list + r.x, depth_key, n, lane);
+        else tds_rank_sort<4>(sl, point_list + r.x, depth_key, n, lane);
     } else if (n > TDS_RANK_CAP && n <= TDS_WAVE_CAP) {
         unsigned long long* sl = s_all + wave * TDS_WAVE_CAP;
         uint32_t m = 2u;
