@@ -529,33 +529,58 @@ __device__ __forceinline__ void tds_cmpx(unsigned long long* s, uint32_t t, uint
     const bool up = (i & k) == 0u;
     if ((a > b) == up) { s[i] = b; s[q] = a; }
 }
-// rank-by-counting sort of a list of n <= 64 NQ entries by one wave (see k_tile_depth_sort); sl: the wave's LDS slice, >= 64 NQ + 2 words
+// rank-by-counting sort of a list of n <= 64 NQ entries by one wave (see k_tile_depth_sort).  sl: the wave's LDS slice (>= 3 * 64 NQ + 8 dwords).
+// Main loop on the 32-BIT depth keys only (v_cmp_lt_u32 + add: a 64-bit compare issues at a quarter of that rate and made the first version
+// of this kernel compute-bound at 27 us); entries whose keys are equal then collide on their rank, which a per-rank counter in LDS detects,
+// and only then (wave-uniform, rare: two gaussians with bit-identical view depth in one tile) the ranks are recomputed with the id as tie-break.
 template <int NQ>
-__device__ __forceinline__ void tds_rank_sort(unsigned long long* sl, uint32_t* __restrict__ list, const uint32_t* __restrict__ depth_key, uint32_t n, uint32_t lane)
+__device__ __forceinline__ void tds_rank_sort(unsigned long long* sl64, uint32_t* __restrict__ list, const uint32_t* __restrict__ depth_key, uint32_t n, uint32_t lane)
 {
-    unsigned long long w[NQ];
+    uint32_t* kk = reinterpret_cast<uint32_t*>(sl64);       // [64 NQ + 8] keys, padded with 0xFFFFFFFF (real keys are positive float bits)
+    uint32_t* ii = kk + 64 * NQ + 8;                        // [64 NQ] ids
+    uint32_t* fl = ii + 64 * NQ;                            // [64 NQ] how many entries took each rank
+    uint32_t key[NQ], id[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         const uint32_t e = lane + 64u * q;
-        w[q] = ~0ull;
-        if (e < n) { const uint32_t id = list[e]; w[q] = ((unsigned long long)depth_key[id] << 32) | id; }
-        sl[e] = w[q];
+        key[q] = 0xFFFFFFFFu; id[q] = 0u;
+        if (e < n) { id[q] = list[e]; key[q] = depth_key[id[q]]; }
+        kk[e] = key[q]; ii[e] = id[q]; fl[e] = 0u;
     }
-    if (lane < 2u) sl[64u * NQ + lane] = ~0ull;              // padding read by the last (odd) iteration
+    if (lane < 8u) kk[64u * NQ + lane] = 0xFFFFFFFFu;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint32_t rank[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) rank[q] = 0u;
-    const uint32_t n2 = (n + 1u) & ~1u;                      // a padding word (~0) is never smaller than a real entry
-    for (uint32_t e = 0; e < n2; e += 2u) {
-        const unsigned long long a = sl[e], b = sl[e + 1u];
+    for (uint32_t e = 0; e < n; e += 8u) {                   // eight keys per iteration: two independent 16-byte broadcast reads
+        uint32_t v[8];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) rank[q] += (a < w[q] ? 1u : 0u) + (b < w[q] ? 1u : 0u);
+        for (int u = 0; u < 8; u++) v[u] = kk[e + u];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) c += (v[u] < key[q]) ? 1u : 0u;
+            rank[q] += c;
+        }
+    }
+    bool dup = false;
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        if (lane + 64u * q < n) dup |= atomicAdd(&fl[rank[q]], 1u) != 0u;
+    if (__ballot(dup) != 0ull) {                             // some keys are equal: ties go by id (the list arrives in id order, the ids are distinct)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) rank[q] = 0u;
+        for (uint32_t e = 0; e < n; e++) {
+            const uint32_t k2 = kk[e], i2 = ii[e];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) rank[q] += ((k2 < key[q]) | ((k2 == key[q]) & (i2 < id[q]))) ? 1u : 0u;
+        }
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++)
-        if (lane + 64u * q < n) list[rank[q]] = (uint32_t)w[q];
+        if (lane + 64u * q < n) list[rank[q]] = id[q];
 }
 __device__ void tds_global_radix(uint32_t* __restrict__ ids_a, uint32_t* __restrict__ keys_a, uint32_t* __restrict__ ids_b, uint32_t* __restrict__ keys_b,
                                  uint32_t n, uint32_t* hist /*LDS [256]*/, uint32_t* cnt /*LDS [4][256]*/, uint32_t* lds17)
