@@ -73,6 +73,25 @@ def stage_bytes(variant, color_mode, P, R, N, T):
             "blend_fwd": fwd_b, "bwd_memset": P * acc, "blend_bwd": bwd_b, "preprocess_bwd": pre_bwd}
 
 
+def clock_prewarm(device, ms):
+    """Keep every CU busy for `ms` milliseconds with work that is NOT the measured path (torch.polygamma over 16 M floats: ~100 VALU
+    instructions per element), so that the shader clock has left its idle state before the W warm-up steps start.  Measured
+    (tools/step_series.py, profiles/r03_clock_ramp.txt): from an idle device the VALU-bound blend kernels need ~20 iterations (~20 ms of
+    load) to come down from 0.53 to 0.475 ms while the HBM-bound kernels of the same iterations (loss, Adam, radix scatter) do not move at
+    all -- the shader clock ramps, not the workload -- so `--steps 20 --warmup 5` from idle reads ~4.5 % below `--steps 500`.  A light or
+    launch-bound load (sin over 4 M floats, a 1 GiB scale) does not lift the clock; 200 ms of this one removes most of the ramp.
+    `--clock-prewarm-ms 0` measures from idle.  Returns the milliseconds spent."""
+    if ms <= 0:
+        return 0.0
+    x = torch.rand(1 << 24, device=device) + 1.0
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(16):
+            torch.polygamma(2, x)
+        torch.cuda.synchronize(device)
+    return (time.perf_counter() - t0) * 1e3
+
+
 def make_step(variant, sc, device):
     """One training iteration.  All gaussian parameters live in ONE flat leaf z (contiguous blocks: means 3P, scales 2P|3P,
     rotations 4P, opacity P, colour 3P|48P), optimised by gsrast.optim.Adam (one fused HIP kernel, include/gsrast.h gsr_adam_step) whose
@@ -391,6 +410,8 @@ def main():
     ap.add_argument("--no-graph-replay", action="store_true", help="skip the informational HIP-graph replay of the same step")
     ap.add_argument("--graph-replay-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--method-iteration-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--clock-prewarm-ms", type=float, default=300.0,
+                    help="busy the device this long with unrelated compute before the warm-up steps so the shader clock is out of idle (0 = measure from idle); see clock_prewarm()")
     ap.add_argument("--stage-steps", type=int, default=20, help="untimed iterations after the timed region in which EVERY stage carries HIP events (stage_ms)")
     ap.add_argument("--profile-all-stages-in-timed-region", action="store_true",
                     help="round-1/2 behaviour: all seven stages timed with HIP events inside the timed region (costs ~6 %% of the step in event gaps)")
@@ -466,6 +487,7 @@ def main():
     def barrier():
         tiles.barrier(device)
 
+    prewarm_ms = clock_prewarm(device, args.clock_prewarm_ms)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -567,6 +589,7 @@ def main():
                                    f"regularisers, statistics) are timed in method_iteration",
                        "variant": args.variant, "P": args.P, "W": args.W, "H": args.H, "tile_instances_R": R, "tile_instances_R_after_timed_steps": R_after,
                        "visible": int((st["radii"] > 0).sum()),
+                       "clock_prewarm_ms": round(prewarm_ms, 1),
                        "depth_order": "global 4-pass radix sort of the gaussians" if depth_order_is_global(args.P, T) else "per-tile sort of the binned lists (k_tile_depth_sort)",
                        "tiles": T, "tiles_touched": int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()),
                        "gaussians_per_tile_mean": round(R / max(int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()), 1), 1),
