@@ -514,7 +514,9 @@ def main():
         gsrast.profile_enable(False)
         prof["blend_bwd_timed_region"] = prof_timed["blend_bwd"]
     graph_info = None
-    if rank == 0 and world == 1 and not args.no_graph_replay:
+    if rank == 0 and world == 1 and not args.no_graph_replay and os.environ.get("GSR_BENCH_TORCH_ADAM", "0") == "1":
+        graph_info = {"skipped": "GSR_BENCH_TORCH_ADAM=1: torch's fused Adam is built with capturable=False and cannot be recorded"}
+    elif rank == 0 and world == 1 and not args.no_graph_replay:
         # informational: the SAME step recorded once into a HIP graph (sync-free rasterizer forward, Adam scalars from device memory) and replayed;
         # `value` above stays the eagerly launched loop, whose dominant kernel is timed live with HIP events as the contract asks.  Run in a child
         # process: nothing that happens while recording / replaying a graph can take the headline line down with it.
