@@ -68,9 +68,11 @@ def stage_bytes(variant, color_mode, P, R, N, T):
     acc = {"ewa": 48, "plane": 64, "surfel": 80}[variant]
     pre_bwd = P * (acc + 12 + 16 + 8 + (2 * 192 if color_mode == "sh" else 0) + 12 + 12 + 12 + 4 + 36 + 8 + 16)
     glob = depth_order_is_global(P, T)
+    tile_sort = 0 if glob else 12 * R          # per-tile depth sort: ids read + depth keys gathered + ids written
+    fused = os.environ.get("GSR_TILE_SORT", "fused")[:1] != "k"      # ... in k_blend_fwd's prologue (default) or as its own launch in the binning stage
     return {"preprocess": pre, "depth_order": (4 * 16 * P + 8 * P) if glob else 8 * P,
-            "binning": 20 * P + 8 * R + tile_passes * 16 * R + 4 * R + 8 * T + (0 if glob else 12 * R),
-            "blend_fwd": fwd_b, "bwd_memset": P * acc, "blend_bwd": bwd_b, "preprocess_bwd": pre_bwd}
+            "binning": 20 * P + 8 * R + tile_passes * 16 * R + 4 * R + 8 * T + (0 if fused else tile_sort),
+            "blend_fwd": fwd_b + (tile_sort if fused else 0), "bwd_memset": P * acc, "blend_bwd": bwd_b, "preprocess_bwd": pre_bwd}
 
 
 def clock_prewarm(device, ms):
@@ -592,7 +594,7 @@ def main():
                        "variant": args.variant, "P": args.P, "W": args.W, "H": args.H, "tile_instances_R": R, "tile_instances_R_after_timed_steps": R_after,
                        "visible": int((st["radii"] > 0).sum()),
                        "clock_prewarm_ms": round(prewarm_ms, 1),
-                       "depth_order": "global 4-pass radix sort of the gaussians" if depth_order_is_global(args.P, T) else "per-tile sort of the binned lists (k_tile_depth_sort)",
+                       "depth_order": "global 4-pass radix sort of the gaussians" if depth_order_is_global(args.P, T) else ("per-tile sort of the binned lists, in k_blend_fwd's prologue" if os.environ.get("GSR_TILE_SORT", "fused")[:1] != "k" else "per-tile sort of the binned lists (k_tile_depth_sort)"),
                        "tiles": T, "tiles_touched": int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()),
                        "gaussians_per_tile_mean": round(R / max(int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()), 1), 1),
                        "gaussians_per_tile_max": int((st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0].astype(np.int64)).max()),

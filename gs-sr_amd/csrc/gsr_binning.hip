@@ -10,6 +10,7 @@
 //   4. tile ranges from key boundaries (identifyTileRanges, rasterizer_impl.cu:116-138).
 // Stability of every pass makes the result identical to the reference's single 64-bit sort.
 #include "gsr_common.h"
+#include "gsr_tile_sort.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------ wave helpers
@@ -522,13 +523,6 @@ bool gsr_tile_order_enabled()
 #define TDS_RANK_CAP 256u
 #define TDS_WAVE_CAP 1024u
 #define TDS_WG_CAP 4096u
-__device__ __forceinline__ void tds_cmpx(unsigned long long* s, uint32_t t, uint32_t j, uint32_t k)
-{
-    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), q = i | j;
-    const unsigned long long a = s[i], b = s[q];
-    const bool up = (i & k) == 0u;
-    if ((a > b) == up) { s[i] = b; s[q] = a; }
-}
 // rank-by-counting sort of a list of n <= 64 NQ entries by one wave (see k_tile_depth_sort).  sl: the wave's LDS slice (>= 3 * 64 NQ + 8 dwords).
 // Main loop on the 32-BIT depth keys only (v_cmp_lt_u32 + add: a 64-bit compare issues at a quarter of that rate and made the first version
 // of this kernel compute-bound at 27 us); entries whose keys are equal then collide on their rank, which a per-rank counter in LDS detects,
@@ -581,51 +575,6 @@ __device__ __forceinline__ void tds_rank_sort(unsigned long long* sl64, uint32_t
 #pragma unroll
     for (int q = 0; q < NQ; q++)
         if (lane + 64u * q < n) list[rank[q]] = id[q];
-}
-__device__ void tds_global_radix(uint32_t* __restrict__ ids_a, uint32_t* __restrict__ keys_a, uint32_t* __restrict__ ids_b, uint32_t* __restrict__ keys_b,
-                                 uint32_t n, uint32_t* hist /*LDS [256]*/, uint32_t* cnt /*LDS [4][256]*/, uint32_t* lds17)
-{
-    // stable LSD radix sort of (keys_a, ids_a)[0, n) by key, 8 bits per pass, ping-ponging with (keys_b, ids_b); four passes end in the a arrays
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    const uint64_t lt = lanemask_lt();
-    for (int pass = 0; pass < 4; pass++) {
-        const uint32_t* ki = (pass & 1) ? keys_b : keys_a; const uint32_t* vi = (pass & 1) ? ids_b : ids_a;
-        uint32_t* ko = (pass & 1) ? keys_a : keys_b; uint32_t* vo = (pass & 1) ? ids_a : ids_b;
-        const int shift = 8 * pass;
-        hist[tid] = 0;
-        __syncthreads();
-        for (uint32_t e = tid; e < n; e += 256u) atomicAdd(&hist[(ki[e] >> shift) & 255u], 1u);
-        __syncthreads();
-        {
-            const uint32_t v = hist[tid];
-            uint32_t tot;
-            const uint32_t incl = block_incl_scan(v, lds17, &tot);
-            hist[tid] = incl - v;                    // start of digit tid's run
-        }
-        __syncthreads();
-        for (uint32_t c0 = 0; c0 < n; c0 += 256u) {
-            cnt[tid] = 0; cnt[256 + tid] = 0; cnt[512 + tid] = 0; cnt[768 + tid] = 0;
-            __syncthreads();
-            const uint32_t e = c0 + tid;
-            const bool valid = e < n;
-            const uint32_t key = valid ? ki[e] : 0u, val = valid ? vi[e] : 0u;
-            const uint32_t d = (key >> shift) & 255u;
-            uint64_t peers = __ballot(valid);
-            if (!valid) peers = ~peers;
-            for (int b = 0; b < 8; b++) { const bool bit = (d >> b) & 1u; const uint64_t m = __ballot(bit); peers &= bit ? m : ~m; }
-            const uint32_t before = (uint32_t)__popcll(peers & lt);
-            if (valid && before == 0) cnt[wave * 256 + d] = (uint32_t)__popcll(peers);
-            __syncthreads();
-            uint32_t pos = 0;
-            if (valid) { pos = hist[d] + before; for (uint32_t w = 0; w < wave; w++) pos += cnt[w * 256 + d]; }
-            __syncthreads();
-            hist[tid] += cnt[tid] + cnt[256 + tid] + cnt[512 + tid] + cnt[768 + tid];
-            if (valid) { ko[pos] = key; vo[pos] = val; }
-            __syncthreads();
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
 }
 __global__ void __launch_bounds__(256) k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t T, uint32_t cap, const uint32_t* __restrict__ depth_key,
                                                          uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
@@ -707,6 +656,14 @@ __global__ void __launch_bounds__(256) k_tile_depth_sort(const uint2* __restrict
     }
 }
 
+// GSR_TILE_SORT=fused (default): k_blend_fwd orders its tile's list in its prologue (gsr_tile_sort.h); =kernel: the separate k_tile_depth_sort launch.
+bool gsr_tile_sort_is_fused()
+{
+    static int fused = -1;
+    if (fused < 0) { const char* e = getenv("GSR_TILE_SORT"); fused = (e && e[0] == 'k') ? 0 : 1; }
+    return fused != 0;
+}
+
 static int tile_bits(int T)
 {
     int b = 1;
@@ -737,7 +694,7 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     bool in_b = false;
     if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true)) return 1;
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
-    if (!global_order)
+    if (!global_order && !gsr_tile_sort_is_fused())
         hipLaunchKernelGGL(k_tile_depth_sort, dim3(gsr_div_up((uint32_t)T, 4u)), dim3(256), 0, s, im.ranges, (uint32_t)T, R, g.depth_key, b.point_list, b.tile_keys,
                            b.keys_b, b.vals_b);
     if (gsr_tile_order_enabled()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);

@@ -15,6 +15,7 @@
 // Behaviour follows 3DGS forward.cu:261-374 / backward.cu:399-557, PLANE forward.cu:273-407 / backward.cu:399-614,
 // SURFEL forward.cu:256-448 / backward.cu:143-447 (thresholds, ordering, recurrences); see DESIGN.md.
 #include "gsr_blend_common.h"
+#include "gsr_tile_sort.h"
 
 // =================================================================================================== forward
 template <int V>
@@ -26,11 +27,17 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ox = tx * GSR_TILE + (wave & 1) * GSR_SUB, oy = ty * GSR_TILE + (wave >> 1) * GSR_SUB;
+    const uint2 range = p.ranges[tile];
+    if (p.depth_key) {
+        // per-tile depth order, fused: the four waves put the tile's list in (depth, id) order before any of them blends (the only barriers of
+        // the kernel; s_rec is free until the first batch is staged).  The backward reads the same list afterwards.
+        TdsScratch sc; sc.tile_keys = p.tile_keys; sc.keys = p.scratch_keys; sc.ids = p.scratch_ids;
+        tds_sort_tile_wg<(int)sizeof(s_rec)>(s_rec, p.list_rw + range.x, range.y > range.x ? range.y - range.x : 0u, range.x, (uint32_t)tile, p.depth_key, sc);
+    }
     if (ox >= p.W || oy >= p.H) return;                 // wave-uniform: this sub-tile is outside the image
     const int px = ox + (lane & 7), py = oy + (lane >> 3);
     const bool inside = px < p.W && py < p.H;
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = p.ranges[tile];
     const size_t HW = (size_t)p.W * p.H;
     const uint32_t pix_id = (uint32_t)p.W * py + px;
 
@@ -423,6 +430,7 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
         p.qmask = reuse ? b.qmask : nullptr;
     }
     p.ranges = im.ranges; p.point_list = b.point_list; p.cull = g.cull; p.rec = g.rec; p.bg = cfg->bg;
+    p.depth_key = nullptr; p.list_rw = nullptr; p.tile_keys = nullptr; p.scratch_keys = nullptr; p.scratch_ids = nullptr;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib;
     return p;
 }
@@ -432,6 +440,9 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
 {
     (void)in;
     BlendParams p = make_bp(cfg, g, b, im);
+    if (!gsr_depth_order_is_global(cfg->P, p.gx * p.gy) && gsr_tile_sort_is_fused()) {
+        p.depth_key = g.depth_key; p.list_rw = b.point_list; p.tile_keys = b.tile_keys; p.scratch_keys = b.keys_b; p.scratch_ids = b.vals_b;
+    }
     p.out_color = out->out_color; p.out_others = out->out_others; p.out_observe = out->out_observe;
     p.out_all_map = out->out_all_map; p.out_plane_depth = out->out_plane_depth;
     dim3 grid(p.gx * p.gy), block(256);

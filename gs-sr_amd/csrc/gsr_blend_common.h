@@ -11,6 +11,11 @@ struct BlendParams {
     const uint32_t* tile_order;      // or nullptr: blockIdx -> tile through tile_of_block
     const uint32_t* point_list;
     unsigned long long* qmask;       // BinView::qmask, or nullptr (GSR_CULL_REUSE=0)
+    // forward only, per-tile depth order with GSR_TILE_SORT=fused: the list arrives grouped by tile but in no particular order inside the tile and
+    // the kernel's prologue sorts it by (depth_key, id) in place (gsr_tile_sort.h); nullptr: the list is already in its final order
+    const uint32_t* depth_key;
+    uint32_t* list_rw;               // == point_list
+    uint32_t* tile_keys; uint32_t* scratch_keys; uint32_t* scratch_ids;      // the long-list fallback's scratch (free ping-pong half of the binning arena)
     const float4* cull;
     const float4* rec;
     const float* bg;

@@ -99,6 +99,7 @@ int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
 // on (measured round 3: vis_idx filled with 0x5A5A5A5A instead of 0xFF...), so while `s` is being captured the fill is a kernel; eagerly it is
 // the runtime's memset.  nbytes must be a multiple of 4.
 bool gsr_depth_order_is_global(int P, int T);     // per-tile depth sort or the global one (GSR_DEPTH_ORDER=tile|global|auto; gsr_binning.hip)
+bool gsr_tile_sort_is_fused();        // GSR_TILE_SORT=fused|kernel: who orders a tile's list by depth when the depth order is per tile (gsr_binning.hip)
 bool gsr_tile_order_enabled();        // GSR_TILE_ORDER=1 (gsr_binning.hip)
 int gsr_memset_async(void* p, int byte_value, size_t nbytes, hipStream_t s);
 int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,

@@ -1,0 +1,179 @@
+// gsr_tile_sort.h -- order ONE tile's list by (depth bits, gaussian id), all 256 threads of a workgroup together.
+//
+// The reference's single 64-bit radix sort (3DGS rasterizer_impl.cu:300-308: key = tile << 32 | depth bits, stable => ties by gaussian id) is
+// reproduced here per tile, after a sort on the tile id alone has grouped the instances (gsr_binning.hip).  Two callers:
+//   * k_blend_fwd (gsr_blend.hip), as its prologue: the sort's dependent loads (ids -> depth keys) hide behind the blending of the
+//     other resident tiles instead of being a latency-bound launch of their own (GSR_TILE_SORT=fused, default);
+//   * k_tile_depth_sort (gsr_binning.hip), one WAVE per tile for short lists (GSR_TILE_SORT=kernel: the round-3 form, kept for A/B).
+// Both leave the same bytes in point_list.
+#pragma once
+#include "gsr_common.h"
+
+__device__ __forceinline__ uint32_t tds_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t tds_wave_incl_scan(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if ((int)tds_lane() >= d) v += t;
+    }
+    return v;
+}
+// inclusive scan over the 256 threads of the workgroup; lds: 17 words
+__device__ __forceinline__ uint32_t tds_block_incl_scan(uint32_t v, uint32_t* lds, uint32_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t s = tds_wave_incl_scan(v);
+    if (lane == 63) lds[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int w = 0; w < 4; w++) { const uint32_t t = lds[w]; lds[w] = run; run += t; } lds[16] = run; }
+    __syncthreads();
+    s += lds[wave];
+    *total = lds[16];
+    __syncthreads();
+    return s;
+}
+
+// one compare-exchange of the bitonic network on 64-bit (depth << 32 | id) words
+__device__ __forceinline__ void tds_cmpx(unsigned long long* s, uint32_t t, uint32_t j, uint32_t k)
+{
+    const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), q = i | j;
+    const unsigned long long a = s[i], b = s[q];
+    const bool up = (i & k) == 0u;
+    if ((a > b) == up) { s[i] = b; s[q] = a; }
+}
+
+// stable LSD radix sort of (keys_a, ids_a)[0, n) by key in GLOBAL memory, 8 bits per pass, ping-ponging with (keys_b, ids_b); the four passes
+// end in the a arrays.  Slow and correct: only lists too long for the LDS network come here.  hist: LDS [256], cnt: LDS [4][256], lds17: LDS [17].
+__device__ inline void tds_global_radix(uint32_t* __restrict__ ids_a, uint32_t* __restrict__ keys_a, uint32_t* __restrict__ ids_b, uint32_t* __restrict__ keys_b,
+                                        uint32_t n, uint32_t* hist, uint32_t* cnt, uint32_t* lds17)
+{
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const uint64_t lt = (1ull << tds_lane()) - 1ull;
+    for (int pass = 0; pass < 4; pass++) {
+        const uint32_t* ki = (pass & 1) ? keys_b : keys_a; const uint32_t* vi = (pass & 1) ? ids_b : ids_a;
+        uint32_t* ko = (pass & 1) ? keys_a : keys_b; uint32_t* vo = (pass & 1) ? ids_a : ids_b;
+        const int shift = 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t e = tid; e < n; e += 256u) atomicAdd(&hist[(ki[e] >> shift) & 255u], 1u);
+        __syncthreads();
+        {
+            const uint32_t v = hist[tid];
+            uint32_t tot;
+            const uint32_t incl = tds_block_incl_scan(v, lds17, &tot);
+            hist[tid] = incl - v;                    // start of digit tid's run
+        }
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += 256u) {
+            cnt[tid] = 0; cnt[256 + tid] = 0; cnt[512 + tid] = 0; cnt[768 + tid] = 0;
+            __syncthreads();
+            const uint32_t e = c0 + tid;
+            const bool valid = e < n;
+            const uint32_t key = valid ? ki[e] : 0u, val = valid ? vi[e] : 0u;
+            const uint32_t d = (key >> shift) & 255u;
+            uint64_t peers = __ballot(valid);
+            if (!valid) peers = ~peers;
+            for (int b = 0; b < 8; b++) { const bool bit = (d >> b) & 1u; const uint64_t m = __ballot(bit); peers &= bit ? m : ~m; }
+            const uint32_t before = (uint32_t)__popcll(peers & lt);
+            if (valid && before == 0) cnt[wave * 256 + d] = (uint32_t)__popcll(peers);
+            __syncthreads();
+            uint32_t pos = 0;
+            if (valid) { pos = hist[d] + before; for (uint32_t w = 0; w < wave; w++) pos += cnt[w * 256 + d]; }
+            __syncthreads();
+            hist[tid] += cnt[tid] + cnt[256 + tid] + cnt[512 + tid] + cnt[768 + tid];
+            if (valid) { ko[pos] = key; vo[pos] = val; }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// What the long-list fallback needs besides the list itself
+struct TdsScratch {
+    uint32_t* tile_keys;        // [R] tile id of every instance (constant inside a tile's range): lent to the radix fallback and rewritten
+    uint32_t* keys;             // [R] free ping-pong half of the binning arena
+    uint32_t* ids;              // [R]
+};
+
+// The tile's list `list[0, n)` (any order) -> ascending (depth_key[id], id).  Called by ALL 256 threads of the workgroup (n is block-uniform);
+// `lds` is LDS_BYTES of workgroup LDS the caller lends (>= 6 KiB; everything in it is overwritten); ends with a barrier, after which the list
+// in global memory is visible to every thread of the workgroup.
+//   n <= 256: rank by counting -- thread t holds entry t and counts, over all entries (broadcast LDS reads, 8 keys per iteration, no dependency
+//             between iterations), how many sort in front of it, on the 32-bit depth keys alone; entries with EQUAL keys then collide on
+//             their rank, which a per-rank counter detects, and only then (rare: bit-identical view depths in one tile) the count is redone with
+//             the id as tie-break.  The ranks are a permutation: each id goes straight to its place.
+//   n <= largest power of two of 64-bit words that fits `lds`: bitonic network on (depth << 32 | id).
+//   longer: four-pass radix sort in global memory.
+template <int LDS_BYTES>
+__device__ __forceinline__ void tds_sort_tile_wg(void* lds, uint32_t* list, uint32_t n, uint32_t first, uint32_t tile,
+                                                 const uint32_t* __restrict__ depth_key, TdsScratch sc)
+{
+    static_assert(LDS_BYTES >= 6144, "tds_sort_tile_wg: at least 6 KiB of LDS");
+    constexpr uint32_t CAPW = (LDS_BYTES / 8 >= 4096) ? 4096u : (LDS_BYTES / 8 >= 2048) ? 2048u : (LDS_BYTES / 8 >= 1024) ? 1024u : 512u;
+    const uint32_t t = threadIdx.x;
+    if (n <= 1u) { __syncthreads(); return; }
+    if (n <= 256u) {
+        uint32_t* kk = reinterpret_cast<uint32_t*>(lds);    // [256] keys, 0xFFFFFFFF behind the list (real keys are positive float bits)
+        uint32_t* ii = kk + 256;                            // [256] ids
+        uint32_t* fl = ii + 256;                            // [256] how many entries took each rank
+        uint32_t key = 0xFFFFFFFFu, id = 0u;
+        if (t < n) { id = list[t]; key = depth_key[id]; }
+        kk[t] = key; ii[t] = id; fl[t] = 0u;
+        if (t == 0) fl[256] = 0u;                           // "some ranks collided" (a word of the lent LDS: __syncthreads_or would allocate its own)
+        __syncthreads();
+        uint32_t rank = 0u;
+        if ((t & ~63u) < n) {                               // wave-uniform: a wave without entries only keeps the barriers
+            for (uint32_t e = 0; e < n; e += 8u) {
+                const uint4 a = *reinterpret_cast<const uint4*>(kk + e), b = *reinterpret_cast<const uint4*>(kk + e + 4);
+                rank += (a.x < key ? 1u : 0u) + (a.y < key ? 1u : 0u) + (a.z < key ? 1u : 0u) + (a.w < key ? 1u : 0u)
+                      + (b.x < key ? 1u : 0u) + (b.y < key ? 1u : 0u) + (b.z < key ? 1u : 0u) + (b.w < key ? 1u : 0u);
+            }
+        }
+        if (t < n && atomicAdd(&fl[rank], 1u) != 0u) fl[256] = 1u;
+        __syncthreads();
+        if (fl[256] != 0u) {
+            rank = 0u;
+            if (t < n)
+                for (uint32_t e = 0; e < n; e++) {
+                    const uint32_t k2 = kk[e], i2 = ii[e];
+                    rank += ((k2 < key) | ((k2 == key) & (i2 < id))) ? 1u : 0u;
+                }
+        }
+        if (t < n) list[rank] = id;
+        __syncthreads();
+        return;
+    }
+    if (n <= CAPW) {
+        unsigned long long* s = reinterpret_cast<unsigned long long*>(lds);
+        uint32_t m = 512u;
+        while (m < n) m <<= 1;
+        for (uint32_t e = t; e < m; e += 256u) {
+            unsigned long long w = ~0ull;                    // padding sorts behind every real entry
+            if (e < n) { const uint32_t id = list[e]; w = ((unsigned long long)depth_key[id] << 32) | id; }
+            s[e] = w;
+        }
+        __syncthreads();
+        for (uint32_t k = 2u; k <= m; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+                for (uint32_t q = t; q < (m >> 1); q += 256u) tds_cmpx(s, q, j, k);
+                __syncthreads();
+            }
+        for (uint32_t e = t; e < n; e += 256u) list[e] = (uint32_t)s[e];
+        __syncthreads();
+        return;
+    }
+    {
+        // (keys, ids) = (sc.keys, list) <-> (sc.tile_keys, sc.ids); the tile's tile_keys are rewritten afterwards (constant = tile id)
+        uint32_t* w32 = reinterpret_cast<uint32_t*>(lds);
+        uint32_t *hist = w32, *cnt = w32 + 256, *lds17 = w32 + 256 + 1024;
+        for (uint32_t e = t; e < n; e += 256u) sc.keys[first + e] = depth_key[list[e]];
+        __threadfence_block();
+        __syncthreads();
+        tds_global_radix(list, sc.keys + first, sc.ids + first, sc.tile_keys + first, n, hist, cnt, lds17);
+        for (uint32_t e = t; e < n; e += 256u) sc.tile_keys[first + e] = tile;
+        __threadfence_block();
+        __syncthreads();
+    }
+}

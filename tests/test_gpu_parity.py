@@ -543,11 +543,13 @@ def test_equal_depths_tie_by_id(variant):
         assert (np.diff(k.astype(np.uint64)) == 0).sum() > 100          # the sorted list really holds runs of equal (tile, depth) keys
 
 
-def test_per_tile_depth_sort_forced():
-    """The long-list cases above with GSR_DEPTH_ORDER=tile, in a child process (the switch is read once per process)."""
+@pytest.mark.parametrize("who", ["fused", "kernel"])
+def test_per_tile_depth_sort_forced(who):
+    """The long-list cases below with GSR_DEPTH_ORDER=tile, in a child process (the switches are read once per process): once with the sort in
+    k_blend_fwd's prologue (GSR_TILE_SORT=fused, the default) and once as the separate k_tile_depth_sort launch (=kernel)."""
     import subprocess
     import sys
-    env = dict(os.environ, GSR_DEPTH_ORDER="tile")
+    env = dict(os.environ, GSR_DEPTH_ORDER="tile", GSR_TILE_SORT=who)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_long_tile_lists or test_forward_backward_parity or test_equal_depths",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
@@ -568,8 +570,9 @@ def test_global_depth_sort_kept_switchable():
 
 @pytest.mark.parametrize("variant,P", [("ewa", 700), ("surfel", 5000), ("plane", 9000), ("ewa", 40000), ("surfel", 24000)])
 def test_long_tile_lists_sort_paths(variant, P, monkeypatch):
-    """(GSR_DEPTH_ORDER=tile unless the environment already chose: "auto" would send these gaussian counts to the global sort.)  A 48x32 image (6 tiles) with thousands of gaussians per tile: the per-tile depth sort's three paths -- one wave (<= 1024 entries), the
-    workgroup's block-level network (<= 4096) and the global-memory radix fallback (longer) -- give the oracle's list bit for bit, and the
+    """(GSR_DEPTH_ORDER=tile unless the environment already chose: "auto" would send these gaussian counts to the global sort.)  A 48x32 image (6 tiles) with thousands of gaussians per tile: the per-tile depth sort's paths -- rank by counting (<= 256 entries), the LDS
+    bitonic network (fused: <= 1024 entries EWA / 2048 PLANE, SURFEL, the forward's staging LDS; kernel: one wave <= 1024, the workgroup <= 4096) and
+    the global-memory radix fallback (longer) -- give the oracle's list bit for bit, and the
     tile keys survive the fallback's use of their array as scratch."""
     hr = _hiprun()
     if "GSR_DEPTH_ORDER" not in os.environ:
