@@ -305,7 +305,7 @@ extern "C" int gsr_adam_step(int64_t n, float* param, const float* grad, float* 
 // The table travels as a kernel argument; block b works on 4096 consecutive elements of the tensor whose [first_block, next first_block) holds b.
 #define GSR_ADAM_MAX 24
 #define GSR_ADAM_CHUNK 4096
-struct AdamEntry { float* p; const float* g; float* m; float* v; const float* sc; int64_t n; float step_size, w1, b2, w2, inv_bc2_sqrt, eps; uint32_t first_block, vec; };
+struct AdamEntry { float* p; const float* g; const float* g2; float* m; float* v; const float* sc; int64_t n; float step_size, w1, b2, w2, inv_bc2_sqrt, eps; uint32_t first_block, vec; };
 struct AdamTable { int32_t count; int32_t first; const float* hyper; AdamEntry e[GSR_ADAM_MAX]; };      // hyper: device [total][2] or null; first: caller index of e[0]
 struct AdamIdx { int32_t idx[GSR_ADAM_MAX]; };
 
@@ -329,7 +329,8 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamTable T, AdamIdx X)
     if (E.vec) {                                   // all five pointers 16-byte aligned: base is a multiple of 4096 elements
         for (int64_t i = base + 4 * (int64_t)threadIdx.x; i + 3 < end; i += 1024) {
             float4 pp = *reinterpret_cast<float4*>(E.p + i), mm = *reinterpret_cast<float4*>(E.m + i), vv = *reinterpret_cast<float4*>(E.v + i);
-            const float4 gg = *reinterpret_cast<const float4*>(E.g + i);
+            float4 gg = *reinterpret_cast<const float4*>(E.g + i);
+            if (E.g2) { const float4 g2 = *reinterpret_cast<const float4*>(E.g2 + i); gg.x += g2.x; gg.y += g2.y; gg.z += g2.z; gg.w += g2.w; }
             float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
             if (E.sc) sc = *reinterpret_cast<const float4*>(E.sc + i);
             upd(pp.x, gg.x, mm.x, vv.x, sc.x); upd(pp.y, gg.y, mm.y, vv.y, sc.y); upd(pp.z, gg.z, mm.z, vv.z, sc.z); upd(pp.w, gg.w, mm.w, vv.w, sc.w);
@@ -338,13 +339,13 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamTable T, AdamIdx X)
         const int64_t tail = base + ((end - base) & ~(int64_t)3);
         for (int64_t i = tail + threadIdx.x; i < end; i += 256) {
             float pp = E.p[i], mm = E.m[i], vv = E.v[i];
-            upd(pp, E.g[i], mm, vv, E.sc ? E.sc[i] : 1.0f);
+            upd(pp, E.g2 ? E.g[i] + E.g2[i] : E.g[i], mm, vv, E.sc ? E.sc[i] : 1.0f);
             E.p[i] = pp; E.m[i] = mm; E.v[i] = vv;
         }
     } else {
         for (int64_t i = base + threadIdx.x; i < end; i += 256) {
             float pp = E.p[i], mm = E.m[i], vv = E.v[i];
-            upd(pp, E.g[i], mm, vv, E.sc ? E.sc[i] : 1.0f);
+            upd(pp, E.g2 ? E.g[i] + E.g2[i] : E.g[i], mm, vv, E.sc ? E.sc[i] : 1.0f);
             E.p[i] = pp; E.m[i] = mm; E.v[i] = vv;
         }
     }
@@ -373,11 +374,11 @@ static int adam_multi(int32_t count, const gsr_adam_tensor* t, const float* hype
             }
             X.idx[T.count] = i;
             AdamEntry& E = T.e[T.count++];
-            E.p = a.param; E.g = a.grad; E.m = a.exp_avg; E.v = a.exp_avg_sq; E.sc = a.lr_scale; E.n = a.n;
+            E.p = a.param; E.g = a.grad; E.g2 = a.grad2; E.m = a.exp_avg; E.v = a.exp_avg_sq; E.sc = a.lr_scale; E.n = a.n;
             E.step_size = a.step_size; E.w1 = (float)(1.0 - a.beta1); E.b2 = (float)a.beta2; E.w2 = (float)(1.0 - a.beta2);
             E.inv_bc2_sqrt = 1.0f / a.bias_correction2_sqrt; E.eps = a.eps;
             E.first_block = blocks;
-            E.vec = ((((uintptr_t)a.param | (uintptr_t)a.grad | (uintptr_t)a.exp_avg | (uintptr_t)a.exp_avg_sq | (uintptr_t)a.lr_scale) & 15) == 0) ? 1u : 0u;
+            E.vec = ((((uintptr_t)a.param | (uintptr_t)a.grad | (uintptr_t)a.grad2 | (uintptr_t)a.exp_avg | (uintptr_t)a.exp_avg_sq | (uintptr_t)a.lr_scale) & 15) == 0) ? 1u : 0u;
             blocks += (uint32_t)((a.n + GSR_ADAM_CHUNK - 1) / GSR_ADAM_CHUNK);
         }
         if (blocks) hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T, X);

@@ -90,6 +90,59 @@ __device__ inline void tds_global_radix(uint32_t* __restrict__ ids_a, uint32_t* 
     }
 }
 
+// Rank by counting, n <= 256 NQ entries, 256 threads: thread t holds entries t, t + 256, ... and counts, over ALL entries (broadcast LDS reads, 8 keys
+// per iteration, no dependency between iterations), how many sort in front of each, on the 32-bit depth keys alone.  Entries with EQUAL keys then
+// collide on their rank, which a per-rank counter detects, and only then (rare: bit-identical view depths in one tile) the count is redone with the
+// id as tie-break.  The ranks are a permutation: each id goes straight to its place.  lds: 3 * 256 NQ + 1 words.  Ends with a barrier.
+// (O(n^2) compares: 2 VALU per (entry, key) -- cheaper than a barrier-laden bitonic network up to ~512 entries, which is where the method pipelines'
+// lists end: mean 200-225, 4-16 % of the tiles between 257 and ~360, tools/tile_list_lengths.py.)
+template <int NQ>
+__device__ __forceinline__ void tds_rank_sort_wg(uint32_t* lds, uint32_t* list, uint32_t n, const uint32_t* __restrict__ depth_key)
+{
+    constexpr uint32_t CAP = 256u * NQ;
+    uint32_t* kk = lds;                                     // [CAP] keys, 0xFFFFFFFF behind the list (real keys are positive float bits)
+    uint32_t* ii = kk + CAP;                                // [CAP] ids
+    uint32_t* fl = ii + CAP;                                // [CAP] how many entries took each rank; fl[CAP]: "some ranks collided"
+    const uint32_t t = threadIdx.x;
+    uint32_t key[NQ], id[NQ], rank[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint32_t e = t + 256u * q;
+        key[q] = 0xFFFFFFFFu; id[q] = 0u; rank[q] = 0u;
+        if (e < n) { id[q] = list[e]; key[q] = depth_key[id[q]]; }
+        kk[e] = key[q]; ii[e] = id[q]; fl[e] = 0u;
+    }
+    if (t == 0) fl[CAP] = 0u;
+    __syncthreads();
+    if ((t & ~63u) < n) {                                   // wave-uniform: a wave without entries only keeps the barriers
+        for (uint32_t e = 0; e < n; e += 8u) {
+            const uint4 a = *reinterpret_cast<const uint4*>(kk + e), b = *reinterpret_cast<const uint4*>(kk + e + 4);
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                rank[q] += (a.x < key[q] ? 1u : 0u) + (a.y < key[q] ? 1u : 0u) + (a.z < key[q] ? 1u : 0u) + (a.w < key[q] ? 1u : 0u)
+                         + (b.x < key[q] ? 1u : 0u) + (b.y < key[q] ? 1u : 0u) + (b.z < key[q] ? 1u : 0u) + (b.w < key[q] ? 1u : 0u);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        if (t + 256u * q < n && atomicAdd(&fl[rank[q]], 1u) != 0u) fl[CAP] = 1u;
+    __syncthreads();
+    if (fl[CAP] != 0u) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) rank[q] = 0u;
+        if (t < n)
+            for (uint32_t e = 0; e < n; e++) {
+                const uint32_t k2 = kk[e], i2 = ii[e];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) rank[q] += ((k2 < key[q]) | ((k2 == key[q]) & (i2 < id[q]))) ? 1u : 0u;
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        if (t + 256u * q < n) list[rank[q]] = id[q];
+    __syncthreads();
+}
+
 // What the long-list fallback needs besides the list itself
 struct TdsScratch {
     uint32_t* tile_keys;        // [R] tile id of every instance (constant inside a tile's range): lent to the radix fallback and rewritten
@@ -100,54 +153,25 @@ struct TdsScratch {
 // The tile's list `list[0, n)` (any order) -> ascending (depth_key[id], id).  Called by ALL 256 threads of the workgroup (n is block-uniform);
 // `lds` is LDS_BYTES of workgroup LDS the caller lends (>= 6 KiB; everything in it is overwritten); ends with a barrier, after which the list
 // in global memory is visible to every thread of the workgroup.
-//   n <= 256: rank by counting -- thread t holds entry t and counts, over all entries (broadcast LDS reads, 8 keys per iteration, no dependency
-//             between iterations), how many sort in front of it, on the 32-bit depth keys alone; entries with EQUAL keys then collide on
-//             their rank, which a per-rank counter detects, and only then (rare: bit-identical view depths in one tile) the count is redone with
-//             the id as tie-break.  The ranks are a permutation: each id goes straight to its place.
+//   n <= 512: rank by counting (tds_rank_sort_wg).
 //   n <= largest power of two of 64-bit words that fits `lds`: bitonic network on (depth << 32 | id).
 //   longer: four-pass radix sort in global memory.
 template <int LDS_BYTES>
 __device__ __forceinline__ void tds_sort_tile_wg(void* lds, uint32_t* list, uint32_t n, uint32_t first, uint32_t tile,
                                                  const uint32_t* __restrict__ depth_key, TdsScratch sc)
 {
-    static_assert(LDS_BYTES >= 6144, "tds_sort_tile_wg: at least 6 KiB of LDS");
+    static_assert(LDS_BYTES >= 6148, "tds_sort_tile_wg: at least 3 * 512 + 1 words of LDS");
     constexpr uint32_t CAPW = (LDS_BYTES / 8 >= 4096) ? 4096u : (LDS_BYTES / 8 >= 2048) ? 2048u : (LDS_BYTES / 8 >= 1024) ? 1024u : 512u;
     const uint32_t t = threadIdx.x;
     if (n <= 1u) { __syncthreads(); return; }
-    if (n <= 256u) {
-        uint32_t* kk = reinterpret_cast<uint32_t*>(lds);    // [256] keys, 0xFFFFFFFF behind the list (real keys are positive float bits)
-        uint32_t* ii = kk + 256;                            // [256] ids
-        uint32_t* fl = ii + 256;                            // [256] how many entries took each rank
-        uint32_t key = 0xFFFFFFFFu, id = 0u;
-        if (t < n) { id = list[t]; key = depth_key[id]; }
-        kk[t] = key; ii[t] = id; fl[t] = 0u;
-        if (t == 0) fl[256] = 0u;                           // "some ranks collided" (a word of the lent LDS: __syncthreads_or would allocate its own)
-        __syncthreads();
-        uint32_t rank = 0u;
-        if ((t & ~63u) < n) {                               // wave-uniform: a wave without entries only keeps the barriers
-            for (uint32_t e = 0; e < n; e += 8u) {
-                const uint4 a = *reinterpret_cast<const uint4*>(kk + e), b = *reinterpret_cast<const uint4*>(kk + e + 4);
-                rank += (a.x < key ? 1u : 0u) + (a.y < key ? 1u : 0u) + (a.z < key ? 1u : 0u) + (a.w < key ? 1u : 0u)
-                      + (b.x < key ? 1u : 0u) + (b.y < key ? 1u : 0u) + (b.z < key ? 1u : 0u) + (b.w < key ? 1u : 0u);
-            }
-        }
-        if (t < n && atomicAdd(&fl[rank], 1u) != 0u) fl[256] = 1u;
-        __syncthreads();
-        if (fl[256] != 0u) {
-            rank = 0u;
-            if (t < n)
-                for (uint32_t e = 0; e < n; e++) {
-                    const uint32_t k2 = kk[e], i2 = ii[e];
-                    rank += ((k2 < key) | ((k2 == key) & (i2 < id))) ? 1u : 0u;
-                }
-        }
-        if (t < n) list[rank] = id;
-        __syncthreads();
+    if (n <= 512u) {
+        if (n <= 256u) tds_rank_sort_wg<1>(reinterpret_cast<uint32_t*>(lds), list, n, depth_key);
+        else tds_rank_sort_wg<2>(reinterpret_cast<uint32_t*>(lds), list, n, depth_key);
         return;
     }
     if (n <= CAPW) {
         unsigned long long* s = reinterpret_cast<unsigned long long*>(lds);
-        uint32_t m = 512u;
+        uint32_t m = 1024u;
         while (m < n) m <<= 1;
         for (uint32_t e = t; e < m; e += 256u) {
             unsigned long long w = ~0ull;                    // padding sorts behind every real entry

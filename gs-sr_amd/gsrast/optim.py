@@ -14,7 +14,12 @@ models that keep all their parameters in one flat tensor (bench.py).
 HIP graphs (round 3): a `step()` issued while the current stream is being captured (torch.cuda.graph) records ONE launch whose per-step scalars
 (step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t)) are read from a small device buffer instead of being baked into the kernel arguments
 (gsr_adam_step_multi_dev).  `prepare_replay()` -- call it before every `graph.replay()`; gsrast.graphs.GraphedStep does -- bumps the step counters,
-re-reads every group's `lr` (schedulers keep working) and refreshes that buffer with one small asynchronous copy."""
+re-reads every group's `lr` (schedulers keep working) and refreshes that buffer with one small asynchronous copy.
+
+Two render passes over the same parameters (PGSR's reference + neighbour camera, gssr/scene/pgsr_scene.py:226-338): autograd sums the two passes'
+gradients with one `add` kernel per parameter tensor (27 launches, 130 us per octree-pgsr iteration).  `shadow_parameters(x)` returns a second set of
+leaves over the SAME storage for the second pass; `Adam.add_shadows(params, shadows)` makes step() read both gradients in the update kernel
+(grad + grad2, the same single fp32 add) and zero_grad() clear both."""
 import ctypes as C
 import math
 
@@ -27,7 +32,35 @@ from . import check, lib, stream_ptr
 class _AdamTensor(C.Structure):          # include/gsrast.h gsr_adam_tensor
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr_scale", C.c_void_p),
                 ("n", C.c_int64), ("beta1", C.c_double), ("beta2", C.c_double), ("step_size", C.c_float), ("bias_correction2_sqrt", C.c_float),
-                ("eps", C.c_float), ("pad_", C.c_float)]
+                ("eps", C.c_float), ("pad_", C.c_float), ("grad2", C.c_void_p)]
+
+
+def shadow_parameters(x):
+    """A second set of autograd leaves over the SAME storage as `x` (a tensor, a list / tuple / dict of them, or an nn.Module, whose structure is
+    copied): what the second of two render passes of one iteration reads, so that its gradients arrive in their own .grad instead of being added
+    to the first pass's by one kernel per tensor.  In-place updates of the originals (the optimizer's) are seen by the shadows."""
+    if isinstance(x, torch.nn.Module):
+        import copy
+        memo = {id(q): torch.nn.Parameter(q.detach(), requires_grad=q.requires_grad) for q in x.parameters()}
+        memo.update({id(b): b for b in x.buffers()})               # buffers are shared as they are
+        return copy.deepcopy(x, memo)
+    if isinstance(x, torch.Tensor):
+        return x.detach().requires_grad_(x.requires_grad)
+    if isinstance(x, dict):
+        return {k: shadow_parameters(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(shadow_parameters(v) for v in x)
+    raise TypeError(f"shadow_parameters: {type(x)}")
+
+
+def _leaves(x):
+    if isinstance(x, torch.nn.Module):
+        return list(x.parameters())
+    if isinstance(x, torch.Tensor):
+        return [x]
+    if isinstance(x, dict):
+        return [t for v in x.values() for t in _leaves(v)]
+    return [t for v in x for t in _leaves(v)]
 
 
 def _covered(p, group):
@@ -41,12 +74,34 @@ class Adam(torch.optim.Adam):
         kw.setdefault("foreach", False); kw.setdefault("fused", False)        # the fallback path: torch's plain per-tensor implementation
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
 
+    def add_shadows(self, params, shadows):
+        """`shadows` = shadow_parameters(`params`) (same structure): step() adds a shadow's gradient to its parameter's inside the update
+        kernel, zero_grad() clears it.  One shadow per parameter."""
+        sh = self.__dict__.setdefault("_gsr_shadows", {})
+        ps, ss = _leaves(params), _leaves(shadows)
+        if len(ps) != len(ss):
+            raise ValueError("add_shadows: params and shadows differ in structure")
+        for p, q in zip(ps, ss):
+            if q.data_ptr() != p.data_ptr() or q.shape != p.shape:
+                raise ValueError("add_shadows: a shadow must share its parameter's storage (shadow_parameters)")
+            sh[id(p)] = q
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+        for q in self.__dict__.get("_gsr_shadows", {}).values():
+            if q.grad is not None:
+                if set_to_none:
+                    q.grad = None
+                else:
+                    q.grad.zero_()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        shadows = self.__dict__.get("_gsr_shadows", {})
         L = lib()
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         captured = []                              # capture: (param, group) in table order, for prepare_replay
@@ -64,9 +119,20 @@ class Adam(torch.optim.Adam):
             sc = group.get("lr_scale")             # optional: one learning-rate multiplier per element (float32, shaped like the parameter)
             other = []
             for p in group["params"]:
+                g2 = None
+                if shadows:
+                    q = shadows.get(id(p))
+                    if q is not None and q.grad is not None:
+                        if p.grad is None:
+                            p.grad = q.grad; q.grad = None         # only the second pass reached this parameter
+                        else:
+                            g2 = q.grad
                 if p.grad is None:
                     continue
-                if not _covered(p, group):
+                cov = _covered(p, group)
+                if g2 is not None and not (cov and g2.dtype == torch.float32 and not g2.is_sparse and g2.shape == p.grad.shape):
+                    p.grad = p.grad + g2; g2 = None                # the torch path below knows one gradient
+                if not cov:
                     other.append(p)
                     continue
                 st = self.state[p]
@@ -94,11 +160,13 @@ class Adam(torch.optim.Adam):
                 g = p.grad
                 if not g.is_contiguous():
                     g = g.contiguous(); keep.append(g)
+                if g2 is not None and not g2.is_contiguous():
+                    g2 = g2.contiguous(); keep.append(g2)
                 if sc is not None and (sc.numel() != p.numel() or sc.dtype != torch.float32 or not sc.is_contiguous() or sc.device != p.device):
                     raise RuntimeError("gsrast.optim.Adam: lr_scale must be a contiguous float32 tensor with one entry per parameter element")
                 batch.setdefault(p.device, []).append(
                     (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), 0 if sc is None else sc.data_ptr(), p.numel(), beta1, beta2,
-                     lr / (1.0 - beta1 ** t), math.sqrt(1.0 - beta2 ** t), group["eps"], 0.0))
+                     lr / (1.0 - beta1 ** t), math.sqrt(1.0 - beta2 ** t), group["eps"], 0.0, 0 if g2 is None else g2.data_ptr()))
             if other:
                 rest.append((group, other))
         if capturing:

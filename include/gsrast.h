@@ -243,6 +243,9 @@ typedef struct gsr_adam_tensor {
     float step_size;                  /* lr / (1 - beta1^t) */
     float bias_correction2_sqrt;      /* sqrt(1 - beta2^t) */
     float eps, pad_;
+    const float* grad2;               /* optional second gradient of the same tensor, or NULL: the update uses grad + grad2 (one fp32 add per element,
+                                       * what autograd's accumulation would have produced).  For parameters that feed two render passes through two
+                                       * sets of leaves over the same storage (gsrast.optim.shadow_parameters): no add kernel per tensor, no summed copy. */
 } gsr_adam_tensor;
 int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor* t, void* stream);
 /* The same with the two per-step scalars of every tensor read from DEVICE memory at run time -- hyper_dev[2 * i] = step_size,

@@ -132,3 +132,48 @@ def test_step_recorded_in_a_hip_graph_matches_torch():
             assert float(oa.state[a]["step"]) == t
             lr = oa.param_groups[i]["lr"]
             assert torch.allclose(a, b, rtol=0, atol=1e-4 * lr + 5e-7), (t, i, (a - b).abs().max().item())
+
+
+def test_shadow_parameters_two_passes_one_update():
+    """Two passes over the same parameters in one backward (PGSR's reference + neighbour camera): with shadow leaves for the second pass and
+    Adam.add_shadows the update kernel reads both gradients; parameters and optimizer state stay bit-identical to the plain form in which
+    autograd adds the two passes' gradients itself, over several steps, for tensors, a module, an odd-sized tensor and a parameter only the second
+    pass touches."""
+    from gsrast.optim import Adam, shadow_parameters
+    torch.manual_seed(5)
+
+    def model():
+        g = torch.Generator().manual_seed(11)
+        w = torch.randn(4099, 3, generator=g).to(DEV).requires_grad_(True)
+        b = torch.randn(7, generator=g).to(DEV).requires_grad_(True)
+        only2 = torch.randn(33, generator=g).to(DEV).requires_grad_(True)
+        lin = torch.nn.Linear(3, 5).to(DEV)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(5, 3, generator=g)); lin.bias.copy_(torch.randn(5, generator=g))
+        return {"w": w, "b": b, "only2": only2, "lin": lin}
+
+    def loss_of(L1, L2, x1, x2):
+        a = (L1["lin"](x1 * L1["w"]).tanh().sum(1) * 0.01).sum() + (L1["b"] ** 2).sum()
+        c = (L2["lin"](x2 * L2["w"]).sin().sum(1) * 0.02).sum() + (L2["b"] * 0.5).sum() + (L2["only2"] ** 3).sum()
+        return a + c
+
+    A, B = model(), model()
+    pa = [A["w"], A["b"], A["only2"]] + list(A["lin"].parameters())
+    pb = [B["w"], B["b"], B["only2"]] + list(B["lin"].parameters())
+    oa, ob = Adam(pa, lr=1e-2, eps=1e-15), Adam(pb, lr=1e-2, eps=1e-15)
+    S = shadow_parameters(B)
+    assert S["w"].data_ptr() == B["w"].data_ptr() and S["lin"].weight.data_ptr() == B["lin"].weight.data_ptr() and S["w"] is not B["w"]
+    ob.add_shadows(B, S)
+    g = torch.Generator().manual_seed(2)
+    for t in range(5):
+        x1 = torch.randn(4099, 3, generator=g).to(DEV); x2 = torch.randn(4099, 3, generator=g).to(DEV)
+        loss_of(A, A, x1, x2).backward()
+        loss_of(B, S, x1, x2).backward()
+        assert B["only2"].grad is None and S["only2"].grad is not None
+        oa.step(); ob.step()
+        oa.zero_grad(set_to_none=True); ob.zero_grad(set_to_none=True)
+        assert S["w"].grad is None and S["lin"].weight.grad is None
+        for p, q in zip(pa, pb):
+            assert torch.equal(p, q), t
+            assert torch.equal(oa.state[p]["exp_avg"], ob.state[q]["exp_avg"]) and torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"])
+        assert torch.equal(S["w"], B["w"])                       # the shadow sees the in-place update

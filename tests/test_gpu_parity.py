@@ -568,7 +568,7 @@ def test_global_depth_sort_kept_switchable():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("variant,P", [("ewa", 700), ("surfel", 5000), ("plane", 9000), ("ewa", 40000), ("surfel", 24000)])
+@pytest.mark.parametrize("variant,P", [("ewa", 700), ("surfel", 1500), ("plane", 2200), ("surfel", 5000), ("plane", 9000), ("ewa", 40000), ("surfel", 24000)])
 def test_long_tile_lists_sort_paths(variant, P, monkeypatch):
     """(GSR_DEPTH_ORDER=tile unless the environment already chose: "auto" would send these gaussian counts to the global sort.)  A 48x32 image (6 tiles) with thousands of gaussians per tile: the per-tile depth sort's paths -- rank by counting (<= 256 entries), the LDS
     bitonic network (fused: <= 1024 entries EWA / 2048 PLANE, SURFEL, the forward's staging LDS; kernel: one wave <= 1024, the workgroup <= 4096) and

@@ -1,6 +1,7 @@
 """The Adam oracle (tests/oracle_optim.py) against torch.optim.Adam itself -- the optimizer the reference constructs
 (gssr/gaussian/vanilla_gaussian.py:133: Adam(l, lr=0.0, eps=1e-15), per-group learning rates) -- over several steps."""
 import numpy as np
+import pytest
 import torch
 
 import oracle_optim
@@ -60,3 +61,30 @@ def test_uncovered_parameters_take_torchs_update_and_hooks_fire_once():
             assert torch.equal(p, q) and torch.equal(oa.state[p]["exp_avg_sq"], ob.state[q]["exp_avg_sq"]) and float(oa.state[p]["step"]) == t + 1
     assert len(fired) == 3
     assert len(oa.param_groups) == 2 and oa.param_groups[0]["params"][0] is a[0]
+
+
+def test_shadow_parameters_on_the_torch_path():
+    """CPU parameters are not covered by the HIP kernel: the shadows' gradients are added before torch's own update (same result as one set of
+    leaves), the shadows share storage and are cleared by zero_grad."""
+    from gsrast.optim import Adam, shadow_parameters
+    g = torch.Generator().manual_seed(3)
+    w0 = torch.randn(50, 3, generator=g)
+    lin0 = torch.nn.Linear(3, 2)
+    A = {"w": w0.clone().requires_grad_(True), "lin": torch.nn.Linear(3, 2)}
+    B = {"w": w0.clone().requires_grad_(True), "lin": torch.nn.Linear(3, 2)}
+    for M in (A, B):
+        M["lin"].load_state_dict(lin0.state_dict())
+    oa = Adam([A["w"]] + list(A["lin"].parameters()), lr=1e-2)
+    ob = Adam([B["w"]] + list(B["lin"].parameters()), lr=1e-2)
+    S = shadow_parameters(B)
+    assert S["w"].data_ptr() == B["w"].data_ptr() and S["lin"].weight.data_ptr() == B["lin"].weight.data_ptr()
+    ob.add_shadows(B, S)
+    with pytest.raises(ValueError):
+        ob.add_shadows(B, {"w": w0.clone().requires_grad_(True), "lin": torch.nn.Linear(3, 2)})       # not the same storage
+    for t in range(3):
+        x1, x2 = torch.randn(50, 3, generator=g), torch.randn(50, 3, generator=g)
+        (A["lin"](x1 * A["w"]).sum() + (A["lin"](x2 * A["w"]) ** 2).sum()).backward()
+        (B["lin"](x1 * B["w"]).sum() + (S["lin"](x2 * S["w"]) ** 2).sum()).backward()
+        oa.step(); ob.step(); oa.zero_grad(); ob.zero_grad()
+        assert S["w"].grad is None
+        assert torch.allclose(A["w"], B["w"], rtol=0, atol=1e-7) and torch.allclose(A["lin"].weight, B["lin"].weight, rtol=0, atol=1e-7)

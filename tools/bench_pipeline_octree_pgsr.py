@@ -24,7 +24,7 @@ from bench_pipeline_pgsr import cam_of   # noqa: E402
 from gsrast import decode, octree      # noqa: E402
 from gsrast.losses import l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss  # noqa: E402
 from gsrast.plane_prep import plane_input_all_map  # noqa: E402
-from gsrast.optim import Adam          # noqa: E402
+from gsrast.optim import Adam, shadow_parameters          # noqa: E402
 
 
 def build(a, dev, seed=0):
@@ -58,6 +58,13 @@ def build(a, dev, seed=0):
     emb = torch.nn.Embedding(4, A).to(dev)
     params = [anchor, scaling_log, feat, offset, emb.weight] + [p for m in (mlp_o, mlp_c, mlp_k) for p in m.parameters()]
     opt = (Adam(params, lr=1e-4, eps=1e-15) if os.environ.get("GSR_PIPE_TORCH_ADAM", "0") != "1" else torch.optim.Adam(params, lr=1e-4, eps=1e-15, fused=True))
+    # The neighbour camera's pass reads a second set of leaves over the same storage, and the optimizer adds the two passes' gradients inside its
+    # update kernel: without it autograd sums them with one `add` launch per parameter tensor (27 per iteration, 130 us).  GSR_PIPE_SHADOWS=0: one set.
+    first = {"anchor": anchor, "scaling_log": scaling_log, "feat": feat, "offset": offset, "emb": emb, "mlp_o": mlp_o, "mlp_c": mlp_c, "mlp_k": mlp_k}
+    second = first
+    if os.environ.get("GSR_PIPE_SHADOWS", "1") != "0" and isinstance(opt, Adam):
+        second = shadow_parameters(first)
+        opt.add_shadows(first, second)
     gt = torch.rand((3, H, W), generator=g).to(dev)
     gray1 = gt.mean(0, keepdim=True).contiguous(); gray2 = torch.rand((1, H, W), generator=g).to(dev)
     c1, c2 = cam_of(t, W, H), cam_of(t2, W, H)
@@ -69,8 +76,10 @@ def build(a, dev, seed=0):
            "offset_gradient_accum": torch.zeros(a.Na * k, 1, device=dev), "offset_denom": torch.zeros(a.Na * k, 1, device=dev)}
     st = {}
 
-    def render(view, cam_id, scaling):
+    def render(view, cam_id, L):
         tt, rs, fs = view
+        anchor, feat, offset, emb, mlp_o, mlp_c, mlp_k = L["anchor"], L["feat"], L["offset"], L["emb"], L["mlp_o"], L["mlp_c"], L["mlp_k"]
+        scaling = torch.exp(L["scaling_log"])
         vis = octree.octree_visible(fs, anchor, level, scaling, rot_anchor, voxel_size, FORK, standard_dist, LEVELS, dist2level="round",
                                     extra_level=extra_level)   # set_anchor_mask + prefilter_voxel, no host sync
         vis_idx = decode.compact_visible(vis["visible_mask"], padded=True)
@@ -85,9 +94,8 @@ def build(a, dev, seed=0):
         return img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vis["visible_mask"], count
 
     def step():
-        scaling = torch.exp(scaling_log)
-        img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask, count = render(views[0], 1, scaling)
-        pd2 = render(views[1], 2, scaling)[3]
+        img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask, count = render(views[0], 1, first)
+        pd2 = render(views[1], 2, second)[3]
         sx, sy, sz = scl.unbind(dim=1)                    # x*y*z on unbound columns (backward = ONE stack), not prod(dim=1): prod's backward
         vol = sx * sy * sz                                # synchronises (nonzero) when an entry is 0, and not scl[:, i]: one zero-filled (P,3) per slice
         reg = 0.01 * (vol.sum() / count.to(torch.float32)[0] if static else vol.mean())
