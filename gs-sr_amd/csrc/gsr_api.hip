@@ -419,6 +419,12 @@ extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int3
 }
 
 // ------------------------------------------------------------------------------------------------ debug reads
+__global__ void k_debug_ranges_view(uint2* r, int T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T && r[i].x > r[i].y) r[i] = make_uint2(0u, 0u);
+}
+
 extern "C" int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, size_t binning_bytes,
                               const void* img, uint32_t num_rendered, void* dst, void* stream)
 {
@@ -437,5 +443,8 @@ extern "C" int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geo
     default: gsr_set_error("unknown debug field %d", field); return 1;
     }
     if (bytes) GSR_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s), "debug copy");
+    // a tile without instances is held as (0xFFFFFFFF, 0) (gsr_binning.hip: range candidates are merged with atomicMin / atomicMax); the reference's
+    // view of it is (0, 0) (cudaMemset, rasterizer_impl.cu:310)
+    if (field == GSR_DBG_RANGES && bytes) hipLaunchKernelGGL(k_debug_ranges_view, dim3((gx * gy + 255) / 256), dim3(256), 0, s, (uint2*)dst, gx * gy);
     return 0;
 }

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                     uint32_t n, const uint32_t* __restrict__ n_dev, int shift, int bits,
                                                                     const uint32_t* __restrict__ H, const uint32_t* __restrict__ GH, uint32_t ngroups,
-                                                                    uint32_t* __restrict__ GH_next, uint32_t digit_major_nblk)
+                                                                    uint32_t* __restrict__ GH_next, uint32_t digit_major_nblk, uint2* __restrict__ ranges_out)
 {
     constexpr int DPT = NB / GSR_SORT_THREADS;
     if (n_dev) n = min(n, *n_dev);
@@ -260,13 +260,24 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
         const uint32_t pos = gbase[d] + (q - lbase[d]);
         keys_out[pos] = k;
         vals_out[pos] = sval[q];
+        if (ranges_out) {
+            // identifyTileRanges (3DGS rasterizer_impl.cu:116-138) folded into the LAST pass of the tile sort, whose keys are the tile ids: a key
+            // change inside this block's run of digit d is a tile boundary of the output (the run lands contiguously); at the two ends of the run
+            // the neighbour belongs to another block, so the candidates are merged with atomicMin / atomicMax (the tile's true first / last
+            // position is among them).  ranges was initialised to (0xFFFFFFFF, 0) by k_duplicate: an untouched tile reads as x > y = empty.
+            const uint32_t run_end = (d == mask) ? nb : lbase[d + 1];
+            if (q == lbase[d]) atomicMin(&ranges_out[k].x, pos);
+            else if (skey[q - 1] != k) ranges_out[k].x = pos;
+            if (q + 1 == run_end) atomicMax(&ranges_out[k].y, pos + 1u);
+            else if (skey[q + 1] != k) ranges_out[k].y = pos + 1u;
+        }
     }
 }
 
 // hist must hold gsr_sort_hist_words(nblk for the 1024-key geometry, NB) words, NB = 256 (digits <= 8 bits) or 2048
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
-                         bool* result_in_b, hipStream_t s, bool big_blocks, bool group0_zeroed)
+                         bool* result_in_b, hipStream_t s, bool big_blocks, bool group0_zeroed, uint2* ranges_out)
 {
     // keys per block: 1024 (many blocks: small inputs are latency-bound) or 4096 (longer digit runs -> full-line writes on big inputs).
     // The histogram area is always sized for the 1024-key geometry, the larger upper bound.
@@ -294,18 +305,19 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         const dim3 g(nblk), b(GSR_SORT_THREADS);
         uint32_t* gh = dm ? GH[0] : GH[pass & 1];
         uint32_t* gh_next = (!dm && passes_left > 1) ? GH[(pass + 1) & 1] : nullptr;
+        uint2* ro = (passes_left == 1) ? ranges_out : nullptr;      // tile ranges from the last pass (keys == tile ids), see k_radix_scatter
         if (wide) {
             if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
             else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
             if (dm) hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, H, nblk, gh);
-            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
-            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm, ro);
+            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm, ro);
         } else {
             if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
             else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
             if (dm) hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, H, nblk, gh);
-            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
-            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
+            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm, ro);
+            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm, ro);
         }
         uint32_t* t;
         t = kin; kin = kout; kout = t;
@@ -400,7 +412,8 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x);          // position in depth order
-    if (i < T) ranges[i] = make_uint2(0u, 0u);                           // the cudaMemset of rasterizer_impl.cu:310, folded in (k_tile_ranges runs later)
+    if (i < T) ranges[i] = make_uint2(0xFFFFFFFFu, 0u);                  // the cudaMemset of rasterizer_impl.cu:310, folded in; x > y = no instance (the
+                                                                         // last scatter pass merges range candidates with atomicMin / atomicMax)
     for (uint32_t z = i; z < zero_n; z += gridDim.x * blockDim.x) zero_ptr[z] = 0u;      // first group-histogram buffer of the tile sort that follows
     const bool v = i < P;
     const uint32_t g = v ? (sorted_idx ? sorted_idx[i] : i) : 0u;
@@ -692,8 +705,13 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
                        global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
                        g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256));
     bool in_b = false;
-    if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true)) return 1;
-    hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
+    // tile ranges: k_tile_ranges over the sorted keys (default), or written by the last scatter pass (GSR_TILE_RANGES=scatter).  MEASURED (round 3,
+    // P = 300k, 1080p): the fold loses -- binning 0.0847 ms against 0.0748 with the separate 5 us kernel: two more LDS reads, a compare and
+    // ~22k global atomics at the ends of the digit runs lengthen the tail of every scatter block by more than the launch they save.
+    static int ranges_fused = -1;
+    if (ranges_fused < 0) { const char* e = getenv("GSR_TILE_RANGES"); ranges_fused = (e && e[0] == 's') ? 1 : 0; }
+    if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true, ranges_fused ? im.ranges : nullptr)) return 1;
+    if (!ranges_fused) hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
     if (!global_order && !gsr_tile_sort_is_fused())
         hipLaunchKernelGGL(k_tile_depth_sort, dim3(gsr_div_up((uint32_t)T, 4u)), dim3(256), 0, s, im.ranges, (uint32_t)T, R, g.depth_key, b.point_list, b.tile_keys,
                            b.keys_b, b.vals_b);

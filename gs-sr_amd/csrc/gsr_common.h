@@ -115,5 +115,5 @@ static inline uint32_t gsr_sort_group_words(uint32_t n, bool big_blocks, uint32_
 static inline size_t gsr_sort_hist_words(uint32_t nblk_1024, uint32_t NB) { return (size_t)NB * nblk_1024 + 2 * (size_t)NB * (nblk_1024 / GSR_SORT_GROUP + 1); }
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
-                         bool* result_in_b, hipStream_t s, bool big_blocks = false, bool group0_zeroed = false);
+                         bool* result_in_b, hipStream_t s, bool big_blocks = false, bool group0_zeroed = false, uint2* ranges_out = nullptr);
 uint32_t gsr_depth_sort_digit_bins();      // 256, or 2048 with GSR_DEPTH_BITS=11 (gsr_binning.hip)

@@ -592,6 +592,18 @@ def test_long_tile_lists_sort_paths(variant, P, monkeypatch):
     return int(lens.max())
 
 
+def test_tile_ranges_from_the_last_scatter_pass():
+    """GSR_TILE_RANGES=scatter (the tile ranges written by the last scatter pass of the tile sort instead of k_tile_ranges; measured slower, kept
+    for A/B): the integer checks (ranges == histogram of the tile keys, bit-exact lists, empty tiles) re-run in a child process with the switch set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSR_TILE_RANGES="scatter")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity or test_full_size_properties or test_edge_cases or test_speculative_forward",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_eleven_bit_depth_sort_kept_switchable():
     """GSR_DEPTH_BITS=11 (three 2048-bin passes instead of four 256-bin ones, kept for A/B) has to give the same bit-exact lists: the integer
     checks of the parity cases are re-run in a child process with the switch set."""
