@@ -51,9 +51,9 @@ def algorithmic_bytes(variant, R, N, T):
 
 
 def depth_order_is_global(P, T):
-    """The library's choice (gsr_binning.hip gsr_depth_order_is_global): per-tile depth sort while P <= 96 T unless GSR_DEPTH_ORDER says otherwise."""
+    """The library's choice (gsr_binning.hip gsr_depth_order_is_global): per-tile depth sort while P <= 192 T unless GSR_DEPTH_ORDER says otherwise."""
     e = os.environ.get("GSR_DEPTH_ORDER", "")
-    return True if e[:1] == "g" else (False if e[:1] == "t" else P > 96 * T)
+    return True if e[:1] == "g" else (False if e[:1] == "t" else P > 192 * T)
 
 
 def stage_bytes(variant, color_mode, P, R, N, T):

@@ -351,22 +351,24 @@ uint32_t gsr_depth_sort_digit_bins()
 }
 
 // Where the depth order of a tile's list comes from.
-//   "tile" (default, round 3): no global depth sort.  Instances are emitted in ID order, the stable tile sort bins them, and k_tile_depth_sort
-//           orders every tile's list by (depth bits, id) in LDS -- one launch over R instances instead of the eight launches of a 4-pass radix
-//           sort over P keys, each of which costs its ~5-10 us latency floor whatever P is (profiles/r03_timeline_surfel.json).
+//   "tile" (default, round 3): no global depth sort.  Instances are emitted in ID order, the stable tile sort bins them, and every tile's list is put
+//           in (depth bits, id) order in LDS -- in k_blend_fwd's prologue (gsr_tile_sort.h, GSR_TILE_SORT=fused) or by k_tile_depth_sort (=kernel) --
+//           instead of the eight launches of a 4-pass radix sort over P keys, each of which costs its ~5-10 us latency floor whatever P is
+//           (profiles/r03_timeline_surfel.json).
 //   "global" (GSR_DEPTH_ORDER=global, rounds 1-2): stable LSD sort of the P gaussians by depth bits first, instances emitted in that order.
 // Both give the reference's order: by tile, then depth bits, then gaussian id (3DGS rasterizer_impl.cu:70-111, 300-308).
-// Measured (MI355X, 1080p, surfel; profiles/r03_depth_order_ab.txt), ordering chain = depth_order + binning stages, tile / global:
-//   P = 100k (57 entries per tile)  85 / 118 us;   300k (169)  116 / 144 us;   600k (337)  172 / 180 us;   1M (562)  296 / 267 us;   3M (1690)  773 / 658 us
-// -- the per-tile sort is O(n^2 / 64) per list up to 256 entries and a bitonic network above, so the global sort wins again on long lists:
-// "auto" (default) takes the per-tile path while P <= 96 tiles' worth of gaussians (about 780k at 1080p).
+// Measured with the fused per-tile sort (MI355X, 1080p, surfel, tools/ab_depth_order.sh): depth_order + binning + blend_fwd, tile / global, in ms:
+//   P = 600k (337 entries per tile) 0.548 / 0.582;  800k (450) 0.698 / 0.742;  1M (562) 0.878 / 0.889;  1.5M (845) 1.008 / 1.050;
+//   2M (1125) 1.197 / 1.165;  3M (1688) 1.317 / 1.381 -- a tie above ~1.5M (rank by counting is O(n^2) up to 512 entries, a bitonic network above).
+// "auto" (default) takes the per-tile path while P <= 192 tiles' worth of gaussians (1.57M at 1080p).  (With the separate k_tile_depth_sort launch
+// the crossover was at ~96 T: profiles/r03_depth_order_ab.txt.)
 bool gsr_depth_order_is_global(int P, int T)
 {
     static int mode = -1;                       // 0 auto, 1 global, 2 tile
     if (mode < 0) { const char* e = getenv("GSR_DEPTH_ORDER"); mode = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 't' ? 2 : 0)); }
     if (mode == 1) return true;
     if (mode == 2) return false;
-    return (long long)P > 96ll * (long long)T;
+    return (long long)P > 192ll * (long long)T;
 }
 
 int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s)

@@ -513,3 +513,46 @@ extern "C" int gsr_loss_plane_geo(int32_t H, int32_t W, const float* plane_depth
     hipLaunchKernelGGL(k_geo_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, (int)(grid.x * grid.y), loss_out, inv_n, lambda_normal, 0.0f);
     return gsr_check_launch("loss_plane_geo", s, false);
 }
+
+// ---- scaling regulariser: lambda * mean_i prod_{c < cols} scaling[i, c]  (scaffold_scene.py:184, scaffold_2dgs_scene.py:25, scaffold_pgsr_scene.py:20,
+// octree_2dgs_scene.py:25, octree_pgsr_scene.py:23: `lambda_scaling * outputs["scaling"].prod(dim=1).mean()`), value and gradient in one pass.
+// d/d scaling[i, c] = lambda / n * product of the row's OTHER columns (what prod's backward gives, without its division -- and without the
+// `nonzero` host synchronisation torch's prod backward runs when an entry is 0).  `stride` >= cols floats per row: the first `cols` of a wider
+// tensor (2DGS uses two of the decode's three) without a copy; the gradient of the remaining columns is written as 0.  With count_dev (static-shape
+// iterations) only the first *count_dev rows are live: the mean divides by that, the rows behind get no value and zero gradient.  loss_out must be zero on entry (one atomic per block).
+__global__ void __launch_bounds__(256) k_scaling_prod(int64_t P, int cols, int stride, const float* __restrict__ sc, const int32_t* __restrict__ count_dev,
+                                                      float lambda, float* __restrict__ loss_out, float* __restrict__ grad)
+{
+    __shared__ float red[4];
+    const int64_t live = count_dev ? (int64_t)max(*count_dev, 0) : P;          // rows [live, P) are parked: no value, zero gradient
+    const float wgt = lambda / (float)max(live, (int64_t)1);
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* r = sc + i * stride;
+        float* g = grad + i * stride;
+        const float x = r[0], y = cols > 1 ? r[1] : 1.f, z = cols > 2 ? r[2] : 1.f;
+        const float wi = i < live ? wgt : 0.f;
+        if (i < live) acc += (x * y) * z;
+        g[0] = wi * (y * z);
+        if (cols > 1) g[1] = wi * (x * z);
+        if (cols > 2) g[2] = wi * (x * y);
+        for (int c = cols; c < stride; c++) g[c] = 0.f;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss_out, wgt * ((red[0] + red[1]) + (red[2] + red[3])));
+}
+
+extern "C" int gsr_loss_scaling_prod(int64_t P, int32_t cols, int32_t stride, const float* scaling, const int32_t* count_dev, float lambda_scaling,
+                                     float* loss_out, float* dL_dscaling, void* stream)
+{
+    if (P < 0 || cols < 1 || cols > 3 || stride < cols) { gsr_set_error("loss_scaling_prod: P=%lld cols=%d stride=%d", (long long)P, cols, stride); return 1; }
+    if (P == 0) return 0;
+    if (!scaling || !loss_out || !dL_dscaling) { gsr_set_error("loss_scaling_prod: null pointer"); return 1; }
+    const uint32_t blocks = (uint32_t)min((int64_t)1024, (P + 255) / 256);
+    hipLaunchKernelGGL(k_scaling_prod, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, (int)cols, (int)stride, scaling, count_dev, lambda_scaling,
+                       loss_out, dL_dscaling);
+    return gsr_check_launch("loss_scaling_prod", (hipStream_t)stream, false);
+}

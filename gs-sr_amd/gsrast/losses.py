@@ -56,6 +56,37 @@ def l1_plus_linear(color, gt, aux=None, waux=None, root=False):
     return _L1PlusLinear.apply(color, gt, aux, waux, root)
 
 
+class _ScalingProd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling, lam, cols, count, unit_upstream):
+        s = dev_f32(scaling, "scaling", allow_empty=False)
+        if s.dim() != 2 or not (1 <= cols <= min(3, s.shape[1])):
+            raise RuntimeError("scaling_prod_mean: scaling must be (P, >= cols) with cols in 1..3")
+        if count is not None and (count.dtype != torch.int32 or not count.is_cuda):
+            raise RuntimeError("scaling_prod_mean: count must be a device int32 tensor")
+        grad = torch.empty_like(s)
+        loss = zero_scalar(s.device)
+        check(lib().gsr_loss_scaling_prod(s.shape[0], int(cols), s.shape[1], ptr(s), ptr(count) if count is not None else None, float(lam), ptr(loss),
+                                          ptr(grad), stream_ptr(s.device)), "loss_scaling_prod")
+        ctx.save_for_backward(grad)
+        ctx.unit = bool(unit_upstream)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad if ctx.unit else grad * g), None, None, None, None
+
+
+def scaling_prod_mean(scaling, lambda_scaling=1.0, cols=None, count=None, unit_upstream=False):
+    """`lambda_scaling * scaling[:, :cols].prod(dim=1).mean()` (the scaling_loss of the scaffold / octree scenes, scaffold_scene.py:184 and its
+    2DGS / PGSR variants) -- value and gradient in one HIP kernel instead of torch's slice / prod / mean chain and its backward (7-9 launches; prod's
+    backward also synchronises the host when a scale is exactly 0).  cols: leading columns in the product (default: all; 2DGS uses 2 of the decode's 3).
+    count: device int32 [1] divisor instead of the number of rows (static-shape iterations).  unit_upstream=True: the value is a plain summand of the
+    scalar .backward() is called on (upstream gradient exactly 1), the stored gradient is handed to autograd as it is."""
+    return _ScalingProd.apply(scaling, float(lambda_scaling), int(cols if cols is not None else scaling.shape[1]), count, unit_upstream)
+
+
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, gt, lambda_dssim, unit_upstream=False):

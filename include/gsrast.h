@@ -296,6 +296,14 @@ int gsr_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, const float* 
 int gsr_loss_plane_geo(int32_t H, int32_t W, const float* plane_depth, const float* alpha, const float* normal, const float* weight,
                        const float* ray_mat, float lambda_normal, float* loss_out, float* dL_ddepth, float* dL_dnormal,
                        float* out_depth_normal, void* scratch, size_t scratch_bytes, void* stream);
+/* Scaling regulariser of the scaffold / octree scenes (gssr/scene/scaffold_scene.py:184, scaffold_2dgs_scene.py:25, scaffold_pgsr_scene.py:20,
+ * octree_2dgs_scene.py:25, octree_pgsr_scene.py:23): loss = lambda_scaling * mean_i prod_{c < cols} scaling[i*stride + c], value and gradient in one
+ * pass.  cols 1..3, stride >= cols floats per row (the first `cols` columns of a wider tensor without a copy; the other columns get gradient 0).
+ * With count_dev (device int32; static-shape iterations) only the first *count_dev rows are live: the mean divides by that count and the rows behind
+ * it contribute nothing and get zero gradient; NULL: all P rows.
+ * loss_out (device float) must be ZERO on entry (one atomic per block adds into it); dL_dscaling [P, stride] is overwritten. */
+int gsr_loss_scaling_prod(int64_t P, int32_t cols, int32_t stride, const float* scaling, const int32_t* count_dev, float lambda_scaling,
+                          float* loss_out, float* dL_dscaling, void* stream);
 
 /* Per-iteration densification statistics of the explicit-Gaussian methods (gssr/gaussian/vanilla_gaussian.py:467-472 densify + :428-430
  * add_densification_stats; gssr/gaussian/pgsr_gaussian.py:164-172 + :157-161).  For every p with visibility_filter[p] != 0:

@@ -177,3 +177,31 @@ def test_unit_upstream_flag_same_gradients_and_unused_loss_sends_none():
     unused = surfel_geo_loss(b, rm, nr, 0.0, 0.05, 100.0)[0]          # computed, not part of the total
     l1_ssim(a, gt, 0.2).backward()
     assert b.grad is None and a.grad is not None and unused.item() == unused.item()
+
+
+@pytest.mark.parametrize("cols,width", [(3, 3), (2, 3), (2, 2), (1, 1)])
+def test_scaling_prod_mean_matches_torch(cols, width):
+    """scaling_loss of the scaffold / octree scenes (scaffold_scene.py:184: lambda * scaling.prod(dim=1).mean()) against the torch expression,
+    value and gradient, incl. rows with a zero scale (where torch's prod backward takes its special path), a device-side divisor, and an
+    upstream factor."""
+    from gsrast.losses import scaling_prod_mean
+    g = torch.Generator().manual_seed(4)
+    P = 70001
+    s0 = torch.rand(P, width, generator=g) * 0.1 + 0.001
+    s0[17] = 0.0; s0[99, 0] = 0.0
+    a = s0.to("cuda").requires_grad_(True); b = s0.to("cuda").requires_grad_(True)
+    la = scaling_prod_mean(a, 0.01, cols=cols)
+    lb = 0.01 * b[:, :cols].prod(dim=1).mean()
+    (3.0 * la).backward(); (3.0 * lb).backward()
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb)) + 1e-12
+    assert torch.allclose(a.grad, b.grad, rtol=2e-6, atol=1e-12)
+    assert cols == width or float(a.grad[:, cols:].abs().max()) == 0.0
+    # static-shape form: trailing rows parked at scale 0, divisor from the device
+    cnt = torch.tensor([P - 5000], dtype=torch.int32, device="cuda")
+    s1 = s0.clone(); s1[P - 5000:] = 0.0
+    c = s1.to("cuda").requires_grad_(True); d = s1.to("cuda").requires_grad_(True)
+    lc = scaling_prod_mean(c, 0.01, cols=cols, count=cnt, unit_upstream=True)
+    ld = 0.01 * d[:P - 5000, :cols].prod(dim=1).mean()
+    lc.backward(); ld.backward()
+    assert abs(float(lc) - float(ld)) <= 1e-6 * abs(float(ld)) + 1e-12
+    assert torch.allclose(c.grad, d.grad, rtol=2e-6, atol=1e-12)

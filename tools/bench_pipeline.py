@@ -19,7 +19,7 @@ import scenes                          # noqa: E402
 import diff_surfel_rasterization as dsr   # noqa: E402
 import scaffold_filter as sf           # noqa: E402
 from gsrast import decode              # noqa: E402
-from gsrast.losses import camera_ray_matrices, l1_plus_linear, l1_ssim, surfel_geo_loss  # noqa: E402
+from gsrast.losses import scaling_prod_mean, camera_ray_matrices, l1_plus_linear, l1_ssim, surfel_geo_loss  # noqa: E402
 import ref_geo_torch                   # noqa: E402
 import ref_loss_torch                  # noqa: E402
 from gsrast.optim import Adam          # noqa: E402
@@ -112,13 +112,14 @@ def build(a, dev, seed=0):
                                                       scales=scl[:, :2].contiguous(), rotations=rot)
         if stop == "raster":
             return [img.clone(), rad.clone(), allmap.clone()]
-        # scaling_loss (scaffold_2dgs_scene.py:26) as x*y on unbound columns: prod(dim=1)'s backward synchronises the host (nonzero) when an entry
-        # is 0, and scl[:, i] slices cost one zero-filled (P,3) gradient each; unbind's backward is one stack
-        sx, sy, _sz = scl.unbind(dim=1)
-        if static and a.decode == "hip":        # mean over the P emitted Gaussians: the parked rows have scale 0 and only the divisor differs
-            reg = 0.01 * (sx * sy).sum() / count.to(torch.float32)[0]
+        # scaling_loss (scaffold_2dgs_scene.py:25: lambda_scaling * scaling.prod(dim=1).mean(), two columns for 2DGS): gsrast.losses.scaling_prod_mean --
+        # value and gradient in one kernel; GSR_PIPE_TORCH_REG=1 keeps the torch chain (x*y on unbound columns: prod's backward synchronises the host
+        # when an entry is 0, slices cost one zero-filled (P,3) gradient each)
+        if os.environ.get("GSR_PIPE_TORCH_REG", "0") == "1" or a.decode != "hip":
+            sx, sy, _sz = scl.unbind(dim=1)
+            reg = 0.01 * ((sx * sy).sum() / count.to(torch.float32)[0] if (static and a.decode == "hip") else (sx * sy).mean())
         else:
-            reg = 0.01 * (sx * sy).mean()
+            reg = scaling_prod_mean(scl, 0.01, cols=2, count=count if static else None, unit_upstream=True)
         if a.loss == "bench":
             loss = l1_plus_linear(img, gt, allmap, wmap) + reg
         elif a.loss == "full-hip":

@@ -22,7 +22,7 @@ import diff_plane_rasterization as dpr   # noqa: E402
 import scaffold_filter as sf           # noqa: E402
 from bench_pipeline_pgsr import cam_of   # noqa: E402
 from gsrast import decode, octree      # noqa: E402
-from gsrast.losses import l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss  # noqa: E402
+from gsrast.losses import scaling_prod_mean, l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss  # noqa: E402
 from gsrast.plane_prep import plane_input_all_map  # noqa: E402
 from gsrast.optim import Adam, shadow_parameters          # noqa: E402
 
@@ -96,9 +96,12 @@ def build(a, dev, seed=0):
     def step():
         img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask, count = render(views[0], 1, first)
         pd2 = render(views[1], 2, second)[3]
-        sx, sy, sz = scl.unbind(dim=1)                    # x*y*z on unbound columns (backward = ONE stack), not prod(dim=1): prod's backward
-        vol = sx * sy * sz                                # synchronises (nonzero) when an entry is 0, and not scl[:, i]: one zero-filled (P,3) per slice
-        reg = 0.01 * (vol.sum() / count.to(torch.float32)[0] if static else vol.mean())
+        if os.environ.get("GSR_PIPE_TORCH_REG", "0") == "1":
+            sx, sy, sz = scl.unbind(dim=1)                # x*y*z on unbound columns (backward = ONE stack), not prod(dim=1): prod's backward
+            vol = sx * sy * sz                            # synchronises (nonzero) when an entry is 0, and not scl[:, i]: one zero-filled (P,3) per slice
+            reg = 0.01 * (vol.sum() / count.to(torch.float32)[0] if static else vol.mean())
+        else:                                             # scaling_loss (octree_pgsr_scene.py:23), value and gradient in one kernel
+            reg = scaling_prod_mean(scl, 0.01, count=count if static else None, unit_upstream=True)
         loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + plane_geo_loss(pd, oam, rm1, weight, 0.015, unit_upstream=True)[0] + reg
         geo, ncc = plane_multiview_loss(pd, pd2, None, None, gray1, gray2, mcfg, 0.03, 0.15, out_all_map=oam)
         (loss + geo + ncc).backward()
