@@ -141,7 +141,7 @@ template <> struct SpPix<GSR_SURFEL> {
 // one pixel step of a row: pixel I of the block against the 16 splats held by the row's lanes
 template <int V, int I, int NACC>
 __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
-                                        bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc)
+                                        bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc, bool mn_live)
 {
     const float pxf = K.rowx + (float)(I & 3), pyf = K.rowy + (float)(I >> 2);
     const uint32_t last = bc_movu<I>(K.last);
@@ -243,6 +243,8 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
             const bool mine = (j == I);
             K.Tc = mine ? nT : K.Tc; K.Sc = mine ? nS : K.Sc;
         }
+        // (skipping the three instructions below when no pixel of the wave has a median-depth gradient was tried: a wave-uniform branch here splits
+        // the step's basic block and costs the taken side 13 us, 0.485 vs 0.472 ms; two copies of the 16 steps spill 29 VGPRs, 0.540 ms)
         const uint32_t med = bc_movu<I>(K.med);
         const float dLmd = bc_mov<I>(K.dLmd);
         float dL_dz = (ok & (idx0 + 1u == med)) ? dLmd : 0.0f;      // contributor == median_contributor-1
@@ -262,13 +264,15 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         acc[0] = bc_fmac<I>(acc[0], K.dLp0, w); acc[1] = bc_fmac<I>(acc[1], K.dLp1, w); acc[2] = bc_fmac<I>(acc[2], K.dLp2, w);
         acc[3] += G * dL_dalpha;
         acc[4] = bc_fmac<I>(acc[4], K.dN0, w); acc[5] = bc_fmac<I>(acc[5], K.dN1, w); acc[6] = bc_fmac<I>(acc[6], K.dN2, w);
-        acc[4] = bc_fmac<I>(acc[4], K.dMN0, okf); acc[5] = bc_fmac<I>(acc[5], K.dMN1, okf); acc[6] = bc_fmac<I>(acc[6], K.dMN2, okf);   // median-normal quirk (backward.cu:381)
         acc[7] += tux; acc[8] += tuy; acc[9] += tuz; acc[10] += tvx; acc[11] += tvy; acc[12] += tvz;
         acc[13] += dL_dz3 * sx - (pxf * tux + pyf * tvx);
         acc[14] += dL_dz3 * sy - (pxf * tuy + pyf * tvy);
         acc[15] += dL_dz - (pxf * tuz + pyf * tvz);
         acc[16] += dL_dG2 * (-G * FILTER_INV_SQ * dx);
         acc[17] += dL_dG2 * (-G * FILTER_INV_SQ * dy);
+        // median-normal quirk (backward.cu:381): every contributor receives dL/d(median normal).  The 2DGS scenes send no gradient to those channels
+        // (twodgs_scene.py:88-105), so the three DPP fmacs are skipped -- wave-uniformly -- when none of the wave's 64 pixels has one.
+        if (mn_live) { acc[4] = bc_fmac<I>(acc[4], K.dMN0, okf); acc[5] = bc_fmac<I>(acc[5], K.dMN1, okf); acc[6] = bc_fmac<I>(acc[6], K.dMN2, okf); }
     }
 }
 
@@ -340,6 +344,8 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             K.fD = p.final_T[pix_id + HW]; K.fD2 = p.final_T[pix_id + 2 * HW];
         }
     }
+    bool mn_live = false;
+    if constexpr (V == GSR_SURFEL) mn_live = __ballot((K.dMN0 != 0.f) | (K.dMN1 != 0.f) | (K.dMN2 != 0.f)) != 0ull;
     const uint32_t mlast_row = row_max_u32(K.last);                                 // deepest contributor of this 4x4 block
     uint32_t mlast_b[4];
 #pragma unroll
@@ -452,7 +458,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             // the basic block, so the 16 unrolled steps are scheduled one at a time -- as ONE block the scheduler overlaps them and the
             // kernel needs 280+ VGPRs (one wave per SIMD); split, every step's temporaries die inside the step.
             const bool never = p.gx == 0x7fffffff;
-#define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc); sp_pin<NACC>(acc); if (never) asm volatile("s_nop 0");
+#define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc, mn_live); sp_pin<NACC>(acc); if (never) asm volatile("s_nop 0");
             SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6) SP_STEP(7)
             SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11) SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
 #undef SP_STEP

@@ -107,7 +107,12 @@ def build(a, dev, seed=0):
             xyz, color, opacity, scl, rot = o["xyz"], o["color"], o["opacity"].view(-1, 1), o["scaling"], o["rot"]
         if stop == "decode":
             return [xyz.clone(), opacity.clone(), scl.clone(), rot.clone(), color.clone()] + ([count.clone()] if static else [])
-        means2D = torch.zeros_like(xyz, requires_grad=True)
+        if static:                     # screen-space gradient carrier (only its .grad slot is used): one persistent zero leaf while shapes are static
+            if st.get("m2") is None or st["m2"].shape != xyz.shape:
+                st["m2"] = torch.zeros_like(xyz, requires_grad=True)
+            means2D = st["m2"]; means2D.grad = None
+        else:
+            means2D = torch.zeros_like(xyz, requires_grad=True)
         img, rad, allmap = dsr.GaussianRasterizer(rs)(means3D=xyz, means2D=means2D, opacities=opacity, colors_precomp=color,
                                                       scales=scl[:, :2].contiguous(), rotations=rot)
         if stop == "raster":

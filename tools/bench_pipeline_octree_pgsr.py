@@ -75,6 +75,7 @@ def build(a, dev, seed=0):
     acc = {"opacity_accum": torch.zeros(a.Na, 1, device=dev), "anchor_demon": torch.zeros(a.Na, 1, device=dev),
            "offset_gradient_accum": torch.zeros(a.Na * k, 1, device=dev), "offset_denom": torch.zeros(a.Na * k, 1, device=dev)}
     st = {}
+    carriers = {}
 
     def render(view, cam_id, L):
         tt, rs, fs = view
@@ -88,7 +89,16 @@ def build(a, dev, seed=0):
         xyz, color, opacity, scl, rot, nop, mask = out[:7]
         count = out[7] if static else None
         am = plane_input_all_map(xyz, rot, scl, tt["viewmatrix"], tt["campos"])
-        m2 = torch.zeros_like(xyz, requires_grad=True); m2a = torch.zeros_like(xyz, requires_grad=True)
+        # screen-space gradient carriers: the rasterizer only uses their .grad slot.  Static shapes: two persistent zero leaves per camera (no fill per
+        # iteration); dynamic shapes: fresh ones, as the reference makes them (pgsr_scene.py: torch.zeros_like(means3D, requires_grad=True) + 0).
+        if static:
+            key = (cam_id, xyz.shape[0])
+            if key not in carriers:
+                carriers[key] = (torch.zeros_like(xyz, requires_grad=True), torch.zeros_like(xyz, requires_grad=True))
+            m2, m2a = carriers[key]
+            m2.grad = None; m2a.grad = None
+        else:
+            m2 = torch.zeros_like(xyz, requires_grad=True); m2a = torch.zeros_like(xyz, requires_grad=True)
         img, radii, obs, oam, pd = dpr.GaussianRasterizer(rs)(means3D=xyz, means2D=m2, means2D_abs=m2a, opacities=opacity, colors_precomp=color,
                                                              scales=scl, rotations=rot, all_map=am)
         return img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vis["visible_mask"], count
