@@ -53,6 +53,7 @@ int gsr_memset_async(void* p, int byte_value, size_t nbytes, hipStream_t s)
 // Optional: HIP events recorded on the launch stream around every stage; read back with gsr_profile_read.
 // Used by bench.py for the live kernel durations behind the roofline figure.  One mutex guards the record lists, so concurrent
 // forwards from several host threads / streams only serialise on the bookkeeping (a few hundred ns), never on the GPU work.
+#include <chrono>
 #include <vector>
 #include <algorithm>
 struct ProfRec { int label; hipEvent_t a, b; };
@@ -338,13 +339,36 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
     if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
     const unsigned slot = take_slot(mb);
     struct SlotGuard { Mailbox* m; unsigned s; ~SlotGuard() { release_slot(m, s); } } guard{mb, slot};
+    // How the host learns num_rendered while stage 2 is already queued: the scan kernel stores it into the slot's mapped pinned word (system-scope
+    // store) and the host POLLS that word -- preset to a sentinel -- instead of waiting on an event recorded behind stage 1: the event record is a
+    // packet of its own and left ~6 us of stream idle time between the prefix and k_duplicate in every forward (profiles/r03_timeline_surfel.json).
+    // GSR_MAILBOX_POLL=0: the event.  The poll gives up after 2 s and synchronises the stream instead.
+    static int poll = -1;
+    if (poll < 0) { const char* e = getenv("GSR_MAILBOX_POLL"); poll = e ? (atoi(e) != 0) : 1; }
+    volatile uint32_t* word = mb->host + 16 * slot;
+    if (poll) { *word = 0xFFFFFFFFu; std::atomic_thread_fence(std::memory_order_seq_cst); }
     { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
     { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s)) return 1; }
-    GSR_CHECK(hipEventRecord(mb->ev[slot], s), "event record");
+    if (!poll) GSR_CHECK(hipEventRecord(mb->ev[slot], s), "event record");
     { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s)) return 1; }
     { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1; }
-    GSR_CHECK(hipEventSynchronize(mb->ev[slot]), "stage1 event sync");
-    const uint32_t R = *(volatile uint32_t*)(mb->host + 16 * slot);
+    uint32_t R;
+    if (poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t spins = 0;
+        while ((R = *word) == 0xFFFFFFFFu) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                GSR_CHECK(hipStreamSynchronize(s), "stage1 sync (mailbox poll timed out)");
+                R = *word;
+                if (R == 0xFFFFFFFFu) { gsr_set_error("gsr_forward: num_rendered never arrived"); return 1; }
+                break;
+            }
+        }
+    } else {
+        GSR_CHECK(hipEventSynchronize(mb->ev[slot]), "stage1 event sync");
+        R = *word;
+    }
     *num_rendered_host = R;
     *overflow_host = (R > cap) ? 1 : 0;
     return 0;
@@ -402,8 +426,24 @@ extern "C" int gsr_backward_ex(const gsr_cfg* cfg, const gsr_inputs* in, const i
     float* acc = reinterpret_cast<float*>(scratch);
     if (!(flags & GSR_BWD_SCRATCH_IS_ZERO)) { ProfScope ps(GSR_PROF_BWD_MEMSET, s); if (gsr_memset_async(acc, 0, need, s)) { gsr_set_error("memset acc"); return 1; }; }
     if (num_rendered > 0) {
-        ProfScope ps(GSR_PROF_BLEND_BWD, s);
-        if (gsr_launch_blend_bwd(cfg, in, g, b, im, og, acc, s)) return 1;
+        if (gsr_blend_bwd_is_sp() && ((g_prof_on.load(std::memory_order_relaxed) >> GSR_PROF_BLEND_BWD) & 1u)) {
+            // one kernel: its own dispatch carries the two events (no event-record packets in front of and behind the dominant kernel)
+            ProfRec r;
+            {
+                std::lock_guard<std::mutex> lk(g_prof_mu);
+                if (g_prof.size() >= 8192) prof_drain();
+                if (!g_prof_free.empty()) { r = g_prof_free.back(); g_prof_free.pop_back(); }
+                else { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); }
+            }
+            r.label = GSR_PROF_BLEND_BWD;
+            gsr_blend_bwd_attach_events(r.a, r.b);
+            const int rc = gsr_launch_blend_bwd(cfg, in, g, b, im, og, acc, s);
+            { std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(r); }
+            if (rc) return 1;
+        } else {
+            ProfScope ps(GSR_PROF_BLEND_BWD, s);
+            if (gsr_launch_blend_bwd(cfg, in, g, b, im, og, acc, s)) return 1;
+        }
     }
     { ProfScope ps(GSR_PROF_PREPROCESS_BWD, s); if (gsr_launch_preprocess_bwd(cfg, in, radii, g, acc, ig, (flags & GSR_BWD_LEAVE_ZERO) != 0, s)) return 1; }
     return 0;

@@ -454,6 +454,14 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
     return gsr_check_launch("blend_fwd", s, cfg->debug);
 }
 
+bool gsr_blend_bwd_is_sp()
+{
+    static int use_sp = -1;
+    if (use_sp < 0) { const char* e = getenv("GSR_BWD"); use_sp = (e && e[0] == 'p') ? 0 : 1; }
+    return use_sp != 0;
+}
+void gsr_blend_bwd_attach_events(hipEvent_t start, hipEvent_t stop) { gsr_blend_bwd_sp_attach_events(start, stop); }
+
 int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_out_grads* og, float* acc, hipStream_t s)
 {
@@ -465,8 +473,7 @@ int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
     // GSR_BWD=sp (default): the splat-parallel backward of gsr_blend_sp.hip; GSR_BWD=px: the pixel-parallel kernel below (round 1's
     // formulation, kept switchable for A/B).  Both pass the full parity suite incl. the 300k / 1080p oracle cases.  Measured on MI355X,
     // 300k splats, 1080p (round 2): surfel sp 0.486 / px 0.524 ms, EWA 0.390 / 0.483, PLANE 0.331 / 0.372 -- DESIGN.md section 4.
-    static int use_sp = -1;
-    if (use_sp < 0) { const char* e = getenv("GSR_BWD"); use_sp = (e && e[0] == 'p') ? 0 : 1; }
+    const int use_sp = gsr_blend_bwd_is_sp() ? 1 : 0;
     if (use_sp) {
         if (gsr_launch_blend_bwd_sp(p, cfg->variant, s)) return 1;
         return gsr_check_launch("blend_bwd_sp", s, cfg->debug);

@@ -238,6 +238,7 @@ __device__ __forceinline__ bool cull_hit(const float4* __restrict__ cull, uint32
 }
 
 int gsr_launch_blend_bwd_sp(const BlendParams& p, int variant, hipStream_t s);      // gsr_blend_sp.hip
+void gsr_blend_bwd_sp_attach_events(hipEvent_t start, hipEvent_t stop);            // the next gsr_launch_blend_bwd_sp of this thread carries them
 
 static constexpr float NEAR_N = 0.2f, FAR_N = 100.0f, FILTER_INV_SQ = 2.0f;
 

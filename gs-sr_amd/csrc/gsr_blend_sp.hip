@@ -29,6 +29,7 @@
 // Reference semantics: 3DGS backward.cu:399-557, SURFEL backward.cu:143-447, PLANE backward.cu:399-614 (gates, thresholds, the
 // median-normal quirk, no gradient through the 0.99 clamp test); see DESIGN.md "splat-parallel backward".
 #include "gsr_blend_common.h"
+#include <hip/hip_ext.h>
 
 // Waves per SIMD the register budget of each variant is sized for.  SURFEL (128 VGPRs, 12 spills outside the step loop): 3 waves 0.693 ms,
 // 4 waves 0.633, 5 waves (96 VGPRs, 37 spills) 0.759 -- measured on the first table version; EWA needs 94 VGPRs and runs 5 waves per SIMD:
@@ -501,9 +502,25 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     }
 }
 
+// Stage profiler, single-kernel stage: start / stop events ATTACHED to the dispatch (hipExtLaunchKernel) instead of two hipEventRecord around it.
+// An event record is a barrier packet of its own: ~6 us of stream idle time each, on both sides of the kernel it measures
+// (profiles/r03_timeline_surfel.json) -- 1.3 % of the iteration bench.py times with this stage's profiling on.  Thread-local, consumed by the next launch.
+static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
+void gsr_blend_bwd_sp_attach_events(hipEvent_t start, hipEvent_t stop) { t_ev_start = start; t_ev_stop = stop; }
+
 int gsr_launch_blend_bwd_sp(const BlendParams& p, int variant, hipStream_t s)
 {
     dim3 grid(p.gx * p.gy), block(256);
+    if (t_ev_start && t_ev_stop) {
+        hipEvent_t a = t_ev_start, b = t_ev_stop;
+        t_ev_start = t_ev_stop = nullptr;
+        switch (variant) {
+        case GSR_EWA: hipExtLaunchKernelGGL(k_blend_bwd_sp<GSR_EWA>, grid, block, 0, s, a, b, 0, p); break;
+        case GSR_PLANE: hipExtLaunchKernelGGL(k_blend_bwd_sp<GSR_PLANE>, grid, block, 0, s, a, b, 0, p); break;
+        default: hipExtLaunchKernelGGL(k_blend_bwd_sp<GSR_SURFEL>, grid, block, 0, s, a, b, 0, p); break;
+        }
+        return 0;
+    }
     switch (variant) {
     case GSR_EWA: hipLaunchKernelGGL(k_blend_bwd_sp<GSR_EWA>, grid, block, 0, s, p); break;
     case GSR_PLANE: hipLaunchKernelGGL(k_blend_bwd_sp<GSR_PLANE>, grid, block, 0, s, p); break;

@@ -95,6 +95,8 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
                          const gsr_outputs* out, hipStream_t s);
 int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_out_grads* og, float* acc, hipStream_t s);
+bool gsr_blend_bwd_is_sp();            // GSR_BWD=sp (default) | px (gsr_blend.hip)
+void gsr_blend_bwd_attach_events(hipEvent_t start, hipEvent_t stop);     // splat-parallel backward only: the next launch of this thread carries them
 // hipMemsetAsync that is safe to record into a HIP graph: on ROCm 7.2 a memset NODE replays with a corrupted fill value from the second replay
 // on (measured round 3: vis_idx filled with 0x5A5A5A5A instead of 0xFF...), so while `s` is being captured the fill is a kernel; eagerly it is
 // the runtime's memset.  nbytes must be a multiple of 4.
