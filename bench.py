@@ -94,6 +94,18 @@ def clock_prewarm(device, ms):
     return (time.perf_counter() - t0) * 1e3
 
 
+def concentrate(sc, frac, scale):
+    """Pull the first `frac` of the gaussians towards the optical axis (camera-space x, y scaled by `scale`): object-centric density, a few hundred
+    tiles with lists several thousand entries long.  For the long-list paths of the per-tile depth sort; not the BASELINE workload."""
+    V = sc["viewmatrix"].astype(np.float64)
+    n = int(frac * sc["means3D"].shape[0])
+    pc = sc["means3D"][:n].astype(np.float64) @ V[:3, :3] + V[3, :3]
+    pc[:, :2] *= scale
+    sc["means3D"][:n] = ((pc - V[3, :3]) @ np.linalg.inv(V[:3, :3])).astype(np.float32)
+    if sc.get("all_map") is not None:
+        sc["all_map"] = scenes.plane_all_map(sc)
+
+
 def make_step(variant, sc, device):
     """One training iteration.  All gaussian parameters live in ONE flat leaf z (contiguous blocks: means 3P, scales 2P|3P,
     rotations 4P, opacity P, colour 3P|48P), optimised by gsrast.optim.Adam (one fused HIP kernel, include/gsrast.h gsr_adam_step) whose
@@ -408,6 +420,8 @@ def main():
     ap.add_argument("--H", type=int, default=1080)
     ap.add_argument("--color-mode", default="precomp", choices=["precomp", "sh"],
                     help="precomp = scaffold/octree path (configs 2-5, default); sh = vanilla path with degree-3 SH (config 1)")
+    ap.add_argument("--skew-frac", type=float, default=0.0, help="side experiment: this fraction of the gaussians is pulled towards the image centre (see concentrate())")
+    ap.add_argument("--skew-scale", type=float, default=0.15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph-replay", action="store_true", help="skip the informational HIP-graph replay of the same step")
     ap.add_argument("--graph-replay-child", action="store_true", help=argparse.SUPPRESS)
@@ -482,6 +496,8 @@ def main():
         return
     # one independent tile-scene per rank (train_split.py trains tiles independently; seed = tile index)
     sc = scenes.make_scene(args.variant, args.P, args.W, args.H, seed=rank, color_mode=args.color_mode)
+    if args.skew_frac > 0:      # side experiment (not the BASELINE workload): a fraction of the gaussians pulled towards the image centre -> a few very long tile lists
+        concentrate(sc, args.skew_frac, args.skew_scale)
     step, state = make_step(args.variant, sc, device)
 
     from gsrast import tiles
@@ -594,6 +610,7 @@ def main():
                        "variant": args.variant, "P": args.P, "W": args.W, "H": args.H, "tile_instances_R": R, "tile_instances_R_after_timed_steps": R_after,
                        "visible": int((st["radii"] > 0).sum()),
                        "clock_prewarm_ms": round(prewarm_ms, 1),
+                       **({"skew": {"frac": args.skew_frac, "scale": args.skew_scale, "what": "NOT the BASELINE workload: gaussians concentrated at the image centre"}} if args.skew_frac > 0 else {}),
                        "depth_order": "global 4-pass radix sort of the gaussians" if depth_order_is_global(args.P, T) else ("per-tile sort of the binned lists, in k_blend_fwd's prologue" if os.environ.get("GSR_TILE_SORT", "fused")[:1] != "k" else "per-tile sort of the binned lists (k_tile_depth_sort)"),
                        "tiles": T, "tiles_touched": int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()),
                        "gaussians_per_tile_mean": round(R / max(int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()), 1), 1),
