@@ -177,7 +177,7 @@ ImgView gsr_carve_img(int variant, int W, int H, void* base)
     im.final_T = take<float>(p, N * (variant == GSR_SURFEL ? 3 : 1));
     im.n_contrib = take<uint32_t>(p, N * (variant == GSR_SURFEL ? 2 : 1));
     im.ranges = take<uint2>(p, (size_t)gx * gy);
-    im.tile_order = take<uint32_t>(p, (size_t)gx * gy);
+    im.tile_order = take<uint32_t>(p, (size_t)gx * gy + 1);
     im.bytes = (size_t)(p - reinterpret_cast<char*>(base));
     return im;
 }
@@ -224,6 +224,7 @@ struct Mailbox {
     uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev[GSR_MAIL_SLOTS] = {};
     std::atomic<unsigned> next{0};
     std::atomic<int> busy[GSR_MAIL_SLOTS];
+    std::atomic<int> order_ttl{0};          // forwards for which the longest-first launch order stays on after the last long-list report
 };
 static Mailbox g_mail[64];
 static std::mutex g_mail_mu;
@@ -244,7 +245,8 @@ static Mailbox* mailbox()
     std::lock_guard<std::mutex> lk(g_mail_mu);
     if (!m.host) {
         void* h = nullptr; void* dp = nullptr;
-        if (hipHostMalloc(&h, GSR_MAIL_SLOTS * 64, hipHostMallocMapped) != hipSuccess) return nullptr;     // one cache line per slot
+        if (hipHostMalloc(&h, (GSR_MAIL_SLOTS + 1) * 64, hipHostMallocMapped) != hipSuccess) return nullptr;     // one cache line per slot + the long-list feedback word
+        ((uint32_t*)h)[16 * GSR_MAIL_SLOTS] = 0u;
         if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
         for (int i = 0; i < GSR_MAIL_SLOTS; i++) {
             m.busy[i].store(0);
@@ -253,6 +255,32 @@ static Mailbox* mailbox()
         m.host = (uint32_t*)h; m.dev = (uint32_t*)dp;
     }
     return &m;
+}
+
+// Launch order of the blend workgroups, decided per forward.  Raster order (workgroup b = tile b, XCD b % 8) spreads every image region over the
+// eight XCDs; on object-centric scenes a few hundred tiles carry lists 5-50x the mean and the launch ends on whichever of them start late, which
+// k_tile_order (longest lists first, 11 us) removes: 986 -> 1209 it/s with lists up to 3800 entries, but -1.7 % on the uniform BASELINE scene
+// (tools/ab_tile_order.sh, profiles/r03_launch_order.txt).  So the order is used when it pays: every blend forward stores its tile's list length into a
+// mapped per-device word when it exceeds max(1024, 4 x mean) (BlendParams::long_word), and the forwards that follow a report -- the next 64 -- run
+// k_tile_order.  The decision costs the host one read of pinned memory; a stale decision is only a slower or faster launch order, never a wrong one
+// (the order's validity travels in the image arena, ImgView::tile_order[T]).  GSR_TILE_ORDER=0|1 forces it.
+bool gsr_tile_order_wanted()
+{
+    static int mode = -2;                       // -1 auto, 0 off, 1 on
+    if (mode == -2) { const char* e = getenv("GSR_TILE_ORDER"); mode = (!e || e[0] == 'a') ? -1 : (atoi(e) != 0 ? 1 : 0); }
+    if (mode >= 0) return mode != 0;
+    Mailbox* mb = mailbox();
+    if (!mb) return false;
+    volatile uint32_t* w = mb->host + 16 * GSR_MAIL_SLOTS;
+    if (*w != 0u) { *w = 0u; mb->order_ttl.store(64, std::memory_order_relaxed); return true; }
+    int t = mb->order_ttl.load(std::memory_order_relaxed);
+    if (t > 0) { mb->order_ttl.store(t - 1, std::memory_order_relaxed); return true; }
+    return false;
+}
+uint32_t* gsr_long_list_word()
+{
+    Mailbox* mb = mailbox();
+    return mb ? mb->dev + 16 * GSR_MAIL_SLOTS : nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------ forward

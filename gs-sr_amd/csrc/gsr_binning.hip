@@ -410,13 +410,15 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
                                                    const uint32_t* __restrict__ block_prefix, const uint32_t* __restrict__ tiles_touched,
                                                    const ushort4* __restrict__ rect, int gx,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap,
-                                                   uint2* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ zero_ptr, uint32_t zero_n)
+                                                   uint2* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ zero_ptr, uint32_t zero_n,
+                                                   uint32_t* __restrict__ order_valid)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x);          // position in depth order
     if (i < T) ranges[i] = make_uint2(0xFFFFFFFFu, 0u);                  // the cudaMemset of rasterizer_impl.cu:310, folded in; x > y = no instance (the
                                                                          // last scatter pass merges range candidates with atomicMin / atomicMax)
     for (uint32_t z = i; z < zero_n; z += gridDim.x * blockDim.x) zero_ptr[z] = 0u;      // first group-histogram buffer of the tile sort that follows
+    if (i == 0) *order_valid = 0u;                                       // ImgView::tile_order[T]: set again by k_tile_order if it runs for this forward
     const bool v = i < P;
     const uint32_t g = v ? (sorted_idx ? sorted_idx[i] : i) : 0u;
     const uint32_t cnt = v ? tiles_touched[g] : 0u;
@@ -520,13 +522,7 @@ __global__ void __launch_bounds__(1024) k_tile_order(const uint2* __restrict__ r
         for (int q = 0; q < NB; q++) if (q == k) { dst = pos[q]; pos[q]++; }
         order[dst] = t;
     }
-}
-
-bool gsr_tile_order_enabled()
-{
-    static int order = -1;
-    if (order < 0) { const char* e = getenv("GSR_TILE_ORDER"); order = (e && atoi(e) != 0) ? 1 : 0; }
-    return order != 0;
+    if (tid == 0) order[T] = 1u;                  // the order of this forward is in place (k_duplicate cleared the word)
 }
 
 // ------------------------------------------------------------------------------------------------ per-tile depth order
@@ -694,8 +690,9 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     const int T = gx * gy;
     if (R == 0) {
-        if (gsr_memset_async(im.ranges, 0, (size_t)T * sizeof(uint2), s)) { gsr_set_error("memset ranges"); return 1; }
-        if (gsr_tile_order_enabled()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
+        // ranges [T] and the tile order [T + 1] are contiguous in the image arena: all empty, order word "not in place"
+        const size_t span = (size_t)(reinterpret_cast<char*>(im.tile_order + T + 1) - reinterpret_cast<char*>(im.ranges));      // incl. the arena's alignment gap
+        if (gsr_memset_async(im.ranges, 0, (span + 3) & ~(size_t)3, s)) { gsr_set_error("memset ranges"); return 1; }
         return 0;
     }
     // unsorted instances go to the buffer from which an integral number of passes lands in (tile_keys, point_list)
@@ -705,7 +702,7 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     const bool global_order = gsr_depth_order_is_global(cfg->P, T);
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P,
                        global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
-                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256));
+                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256), im.tile_order + T);
     bool in_b = false;
     // tile ranges: k_tile_ranges over the sorted keys (default), or written by the last scatter pass (GSR_TILE_RANGES=scatter).  MEASURED (round 3,
     // P = 300k, 1080p): the fold loses -- binning 0.0847 ms against 0.0748 with the separate 5 us kernel: two more LDS reads, a compare and
@@ -717,6 +714,6 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     if (!global_order && !gsr_tile_sort_is_fused())
         hipLaunchKernelGGL(k_tile_depth_sort, dim3(gsr_div_up((uint32_t)T, 4u)), dim3(256), 0, s, im.ranges, (uint32_t)T, R, g.depth_key, b.point_list, b.tile_keys,
                            b.keys_b, b.vals_b);
-    if (gsr_tile_order_enabled()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
+    if (gsr_tile_order_wanted()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
     return gsr_check_launch("binning", s, cfg->debug);
 }

@@ -15,6 +15,7 @@
 // Behaviour follows 3DGS forward.cu:261-374 / backward.cu:399-557, PLANE forward.cu:273-407 / backward.cu:399-614,
 // SURFEL forward.cu:256-448 / backward.cu:143-447 (thresholds, ordering, recurrences); see DESIGN.md.
 #include "gsr_blend_common.h"
+#include <algorithm>
 #include "gsr_tile_sort.h"
 
 // =================================================================================================== forward
@@ -34,6 +35,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         TdsScratch sc; sc.tile_keys = p.tile_keys; sc.keys = p.scratch_keys; sc.ids = p.scratch_ids;
         tds_sort_tile_wg<(int)sizeof(s_rec)>(s_rec, p.list_rw + range.x, range.y > range.x ? range.y - range.x : 0u, range.x, (uint32_t)tile, p.depth_key, sc);
     }
+    if (p.long_word && threadIdx.x == 0 && range.y > range.x && range.y - range.x > p.long_len) *p.long_word = range.y - range.x;      // feedback for the launch order
     if (ox >= p.W || oy >= p.H) return;                 // wave-uniform: this sub-tile is outside the image
     const int px = ox + (lane & 7), py = oy + (lane >> 3);
     const bool inside = px < p.W && py < p.H;
@@ -411,18 +413,17 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
     p.gx = (cfg->W + GSR_TILE - 1) / GSR_TILE; p.gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     p.variant = cfg->variant; p.render_geo = cfg->render_geo;
     {
+        // GSR_XCD_REMAP=1: a contiguous band of tiles per XCD (neighbouring tiles share an L2).  Default since round 3: OFF -- it is worth 0.5 % on the
+        // uniform BASELINE scene (1103 vs 1097 it/s) and costs 30-50 % as soon as the density is not uniform, because the busy band is then one XCD's
+        // alone (693 vs 1073 it/s with half of the gaussians in the image centre: tools/ab_tile_order.sh).
         static int remap = -1;
-        if (remap < 0) { const char* e = getenv("GSR_XCD_REMAP"); remap = e ? (atoi(e) != 0) : 1; }
+        if (remap < 0) { const char* e = getenv("GSR_XCD_REMAP"); remap = e ? (atoi(e) != 0) : 0; }
         p.xcd_remap = remap;
     }
     p.fy = cfg->H / (2.0f * cfg->tanfovy);
     p.fx = cfg->W / (2.0f * cfg->tanfovx);
-    {
-        // GSR_TILE_ORDER=1: blend workgroups by descending tile-list length (k_tile_order) instead of raster / XCD-band order.  MEASURED on the
-        // BASELINE scene (uniform density, round 3): blend fwd 0.2016 vs 0.2010 ms, bwd 0.4840 vs 0.4838 -- no tail to remove -- while the
-        // ordering kernel costs 11 us; off by default, kept for scenes with a few very long tiles.
-        p.tile_order = gsr_tile_order_enabled() ? im.tile_order : nullptr;
-    }
+    p.tile_order = im.tile_order;         // used when its word T is set: decided per forward (gsr_tile_order_wanted, gsr_api.hip)
+    p.long_word = nullptr; p.long_len = 0xFFFFFFFFu;
     {
         // GSR_CULL_REUSE=0: the backward re-tests every entry against the four 8x8 quadrants (round 2) instead of reading the forward's ballots
         static int reuse = -1;
@@ -442,6 +443,12 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
     BlendParams p = make_bp(cfg, g, b, im);
     if (!gsr_depth_order_is_global(cfg->P, p.gx * p.gy) && gsr_tile_sort_is_fused()) {
         p.depth_key = g.depth_key; p.list_rw = b.point_list; p.tile_keys = b.tile_keys; p.scratch_keys = b.keys_b; p.scratch_ids = b.vals_b;
+    }
+    {   // long-list feedback for the launch order of the forwards that follow (gsr_tile_order_wanted): "long" = beyond max(1024, ~4 x the mean list,
+        // the mean taken as 5 instances per gaussian over T tiles)
+        const long long T = (long long)p.gx * p.gy;
+        p.long_word = gsr_long_list_word();
+        p.long_len = (uint32_t)std::max(1024ll, 20ll * (long long)cfg->P / std::max(T, 1ll));
     }
     p.out_color = out->out_color; p.out_others = out->out_others; p.out_observe = out->out_observe;
     p.out_all_map = out->out_all_map; p.out_plane_depth = out->out_plane_depth;

@@ -70,7 +70,8 @@ struct ImgView {
     float* final_T;           // [N] (SURFEL [3N]: T, M1, M2)
     uint32_t* n_contrib;      // [N] (SURFEL [2N]: last, median)
     uint2* ranges;            // [T]
-    uint32_t* tile_order;     // [T] launch order of the blend kernels: tiles by descending list length (gsr_binning.hip k_tile_order)
+    uint32_t* tile_order;     // [T + 1] launch order of the blend kernels: tiles by descending list length (gsr_binning.hip k_tile_order); word T: 1 = the
+                              // order of THIS forward is in place (k_tile_order ran), 0 = blockIdx -> tile directly
     size_t bytes;
 };
 
@@ -102,7 +103,8 @@ void gsr_blend_bwd_attach_events(hipEvent_t start, hipEvent_t stop);     // spla
 // the runtime's memset.  nbytes must be a multiple of 4.
 bool gsr_depth_order_is_global(int P, int T);     // per-tile depth sort or the global one (GSR_DEPTH_ORDER=tile|global|auto; gsr_binning.hip)
 bool gsr_tile_sort_is_fused();        // GSR_TILE_SORT=fused|kernel: who orders a tile's list by depth when the depth order is per tile (gsr_binning.hip)
-bool gsr_tile_order_enabled();        // GSR_TILE_ORDER=1 (gsr_binning.hip)
+bool gsr_tile_order_wanted();         // GSR_TILE_ORDER=0|1, default auto: on while recent forwards reported long tile lists (gsr_api.hip); once per forward
+uint32_t* gsr_long_list_word();       // device pointer of the per-device feedback word the blend forward reports long lists into, or nullptr (gsr_api.hip)
 int gsr_memset_async(void* p, int byte_value, size_t nbytes, hipStream_t s);
 int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,
                               float* acc, const gsr_in_grads* ig, bool leave_zero, hipStream_t s);

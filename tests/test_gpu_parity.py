@@ -614,3 +614,22 @@ def test_eleven_bit_depth_sort_kept_switchable():
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_launch_order_feedback_leaves_results_alone():
+    """GSR_TILE_ORDER auto (default): a forward whose longest tile list exceeds max(1024, 4 x mean) reports it through the mapped feedback word and the
+    forwards that follow launch their blend workgroups longest-list-first (k_tile_order).  The order is a permutation of the tiles: every output of the
+    later forwards and backwards stays bit-identical to the first one's, and equal to the oracle's integer stages."""
+    import bench
+    hr = _hiprun()
+    W, H, P = 256, 256, 24000
+    sc = scenes.make_scene("surfel", P, W, H, seed=13)
+    bench.concentrate(sc, 0.6, 0.12)
+    runs = [hr.run_raw("surfel", sc) for _ in range(4)]
+    lens = runs[0]["ranges"][:, 1].astype(np.int64) - runs[0]["ranges"][:, 0].astype(np.int64)
+    assert lens.max() > max(1024, 20 * P // (16 * 16))               # the scene does trigger the report
+    for r in runs[1:]:
+        for k in ("color", "radii", "point_list", "tile_keys", "ranges", "final_T", "n_contrib"):
+            assert np.array_equal(r[k], runs[0][k]), k
+    with oracle.Forward(sc, "surfel") as f:
+        assert np.array_equal(runs[-1]["point_list"], f.point_list())
