@@ -141,7 +141,7 @@ GeomView gsr_carve_geom(int variant, int P, void* base)
     g.vals_b = take<uint32_t>(p, n);
     g.sorted_idx = g.vals_a;                 // four sort passes: identity -> vals_b -> vals_a -> vals_b -> vals_a (gsr_launch_depth_order)
     g.hist = take<uint32_t>(p, gsr_sort_hist_words(nblk, gsr_depth_sort_digit_bins()));   // 256-bin digits (2048 only under GSR_DEPTH_BITS=11: the size query and the carve run in one process, after the environment is read)
-    g.scan_tmp = take<uint32_t>(p, gsr_div_up((uint32_t)n, GSR_SCAN_BLOCK) + 64);
+    g.scan_tmp = take<uint32_t>(p, gsr_div_up((uint32_t)n, 256) + 64);       // block sums of the prefix: 256-gaussian blocks when the preprocess writes them
     g.counters = take<uint32_t>(p, 64);
     g.bytes = (size_t)(p - reinterpret_cast<char*>(base));
     return g;

@@ -362,6 +362,15 @@ uint32_t gsr_depth_sort_digit_bins()
 //   2M (1125) 1.197 / 1.165;  3M (1688) 1.317 / 1.381 -- a tie above ~1.5M (rank by counting is O(n^2) up to 512 entries, a bitonic network above).
 // "auto" (default) takes the per-tile path while P <= 192 tiles' worth of gaussians (1.57M at 1080p).  (With the separate k_tile_depth_sort launch
 // the crossover was at ~96 T: profiles/r03_depth_order_ab.txt.)
+// The preprocess kernel also writes the block-local prefix of tiles_touched (per-tile depth order only: the global order needs the prefix in
+// depth-sorted order).  GSR_PREFIX=kernel keeps the separate k_offsets_local launch.
+bool gsr_prefix_in_preprocess(const gsr_cfg* cfg)
+{
+    static int fused = -1;
+    if (fused < 0) { const char* e = getenv("GSR_PREFIX"); fused = (e && e[0] == 'k') ? 0 : 1; }
+    const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
+    return fused != 0 && !gsr_depth_order_is_global(cfg->P, T);
+}
 bool gsr_depth_order_is_global(int P, int T)
 {
     static int mode = -1;                       // 0 auto, 1 global, 2 tile
@@ -376,9 +385,11 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
     const uint32_t P = (uint32_t)cfg->P;
     const int T_tiles = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
     if (!gsr_depth_order_is_global(cfg->P, T_tiles)) {
-        // id order: only the prefix sum of tiles_touched (block-local + block sums; k_duplicate adds the two) and num_rendered
-        const uint32_t nb = gsr_div_up(P, GSR_SCAN_BLOCK);
-        hipLaunchKernelGGL(k_offsets_local, dim3(nb), dim3(GSR_SCAN_BLOCK), 0, s, (const uint32_t*)nullptr, g.tiles_touched, P, g.offsets, g.scan_tmp);
+        // id order: only the prefix sum of tiles_touched (block-local + block sums; k_duplicate adds the two) and num_rendered.  The block-local
+        // part is written by the preprocess kernel itself (256-gaussian blocks, gsr_prefix_in_preprocess) unless GSR_PREFIX=kernel.
+        const bool fused = gsr_prefix_in_preprocess(cfg);
+        const uint32_t nb = gsr_div_up(P, fused ? 256u : (uint32_t)GSR_SCAN_BLOCK);
+        if (!fused) hipLaunchKernelGGL(k_offsets_local, dim3(nb), dim3(GSR_SCAN_BLOCK), 0, s, (const uint32_t*)nullptr, g.tiles_touched, P, g.offsets, g.scan_tmp);
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nb, g.counters, host_word_dev);
         return gsr_check_launch("depth_order", s, cfg->debug);
     }
@@ -411,7 +422,7 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
                                                    const ushort4* __restrict__ rect, int gx,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap,
                                                    uint2* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ zero_ptr, uint32_t zero_n,
-                                                   uint32_t* __restrict__ order_valid)
+                                                   uint32_t* __restrict__ order_valid, uint32_t scan_block)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x);          // position in depth order
@@ -423,7 +434,7 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
     const uint32_t g = v ? (sorted_idx ? sorted_idx[i] : i) : 0u;
     const uint32_t cnt = v ? tiles_touched[g] : 0u;
     // inclusive prefix of tiles_touched in depth order = block-local prefix (k_offsets_local) + exclusive prefix of the block sums
-    const uint32_t incl = v ? offsets[i] + block_prefix[i / GSR_SCAN_BLOCK] : 0u;
+    const uint32_t incl = v ? offsets[i] + block_prefix[i / scan_block] : 0u;
     ushort4 r = make_ushort4(0, 0, 1, 1);
     if (cnt) r = rect[g];
     const uint32_t wave_base = __shfl(incl - cnt, 0, 64);
@@ -702,7 +713,8 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     const bool global_order = gsr_depth_order_is_global(cfg->P, T);
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P,
                        global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
-                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256), im.tile_order + T);
+                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256), im.tile_order + T,
+                       gsr_prefix_in_preprocess(cfg) ? 256u : (uint32_t)GSR_SCAN_BLOCK);
     bool in_b = false;
     // tile ranges: k_tile_ranges over the sorted keys (default), or written by the last scatter pass (GSR_TILE_RANGES=scatter).  MEASURED (round 3,
     // P = 300k, 1080p): the fold loses -- binning 0.0847 ms against 0.0748 with the separate 5 us kernel: two more LDS reads, a compare and

@@ -4,6 +4,7 @@
 //   helpers : visible_filter (scaffold-filter), mark_visible
 // Built with -ffp-contract=off (see gsr_math.h).  Reference behaviour cited per kernel.
 #include "gsr_common.h"
+#include "gsr_tile_sort.h"
 #include <stdlib.h>
 #include "gsr_math.h"
 
@@ -19,6 +20,9 @@ struct PreParams {
     int scale_stride;         // floats between consecutive scale triples (3, or 6 when fed get_scaling directly)
     int no_cull;           // GSR_NO_CULL=1 (diagnostic): every visible gaussian passes the sub-tile cull -> outputs must not change
     uint32_t* zero_ptr; uint32_t zero_n;      // first group-histogram buffer of the depth sort that follows (gsr_binning.hip): cleared here
+    // per-tile depth order (instances emitted in id order): the block-local inclusive prefix of tiles_touched and the block totals are written here, by
+    // this kernel, instead of by a k_offsets_local launch of their own (5 us); nullptr: not wanted (global depth order, visible_filter)
+    uint32_t* scan_offsets; uint32_t* scan_sums;
 };
 
 __device__ __forceinline__ void load16(const float* p, float* m)
@@ -39,12 +43,9 @@ __device__ __forceinline__ float two_tau(float o)
 // ------------------------------------------------------------------------------------------------ EWA / PLANE
 // 3DGS forward.cu:156-256 (PLANE forward.cu:156-268 is identical); FILTER forward.cu:268-340 when FILTER_ONLY.
 template <bool FILTER_ONLY>
-__global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
+__device__ __forceinline__ uint32_t pre_ewa_one(const PreParams& p, const int idx)      // -> tiles_touched
 {
-    for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.P) return;
-    if (FILTER_ONLY && p.in_mask && !p.in_mask[idx]) { p.radii[idx] = 0; return; }
+    if (FILTER_ONLY && p.in_mask && !p.in_mask[idx]) { p.radii[idx] = 0; return 0u; }
     float view[16], proj[16];
     load16(p.view, view); load16(p.proj, proj);
 
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
     } while (0);
 
     p.radii[idx] = radius_out;
-    if (FILTER_ONLY) return;
+    if (FILTER_ONLY) return 0u;
     p.g.depth_key[idx] = key;
     p.g.tiles_touched[idx] = tiles;
     p.g.rect[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
@@ -123,15 +124,32 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
     float4* rec = p.g.rec + (size_t)idx * st;
     rec[0] = q0; rec[1] = q1; rec[2] = q2;
     if (p.variant == GSR_PLANE) rec[3] = q3;
+    return tiles;
+}
+// the prefix of tiles_touched the id-order binning needs, block part: inclusive scan over the block's 256 gaussians + the block total
+__device__ __forceinline__ void pre_block_scan(const PreParams& p, const int idx, const uint32_t tiles)
+{
+    if (!p.scan_offsets) return;                 // kernel-uniform
+    __shared__ uint32_t lds[17];
+    uint32_t tot;
+    const uint32_t incl = tds_block_incl_scan(tiles, lds, &tot);
+    if (idx < p.P) p.scan_offsets[idx] = incl;
+    if (threadIdx.x == 0) p.scan_sums[blockIdx.x] = tot;
+}
+template <bool FILTER_ONLY>
+__global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
+{
+    for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t tiles = 0u;
+    if (idx < p.P) tiles = pre_ewa_one<FILTER_ONLY>(p, idx);
+    if (!FILTER_ONLY) pre_block_scan(p, idx, tiles);
 }
 
 // ------------------------------------------------------------------------------------------------ SURFEL
 // SURFEL forward.cu:149-251
-__global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
+__device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int idx)      // -> tiles_touched
 {
-    for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.P) return;
     float view[16], proj[16];
     load16(p.view, view); load16(p.proj, proj);
 
@@ -233,6 +251,15 @@ __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
     rec[2] = make_float4(T[8], pix, piy, o);
     rec[3] = make_float4(normal.x, normal.y, normal.z, rgb.x);
     rec[4] = make_float4(rgb.y, rgb.z, 0.f, 0.f);
+    return tiles;
+}
+__global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
+{
+    for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t tiles = 0u;
+    if (idx < p.P) tiles = pre_surfel_one(p, idx);
+    pre_block_scan(p, idx, tiles);
 }
 
 // 3DGS rasterizer_impl.cu:54-66
@@ -260,6 +287,7 @@ static PreParams make_params(const gsr_cfg* cfg, const gsr_inputs* in, GeomView 
     p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
     { const char* e = getenv("GSR_NO_CULL"); p.no_cull = (e && atoi(e) != 0) ? 1 : 0; }
     p.in_mask = nullptr; p.scale_stride = 3;
+    p.scan_offsets = nullptr; p.scan_sums = nullptr;
     p.radii = radii; p.g = g;
     p.zero_ptr = nullptr; p.zero_n = 0;
     return p;
@@ -269,6 +297,7 @@ int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, 
 {
     PreParams p = make_params(cfg, in, g, radii);
     p.zero_ptr = g.hist; p.zero_n = gsr_sort_group_words((uint32_t)cfg->P, false, gsr_depth_sort_digit_bins());
+    if (gsr_prefix_in_preprocess(cfg)) { p.scan_offsets = g.offsets; p.scan_sums = g.scan_tmp; }
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);
     if (cfg->variant == GSR_SURFEL) hipLaunchKernelGGL(k_preprocess_surfel, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_preprocess_ewa<false>, grid, block, 0, s, p);
