@@ -277,6 +277,44 @@ bool gsr_tile_order_wanted()
     if (t > 0) { mb->order_ttl.store(t - 1, std::memory_order_relaxed); return true; }
     return false;
 }
+// blockIdx -> tile with 4x4-tile blocks dealt out to the eight XCDs cyclically (workgroup b runs on XCD b % 8): XCD x owns the blocks with
+// (bx + 3 by) % 8 == x and walks them in raster order, 16 tiles each; the eight lists are interleaved so that b % 8 selects the list.  Where the
+// lists differ in length the tail is filled from whichever list still has tiles (a permutation in any case).  Built on the host once per
+// (device, grid), kept for the life of the process; not built while a stream is being captured (raster order until an eager call has built it).
+const uint32_t* gsr_static_tile_map(int gx, int gy, hipStream_t s)
+{
+    struct Ent { int dev, gx, gy; uint32_t* map; };
+    static std::mutex mu;
+    static std::vector<Ent> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Ent& e : cache) if (e.dev == dev && e.gx == gx && e.gy == gy) return e.map;
+    {   // hipMalloc / hipMemcpy are illegal while the launch stream is being captured: raster order until an eager call has built the map
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    }
+    const int T = gx * gy, B = 4, bxn = (gx + B - 1) / B, byn = (gy + B - 1) / B;
+    std::vector<std::vector<uint32_t>> lists(8);
+    for (int by = 0; by < byn; by++)
+        for (int bx = 0; bx < bxn; bx++) {
+            std::vector<uint32_t>& L = lists[(bx + 3 * by) & 7];
+            for (int ty = by * B; ty < std::min(gy, by * B + B); ty++)
+                for (int tx = bx * B; tx < std::min(gx, bx * B + B); tx++) L.push_back((uint32_t)(ty * gx + tx));
+        }
+    std::vector<uint32_t> map((size_t)T);
+    size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < T; b++) {
+        int x = b & 7;
+        for (int k = 0; k < 8 && pos[x] >= lists[x].size(); k++) x = (x + 1) & 7;      // this XCD's list is used up: take from the next that is not
+        map[(size_t)b] = lists[x][pos[x]++];
+    }
+    uint32_t* d = nullptr;
+    if (hipMalloc(&d, (size_t)T * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemcpy(d, map.data(), (size_t)T * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return nullptr; }
+    cache.push_back({dev, gx, gy, d});
+    return d;
+}
 uint32_t* gsr_long_list_word()
 {
     Mailbox* mb = mailbox();

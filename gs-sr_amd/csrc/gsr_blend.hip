@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
 {
     constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
     __shared__ float4 s_rec[4 * ST * 64];               // [wave][record quarter][candidate slot]: private to the wave, no barrier
-    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order);
+    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order, p.static_map);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ox = tx * GSR_TILE + (wave & 1) * GSR_SUB, oy = ty * GSR_TILE + (wave >> 1) * GSR_SUB;
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 {
     constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
     constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
-    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order);
+    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order, p.static_map);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ox = tx * GSR_TILE + (wave & 1) * GSR_SUB, oy = ty * GSR_TILE + (wave >> 1) * GSR_SUB;
@@ -406,19 +406,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 }
 
 // =================================================================================================== launchers
-static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im)
+static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, hipStream_t s)
 {
     BlendParams p = {};
     p.W = cfg->W; p.H = cfg->H;
     p.gx = (cfg->W + GSR_TILE - 1) / GSR_TILE; p.gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     p.variant = cfg->variant; p.render_geo = cfg->render_geo;
     {
-        // GSR_XCD_REMAP=1: a contiguous band of tiles per XCD (neighbouring tiles share an L2).  Default since round 3: OFF -- it is worth 0.5 % on the
-        // uniform BASELINE scene (1103 vs 1097 it/s) and costs 30-50 % as soon as the density is not uniform, because the busy band is then one XCD's
-        // alone (693 vs 1073 it/s with half of the gaussians in the image centre: tools/ab_tile_order.sh).
+        // Which tile workgroup b works on (it runs on XCD b % 8, every XCD has its own L2):
+        //   GSR_XCD_REMAP=0  raster: b = tile.  Neighbouring tiles -- which share most of their splats -- sit on eight different XCDs.
+        //   GSR_XCD_REMAP=1  one contiguous band of tiles per XCD (rounds 1-3): best L2 reuse, but the busy band of a scene whose density is
+        //                    not uniform is one XCD's alone: 701 vs 1070 it/s with half of the gaussians in the image centre (tools/ab_tile_order.sh).
+        //   GSR_XCD_REMAP=2  (default) 4x4-tile blocks dealt out to the XCDs cyclically (gsr_static_tile_map): a block's tiles share an L2,
+        //                    every image region is spread over all eight XCDs.
         static int remap = -1;
-        if (remap < 0) { const char* e = getenv("GSR_XCD_REMAP"); remap = e ? (atoi(e) != 0) : 0; }
-        p.xcd_remap = remap;
+        if (remap < 0) { const char* e = getenv("GSR_XCD_REMAP"); remap = e ? atoi(e) : 2; }
+        p.xcd_remap = remap == 1 ? 1 : 0;
+        p.static_map = remap == 2 ? gsr_static_tile_map(p.gx, p.gy, s) : nullptr;
     }
     p.fy = cfg->H / (2.0f * cfg->tanfovy);
     p.fx = cfg->W / (2.0f * cfg->tanfovx);
@@ -440,7 +444,7 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
                          const gsr_outputs* out, hipStream_t s)
 {
     (void)in;
-    BlendParams p = make_bp(cfg, g, b, im);
+    BlendParams p = make_bp(cfg, g, b, im, s);
     if (!gsr_depth_order_is_global(cfg->P, p.gx * p.gy) && gsr_tile_sort_is_fused()) {
         p.depth_key = g.depth_key; p.list_rw = b.point_list; p.tile_keys = b.tile_keys; p.scratch_keys = b.keys_b; p.scratch_ids = b.vals_b;
     }
@@ -473,7 +477,7 @@ int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
                          const gsr_out_grads* og, float* acc, hipStream_t s)
 {
     (void)in;
-    BlendParams p = make_bp(cfg, g, b, im);
+    BlendParams p = make_bp(cfg, g, b, im, s);
     p.dL_dcolor = og->dL_dcolor; p.dL_dothers = og->dL_dothers; p.dL_dout_all_map = og->dL_dout_all_map;
     p.dL_dplane_depth = og->dL_dplane_depth; p.all_map_pixels = og->all_map_pixels;
     p.acc = acc;

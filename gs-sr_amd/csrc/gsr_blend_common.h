@@ -9,6 +9,7 @@ struct BlendParams {
     float fx, fy;
     const uint2* ranges;
     const uint32_t* tile_order;      // ImgView::tile_order [T + 1]: used when word T is set (k_tile_order ran for this forward)
+    const uint32_t* static_map;      // [T] blockIdx -> tile, block-cyclic over the XCDs (gsr_static_tile_map, GSR_XCD_REMAP=2), or nullptr
     uint32_t* long_word; uint32_t long_len;     // forward: a tile whose list is longer than long_len stores its length into *long_word (feedback, or nullptr)
     const uint32_t* point_list;
     unsigned long long* qmask;       // BinView::qmask, or nullptr (GSR_CULL_REUSE=0)
@@ -32,9 +33,10 @@ struct BlendParams {
 
 // Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md); give each XCD a contiguous band of tiles so that
 // neighbouring tiles -- which share most of their splats -- hit the same 4 MiB L2.  Bijective for any T; speed only.
-__device__ __forceinline__ int tile_of_block(int b, int T, int remap, const uint32_t* __restrict__ order)
+__device__ __forceinline__ int tile_of_block(int b, int T, int remap, const uint32_t* __restrict__ order, const uint32_t* __restrict__ smap = nullptr)
 {
     if (order[T]) return (int)order[b];   // longest tile lists first: the launch does not end on a few long tiles (k_tile_order ran for this forward)
+    if (smap) return (int)smap[b];        // 4x4-tile blocks dealt out to the XCDs cyclically
     if (!remap) return b;
     const int q = T >> 3, r = T & 7, xcd = b & 7, idx = b >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;

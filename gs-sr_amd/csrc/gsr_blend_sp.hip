@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     __shared__ uint8_t s_queue[4 * 4 * SP_CH];              // [wave][block][position] -> chunk-local entry, list order
     __shared__ uint32_t s_wmax[4];
 
-    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order);
+    const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order, p.static_map);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = lane >> 4, j = lane & 15;                 // row (= 4x4 block of the quadrant), slot / pixel inside it

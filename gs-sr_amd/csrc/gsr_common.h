@@ -105,6 +105,7 @@ bool gsr_prefix_in_preprocess(const gsr_cfg* cfg);      // the preprocess kernel
 bool gsr_depth_order_is_global(int P, int T);     // per-tile depth sort or the global one (GSR_DEPTH_ORDER=tile|global|auto; gsr_binning.hip)
 bool gsr_tile_sort_is_fused();        // GSR_TILE_SORT=fused|kernel: who orders a tile's list by depth when the depth order is per tile (gsr_binning.hip)
 bool gsr_tile_order_wanted();         // GSR_TILE_ORDER=0|1, default auto: on while recent forwards reported long tile lists (gsr_api.hip); once per forward
+const uint32_t* gsr_static_tile_map(int gx, int gy, hipStream_t s);     // device [gx*gy] blockIdx -> tile, block-cyclic over the XCDs; cached per device and grid; nullptr if unavailable (gsr_api.hip)
 uint32_t* gsr_long_list_word();       // device pointer of the per-device feedback word the blend forward reports long lists into, or nullptr (gsr_api.hip)
 int gsr_memset_async(void* p, int byte_value, size_t nbytes, hipStream_t s);
 int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,

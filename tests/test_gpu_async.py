@@ -123,7 +123,8 @@ def test_iteration_replays_from_a_hip_graph():
     zero()
     ref_loss = float(iteration())
     ref = grads()
-    assert abs(got_loss - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-7
+    # the loss is a float-atomic sum over ~2000 blocks of terms that largely cancel (signed weights): its last digits depend on the order of arrival
+    assert abs(got_loss - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-7
     for k in names:
         d = (got[k] - ref[k]).norm().item(); n = ref[k].norm().item()
         assert d <= 2e-5 * n + 1e-30, (k, d, n)
