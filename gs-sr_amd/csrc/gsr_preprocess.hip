@@ -43,7 +43,7 @@ __device__ __forceinline__ float two_tau(float o)
 // ------------------------------------------------------------------------------------------------ EWA / PLANE
 // 3DGS forward.cu:156-256 (PLANE forward.cu:156-268 is identical); FILTER forward.cu:268-340 when FILTER_ONLY.
 template <bool FILTER_ONLY>
-__device__ __forceinline__ uint32_t pre_ewa_one(const PreParams& p, const int idx)      // -> tiles_touched
+__device__ __forceinline__ uint32_t pre_ewa_one(const PreParams& p, const int idx, const float* sh_staged = nullptr)      // -> tiles_touched
 {
     if (FILTER_ONLY && p.in_mask && !p.in_mask[idx]) { p.radii[idx] = 0; return 0u; }
     float view[16], proj[16];
@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t pre_ewa_one(const PreParams& p, const int id
 
         float3 rgb;
         if (p.colors) rgb = make_float3(p.colors[3 * idx], p.colors[3 * idx + 1], p.colors[3 * idx + 2]);
-        else rgb = sh_to_rgb(p.D, p.shs + (size_t)idx * p.M * 3, p_orig,
+        else rgb = sh_to_rgb(p.D, sh_staged ? sh_staged : p.shs + (size_t)idx * p.M * 3, p_orig,
                              make_float3(p.campos[0], p.campos[1], p.campos[2]), clamped);
         const float o = p.opac[idx];
         key = __float_as_uint(p_view.z);
@@ -146,9 +146,58 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
     if (!FILTER_ONLY) pre_block_scan(p, idx, tiles);
 }
 
+// The same with the SH coefficients (16 x 3 floats = 192 B per gaussian) staged through LDS.  Read straight from global memory, lane l's 48 floats
+// sit 192 B from lane l+1's: every load instruction of the wave touches 64 different cache lines and the texture addresser, which takes a line per
+// cycle, becomes the kernel (46 us against 15 us with precomputed colours at P = 300k).  Here the wave copies its 64 gaussians' 12 KB with 12 fully
+// coalesced 16-byte-per-lane loads into its private LDS slice, one row of 49 words per gaussian (odd stride: lane l reading word k of row l is
+// conflict-free), and sh_to_rgb reads from there.  Same arithmetic on the same values: bit-identical results.  M = 16 only (degree-3 models).
+#define GSR_SH_ROW 49
+// ---- SH rows through LDS (see k_preprocess_ewa_sh16): the wave's 64 gaussians x 48 floats, 16 bytes per lane and instruction
+__device__ __forceinline__ void sh_rows_load(float* my, const float* __restrict__ shs, size_t g0, int lane, size_t total)
+{
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int w = 4 * (i * 64 + lane);                     // word offset inside the wave's 64 x 48 block: 1 KB per instruction
+        if (g0 * 48 + w + 3 < total) {
+            const float4 v = *reinterpret_cast<const float4*>(shs + g0 * 48 + w);
+            const int g = w / 48, j = w - g * 48;              // 48 is a multiple of 4: the four words stay inside one gaussian's row
+            float* d = my + g * GSR_SH_ROW + j;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void sh_rows_store(const float* my, float* __restrict__ dst, size_t g0, int lane, size_t total)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int w = 4 * (i * 64 + lane);
+        if (g0 * 48 + w + 3 < total) {
+            const int g = w / 48, j = w - g * 48;
+            const float* r = my + g * GSR_SH_ROW + j;
+            *reinterpret_cast<float4*>(dst + g0 * 48 + w) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_preprocess_ewa_sh16(PreParams p)
+{
+    __shared__ float s_sh[4 * 64 * GSR_SH_ROW];
+    for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = s_sh + wave * 64 * GSR_SH_ROW;
+    sh_rows_load(my, p.shs, (size_t)(idx - lane), lane, (size_t)p.P * 48);
+    uint32_t tiles = 0u;
+    if (idx < p.P) tiles = pre_ewa_one<false>(p, idx, my + lane * GSR_SH_ROW);
+    pre_block_scan(p, idx, tiles);
+}
+
 // ------------------------------------------------------------------------------------------------ SURFEL
 // SURFEL forward.cu:149-251
-__device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int idx)      // -> tiles_touched
+__device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int idx, const float* sh_staged = nullptr)      // -> tiles_touched
 {
     float view[16], proj[16];
     load16(p.view, view); load16(p.proj, proj);
@@ -184,7 +233,7 @@ __device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int
         if ((x1 - x0) * (y1 - y0) == 0) break;
         radius_out = (int)radius;
         if (p.colors) rgb = make_float3(p.colors[3 * idx], p.colors[3 * idx + 1], p.colors[3 * idx + 2]);
-        else rgb = sh_to_rgb(p.D, p.shs + (size_t)idx * p.M * 3, p_orig,
+        else rgb = sh_to_rgb(p.D, sh_staged ? sh_staged : p.shs + (size_t)idx * p.M * 3, p_orig,
                              make_float3(p.campos[0], p.campos[1], p.campos[2]), clamped);
         o = p.opac[idx];
         key = __float_as_uint(p_view.z);
@@ -253,12 +302,21 @@ __device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int
     rec[4] = make_float4(rgb.y, rgb.z, 0.f, 0.f);
     return tiles;
 }
+template <bool SH16>
 __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
 {
     for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* sh_row = nullptr;
+    if constexpr (SH16) {          // SH coefficients through LDS, as in k_preprocess_ewa_sh16
+        __shared__ float s_sh[4 * 64 * GSR_SH_ROW];
+        const int lane = threadIdx.x & 63;
+        float* my = s_sh + (threadIdx.x >> 6) * 64 * GSR_SH_ROW;
+        sh_rows_load(my, p.shs, (size_t)(idx - lane), lane, (size_t)p.P * 48);
+        sh_row = my + lane * GSR_SH_ROW;
+    }
     uint32_t tiles = 0u;
-    if (idx < p.P) tiles = pre_surfel_one(p, idx);
+    if (idx < p.P) tiles = pre_surfel_one(p, idx, sh_row);
     pre_block_scan(p, idx, tiles);
 }
 
@@ -299,7 +357,11 @@ int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, 
     p.zero_ptr = g.hist; p.zero_n = gsr_sort_group_words((uint32_t)cfg->P, false, gsr_depth_sort_digit_bins());
     if (gsr_prefix_in_preprocess(cfg)) { p.scan_offsets = g.offsets; p.scan_sums = g.scan_tmp; }
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);
-    if (cfg->variant == GSR_SURFEL) hipLaunchKernelGGL(k_preprocess_surfel, grid, block, 0, s, p);
+    static int stage_sh = -1;                  // GSR_SH_STAGE=0: SH coefficients read straight from global memory (rounds 1-3)
+    if (stage_sh < 0) { const char* e = getenv("GSR_SH_STAGE"); stage_sh = e ? (atoi(e) != 0) : 1; }
+    const bool sh16 = stage_sh && p.shs && !p.colors && cfg->M == 16 && (((uintptr_t)p.shs) & 15) == 0;
+    if (cfg->variant == GSR_SURFEL) { if (sh16) hipLaunchKernelGGL(k_preprocess_surfel<true>, grid, block, 0, s, p); else hipLaunchKernelGGL(k_preprocess_surfel<false>, grid, block, 0, s, p); }
+    else if (sh16) hipLaunchKernelGGL(k_preprocess_ewa_sh16, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_preprocess_ewa<false>, grid, block, 0, s, p);
     return gsr_check_launch("preprocess", s, cfg->debug);
 }
@@ -405,28 +467,24 @@ template <int AS4> __device__ __forceinline__ void clear_acc_row(float* acc_clea
 }
 
 // SH backward, 3DGS backward.cu:20-139.  Writes dL_dsh[idx] and returns the view-direction term of dL/dmean.
-__device__ __forceinline__ float3 sh_backward(int deg, int M, const float* sh, float3 mean, float3 campos, uint32_t clamped,
-                                              const float* dL_dcolor, float* dL_dsh)
+// Two phases over the same statements: first everything that READS sh (the direction term), then everything that WRITES dL_dsh -- the two are
+// independent, and with the reads done first `sh` and `dL_dsh` may be the same LDS row (k_preprocess_bwd_ewa<true> stages both through one buffer).
+template <bool WRITE>
+__device__ __forceinline__ void sh_backward_phase(int deg, const float* sh, float x, float y, float z, const float* dRGB, float* dL_dsh,
+                                                  float* dRGBdx, float* dRGBdy, float* dRGBdz)
 {
-    float3 dir_orig = make_float3(mean.x - campos.x, mean.y - campos.y, mean.z - campos.z);
-    float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-    float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-    float dRGB[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[c] * (((clamped >> c) & 1u) ? 0.0f : 1.0f);
-    float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
-#define SHSET(k, coef) do { float cf_ = (coef); for (int c = 0; c < 3; c++) dL_dsh[(k) * 3 + c] = cf_ * dRGB[c]; } while (0)
+#define SHSET(k, coef) do { if constexpr (WRITE) { float cf_ = (coef); for (int c = 0; c < 3; c++) dL_dsh[(k) * 3 + c] = cf_ * dRGB[c]; } } while (0)
     SHSET(0, GSR_SH_C0);
     if (deg > 0) {
         SHSET(1, -GSR_SH_C1 * y); SHSET(2, GSR_SH_C1 * z); SHSET(3, -GSR_SH_C1 * x);
-        for (int c = 0; c < 3; c++) {
+        if constexpr (!WRITE) for (int c = 0; c < 3; c++) {
             dRGBdx[c] = -GSR_SH_C1 * sh[3 * 3 + c]; dRGBdy[c] = -GSR_SH_C1 * sh[1 * 3 + c]; dRGBdz[c] = GSR_SH_C1 * sh[2 * 3 + c];
         }
         if (deg > 1) {
             float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
             SHSET(4, GSR_SH_C2[0] * xy); SHSET(5, GSR_SH_C2[1] * yz); SHSET(6, GSR_SH_C2[2] * (2.f * zz - xx - yy));
             SHSET(7, GSR_SH_C2[3] * xz); SHSET(8, GSR_SH_C2[4] * (xx - yy));
-            for (int c = 0; c < 3; c++) {
+            if constexpr (!WRITE) for (int c = 0; c < 3; c++) {
                 dRGBdx[c] += GSR_SH_C2[0] * y * sh[4 * 3 + c] + GSR_SH_C2[2] * 2.f * -x * sh[6 * 3 + c] + GSR_SH_C2[3] * z * sh[7 * 3 + c] + GSR_SH_C2[4] * 2.f * x * sh[8 * 3 + c];
                 dRGBdy[c] += GSR_SH_C2[0] * x * sh[4 * 3 + c] + GSR_SH_C2[1] * z * sh[5 * 3 + c] + GSR_SH_C2[2] * 2.f * -y * sh[6 * 3 + c] + GSR_SH_C2[4] * 2.f * -y * sh[8 * 3 + c];
                 dRGBdz[c] += GSR_SH_C2[1] * y * sh[5 * 3 + c] + GSR_SH_C2[2] * 2.f * 2.f * z * sh[6 * 3 + c] + GSR_SH_C2[3] * x * sh[7 * 3 + c];
@@ -439,7 +497,7 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* sh, f
                 SHSET(13, GSR_SH_C3[4] * x * (4.f * zz - xx - yy));
                 SHSET(14, GSR_SH_C3[5] * z * (xx - yy));
                 SHSET(15, GSR_SH_C3[6] * x * (xx - 3.f * yy));
-                for (int c = 0; c < 3; c++) {
+                if constexpr (!WRITE) for (int c = 0; c < 3; c++) {
                     dRGBdx[c] += (GSR_SH_C3[0] * sh[9 * 3 + c] * 3.f * 2.f * xy + GSR_SH_C3[1] * sh[10 * 3 + c] * yz +
                                   GSR_SH_C3[2] * sh[11 * 3 + c] * -2.f * xy + GSR_SH_C3[3] * sh[12 * 3 + c] * -3.f * 2.f * xz +
                                   GSR_SH_C3[4] * sh[13 * 3 + c] * (-3.f * xx + 4.f * zz - yy) + GSR_SH_C3[5] * sh[14 * 3 + c] * 2.f * xz +
@@ -456,15 +514,41 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, const float* sh, f
         }
     }
 #undef SHSET
+}
+__device__ __forceinline__ float3 sh_backward(int deg, int M, const float* sh, float3 mean, float3 campos, uint32_t clamped,
+                                              const float* dL_dcolor, float* dL_dsh)
+{
+    (void)M;
+    float3 dir_orig = make_float3(mean.x - campos.x, mean.y - campos.y, mean.z - campos.z);
+    float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    float dRGB[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[c] * (((clamped >> c) & 1u) ? 0.0f : 1.0f);
+    float dRGBdx[3] = { 0, 0, 0 }, dRGBdy[3] = { 0, 0, 0 }, dRGBdz[3] = { 0, 0, 0 };
+    sh_backward_phase<false>(deg, sh, x, y, z, dRGB, dL_dsh, dRGBdx, dRGBdy, dRGBdz);
+    sh_backward_phase<true>(deg, sh, x, y, z, dRGB, dL_dsh, dRGBdx, dRGBdy, dRGBdz);
     float3 dL_ddir = make_float3(dot3(dRGBdx, dRGB), dot3(dRGBdy, dRGB), dot3(dRGBdz, dRGB));
     return dnormvdv(dir_orig, dL_ddir);
 }
 
 // EWA/PLANE: computeCov2DCUDA + preprocessCUDA + computeCov3D of 3DGS backward.cu:144-396 fused in one pass.
+// SH16: the 16 x 3 SH coefficients and their gradients go through one LDS row per gaussian (see k_preprocess_ewa_sh16: coalesced 16-byte-per-lane
+// copies instead of 48 loads + 48 stores per lane that each touch 64 cache lines) -- sh_backward reads the row, then overwrites it with dL_dsh.
+template <bool SH16>
 __global__ void __launch_bounds__(256) k_preprocess_bwd_ewa(PreBwdParams p)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.P) return;
+    float* sh_row = nullptr;
+    const int lane = threadIdx.x & 63;
+    const size_t g0 = (size_t)(idx - lane);
+    if constexpr (SH16) {
+        __shared__ float s_sh[4 * 64 * GSR_SH_ROW];
+        float* my = s_sh + (threadIdx.x >> 6) * 64 * GSR_SH_ROW;
+        sh_row = my + lane * GSR_SH_ROW;
+        sh_rows_load(my, p.shs, g0, lane, (size_t)p.P * 48);
+    }
+    auto body = [&]() {
     const int AS = (p.variant == GSR_PLANE) ? GSR_ACC_PLANE : GSR_ACC_EWA;
     const float* a = p.acc + (size_t)idx * AS;
     const float dcol[3] = { a[0], a[1], a[2] };
@@ -532,11 +616,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_ewa(PreBwdParams p)
         dmean[2] += (proj[8] * m_w - proj[11] * mul1) * dm2x + (proj[9] * m_w - proj[11] * mul2) * dm2y;
         // ---- SH (backward.cu:389-391)
         if (p.shs) {
-            float3 ds = sh_backward(p.D, p.M, p.shs + (size_t)idx * p.M * 3, mean, make_float3(p.campos[0], p.campos[1], p.campos[2]),
-                                    p.clamped[idx], dcol, ig.dL_dsh + (size_t)idx * p.M * 3);
+            float* dsh = SH16 ? sh_row : ig.dL_dsh + (size_t)idx * p.M * 3;
+            float3 ds = sh_backward(p.D, p.M, SH16 ? sh_row : p.shs + (size_t)idx * p.M * 3, mean, make_float3(p.campos[0], p.campos[1], p.campos[2]),
+                                    p.clamped[idx], dcol, dsh);
             // coefficients above the active degree are never written by sh_backward: zero them
             const int used = (p.D + 1) * (p.D + 1);
-            for (int k = used; k < p.M; k++) for (int c = 0; c < 3; c++) ig.dL_dsh[((size_t)idx * p.M + k) * 3 + c] = 0.f;
+            for (int k = used; k < p.M; k++) for (int c = 0; c < 3; c++) dsh[k * 3 + c] = 0.f;
             dmean[0] += ds.x; dmean[1] += ds.y; dmean[2] += ds.z;
         }
         // ---- cov3D -> scale, rotation (backward.cu:278-341; no quaternion-normalisation Jacobian)
@@ -562,20 +647,34 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_ewa(PreBwdParams p)
             drot[3] = 2 * r * (dMt.c[0][1] - dMt.c[1][0]) + 2 * x * (dMt.c[2][0] + dMt.c[0][2]) + 2 * y * (dMt.c[1][2] + dMt.c[2][1]) - 4 * z * (dMt.c[1][1] + dMt.c[0][0]);
         }
     } else if (p.shs && ig.dL_dsh) {
-        for (int k = 0; k < p.M * 3; k++) ig.dL_dsh[(size_t)idx * p.M * 3 + k] = 0.f;
+        float* dsh = SH16 ? sh_row : ig.dL_dsh + (size_t)idx * p.M * 3;
+        for (int k = 0; k < p.M * 3; k++) dsh[k] = 0.f;
     }
     for (int i = 0; i < 3; i++) ig.dL_dmeans3D[3 * idx + i] = dmean[i];
     for (int i = 0; i < 6; i++) ig.dL_dcov3D[6 * idx + i] = dcov[i];
     for (int i = 0; i < 3; i++) ig.dL_dscales[3 * idx + i] = dsc[i];
     for (int i = 0; i < 4; i++) ig.dL_drotations[4 * idx + i] = drot[i];
     if (p.acc_clear) { if (p.variant == GSR_PLANE) clear_acc_row<GSR_ACC_PLANE / 4>(p.acc_clear, idx); else clear_acc_row<GSR_ACC_EWA / 4>(p.acc_clear, idx); }
+    };
+    if (idx < p.P) body();
+    if constexpr (SH16) sh_rows_store(sh_row - lane * GSR_SH_ROW, p.ig.dL_dsh, g0, lane, (size_t)p.P * 48);      // the wave's 64 rows of dL_dsh
 }
 
 // SURFEL backward.cu:450-637
+template <bool SH16>
 __global__ void __launch_bounds__(256) k_preprocess_bwd_surfel(PreBwdParams p)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.P) return;
+    float* sh_row = nullptr;
+    const int lane = threadIdx.x & 63;
+    const size_t g0 = (size_t)(idx - lane);
+    if constexpr (SH16) {          // SH coefficients and their gradients through one LDS row per gaussian, as in k_preprocess_bwd_ewa<true>
+        __shared__ float s_sh[4 * 64 * GSR_SH_ROW];
+        float* my = s_sh + (threadIdx.x >> 6) * 64 * GSR_SH_ROW;
+        sh_row = my + lane * GSR_SH_ROW;
+        sh_rows_load(my, p.shs, g0, lane, (size_t)p.P * 48);
+    }
+    auto body = [&]() {
     const float* a = p.acc + (size_t)idx * GSR_ACC_SURFEL;
     const float dcol[3] = { a[0], a[1], a[2] };
     const float dop = a[3];
@@ -667,10 +766,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_surfel(PreBwdParams p)
         }
         if (p.shs) {
             float3 mean = make_float3(p.means3D[3 * idx], p.means3D[3 * idx + 1], p.means3D[3 * idx + 2]);
-            float3 ds = sh_backward(p.D, p.M, p.shs + (size_t)idx * p.M * 3, mean, make_float3(p.campos[0], p.campos[1], p.campos[2]),
-                                    p.clamped[idx], dcol, ig.dL_dsh + (size_t)idx * p.M * 3);
+            float* dsh = SH16 ? sh_row : ig.dL_dsh + (size_t)idx * p.M * 3;
+            float3 ds = sh_backward(p.D, p.M, SH16 ? sh_row : p.shs + (size_t)idx * p.M * 3, mean, make_float3(p.campos[0], p.campos[1], p.campos[2]),
+                                    p.clamped[idx], dcol, dsh);
             const int used = (p.D + 1) * (p.D + 1);
-            for (int k = used; k < p.M; k++) for (int c = 0; c < 3; c++) ig.dL_dsh[((size_t)idx * p.M + k) * 3 + c] = 0.f;
+            for (int k = used; k < p.M; k++) for (int c = 0; c < 3; c++) dsh[k * 3 + c] = 0.f;
             dmean[0] += ds.x; dmean[1] += ds.y; dmean[2] += ds.z;
         }
         // densification proxy (backward.cu:633-636): uses the transMat the blend used and the (possibly updated) dL_dtransMat
@@ -678,7 +778,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_surfel(PreBwdParams p)
         m2x = (float)(dTout[2] * depth * 0.5 * (float)Wb);
         m2y = (float)(dTout[5] * depth * 0.5 * (float)Hb);
     } else if (p.shs && ig.dL_dsh) {
-        for (int k = 0; k < p.M * 3; k++) ig.dL_dsh[(size_t)idx * p.M * 3 + k] = 0.f;
+        float* dsh = SH16 ? sh_row : ig.dL_dsh + (size_t)idx * p.M * 3;
+        for (int k = 0; k < p.M * 3; k++) dsh[k] = 0.f;
     }
     ig.dL_dmeans2D[3 * idx] = m2x; ig.dL_dmeans2D[3 * idx + 1] = m2y; ig.dL_dmeans2D[3 * idx + 2] = 0.f;
     for (int i = 0; i < 3; i++) ig.dL_dmeans3D[3 * idx + i] = dmean[i];
@@ -686,6 +787,9 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_surfel(PreBwdParams p)
     ig.dL_dscales[2 * idx] = dsc[0]; ig.dL_dscales[2 * idx + 1] = dsc[1];
     for (int i = 0; i < 4; i++) ig.dL_drotations[4 * idx + i] = drot[i];
     if (p.acc_clear) clear_acc_row<GSR_ACC_SURFEL / 4>(p.acc_clear, idx);
+    };
+    if (idx < p.P) body();
+    if constexpr (SH16) sh_rows_store(sh_row - lane * GSR_SH_ROW, p.ig.dL_dsh, g0, lane, (size_t)p.P * 48);
 }
 
 int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* radii, GeomView g,
@@ -701,7 +805,11 @@ int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const in
     p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
     p.radii = radii; p.clamped = g.clamped; p.rec = g.rec; p.acc = acc; p.acc_clear = leave_zero ? acc : nullptr; p.ig = *ig;
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);
-    if (cfg->variant == GSR_SURFEL) hipLaunchKernelGGL(k_preprocess_bwd_surfel, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(k_preprocess_bwd_ewa, grid, block, 0, s, p);
+    static int stage_sh = -1;                  // GSR_SH_STAGE=0: SH coefficients and their gradients straight from / to global memory (rounds 1-3)
+    if (stage_sh < 0) { const char* e = getenv("GSR_SH_STAGE"); stage_sh = e ? (atoi(e) != 0) : 1; }
+    const bool sh16 = stage_sh && p.shs && p.ig.dL_dsh && cfg->M == 16 && ((((uintptr_t)p.shs) | ((uintptr_t)p.ig.dL_dsh)) & 15) == 0;
+    if (cfg->variant == GSR_SURFEL) { if (sh16) hipLaunchKernelGGL(k_preprocess_bwd_surfel<true>, grid, block, 0, s, p); else hipLaunchKernelGGL(k_preprocess_bwd_surfel<false>, grid, block, 0, s, p); }
+    else if (sh16) hipLaunchKernelGGL(k_preprocess_bwd_ewa<true>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_preprocess_bwd_ewa<false>, grid, block, 0, s, p);
     return gsr_check_launch("preprocess_bwd", s, cfg->debug);
 }
