@@ -414,9 +414,10 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
     volatile uint32_t* word = mb->host + 16 * slot;
     if (poll) { *word = 0xFFFFFFFFu; std::atomic_thread_fence(std::memory_order_seq_cst); }
     { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
-    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s)) return 1; }
+    // with the mailbox polled the total (num_rendered) may arrive a kernel later: k_duplicate adds up the block sums and publishes it
+    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s, poll != 0)) return 1; }
     if (!poll) GSR_CHECK(hipEventRecord(mb->ev[slot], s), "event record");
-    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s)) return 1; }
+    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s, poll != 0, mb->dev + 16 * slot)) return 1; }
     { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1; }
     uint32_t R;
     if (poll) {
@@ -464,9 +465,9 @@ extern "C" int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void*
     ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, img);
     if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
     if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1;
-    if (gsr_launch_depth_order(cfg, g, nullptr, s)) return 1;
-    hipLaunchKernelGGL(k_forward_status, dim3(1), dim3(1), 0, s, g.counters, cap, status_dev);
-    if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s)) return 1;
+    if (gsr_launch_depth_order(cfg, g, nullptr, s, true)) return 1;
+    if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s, true, nullptr)) return 1;
+    hipLaunchKernelGGL(k_forward_status, dim3(1), dim3(1), 0, s, g.counters, cap, status_dev);      // after the binning: k_duplicate may be the one that publishes the total
     if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1;
     return 0;
 }

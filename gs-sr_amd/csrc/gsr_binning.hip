@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t* lds /*
 
 // ------------------------------------------------------------------------------------------------ generic scan
 // in-place exclusive scan of n words by ONE block (n is small: histograms, block sums)
-__global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, uint32_t n, uint32_t* total_out, uint32_t* host_word)
+__global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, uint32_t n, uint32_t* total_out, uint32_t* host_word, int total_only = 0)
 {
     __shared__ uint32_t lds[17];
     const uint32_t chunk = (n + blockDim.x - 1) / blockDim.x;
@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_scan_small(uint32_t* data, u
     uint32_t tot;
     uint32_t incl = block_incl_scan(sum, lds, &tot);
     uint32_t run = incl - sum;
-    for (uint32_t i = b; i < e; i++) { uint32_t v = data[i]; data[i] = run; run += v; }
+    if (!total_only)           // total_only: the block sums stay as they are (k_duplicate adds them up itself), only the total is published
+        for (uint32_t i = b; i < e; i++) { uint32_t v = data[i]; data[i] = run; run += v; }
     if (threadIdx.x == 0) {
         if (total_out) *total_out = tot;
         if (host_word) __hip_atomic_store(host_word, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // mapped pinned word: no D2H copy command
@@ -371,6 +372,12 @@ bool gsr_prefix_in_preprocess(const gsr_cfg* cfg)
     const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
     return fused != 0 && !gsr_depth_order_is_global(cfg->P, T);
 }
+bool gsr_duplicate_scans()      // GSR_SCAN=kernel keeps k_scan_small in the single-call forwards too
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("GSR_SCAN"); on = (e && e[0] == 'k') ? 0 : 1; }
+    return on != 0;
+}
 bool gsr_depth_order_is_global(int P, int T)
 {
     static int mode = -1;                       // 0 auto, 1 global, 2 tile
@@ -380,7 +387,7 @@ bool gsr_depth_order_is_global(int P, int T)
     return (long long)P > 192ll * (long long)T;
 }
 
-int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s)
+int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s, bool total_by_duplicate)
 {
     const uint32_t P = (uint32_t)cfg->P;
     const int T_tiles = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
@@ -390,7 +397,13 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
         const bool fused = gsr_prefix_in_preprocess(cfg);
         const uint32_t nb = gsr_div_up(P, fused ? 256u : (uint32_t)GSR_SCAN_BLOCK);
         if (!fused) hipLaunchKernelGGL(k_offsets_local, dim3(nb), dim3(GSR_SCAN_BLOCK), 0, s, (const uint32_t*)nullptr, g.tiles_touched, P, g.offsets, g.scan_tmp);
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nb, g.counters, host_word_dev);
+        // total_by_duplicate (single-call forwards, where the binning follows at once): k_duplicate adds up the block sums itself and publishes
+        // num_rendered -- nothing to launch here (gsr_duplicate_scans)
+        // with gsr_duplicate_scans() the block sums are left RAW in either case (a redo of the binning after an overflowed speculative forward finds
+        // them as the first one did); two-stage forwards still need the total now: k_scan_small in its total-only form
+        const bool raw = fused && gsr_duplicate_scans();
+        if (!(raw && total_by_duplicate))
+            hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nb, g.counters, host_word_dev, raw ? 1 : 0);
         return gsr_check_launch("depth_order", s, cfg->debug);
     }
     bool in_b = false;
@@ -422,7 +435,8 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
                                                    const ushort4* __restrict__ rect, int gx,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap,
                                                    uint2* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ zero_ptr, uint32_t zero_n,
-                                                   uint32_t* __restrict__ order_valid, uint32_t scan_block)
+                                                   uint32_t* __restrict__ order_valid, uint32_t scan_block,
+                                                   uint32_t self_nblk, uint32_t* __restrict__ total_out, uint32_t* __restrict__ host_word)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x);          // position in depth order
@@ -433,8 +447,29 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
     const bool v = i < P;
     const uint32_t g = v ? (sorted_idx ? sorted_idx[i] : i) : 0u;
     const uint32_t cnt = v ? tiles_touched[g] : 0u;
-    // inclusive prefix of tiles_touched in depth order = block-local prefix (k_offsets_local) + exclusive prefix of the block sums
-    const uint32_t incl = v ? offsets[i] + block_prefix[i / scan_block] : 0u;
+    // inclusive prefix of tiles_touched in depth order = block-local prefix (k_offsets_local / the preprocess kernel) + exclusive prefix of the
+    // block sums.  self_nblk > 0: block_prefix holds the RAW sums of self_nblk 256-gaussian blocks and every workgroup adds up the ones in front of
+    // its own (a few KB of L2 reads) instead of a single-workgroup scan kernel doing it for all (k_scan_small, 4.5 us + a launch); the workgroup of
+    // the last block publishes the total = num_rendered (device word for the kernels that follow, mapped pinned word for the host).
+    uint32_t bp = 0u;
+    if (self_nblk) {
+        __shared__ uint32_t s_red[4];
+        if (blockIdx.x < self_nblk) {                    // workgroup-uniform
+            uint32_t part = 0u;
+            for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256u) part += block_prefix[j];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+            if (lane == 0) s_red[threadIdx.x >> 6] = part;
+            __syncthreads();
+            bp = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+            if (blockIdx.x == self_nblk - 1u && threadIdx.x == 0) {
+                const uint32_t tot = bp + block_prefix[blockIdx.x];
+                *total_out = tot;
+                if (host_word) __hip_atomic_store(host_word, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    } else if (v) bp = block_prefix[i / scan_block];
+    const uint32_t incl = v ? offsets[i] + bp : 0u;
     ushort4 r = make_ushort4(0, 0, 1, 1);
     if (cnt) r = rect[g];
     const uint32_t wave_base = __shfl(incl - cnt, 0, 64);
@@ -696,7 +731,8 @@ int gsr_tile_sort_passes(int T) { return (tile_bits(T) + 7) / 8; }
 
 // R is the exact instance count, or -- when n_dev != nullptr -- the CAPACITY of the binning arena while the exact count
 // is read on the device from *n_dev (speculative forward: the host has not seen it yet).
-int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s)
+int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s,
+                       bool total_by_duplicate, uint32_t* host_word_dev)
 {
     const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     const int T = gx * gy;
@@ -711,10 +747,13 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
     const bool global_order = gsr_depth_order_is_global(cfg->P, T);
+    (void)total_by_duplicate;
+    const bool self_scan = gsr_prefix_in_preprocess(cfg) && gsr_duplicate_scans();      // the block sums are raw: every workgroup adds up the ones in front of it
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P,
                        global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
                        g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256), im.tile_order + T,
-                       gsr_prefix_in_preprocess(cfg) ? 256u : (uint32_t)GSR_SCAN_BLOCK);
+                       gsr_prefix_in_preprocess(cfg) ? 256u : (uint32_t)GSR_SCAN_BLOCK,
+                       self_scan ? gsr_div_up((uint32_t)cfg->P, 256u) : 0u, g.counters, host_word_dev);
     bool in_b = false;
     // tile ranges: k_tile_ranges over the sorted keys (default), or written by the last scatter pass (GSR_TILE_RANGES=scatter).  MEASURED (round 3,
     // P = 300k, 1080p): the fold loses -- binning 0.0847 ms against 0.0748 with the separate 5 us kernel: two more LDS reads, a compare and

@@ -90,8 +90,10 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug);
 
 // ---- stage launchers (each in its own .hip) ------------------------------------------------------------------
 int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s);
-int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s);   // sorted_idx, offsets, counters[0]
-int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s);
+int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s, bool total_by_duplicate = false);   // sorted_idx, offsets, counters[0]
+bool gsr_duplicate_scans();
+int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s,
+                       bool total_by_duplicate = false, uint32_t* host_word_dev = nullptr);
 int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_outputs* out, hipStream_t s);
 int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
