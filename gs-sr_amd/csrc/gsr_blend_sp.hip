@@ -154,8 +154,10 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const bool ok = valid & (idx0 < last) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
         const float al = ok ? alpha : 0.0f, Gm = ok ? G : 0.0f;
         const float om = 1.f - al;
-        const float pi = row_scan_mul(om);
-        const float Tj = bc_fresh<I>(K.Tc) * rcp_(pi);
+        // T_j = T_carry / prod_{k <= j} (1 - alpha_k): the row scan runs on the reciprocals 1 / (1 - alpha_k), which the dL/dalpha term needs anyway --
+        // one v_rcp_f32 (8 issue cycles) per step instead of two
+        const float r1a = rcp_(om);
+        const float Tj = bc_fresh<I>(K.Tc) * row_scan_mul(r1a);
         const float w = al * Tj;
         float u = bc_mul<I>(K.dLp0, q1.z);
         u = bc_fmac<I>(u, K.dLp1, q1.w);
@@ -170,7 +172,6 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float si = row_scan_add(wu);
         const float Scb = bc_fresh<I>(K.Sc);
         const float Sfx = Scb + (si - wu);
-        const float r1a = rcp_(om);
         const float dL_dalpha = ok ? (u * Tj - Sfx * r1a) : 0.0f;
         {   // new carry of pixel I = the state in front of lane 15's splat
             const float nT = bc_fresh<15>(Tj), nS = bc_fresh<15>(Scb + si);
@@ -217,8 +218,10 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const bool ok = valid & (idx0 < last) & !(ppz == 0.0f) & !(c_d < NEAR_N) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
         const float al = ok ? alpha : 0.0f, cd = ok ? c_d : 1.0f, okf = ok ? 1.0f : 0.0f;
         const float om = 1.f - al;
-        const float pi = row_scan_mul(om);
-        const float Tj = bc_fresh<I>(K.Tc) * rcp_(pi);
+        // T_j = T_carry / prod_{k <= j} (1 - alpha_k): the row scan runs on the reciprocals 1 / (1 - alpha_k), which the dL/dalpha term needs anyway --
+        // one v_rcp_f32 (8 issue cycles) per step instead of two
+        const float r1a = rcp_(om);
+        const float Tj = bc_fresh<I>(K.Tc) * row_scan_mul(r1a);
         const float w = al * Tj;
         const float rcd = rcp_(cd);
         const float m_d = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcd);
@@ -237,7 +240,6 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float si = row_scan_add(wu);
         const float Scb = bc_fresh<I>(K.Sc);
         const float Sfx = Scb + (si - wu);
-        const float r1a = rcp_(om);
         const float dL_dalpha = ok ? (u * Tj - Sfx * r1a) : 0.0f;
         {
             const float nT = bc_fresh<15>(Tj), nS = bc_fresh<15>(Scb + si);
