@@ -604,6 +604,21 @@ def test_tile_ranges_from_the_last_scatter_pass():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+@pytest.mark.parametrize("env", [{"GSR_SH_STAGE": "0"}, {"GSR_PREFIX": "kernel"}, {"GSR_SCAN": "kernel"}, {"GSR_MAILBOX_POLL": "0"}, {"GSR_XCD_REMAP": "0"},
+                                 {"GSR_XCD_REMAP": "1"}])
+def test_round3_switches_keep_the_results(env):
+    """The A/B switches of the round-3 changes (SH rows straight from global memory, the prefix / scan kernels as launches of their own, the event
+    instead of the polled mailbox, raster / banded launch order): the parity cases incl. SH colours, the speculative forward with its overflow
+    redo and the edge cases re-run in a child process with each switch set."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_forward_backward_parity or test_speculative_forward or test_edge_cases or test_full_size_properties", "-p", "no:cacheprovider"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_eleven_bit_depth_sort_kept_switchable():
     """GSR_DEPTH_BITS=11 (three 2048-bin passes instead of four 256-bin ones, kept for A/B) has to give the same bit-exact lists: the integer
     checks of the parity cases are re-run in a child process with the switch set."""
