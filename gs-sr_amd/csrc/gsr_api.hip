@@ -321,6 +321,9 @@ uint32_t* gsr_long_list_word()
     return mb ? mb->dev + 16 * GSR_MAIL_SLOTS : nullptr;
 }
 
+// the reference's message (auxiliary.h:157); it then traps the device, this library fails the forward call
+#define GSR_PREFILTERED_MSG "Point is filtered although prefiltered is set. This shouldn't happen!"
+
 // ------------------------------------------------------------------------------------------------ forward
 extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
                                   int32_t* radii, uint32_t* num_rendered_host, void* stream)
@@ -331,15 +334,17 @@ extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void
     if (cfg->P == 0) return 0;
     GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
     if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
-    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
     Mailbox* mb = mailbox();
     const unsigned slot = mb ? take_slot(mb) : 0u;
     struct SlotGuard { Mailbox* m; unsigned s; ~SlotGuard() { if (m) release_slot(m, s); } } guard{mb, slot};
+    if (mb) mb->host[16 * slot + 1] = 0u;                      // "a gaussian failed the frustum test although prefiltered is set"
+    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s, mb ? mb->dev + 16 * slot + 1 : nullptr)) return 1; }
     { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb ? mb->dev + 16 * slot : nullptr, s)) return 1; }
     // the one host<->device sync of the forward (reference: cudaMemcpy of point_offsets[P-1], rasterizer_impl.cu:281)
     if (mb) {
         GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
         *num_rendered_host = *(volatile uint32_t*)(mb->host + 16 * slot);
+        if (cfg->prefiltered && *(volatile uint32_t*)(mb->host + 16 * slot + 1)) { gsr_set_error("%s", GSR_PREFILTERED_MSG); return 1; }
     } else {
         GSR_CHECK(hipMemcpyAsync(num_rendered_host, g.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read num_rendered");
         GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
@@ -412,8 +417,9 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
     static int poll = -1;
     if (poll < 0) { const char* e = getenv("GSR_MAILBOX_POLL"); poll = e ? (atoi(e) != 0) : 1; }
     volatile uint32_t* word = mb->host + 16 * slot;
+    mb->host[16 * slot + 1] = 0u;                              // "a gaussian failed the frustum test although prefiltered is set"
     if (poll) { *word = 0xFFFFFFFFu; std::atomic_thread_fence(std::memory_order_seq_cst); }
-    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1; }
+    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s, mb->dev + 16 * slot + 1)) return 1; }
     // with the mailbox polled the total (num_rendered) may arrive a kernel later: k_duplicate adds up the block sums and publishes it
     { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s, poll != 0)) return 1; }
     if (!poll) GSR_CHECK(hipEventRecord(mb->ev[slot], s), "event record");
@@ -438,6 +444,8 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
     }
     *num_rendered_host = R;
     *overflow_host = (R > cap) ? 1 : 0;
+    // the preprocess has finished by now (num_rendered comes from a kernel behind it), so its word is final
+    if (cfg->prefiltered && *(volatile uint32_t*)(mb->host + 16 * slot + 1)) { gsr_set_error("%s", GSR_PREFILTERED_MSG); return 1; }
     return 0;
 }
 

@@ -89,7 +89,7 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug);
     } while (0)
 
 // ---- stage launchers (each in its own .hip) ------------------------------------------------------------------
-int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s);
+int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s, uint32_t* prefiltered_err = nullptr);
 int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s, bool total_by_duplicate = false);   // sorted_idx, offsets, counters[0]
 bool gsr_duplicate_scans();
 int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s,

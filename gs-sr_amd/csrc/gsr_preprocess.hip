@@ -23,6 +23,10 @@ struct PreParams {
     // per-tile depth order (instances emitted in id order): the block-local inclusive prefix of tiles_touched and the block totals are written here, by
     // this kernel, instead of by a k_offsets_local launch of their own (5 us); nullptr: not wanted (global depth order, visible_filter)
     uint32_t* scan_offsets; uint32_t* scan_sums;
+    // GaussianRasterizationSettings.prefiltered: the caller asserts that no gaussian fails the frustum test.  The reference prints "Point is filtered
+    // although prefiltered is set" and traps the device (auxiliary.h:156-160); here the kernel stores 1 into this mapped word and the forward call
+    // that owns it fails with that message.  nullptr: not checked.
+    uint32_t* prefiltered_err;
 };
 
 __device__ __forceinline__ void load16(const float* p, float* m)
@@ -56,7 +60,10 @@ __device__ __forceinline__ uint32_t pre_ewa_one(const PreParams& p, const int id
     const float3 p_orig = make_float3(p.means3D[3 * idx], p.means3D[3 * idx + 1], p.means3D[3 * idx + 2]);
     const float3 p_view = xform_point4x3(p_orig, view);
     do {
-        if (p_view.z <= 0.2f) break;                                    // in_frustum, auxiliary.h:139-164
+        if (p_view.z <= 0.2f) {                                         // in_frustum, auxiliary.h:139-164
+            if (p.prefiltered_err) __hip_atomic_store(p.prefiltered_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         float4 p_hom = xform_point4x4(p_orig, proj);
         float p_w = 1.0f / (p_hom.w + 0.0000001f);
         float projx = p_hom.x * p_w, projy = p_hom.y * p_w;
@@ -212,7 +219,10 @@ __device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int
     const float3 p_orig = make_float3(p.means3D[3 * idx], p.means3D[3 * idx + 1], p.means3D[3 * idx + 2]);
     const float3 p_view = xform_point4x3(p_orig, view);
     do {
-        if (p_view.z <= 0.2f) break;
+        if (p_view.z <= 0.2f) {
+            if (p.prefiltered_err) __hip_atomic_store(p.prefiltered_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         if (!p.cov3D_pre) {
             M3 R;
             surfel_transmat(p_orig, p.scales + 2 * idx, p.mod, p.rots + 4 * idx, proj, view, p.W, p.H, T, normal, R);
@@ -345,15 +355,16 @@ static PreParams make_params(const gsr_cfg* cfg, const gsr_inputs* in, GeomView 
     p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
     { const char* e = getenv("GSR_NO_CULL"); p.no_cull = (e && atoi(e) != 0) ? 1 : 0; }
     p.in_mask = nullptr; p.scale_stride = 3;
-    p.scan_offsets = nullptr; p.scan_sums = nullptr;
+    p.scan_offsets = nullptr; p.scan_sums = nullptr; p.prefiltered_err = nullptr;
     p.radii = radii; p.g = g;
     p.zero_ptr = nullptr; p.zero_n = 0;
     return p;
 }
 
-int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s)
+int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s, uint32_t* prefiltered_err)
 {
     PreParams p = make_params(cfg, in, g, radii);
+    p.prefiltered_err = cfg->prefiltered ? prefiltered_err : nullptr;
     p.zero_ptr = g.hist; p.zero_n = gsr_sort_group_words((uint32_t)cfg->P, false, gsr_depth_sort_digit_bins());
     if (gsr_prefix_in_preprocess(cfg)) { p.scan_offsets = g.offsets; p.scan_sums = g.scan_tmp; }
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);

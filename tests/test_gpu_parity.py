@@ -648,3 +648,36 @@ def test_launch_order_feedback_leaves_results_alone():
             assert np.array_equal(r[k], runs[0][k]), k
     with oracle.Forward(sc, "surfel") as f:
         assert np.array_equal(runs[-1]["point_list"], f.point_list())
+
+
+@pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
+def test_prefiltered_set_and_a_point_behind_the_camera(variant):
+    """GaussianRasterizationSettings.prefiltered=True asserts that every gaussian passes the frustum test; the reference prints "Point is filtered
+    although prefiltered is set. This shouldn't happen!" and traps the device when one does not (auxiliary.h:156-160).  Here the forward call
+    fails with that message (both the two-stage and the single-call forward), and a scene that keeps the promise renders as with prefiltered=False."""
+    from gsrast import rasterize as rz
+    hr = _hiprun()
+    W, H, P = 160, 112, 1500
+    sc = scenes.make_scene(variant, P, W, H, seed=5)
+    t = hr.to_dev(sc, "cuda")
+    vid = hr.VID[variant]
+    rs = hr.settings(variant, t)._replace(prefiltered=True)
+    args = (t["means3D"], t.get("shs"), t.get("colors_precomp"), t["opacities"], t.get("scales"), t.get("rotations"), t.get("cov3D_precomp"),
+            t.get("all_map") if variant == "plane" else None)
+    key = (torch.cuda.current_device(), vid, W, H)
+    rz._R_HINT.pop(key, None)
+    ok1 = rz.forward(vid, *args, rs)                      # no hint: stage1 + stage2
+    ok2 = rz.forward(vid, *args, rs)                      # hint: single call
+    ref = rz.forward(vid, *args, rs._replace(prefiltered=False))
+    assert ok1[0] == ok2[0] == ref[0]
+    assert torch.equal(ok2[1]["color"], ref[1]["color"])
+    bad = t["means3D"].clone()
+    V = t["viewmatrix"]
+    behind = torch.tensor([0.0, 0.0, -1.0], device=bad.device)        # one gaussian one unit behind the camera (camera space) -> world
+    bad[7] = (behind - V[3, :3]) @ torch.linalg.inv(V[:3, :3])
+    for hint in (False, True):
+        if not hint:
+            rz._R_HINT.pop(key, None)
+        with pytest.raises(RuntimeError, match="prefiltered is set"):
+            rz.forward(vid, bad, *args[1:], rs)
+    rz.forward(vid, bad, *args[1:], rs._replace(prefiltered=False))   # without the promise the point is simply culled
