@@ -51,7 +51,9 @@ def algorithmic_bytes(variant, R, N, T):
 
 
 def depth_order_is_global(P, T):
-    """The library's choice (gsr_binning.hip gsr_depth_order_is_global): per-tile depth sort while P <= 192 T unless GSR_DEPTH_ORDER says otherwise."""
+    """The library's static rule (gsr_binning.hip gsr_depth_order_static_rule): per-tile depth sort while P <= 192 T unless GSR_DEPTH_ORDER says otherwise.
+    (On scenes with tile lists beyond 6000 entries the library's feedback switches to the global order, gsr_api.hip gsr_forward_begin: the skewed side
+    scenes of --skew-frac; not the BASELINE workload.)"""
     e = os.environ.get("GSR_DEPTH_ORDER", "")
     return True if e[:1] == "g" else (False if e[:1] == "t" else P > 192 * T)
 

@@ -225,6 +225,7 @@ struct Mailbox {
     std::atomic<unsigned> next{0};
     std::atomic<int> busy[GSR_MAIL_SLOTS];
     std::atomic<int> order_ttl{0};          // forwards for which the longest-first launch order stays on after the last long-list report
+    std::atomic<int> global_ttl{0};         // forwards for which the global depth order stays on after the last report of a list > 6000 entries
 };
 static Mailbox g_mail[64];
 static std::mutex g_mail_mu;
@@ -270,13 +271,60 @@ bool gsr_tile_order_wanted()
     if (mode == -2) { const char* e = getenv("GSR_TILE_ORDER"); mode = (!e || e[0] == 'a') ? -1 : (atoi(e) != 0 ? 1 : 0); }
     if (mode >= 0) return mode != 0;
     Mailbox* mb = mailbox();
-    if (!mb) return false;
-    volatile uint32_t* w = mb->host + 16 * GSR_MAIL_SLOTS;
-    if (*w != 0u) { *w = 0u; mb->order_ttl.store(64, std::memory_order_relaxed); return true; }
-    int t = mb->order_ttl.load(std::memory_order_relaxed);
-    if (t > 0) { mb->order_ttl.store(t - 1, std::memory_order_relaxed); return true; }
-    return false;
+    return mb && mb->order_ttl.load(std::memory_order_relaxed) > 0;      // set by gsr_forward_begin, once per forward
 }
+
+// Once per forward: read the long-list word the previous forwards' blend kernels stored into, refresh the two counters it drives -- longest-first
+// launch order for 64 forwards after a list beyond max(1024, 4 x mean); GLOBAL depth order for 64 forwards after a list beyond 6000 entries, where
+// the prologue's global-memory radix path loses to it (816 vs 780 it/s at 12 633 entries, a tie at 3800: profiles/r03_skewed_density.txt) --
+// and remember the depth order of this forward under the geom arena's address.
+struct DepthModeEnt { const void* key; int global; };
+static DepthModeEnt g_depth_mode[256];
+static unsigned g_depth_mode_next = 0;
+static std::mutex g_depth_mode_mu;
+void gsr_forward_begin(const gsr_cfg* cfg, const GeomView& g)
+{
+    const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
+    bool forced = false;
+    bool global = gsr_depth_order_static_rule(cfg->P, T, &forced);
+    Mailbox* mb = mailbox();
+    if (mb) {
+        volatile uint32_t* w = mb->host + 16 * GSR_MAIL_SLOTS;
+        const uint32_t longest = *w;
+        if (longest != 0u) {
+            *w = 0u;
+            mb->order_ttl.store(64, std::memory_order_relaxed);
+            if (longest > 6000u) mb->global_ttl.store(64, std::memory_order_relaxed);
+            else { const int t = mb->global_ttl.load(std::memory_order_relaxed); if (t > 0) mb->global_ttl.store(t - 1, std::memory_order_relaxed); }
+        } else {
+            int t = mb->order_ttl.load(std::memory_order_relaxed);
+            if (t > 0) mb->order_ttl.store(t - 1, std::memory_order_relaxed);
+            t = mb->global_ttl.load(std::memory_order_relaxed);
+            if (t > 0) mb->global_ttl.store(t - 1, std::memory_order_relaxed);
+        }
+        static int fb = -1;                     // GSR_DEPTH_FEEDBACK=0: the static rule only
+        if (fb < 0) { const char* e = getenv("GSR_DEPTH_FEEDBACK"); fb = e ? (atoi(e) != 0) : 1; }
+        if (fb && !forced && mb->global_ttl.load(std::memory_order_relaxed) > 0) global = true;
+    }
+    std::lock_guard<std::mutex> lk(g_depth_mode_mu);
+    for (DepthModeEnt& e : g_depth_mode) if (e.key == (const void*)g.depth_key) { e.global = global ? 1 : 0; return; }
+    g_depth_mode[g_depth_mode_next++ & 255u] = DepthModeEnt{(const void*)g.depth_key, global ? 1 : 0};
+}
+bool gsr_depth_order_is_global(const gsr_cfg* cfg, const GeomView& g)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_depth_mode_mu);
+        for (const DepthModeEnt& e : g_depth_mode) if (e.key == (const void*)g.depth_key && e.key) return e.global != 0;
+    }
+    const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
+    return gsr_depth_order_static_rule(cfg->P, T, nullptr);      // a geom arena this process has not run a preprocess on
+}
+uint32_t* gsr_long_list_word()
+{
+    Mailbox* mb = mailbox();
+    return mb ? mb->dev + 16 * GSR_MAIL_SLOTS : nullptr;
+}
+
 // blockIdx -> tile with 4x4-tile blocks dealt out to the eight XCDs cyclically (workgroup b runs on XCD b % 8): XCD x owns the blocks with
 // (bx + 3 by) % 8 == x and walks them in raster order, 16 tiles each; the eight lists are interleaved so that b % 8 selects the list.  Where the
 // lists differ in length the tail is filled from whichever list still has tiles (a permutation in any case).  Built on the host once per
@@ -314,11 +362,6 @@ const uint32_t* gsr_static_tile_map(int gx, int gy, hipStream_t s)
     if (hipMemcpy(d, map.data(), (size_t)T * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return nullptr; }
     cache.push_back({dev, gx, gy, d});
     return d;
-}
-uint32_t* gsr_long_list_word()
-{
-    Mailbox* mb = mailbox();
-    return mb ? mb->dev + 16 * GSR_MAIL_SLOTS : nullptr;
 }
 
 // the reference's message (auxiliary.h:157); it then traps the device, this library fails the forward call

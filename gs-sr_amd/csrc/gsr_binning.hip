@@ -365,12 +365,11 @@ uint32_t gsr_depth_sort_digit_bins()
 // the crossover was at ~96 T: profiles/r03_depth_order_ab.txt.)
 // The preprocess kernel also writes the block-local prefix of tiles_touched (per-tile depth order only: the global order needs the prefix in
 // depth-sorted order).  GSR_PREFIX=kernel keeps the separate k_offsets_local launch.
-bool gsr_prefix_in_preprocess(const gsr_cfg* cfg)
+bool gsr_prefix_in_preprocess(const gsr_cfg* cfg, const GeomView& g)
 {
     static int fused = -1;
     if (fused < 0) { const char* e = getenv("GSR_PREFIX"); fused = (e && e[0] == 'k') ? 0 : 1; }
-    const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
-    return fused != 0 && !gsr_depth_order_is_global(cfg->P, T);
+    return fused != 0 && !gsr_depth_order_is_global(cfg, g);
 }
 bool gsr_duplicate_scans()      // GSR_SCAN=kernel keeps k_scan_small in the single-call forwards too
 {
@@ -378,10 +377,12 @@ bool gsr_duplicate_scans()      // GSR_SCAN=kernel keeps k_scan_small in the sin
     if (on < 0) { const char* e = getenv("GSR_SCAN"); on = (e && e[0] == 'k') ? 0 : 1; }
     return on != 0;
 }
-bool gsr_depth_order_is_global(int P, int T)
+// The rule without feedback: GSR_DEPTH_ORDER=global|tile forces one (the returned flag says so), otherwise per tile while P <= 192 T.
+bool gsr_depth_order_static_rule(int P, int T, bool* forced)
 {
     static int mode = -1;                       // 0 auto, 1 global, 2 tile
     if (mode < 0) { const char* e = getenv("GSR_DEPTH_ORDER"); mode = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 't' ? 2 : 0)); }
+    if (forced) *forced = mode != 0;
     if (mode == 1) return true;
     if (mode == 2) return false;
     return (long long)P > 192ll * (long long)T;
@@ -391,10 +392,11 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
 {
     const uint32_t P = (uint32_t)cfg->P;
     const int T_tiles = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
-    if (!gsr_depth_order_is_global(cfg->P, T_tiles)) {
+    (void)T_tiles;
+    if (!gsr_depth_order_is_global(cfg, g)) {
         // id order: only the prefix sum of tiles_touched (block-local + block sums; k_duplicate adds the two) and num_rendered.  The block-local
         // part is written by the preprocess kernel itself (256-gaussian blocks, gsr_prefix_in_preprocess) unless GSR_PREFIX=kernel.
-        const bool fused = gsr_prefix_in_preprocess(cfg);
+        const bool fused = gsr_prefix_in_preprocess(cfg, g);
         const uint32_t nb = gsr_div_up(P, fused ? 256u : (uint32_t)GSR_SCAN_BLOCK);
         if (!fused) hipLaunchKernelGGL(k_offsets_local, dim3(nb), dim3(GSR_SCAN_BLOCK), 0, s, (const uint32_t*)nullptr, g.tiles_touched, P, g.offsets, g.scan_tmp);
         // total_by_duplicate (single-call forwards, where the binning follows at once): k_duplicate adds up the block sums itself and publishes
@@ -746,13 +748,13 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     const int passes = gsr_tile_sort_passes(T);
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
-    const bool global_order = gsr_depth_order_is_global(cfg->P, T);
+    const bool global_order = gsr_depth_order_is_global(cfg, g);
     (void)total_by_duplicate;
-    const bool self_scan = gsr_prefix_in_preprocess(cfg) && gsr_duplicate_scans();      // the block sums are raw: every workgroup adds up the ones in front of it
+    const bool self_scan = gsr_prefix_in_preprocess(cfg, g) && gsr_duplicate_scans();      // the block sums are raw: every workgroup adds up the ones in front of it
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P,
                        global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
                        g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256), im.tile_order + T,
-                       gsr_prefix_in_preprocess(cfg) ? 256u : (uint32_t)GSR_SCAN_BLOCK,
+                       gsr_prefix_in_preprocess(cfg, g) ? 256u : (uint32_t)GSR_SCAN_BLOCK,
                        self_scan ? gsr_div_up((uint32_t)cfg->P, 256u) : 0u, g.counters, host_word_dev);
     bool in_b = false;
     // tile ranges: k_tile_ranges over the sorted keys (default), or written by the last scatter pass (GSR_TILE_RANGES=scatter).  MEASURED (round 3,

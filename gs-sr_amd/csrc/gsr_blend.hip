@@ -445,7 +445,7 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
 {
     (void)in;
     BlendParams p = make_bp(cfg, g, b, im, s);
-    if (!gsr_depth_order_is_global(cfg->P, p.gx * p.gy) && gsr_tile_sort_is_fused()) {
+    if (!gsr_depth_order_is_global(cfg, g) && gsr_tile_sort_is_fused()) {
         p.depth_key = g.depth_key; p.list_rw = b.point_list; p.tile_keys = b.tile_keys; p.scratch_keys = b.keys_b; p.scratch_ids = b.vals_b;
     }
     {   // long-list feedback for the launch order of the forwards that follow (gsr_tile_order_wanted): "long" = beyond max(1024, ~4 x the mean list,

@@ -103,8 +103,13 @@ void gsr_blend_bwd_attach_events(hipEvent_t start, hipEvent_t stop);     // spla
 // hipMemsetAsync that is safe to record into a HIP graph: on ROCm 7.2 a memset NODE replays with a corrupted fill value from the second replay
 // on (measured round 3: vis_idx filled with 0x5A5A5A5A instead of 0xFF...), so while `s` is being captured the fill is a kernel; eagerly it is
 // the runtime's memset.  nbytes must be a multiple of 4.
-bool gsr_prefix_in_preprocess(const gsr_cfg* cfg);      // the preprocess kernel writes the block-local prefix of tiles_touched (gsr_binning.hip)
-bool gsr_depth_order_is_global(int P, int T);     // per-tile depth sort or the global one (GSR_DEPTH_ORDER=tile|global|auto; gsr_binning.hip)
+bool gsr_prefix_in_preprocess(const gsr_cfg* cfg, const GeomView& g);      // the preprocess kernel writes the block-local prefix of tiles_touched (gsr_binning.hip)
+bool gsr_depth_order_static_rule(int P, int T, bool* forced);   // GSR_DEPTH_ORDER=tile|global|auto and the P <= 192 T rule (gsr_binning.hip)
+// The depth order (global sort of the gaussians or per-tile sort) is decided ONCE per forward, in gsr_forward_begin (called by gsr_launch_preprocess, the
+// first launcher of every forward path) and remembered under the geom arena's address, where every later stage of the same forward -- and the second
+// call of a two-stage forward -- finds it (gsr_api.hip).
+void gsr_forward_begin(const gsr_cfg* cfg, const GeomView& g);
+bool gsr_depth_order_is_global(const gsr_cfg* cfg, const GeomView& g);
 bool gsr_tile_sort_is_fused();        // GSR_TILE_SORT=fused|kernel: who orders a tile's list by depth when the depth order is per tile (gsr_binning.hip)
 bool gsr_tile_order_wanted();         // GSR_TILE_ORDER=0|1, default auto: on while recent forwards reported long tile lists (gsr_api.hip); once per forward
 const uint32_t* gsr_static_tile_map(int gx, int gy, hipStream_t s);     // device [gx*gy] blockIdx -> tile, block-cyclic over the XCDs; cached per device and grid; nullptr if unavailable (gsr_api.hip)

@@ -366,7 +366,8 @@ int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, 
     PreParams p = make_params(cfg, in, g, radii);
     p.prefiltered_err = cfg->prefiltered ? prefiltered_err : nullptr;
     p.zero_ptr = g.hist; p.zero_n = gsr_sort_group_words((uint32_t)cfg->P, false, gsr_depth_sort_digit_bins());
-    if (gsr_prefix_in_preprocess(cfg)) { p.scan_offsets = g.offsets; p.scan_sums = g.scan_tmp; }
+    gsr_forward_begin(cfg, g);          // the one place per forward where the feedback is polled and the depth order of THIS forward is decided
+    if (gsr_prefix_in_preprocess(cfg, g)) { p.scan_offsets = g.offsets; p.scan_sums = g.scan_tmp; }
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);
     static int stage_sh = -1;                  // GSR_SH_STAGE=0: SH coefficients read straight from global memory (rounds 1-3)
     if (stage_sh < 0) { const char* e = getenv("GSR_SH_STAGE"); stage_sh = e ? (atoi(e) != 0) : 1; }

@@ -631,18 +631,20 @@ def test_eleven_bit_depth_sort_kept_switchable():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-def test_launch_order_feedback_leaves_results_alone():
-    """GSR_TILE_ORDER auto (default): a forward whose longest tile list exceeds max(1024, 4 x mean) reports it through the mapped feedback word and the
-    forwards that follow launch their blend workgroups longest-list-first (k_tile_order).  The order is a permutation of the tiles: every output of the
-    later forwards and backwards stays bit-identical to the first one's, and equal to the oracle's integer stages."""
+@pytest.mark.parametrize("P,frac,scale,longest", [(24000, 0.6, 0.12, 1562), (40000, 0.7, 0.05, 6000)])
+def test_launch_order_feedback_leaves_results_alone(P, frac, scale, longest):
+    """The feedback of the longest tile list (a mapped per-device word the blend forward stores into): forwards that follow a report launch their
+    blend workgroups longest-list-first (k_tile_order; lists beyond max(1024, 4 x mean)) and, after a list beyond 6000 entries, take the GLOBAL depth
+    order instead of the per-tile one.  Both are decided once per forward and change nothing in the results: every output of the later forwards
+    stays bit-identical to the first one's (which ran before any report), and equal to the oracle's integer stages."""
     import bench
     hr = _hiprun()
-    W, H, P = 256, 256, 24000
+    W, H = 256, 256
     sc = scenes.make_scene("surfel", P, W, H, seed=13)
-    bench.concentrate(sc, 0.6, 0.12)
+    bench.concentrate(sc, frac, scale)
     runs = [hr.run_raw("surfel", sc) for _ in range(4)]
     lens = runs[0]["ranges"][:, 1].astype(np.int64) - runs[0]["ranges"][:, 0].astype(np.int64)
-    assert lens.max() > max(1024, 20 * P // (16 * 16))               # the scene does trigger the report
+    assert lens.max() > max(longest, 20 * P // (16 * 16))            # the scene does trigger the report (and, second case, the depth-order switch)
     for r in runs[1:]:
         for k in ("color", "radii", "point_list", "tile_keys", "ranges", "final_T", "n_contrib"):
             assert np.array_equal(r[k], runs[0][k]), k
