@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         // per-tile depth order, fused: the four waves put the tile's list in (depth, id) order before any of them blends (the only barriers of
         // the kernel; s_rec is free until the first batch is staged).  The backward reads the same list afterwards.
         TdsScratch sc; sc.tile_keys = p.tile_keys; sc.keys = p.scratch_keys; sc.ids = p.scratch_ids;
-        tds_sort_tile_wg<(int)sizeof(s_rec)>(s_rec, p.list_rw + range.x, range.y > range.x ? range.y - range.x : 0u, range.x, (uint32_t)tile, p.depth_key, sc);
+        tds_sort_tile_wg<(int)sizeof(s_rec)>(s_rec, p.list_rw + range.x, range.y > range.x ? range.y - range.x : 0u, range.x, (uint32_t)tile, p.depth_key, sc, p.sort_buckets != 0);
     }
     if (p.long_word && threadIdx.x == 0 && range.y > range.x && range.y - range.x > p.long_len) *p.long_word = range.y - range.x;      // feedback for the launch order
     if (ox >= p.W || oy >= p.H) return;                 // wave-uniform: this sub-tile is outside the image
@@ -436,6 +436,7 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
     }
     p.ranges = im.ranges; p.point_list = b.point_list; p.cull = g.cull; p.rec = g.rec; p.bg = cfg->bg;
     p.depth_key = nullptr; p.list_rw = nullptr; p.tile_keys = nullptr; p.scratch_keys = nullptr; p.scratch_ids = nullptr;
+    { static int bk = -1; if (bk < 0) { const char* e = getenv("GSR_TILE_RANK"); bk = (e && e[0] == 'p') ? 0 : 1; } p.sort_buckets = bk; }
     p.final_T = im.final_T; p.n_contrib = im.n_contrib;
     return p;
 }

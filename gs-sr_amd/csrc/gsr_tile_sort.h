@@ -143,6 +143,73 @@ __device__ __forceinline__ void tds_rank_sort_wg(uint32_t* lds, uint32_t* list, 
     __syncthreads();
 }
 
+// Rank by counting INSIDE depth buckets, n <= 256 NQ entries, 256 threads.  The plain rank count above compares every entry with every key of
+// the list (n^2 compares: ~10 us of VALU per launch at the headline size, 100 us at lists of 600).  Here the entries are first dealt into up to
+// 128 buckets by the top bits of (key - smallest key of the list) -- a counting pass with LDS atomics, a 128-entry scan, a scatter -- and every entry
+// then ranks itself among the members of its own bucket only (a few entries; by key, ties by id).  Buckets are in key order, so
+// rank = bucket start + rank inside the bucket.  Worst case (all keys in one bucket, e.g. bit-identical depths) it degenerates to the plain count.
+// lds: 2 * 256 NQ + 264 words (keys and ids stay in registers until they are dealt into the buckets).  Ends with a barrier.
+template <int NQ>
+__device__ __forceinline__ void tds_bucket_rank_wg(uint32_t* lds, uint32_t* list, uint32_t n, const uint32_t* __restrict__ depth_key)
+{
+    constexpr uint32_t CAP = 256u * NQ;
+    uint32_t* k2 = lds;                     // [CAP] keys in bucket order
+    uint32_t* i2 = k2 + CAP;                // [CAP] ids in bucket order
+    uint32_t* bcnt = i2 + CAP;              // [128] entries per bucket, then [129] bucket starts (in place, shifted by the scan)
+    uint32_t* bst = bcnt + 128;             // [129]
+    uint32_t* mm = bst + 132;               // [2] smallest / largest key
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    uint32_t key[NQ], id[NQ], b[NQ], slot[NQ];
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint32_t e = t + 256u * q;
+        key[q] = 0u; id[q] = 0u;
+        if (e < n) { id[q] = list[e]; key[q] = depth_key[id[q]]; lo = min(lo, key[q]); hi = max(hi, key[q]); }
+    }
+    if (t < 128u) bcnt[t] = 0u;
+    if (t == 0u) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, 64)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, 64)); }
+    if (lane == 0u && lo <= hi) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+    __syncthreads();
+    const uint32_t kmin = mm[0], range = mm[1] - kmin;
+    const int shift = range ? max(0, 32 - (int)__builtin_clz(range) - 7) : 0;      // (range >> shift) <= 127
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        b[q] = 0u; slot[q] = 0u;
+        if (t + 256u * q < n) { b[q] = (key[q] - kmin) >> shift; slot[q] = atomicAdd(&bcnt[b[q]], 1u); }
+    }
+    __syncthreads();
+    if (t < 64u) {                          // exclusive scan of the 128 bucket counts by one wave, two buckets per lane
+        const uint32_t c0 = bcnt[2u * t], c1 = bcnt[2u * t + 1u];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += v; }
+        const uint32_t ex = incl - (c0 + c1);
+        bst[2u * t] = ex; bst[2u * t + 1u] = ex + c0;
+        if (t == 63u) bst[128] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        if (t + 256u * q < n) { const uint32_t p = bst[b[q]] + slot[q]; k2[p] = key[q]; i2[p] = id[q]; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        if (t + 256u * q < n) {
+            const uint32_t s0 = bst[b[q]], s1 = bst[b[q] + 1u];
+            uint32_t rank = s0;
+            for (uint32_t j = s0; j < s1; j++) {
+                const uint32_t kj = k2[j], ij = i2[j];
+                rank += ((kj < key[q]) | ((kj == key[q]) & (ij < id[q]))) ? 1u : 0u;
+            }
+            list[rank] = id[q];
+        }
+    __syncthreads();
+}
+
 // What the long-list fallback needs besides the list itself
 struct TdsScratch {
     uint32_t* tile_keys;        // [R] tile id of every instance (constant inside a tile's range): lent to the radix fallback and rewritten
@@ -158,12 +225,28 @@ struct TdsScratch {
 //   longer: four-pass radix sort in global memory.
 template <int LDS_BYTES>
 __device__ __forceinline__ void tds_sort_tile_wg(void* lds, uint32_t* list, uint32_t n, uint32_t first, uint32_t tile,
-                                                 const uint32_t* __restrict__ depth_key, TdsScratch sc)
+                                                 const uint32_t* __restrict__ depth_key, TdsScratch sc, bool buckets = true)
 {
     static_assert(LDS_BYTES >= 6148, "tds_sort_tile_wg: at least 3 * 512 + 1 words of LDS");
     constexpr uint32_t CAPW = (LDS_BYTES / 8 >= 4096) ? 4096u : (LDS_BYTES / 8 >= 2048) ? 2048u : (LDS_BYTES / 8 >= 1024) ? 1024u : 512u;
     const uint32_t t = threadIdx.x;
     if (n <= 1u) { __syncthreads(); return; }
+    {
+        // rank by counting inside depth buckets, up to 1024 entries (2 words per entry + 264 of the lent LDS; four entries per thread);
+        // buckets == false (GSR_TILE_RANK=plain): the all-pairs count up to 512 entries and the bitonic network above, as before
+        constexpr uint32_t BCAP = ((LDS_BYTES / 4 - 264) / 2 >= 1024) ? 1024u : ((LDS_BYTES / 4 - 264) / 2 >= 768) ? 768u : 512u;
+        // Lists up to 256 entries keep the all-pairs count: it has three barriers against seven, and at that length the prologue is its chain of
+        // dependent loads and barriers, not its compares (measured: blend forward 0.2307 vs 0.2314 ms at mean 169, 0.1018 vs 0.0979 at mean 56 with
+        // buckets for every length).  Above, the buckets replace n^2 compares / the bitonic network: 0.430 vs 0.448 ms at mean 337, 0.665 vs 0.723
+        // at mean 562 (tools/ab_tile_rank.sh).
+        if (buckets && n > 256u && n <= BCAP) {
+            uint32_t* w = reinterpret_cast<uint32_t*>(lds);
+            if (n <= 512u) tds_bucket_rank_wg<2>(w, list, n, depth_key);
+            else if (BCAP >= 768u && n <= 768u) tds_bucket_rank_wg<(BCAP >= 768u ? 3 : 2)>(w, list, n, depth_key);
+            else tds_bucket_rank_wg<(BCAP >= 1024u ? 4 : 2)>(w, list, n, depth_key);
+            return;
+        }
+    }
     if (n <= 512u) {
         if (n <= 256u) tds_rank_sort_wg<1>(reinterpret_cast<uint32_t*>(lds), list, n, depth_key);
         else tds_rank_sort_wg<2>(reinterpret_cast<uint32_t*>(lds), list, n, depth_key);
