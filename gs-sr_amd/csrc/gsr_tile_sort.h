@@ -232,9 +232,10 @@ __device__ __forceinline__ void tds_sort_tile_wg(void* lds, uint32_t* list, uint
     const uint32_t t = threadIdx.x;
     if (n <= 1u) { __syncthreads(); return; }
     {
-        // rank by counting inside depth buckets, up to 1024 entries (2 words per entry + 264 of the lent LDS; four entries per thread);
+        // rank by counting inside depth buckets, up to 1024 entries (2 words per entry + 264 of the lent LDS; four entries per thread -- eight, for
+        // 2048 entries, cost k_blend_fwd 71 VGPRs and its eighth wave per SIMD);
         // buckets == false (GSR_TILE_RANK=plain): the all-pairs count up to 512 entries and the bitonic network above, as before
-        constexpr uint32_t BCAP = ((LDS_BYTES / 4 - 264) / 2 >= 1024) ? 1024u : ((LDS_BYTES / 4 - 264) / 2 >= 768) ? 768u : 512u;
+        constexpr uint32_t BCAP = ((LDS_BYTES / 4 - 264) / 2 >= 1024) ? 1024u : 512u;
         // Lists up to 256 entries keep the all-pairs count: it has three barriers against seven, and at that length the prologue is its chain of
         // dependent loads and barriers, not its compares (measured: blend forward 0.2307 vs 0.2314 ms at mean 169, 0.1018 vs 0.0979 at mean 56 with
         // buckets for every length).  Above, the buckets replace n^2 compares / the bitonic network: 0.430 vs 0.448 ms at mean 337, 0.665 vs 0.723
@@ -242,7 +243,7 @@ __device__ __forceinline__ void tds_sort_tile_wg(void* lds, uint32_t* list, uint
         if (buckets && n > 256u && n <= BCAP) {
             uint32_t* w = reinterpret_cast<uint32_t*>(lds);
             if (n <= 512u) tds_bucket_rank_wg<2>(w, list, n, depth_key);
-            else if (BCAP >= 768u && n <= 768u) tds_bucket_rank_wg<(BCAP >= 768u ? 3 : 2)>(w, list, n, depth_key);
+            else if (n <= 768u) tds_bucket_rank_wg<(BCAP >= 1024u ? 3 : 2)>(w, list, n, depth_key);
             else tds_bucket_rank_wg<(BCAP >= 1024u ? 4 : 2)>(w, list, n, depth_key);
             return;
         }
