@@ -50,12 +50,12 @@ def algorithmic_bytes(variant, R, N, T):
     return fwd, bwd
 
 
-def depth_order_is_global(P, T):
-    """The library's static rule (gsr_binning.hip gsr_depth_order_static_rule): per-tile depth sort while P <= 192 T unless GSR_DEPTH_ORDER says otherwise.
+def depth_order_is_global(P, T, variant="surfel"):
+    """The library's static rule (gsr_binning.hip gsr_depth_order_static_rule): per-tile depth sort while P <= 192 T (surfel; 176 T plane, 155 T ewa) unless GSR_DEPTH_ORDER says otherwise.
     (On scenes with tile lists beyond 6000 entries the library's feedback switches to the global order, gsr_api.hip gsr_forward_begin: the skewed side
     scenes of --skew-frac; not the BASELINE workload.)"""
     e = os.environ.get("GSR_DEPTH_ORDER", "")
-    return True if e[:1] == "g" else (False if e[:1] == "t" else P > 192 * T)
+    return True if e[:1] == "g" else (False if e[:1] == "t" else P > {"ewa": 155, "plane": 176}.get(variant, 192) * T)
 
 
 def stage_bytes(variant, color_mode, P, R, N, T):
@@ -69,7 +69,7 @@ def stage_bytes(variant, color_mode, P, R, N, T):
     tile_passes = (tile_bits + 7) // 8
     acc = {"ewa": 48, "plane": 64, "surfel": 80}[variant]
     pre_bwd = P * (acc + 12 + 16 + 8 + (2 * 192 if color_mode == "sh" else 0) + 12 + 12 + 12 + 4 + 36 + 8 + 16)
-    glob = depth_order_is_global(P, T)
+    glob = depth_order_is_global(P, T, variant)
     tile_sort = 0 if glob else 12 * R          # per-tile depth sort: ids read + depth keys gathered + ids written
     fused = os.environ.get("GSR_TILE_SORT", "fused")[:1] != "k"      # ... in k_blend_fwd's prologue (default) or as its own launch in the binning stage
     return {"preprocess": pre, "depth_order": (4 * 16 * P + 8 * P) if glob else 8 * P,
@@ -613,7 +613,7 @@ def main():
                        "visible": int((st["radii"] > 0).sum()),
                        "clock_prewarm_ms": round(prewarm_ms, 1),
                        **({"skew": {"frac": args.skew_frac, "scale": args.skew_scale, "what": "NOT the BASELINE workload: gaussians concentrated at the image centre"}} if args.skew_frac > 0 else {}),
-                       "depth_order": "global 4-pass radix sort of the gaussians" if depth_order_is_global(args.P, T) else ("per-tile sort of the binned lists, in k_blend_fwd's prologue" if os.environ.get("GSR_TILE_SORT", "fused")[:1] != "k" else "per-tile sort of the binned lists (k_tile_depth_sort)"),
+                       "depth_order": "global 4-pass radix sort of the gaussians" if depth_order_is_global(args.P, T, args.variant) else ("per-tile sort of the binned lists, in k_blend_fwd's prologue" if os.environ.get("GSR_TILE_SORT", "fused")[:1] != "k" else "per-tile sort of the binned lists (k_tile_depth_sort)"),
                        "tiles": T, "tiles_touched": int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()),
                        "gaussians_per_tile_mean": round(R / max(int((st["ranges"][:, 1] > st["ranges"][:, 0]).sum()), 1), 1),
                        "gaussians_per_tile_max": int((st["ranges"][:, 1].astype(np.int64) - st["ranges"][:, 0].astype(np.int64)).max()),

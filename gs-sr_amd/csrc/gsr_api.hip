@@ -286,7 +286,7 @@ void gsr_forward_begin(const gsr_cfg* cfg, const GeomView& g)
 {
     const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
     bool forced = false;
-    bool global = gsr_depth_order_static_rule(cfg->P, T, &forced);
+    bool global = gsr_depth_order_static_rule(cfg->P, T, &forced, cfg->variant);
     Mailbox* mb = mailbox();
     if (mb) {
         volatile uint32_t* w = mb->host + 16 * GSR_MAIL_SLOTS;
@@ -317,7 +317,7 @@ bool gsr_depth_order_is_global(const gsr_cfg* cfg, const GeomView& g)
         for (const DepthModeEnt& e : g_depth_mode) if (e.key == (const void*)g.depth_key && e.key) return e.global != 0;
     }
     const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
-    return gsr_depth_order_static_rule(cfg->P, T, nullptr);      // a geom arena this process has not run a preprocess on
+    return gsr_depth_order_static_rule(cfg->P, T, nullptr, cfg->variant);      // a geom arena this process has not run a preprocess on
 }
 uint32_t* gsr_long_list_word()
 {

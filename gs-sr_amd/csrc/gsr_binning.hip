@@ -378,14 +378,17 @@ bool gsr_duplicate_scans()      // GSR_SCAN=kernel keeps k_scan_small in the sin
     return on != 0;
 }
 // The rule without feedback: GSR_DEPTH_ORDER=global|tile forces one (the returned flag says so), otherwise per tile while P <= 192 T.
-bool gsr_depth_order_static_rule(int P, int T, bool* forced)
+bool gsr_depth_order_static_rule(int P, int T, bool* forced, int variant)
 {
     static int mode = -1;                       // 0 auto, 1 global, 2 tile
     if (mode < 0) { const char* e = getenv("GSR_DEPTH_ORDER"); mode = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 't' ? 2 : 0)); }
     if (forced) *forced = mode != 0;
     if (mode == 1) return true;
     if (mode == 2) return false;
-    return (long long)P > 192ll * (long long)T;
+    // the crossover sits at a mean tile list of ~900 entries; an EWA gaussian touches ~5.8 tiles of the SURVEY 8d scene, a PLANE one ~5.1, a surfel ~4.6
+    // (EWA at P = 1.5 M, mean 1070: global 640 vs per-tile 609 it/s; surfel at 1.5 M, mean 845: 333 vs 343)
+    const long long per_tile = variant == GSR_EWA ? 155ll : (variant == GSR_PLANE ? 176ll : 192ll);
+    return (long long)P > per_tile * (long long)T;
 }
 
 int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s, bool total_by_duplicate)

@@ -104,7 +104,7 @@ void gsr_blend_bwd_attach_events(hipEvent_t start, hipEvent_t stop);     // spla
 // on (measured round 3: vis_idx filled with 0x5A5A5A5A instead of 0xFF...), so while `s` is being captured the fill is a kernel; eagerly it is
 // the runtime's memset.  nbytes must be a multiple of 4.
 bool gsr_prefix_in_preprocess(const gsr_cfg* cfg, const GeomView& g);      // the preprocess kernel writes the block-local prefix of tiles_touched (gsr_binning.hip)
-bool gsr_depth_order_static_rule(int P, int T, bool* forced);   // GSR_DEPTH_ORDER=tile|global|auto and the P <= 192 T rule (gsr_binning.hip)
+bool gsr_depth_order_static_rule(int P, int T, bool* forced, int variant = GSR_SURFEL);   // GSR_DEPTH_ORDER=tile|global|auto and the P <= 192 T rule (gsr_binning.hip)
 // The depth order (global sort of the gaussians or per-tile sort) is decided ONCE per forward, in gsr_forward_begin (called by gsr_launch_preprocess, the
 // first launcher of every forward path) and remembered under the geom arena's address, where every later stage of the same forward -- and the second
 // call of a two-stage forward -- finds it (gsr_api.hip).
