@@ -33,9 +33,10 @@
 
 // Waves per SIMD the register budget of each variant is sized for.  SURFEL (128 VGPRs, 12 spills outside the step loop): 3 waves 0.693 ms,
 // 4 waves 0.633, 5 waves (96 VGPRs, 37 spills) 0.759 -- measured on the first table version; EWA needs 94 VGPRs and runs 5 waves per SIMD:
-// 0.387 -> 0.355 ms; PLANE needs 113-115 and stays at 4.
+// 0.387 -> 0.355 ms; PLANE needs 113-115 and stays at 4.  Round 3, same-box rebuilds (tools/ab_wpe.sh): EWA at 6 waves (85 VGPRs; its 25 KB of LDS allow
+// exactly six workgroups per CU) 0.3244 vs 0.3337 ms at 5, 0.367 at 4; PLANE stays at 4 (its 35 KB of LDS allow four workgroups per CU).
 #ifndef SP_WPE_EWA
-#define SP_WPE_EWA 5
+#define SP_WPE_EWA 6
 #endif
 #ifndef SP_WPE_PLANE
 #define SP_WPE_PLANE 4
