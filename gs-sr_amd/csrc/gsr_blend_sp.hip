@@ -34,12 +34,13 @@
 // Waves per SIMD the register budget of each variant is sized for.  SURFEL (128 VGPRs, 12 spills outside the step loop): 3 waves 0.693 ms,
 // 4 waves 0.633, 5 waves (96 VGPRs, 37 spills) 0.759 -- measured on the first table version; EWA needs 94 VGPRs and runs 5 waves per SIMD:
 // 0.387 -> 0.355 ms; PLANE needs 113-115 and stays at 4.  Round 3, same-box rebuilds (tools/ab_wpe.sh): EWA at 6 waves (85 VGPRs; its 25 KB of LDS allow
-// exactly six workgroups per CU) 0.3244 vs 0.3337 ms at 5, 0.367 at 4; PLANE stays at 4 (its 35 KB of LDS allow four workgroups per CU).
+// exactly six workgroups per CU) 0.3244 vs 0.3337 ms at 5, 0.367 at 4; PLANE at 5 waves with a 96-row table (31.5 KB of LDS, 102 VGPRs): 0.296 vs 0.320 ms at 4 waves / 112 rows (tools/ab_wpe2.sh; EWA at 7 or 8 waves with
+// shorter tables spills and loses: 0.386 / 0.396 ms).
 #ifndef SP_WPE_EWA
 #define SP_WPE_EWA 6
 #endif
 #ifndef SP_WPE_PLANE
-#define SP_WPE_PLANE 4
+#define SP_WPE_PLANE 5
 #endif
 #ifndef SP_WPE_SURFEL
 #define SP_WPE_SURFEL 4
@@ -48,6 +49,12 @@ template <int V> struct SpOcc { static constexpr int WPE = (V == GSR_EWA) ? SP_W
 #define SP_OCC __attribute__((amdgpu_waves_per_eu(SpOcc<V>::WPE, SpOcc<V>::WPE)))
 #define SP_CH 256                 // tile-list entries per chunk (queues, masks); longer lists take several chunks
 #define SP_CAP 112                // rows of a wave's private accumulation table (entries of the chunk that reach the wave's quadrant)
+#ifndef SP_CAP_EWA
+#define SP_CAP_EWA SP_CAP
+#endif
+#ifndef SP_CAP_PLANE
+#define SP_CAP_PLANE 96             // 96 rows x 16 floats x 4 waves + queues = 31.5 KB: five workgroups per CU (112 rows: four)
+#endif
 
 template <int V> struct SpTraits;
 template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10; };
@@ -288,12 +295,13 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
     constexpr int NACC = TR::NACC, TS = TR::TS;
 
-    __shared__ float2 s_wtab[4 * SP_CAP * (TS / 2)];        // [wave][compact entry][component pair]: PRIVATE to the wave, plain read-add-write
+    constexpr int CAPV = (V == GSR_EWA) ? SP_CAP_EWA : (V == GSR_PLANE ? SP_CAP_PLANE : SP_CAP);      // table rows per wave
+    __shared__ float2 s_wtab[4 * CAPV * (TS / 2)];        // [wave][compact entry][component pair]: PRIVATE to the wave, plain read-add-write
     __shared__ uint8_t s_cidx[4 * SP_CH];                   // [wave][entry] -> row of the wave's table, 0xFF: the entry does not reach the quadrant
     __shared__ uint32_t s_ids[SP_CH];
     __shared__ uint32_t s_over;
     __shared__ uint16_t s_mask[SP_CH];                      // bit q: entry reaches 8x8 quadrant q of the tile
-    __shared__ uint8_t s_cent[4 * SP_CAP];                  // [wave][table row] -> chunk-local entry
+    __shared__ uint8_t s_cent[4 * CAPV];                  // [wave][table row] -> chunk-local entry
     __shared__ uint8_t s_queue[4 * 4 * SP_CH];              // [wave][block][position] -> chunk-local entry, list order
     __shared__ uint32_t s_wmax[4];
 
@@ -365,9 +373,9 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
 
     // The tile list is consumed from its deep end in chunks of <= SP_CH entries [lo, hi).  A chunk whose entries overflow a wave's
     // SP_CAP-row table (dense scenes) is re-staged at half the length: 112 rows always hold a 112-entry chunk.
-    float2* mytab = s_wtab + wave * SP_CAP * (TS / 2);
+    float2* mytab = s_wtab + wave * CAPV * (TS / 2);
     uint8_t* mycidx = s_cidx + wave * SP_CH;
-    uint8_t* mycent = s_cent + wave * SP_CAP;
+    uint8_t* mycent = s_cent + wave * CAPV;
     uint32_t hi = tile_max, want = SP_CH;
     if (threadIdx.x == 0) s_over = 0;
     while (hi > 0) {
@@ -405,16 +413,16 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             const uint64_t am = __ballot(any);
             const uint32_t arank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
             if (e < n) mycidx[e] = any ? (uint8_t)min(cany + arank, 255u) : (uint8_t)0xFF;
-            if (any && cany + arank < SP_CAP) mycent[cany + arank] = (uint8_t)e;
+            if (any && cany + arank < CAPV) mycent[cany + arank] = (uint8_t)e;
             cany += (uint32_t)__popcll(am);
         }
         // ... and, for those only, the exact test against the quadrant's four 4x4 blocks -> one queue per block (list order).  Two levels
         // (4 quadrant tests per entry, then 4 block tests per (entry, quadrant) hit: 1.35 quadrants per entry) cost ~7.6 region tests
         // per entry instead of 16.
         uint32_t cnt[4] = { 0, 0, 0, 0 };
-        for (uint32_t i0 = 0; i0 < min(cany, (uint32_t)SP_CAP); i0 += 64) {
+        for (uint32_t i0 = 0; i0 < min(cany, (uint32_t)CAPV); i0 += 64) {
             const uint32_t i = i0 + lane;
-            const bool v = i < min(cany, (uint32_t)SP_CAP);
+            const bool v = i < min(cany, (uint32_t)CAPV);
             const uint32_t e = v ? (uint32_t)mycent[i] : 0u;
             const uint32_t id = s_ids[e];
             float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = make_float4(0.f, -1.f, 0.f, 0.f);
@@ -429,9 +437,9 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
                 cnt[k] += (uint32_t)__popcll(bm);
             }
         }
-        if (cany > SP_CAP && lane == 0) s_over = 1;
+        if (cany > CAPV && lane == 0) s_over = 1;
         __syncthreads();
-        if (s_over) {                                       // block-uniform: redo this chunk shorter (n > SP_CAP here, so it terminates)
+        if (s_over) {                                       // block-uniform: redo this chunk shorter (n > CAPV here, so it terminates)
             __syncthreads();
             if (threadIdx.x == 0) s_over = 0;
             want = (n + 1) / 2;
@@ -490,7 +498,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             for (int w = 0; w < 4; w++) {
                 const uint32_t ci = s_cidx[w * SP_CH + e];
                 if (ci != 0xFFu) {
-                    const float* t = reinterpret_cast<const float*>(s_wtab + (w * SP_CAP + ci) * (TS / 2));
+                    const float* t = reinterpret_cast<const float*>(s_wtab + (w * CAPV + ci) * (TS / 2));
                     if ((int)c < NACC) v0 += t[c];
                     if (NACC > 16 && (int)c < NACC - 16) v1 += t[16 + c];
                 }
