@@ -35,7 +35,7 @@
 // 4 waves 0.633, 5 waves (96 VGPRs, 37 spills) 0.759 -- measured on the first table version; EWA needs 94 VGPRs and runs 5 waves per SIMD:
 // 0.387 -> 0.355 ms; PLANE needs 113-115 and stays at 4.  Round 3, same-box rebuilds (tools/ab_wpe.sh): EWA at 6 waves (85 VGPRs; its 25 KB of LDS allow
 // exactly six workgroups per CU) 0.3244 vs 0.3337 ms at 5, 0.367 at 4; PLANE at 5 waves with a 96-row table (31.5 KB of LDS, 102 VGPRs): 0.296 vs 0.320 ms at 4 waves / 112 rows (tools/ab_wpe2.sh; EWA at 7 or 8 waves with
-// shorter tables spills and loses: 0.386 / 0.396 ms).
+// shorter tables spills and loses: 0.386 / 0.396 ms; SURFEL at 5 waves with an 80- or 64-row table: 0.615 / 0.714 ms against 0.472).
 #ifndef SP_WPE_EWA
 #define SP_WPE_EWA 6
 #endif
@@ -51,6 +51,9 @@ template <int V> struct SpOcc { static constexpr int WPE = (V == GSR_EWA) ? SP_W
 #define SP_CAP 112                // rows of a wave's private accumulation table (entries of the chunk that reach the wave's quadrant)
 #ifndef SP_CAP_EWA
 #define SP_CAP_EWA SP_CAP
+#endif
+#ifndef SP_CAP_SURFEL
+#define SP_CAP_SURFEL SP_CAP
 #endif
 #ifndef SP_CAP_PLANE
 #define SP_CAP_PLANE 96             // 96 rows x 16 floats x 4 waves + queues = 31.5 KB: five workgroups per CU (112 rows: four)
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
     constexpr int NACC = TR::NACC, TS = TR::TS;
 
-    constexpr int CAPV = (V == GSR_EWA) ? SP_CAP_EWA : (V == GSR_PLANE ? SP_CAP_PLANE : SP_CAP);      // table rows per wave
+    constexpr int CAPV = (V == GSR_EWA) ? SP_CAP_EWA : (V == GSR_PLANE ? SP_CAP_PLANE : SP_CAP_SURFEL);      // table rows per wave
     __shared__ float2 s_wtab[4 * CAPV * (TS / 2)];        // [wave][compact entry][component pair]: PRIVATE to the wave, plain read-add-write
     __shared__ uint8_t s_cidx[4 * SP_CH];                   // [wave][entry] -> row of the wave's table, 0xFF: the entry does not reach the quadrant
     __shared__ uint32_t s_ids[SP_CH];
