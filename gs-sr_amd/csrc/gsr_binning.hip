@@ -751,12 +751,19 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     const int passes = gsr_tile_sort_passes(T);
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
+    // 4096-key blocks for the tile sort from this many instances on, 1024-key blocks below (GSR_SORT_BIG_FROM overrides for A/B).  Re-measured at the end of
+    // round 3, binning stage small / big blocks in ms: R = 0.92 M 0.057 / 0.069; 1.38 M (the headline scene) 0.069 / 0.076; 1.60 M 0.0757 / 0.0771;
+    // 1.83 M 0.0798 / 0.0785; 2.06 M 0.087 / 0.080; 4.6 M 0.157 / 0.144; 17.5 M 0.587 / 0.495 -- the round-2 threshold of 2^19 was half a size class early.
+    static uint32_t big_from0 = 0;
+    if (!big_from0) { const char* e = getenv("GSR_SORT_BIG_FROM"); big_from0 = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 1700000u; }
+    // R is the CAPACITY of the arena when the count is read on the device (speculative / sync-free forwards: 1.25 x the last count + 16384)
+    const uint32_t big_from = n_dev ? big_from0 + big_from0 / 4 : big_from0;
     const bool global_order = gsr_depth_order_is_global(cfg, g);
     (void)total_by_duplicate;
     const bool self_scan = gsr_prefix_in_preprocess(cfg, g) && gsr_duplicate_scans();      // the block sums are raw: every workgroup adds up the ones in front of it
     hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P,
                        global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
-                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= (1u << 19), 256), im.tile_order + T,
+                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= big_from, 256), im.tile_order + T,
                        gsr_prefix_in_preprocess(cfg, g) ? 256u : (uint32_t)GSR_SCAN_BLOCK,
                        self_scan ? gsr_div_up((uint32_t)cfg->P, 256u) : 0u, g.counters, host_word_dev);
     bool in_b = false;
@@ -765,7 +772,7 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     // ~22k global atomics at the ends of the digit runs lengthen the tail of every scatter block by more than the launch they save.
     static int ranges_fused = -1;
     if (ranges_fused < 0) { const char* e = getenv("GSR_TILE_RANGES"); ranges_fused = (e && e[0] == 's') ? 1 : 0; }
-    if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= (1u << 19), true, ranges_fused ? im.ranges : nullptr)) return 1;
+    if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= big_from, true, ranges_fused ? im.ranges : nullptr)) return 1;
     if (!ranges_fused) hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
     if (!global_order && !gsr_tile_sort_is_fused())
         hipLaunchKernelGGL(k_tile_depth_sort, dim3(gsr_div_up((uint32_t)T, 4u)), dim3(256), 0, s, im.ranges, (uint32_t)T, R, g.depth_key, b.point_list, b.tile_keys,
