@@ -288,8 +288,8 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
     const uint32_t ngroups = gsr_div_up(nblk, GSR_SORT_GROUP);
     uint32_t* GH[2] = { hist, hist + (size_t)NB * ngroups };
     uint32_t* H = hist + 2 * (size_t)NB * ngroups;
-    // Every scatter block reads all group rows: O(nblk^2 / 16) words per pass.  Beyond GSR_SORT_MAX_GROUPS groups (~800k keys at 1024 per block,
-    // ~3 M at 4096) that costs more than the row-scan kernel it replaces (measured: 17 M instances, +0.23 ms per forward), so large sorts keep
+    // Every scatter block reads all group rows: O(nblk^2 / 16) words per pass.  Beyond GSR_SORT_MAX_GROUPS groups (~1.5 M keys at 1024 per block,
+    // ~6 M at 4096) that costs more than the row-scan kernel it replaces (measured: 17 M instances, +0.23 ms per forward), so large sorts keep
     // the digit-major matrix + k_scan_rows (digit totals in GH[0]).
     const uint32_t dm = (ngroups > GSR_SORT_MAX_GROUPS) ? nblk : 0u;
     if (!dm && !group0_zeroed) if (gsr_memset_async(GH[0], 0, (size_t)NB * ngroups * sizeof(uint32_t), s)) { gsr_set_error("memset group histogram"); return 1; };

@@ -122,7 +122,9 @@ int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const in
 // Histogram scratch of the sort: [2 group-histogram buffers of NB * groups words][block histograms NB * nblk], groups = ceil(nblk / 16).
 // `group0_zeroed`: the caller's preceding kernel already zeroed the first NB * groups words (gsr_sort_group_words) -- otherwise a memset does.
 #define GSR_SORT_GROUP 16
-#define GSR_SORT_MAX_GROUPS 48
+#ifndef GSR_SORT_MAX_GROUPS
+#define GSR_SORT_MAX_GROUPS 96        // re-measured with 1024-key blocks (tools/ab_sort_groups.sh): binning 0.0678 / 0.0688 / 0.071 ms at 96 / 48 / 160 groups
+#endif
 static inline uint32_t gsr_sort_blocks(uint32_t n, bool big_blocks) { return gsr_div_up(n, GSR_SORT_THREADS * (big_blocks ? 16u : (uint32_t)GSR_SORT_ITEMS)); }
 static inline uint32_t gsr_sort_group_words(uint32_t n, bool big_blocks, uint32_t NB) { return NB * gsr_div_up(gsr_sort_blocks(n, big_blocks), GSR_SORT_GROUP); }
 static inline size_t gsr_sort_hist_words(uint32_t nblk_1024, uint32_t NB) { return (size_t)NB * nblk_1024 + 2 * (size_t)NB * (nblk_1024 / GSR_SORT_GROUP + 1); }
