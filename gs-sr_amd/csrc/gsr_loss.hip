@@ -13,11 +13,19 @@
 // Algorithmic bytes per pixel-channel: fwd 8 read + 12 written, bwd 12 + 8 read + 4 written = 44 B.
 #include "gsr_common.h"
 
-#define SS_T 32                         // output tile edge
+#define SS_T 32                         // output tile width
+#ifndef SS_TY
+#define SS_TY 30                        // output tile height: 40 patch rows fit four workgroups' LDS on a CU (0.1328 ms against 0.1354 with 32)
+#endif
 #define SS_R 5
-#define SS_P (SS_T + 2 * SS_R)        // 42: staged patch edge
+#define SS_P (SS_T + 2 * SS_R)        // 42: staged patch width
+#define SS_PY (SS_TY + 2 * SS_R)      // staged patch height
 #define SS_LD (SS_P + 1)
-#define SS_B 4                          // outputs per thread in each filter pass (sliding window: 14 LDS reads feed 4 outputs, not 44)
+#define SS_NLD ((SS_PY * SS_P + 255) / 256)   // patch elements per thread
+#define SS_B 4                          // outputs per thread in the horizontal pass (sliding window: 14 LDS reads feed 4 outputs, not 44)
+// rows past the patch are only ever read for outputs that are masked off (SS_TY not a multiple of 8)
+#define SS_VROW(r) ((SS_BV * 8 == SS_TY) ? (r) : min((r), SS_PY - 1))
+#define SS_BV ((SS_TY + 7) / 8)         // output rows per thread in the vertical pass (8 row groups x 32 columns = 256 threads)
 
 __constant__ float c_win[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f, 2.130055279e-01f, 2.660117149e-01f,
                                 2.130055279e-01f, 1.093606874e-01f, 3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f};
@@ -43,21 +51,32 @@ __device__ __forceinline__ float block_sum256(float v, float* red)
 __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
                                                   float* __restrict__ maps /*[3][C][H][W]*/, size_t plane_all, float2* __restrict__ partial)
 {
-    __shared__ float sx[SS_P][SS_LD], sy[SS_P][SS_LD];
-    __shared__ float h[5][SS_P][SS_T + 1];
+    __shared__ float sx[SS_PY][SS_LD], sy[SS_PY][SS_LD];
+    __shared__ float h[5][SS_PY][SS_T + 1];
     __shared__ float red[4];
     SS_LOAD_TAPS(wt)
-    const int c = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
+    const int c = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_TY;
     const float* ip = img + (size_t)c * H * W;
     const float* gp = gt + (size_t)c * H * W;
-    for (int e = threadIdx.x; e < SS_P * SS_P; e += 256) {
-        const int ly = e / SS_P, lx = e % SS_P, gy = y0 + ly - SS_R, gx = x0 + lx - SS_R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sx[ly][lx] = in ? ip[(size_t)gy * W + gx] : 0.0f;
-        sy[ly][lx] = in ? gp[(size_t)gy * W + gx] : 0.0f;
+    {   // All of a thread's patch loads are issued before the first LDS write: as a rolled loop with the bounds test as a branch this was seven
+        // dependent HBM round trips per workgroup (ISA: load, s_waitcnt vmcnt(0), ds_write, branch), with three workgroups per CU to hide them.
+        float vx[SS_NLD], vy[SS_NLD];
+#pragma unroll
+        for (int i = 0; i < SS_NLD; i++) {
+            const int e = threadIdx.x + i * 256, ly = e / SS_P, lx = e % SS_P, gy = y0 + ly - SS_R, gx = x0 + lx - SS_R;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && e < SS_PY * SS_P;
+            const size_t o = in ? (size_t)gy * W + gx : 0;          // element 0 always exists: an unconditional load, then a select
+            vx[i] = ip[o]; vy[i] = gp[o];
+            if (!in) { vx[i] = 0.0f; vy[i] = 0.0f; }
+        }
+#pragma unroll
+        for (int i = 0; i < SS_NLD; i++) {
+            const int e = threadIdx.x + i * 256, ly = e / SS_P, lx = e % SS_P;
+            if (e < SS_PY * SS_P) { sx[ly][lx] = vx[i]; sy[ly][lx] = vy[i]; }
+        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < SS_P * (SS_T / SS_B); e += 256) {
+    for (int e = threadIdx.x; e < SS_PY * (SS_T / SS_B); e += 256) {
         const int ly = e / (SS_T / SS_B), lx = (e % (SS_T / SS_B)) * SS_B;
         float a[SS_B], b[SS_B], aa[SS_B], bb[SS_B], ab[SS_B];
 #pragma unroll
@@ -78,19 +97,19 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, const float* __r
         for (int o = 0; o < SS_B; o++) { h[0][ly][lx + o] = a[o]; h[1][ly][lx + o] = b[o]; h[2][ly][lx + o] = aa[o]; h[3][ly][lx + o] = bb[o]; h[4][ly][lx + o] = ab[o]; }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SS_B, gx = x0 + lx;
-    float q[5][SS_B];
+    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SS_BV, gx = x0 + lx;
+    float q[5][SS_BV];
 #pragma unroll
     for (int k = 0; k < 5; k++)
 #pragma unroll
-        for (int o = 0; o < SS_B; o++) q[k][o] = 0.f;
+        for (int o = 0; o < SS_BV; o++) q[k][o] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 11 + SS_B - 1; t++) {
+    for (int t = 0; t < 11 + SS_BV - 1; t++) {
         float hv[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) hv[k] = h[k][ly0 + t][lx];
+        for (int k = 0; k < 5; k++) hv[k] = h[k][SS_VROW(ly0 + t)][lx];
 #pragma unroll
-        for (int o = 0; o < SS_B; o++) {
+        for (int o = 0; o < SS_BV; o++) {
             if (t - o >= 0 && t - o < 11) {
                 const float w = wt[t - o];
 #pragma unroll
@@ -100,9 +119,9 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(int H, int W, const float* __r
     }
     float ssim = 0.f, l1 = 0.f;
 #pragma unroll
-    for (int o = 0; o < SS_B; o++) {
+    for (int o = 0; o < SS_BV; o++) {
         const int gy = y0 + ly0 + o;
-        if (gx < W && gy < H) {
+        if (gx < W && gy < H && ly0 + o < SS_TY) {
             const float mu1 = q[0][o], mu2 = q[1][o], e11 = q[2][o], e22 = q[3][o], e12 = q[4][o];
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
@@ -131,19 +150,31 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
                                                   const float* __restrict__ maps, size_t plane_all, float w_l1, float w_ssim,
                                                   float* __restrict__ dimg)
 {
-    __shared__ float sm[3][SS_P][SS_LD];
-    __shared__ float h[3][SS_P][SS_T + 1];
+    __shared__ float sm[3][SS_PY][SS_LD];
+    __shared__ float h[3][SS_PY][SS_T + 1];
     SS_LOAD_TAPS(wt)
-    const int c = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_T;
-    for (int e = threadIdx.x; e < SS_P * SS_P; e += 256) {
-        const int ly = e / SS_P, lx = e % SS_P, gy = y0 + ly - SS_R, gx = x0 + lx - SS_R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = ((size_t)c * H + (in ? gy : 0)) * W + (in ? gx : 0);
+    const int c = blockIdx.z, x0 = blockIdx.x * SS_T, y0 = blockIdx.y * SS_TY;
+    {   // loads first, LDS writes after (see k_ssim_fwd)
+        float vm[3][SS_NLD];
 #pragma unroll
-        for (int m = 0; m < 3; m++) sm[m][ly][lx] = in ? maps[m * plane_all + o] : 0.0f;
+        for (int i = 0; i < SS_NLD; i++) {
+            const int e = threadIdx.x + i * 256, ly = e / SS_P, lx = e % SS_P, gy = y0 + ly - SS_R, gx = x0 + lx - SS_R;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && e < SS_PY * SS_P;
+            const size_t o = ((size_t)c * H + (in ? gy : 0)) * W + (in ? gx : 0);
+#pragma unroll
+            for (int m = 0; m < 3; m++) { vm[m][i] = maps[m * plane_all + o]; if (!in) vm[m][i] = 0.0f; }
+        }
+#pragma unroll
+        for (int i = 0; i < SS_NLD; i++) {
+            const int e = threadIdx.x + i * 256, ly = e / SS_P, lx = e % SS_P;
+            if (e < SS_PY * SS_P) {
+#pragma unroll
+                for (int m = 0; m < 3; m++) sm[m][ly][lx] = vm[m][i];
+            }
+        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < SS_P * (SS_T / SS_B); e += 256) {
+    for (int e = threadIdx.x; e < SS_PY * (SS_T / SS_B); e += 256) {
         const int ly = e / (SS_T / SS_B), lx = (e % (SS_T / SS_B)) * SS_B;
         float a[3][SS_B];
 #pragma unroll
@@ -167,17 +198,18 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
             for (int o = 0; o < SS_B; o++) h[m][ly][lx + o] = a[m][o];
     }
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SS_B, gx = x0 + lx;
-    float q[3][SS_B];
+    const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SS_BV, gx = x0 + lx;
+    float q[3][SS_BV];
 #pragma unroll
     for (int m = 0; m < 3; m++)
 #pragma unroll
-        for (int o = 0; o < SS_B; o++) q[m][o] = 0.f;
+        for (int o = 0; o < SS_BV; o++) q[m][o] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 11 + SS_B - 1; t++) {
-        const float v0 = h[0][ly0 + t][lx], v1 = h[1][ly0 + t][lx], v2 = h[2][ly0 + t][lx];
+    for (int t = 0; t < 11 + SS_BV - 1; t++) {
+        const int r = SS_VROW(ly0 + t);
+        const float v0 = h[0][r][lx], v1 = h[1][r][lx], v2 = h[2][r][lx];
 #pragma unroll
-        for (int o = 0; o < SS_B; o++) {
+        for (int o = 0; o < SS_BV; o++) {
             if (t - o >= 0 && t - o < 11) {
                 const float w = wt[t - o];
                 q[0][o] = fmaf(w, v0, q[0][o]); q[1][o] = fmaf(w, v1, q[1][o]); q[2][o] = fmaf(w, v2, q[2][o]);
@@ -186,9 +218,9 @@ __global__ void __launch_bounds__(256) k_ssim_bwd(int H, int W, const float* __r
     }
     if (gx >= W) return;
 #pragma unroll
-    for (int o = 0; o < SS_B; o++) {
+    for (int o = 0; o < SS_BV; o++) {
         const int gy = y0 + ly0 + o;
-        if (gy < H) {
+        if (gy < H && ly0 + o < SS_TY) {
             const size_t oo = ((size_t)c * H + gy) * W + gx;
             const float x = img[oo], y = gt[oo], df = x - y;
             const float sgn = df > 0.f ? 1.0f : (df < 0.f ? -1.0f : 0.0f);
@@ -201,7 +233,13 @@ __global__ void __launch_bounds__(1024) k_ssim_finish(const float2* __restrict__
 {
     __shared__ float r1[16], r2[16];
     float a = 0.f, b = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) { const float2 p = partial[i]; a += p.x; b += p.y; }
+    for (int i0 = 0; i0 < n; i0 += 8 * 1024) {           // eight loads in flight per thread, summed in index order
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 1024 + threadIdx.x; v[u] = partial[i < n ? i : 0]; if (i >= n) v[u] = make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a += v[u].x; b += v[u].y; }
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
     if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = a; r2[threadIdx.x >> 6] = b; }
@@ -214,7 +252,7 @@ __global__ void __launch_bounds__(1024) k_ssim_finish(const float2* __restrict__
     }
 }
 
-static size_t ssim_blocks(int32_t C, int32_t H, int32_t W) { return (size_t)gsr_div_up(W, SS_T) * gsr_div_up(H, SS_T) * C; }
+static size_t ssim_blocks(int32_t C, int32_t H, int32_t W) { return (size_t)gsr_div_up(W, SS_T) * gsr_div_up(H, SS_TY) * C; }
 extern "C" size_t gsr_loss_l1_ssim_scratch_bytes(int32_t C, int32_t H, int32_t W)
 {
     return (C > 0 && H > 0 && W > 0) ? gsr_align((size_t)3 * C * H * W * sizeof(float)) + ssim_blocks(C, H, W) * sizeof(float2) : 0;
@@ -231,7 +269,7 @@ extern "C" int gsr_loss_l1_ssim(int32_t C, int32_t H, int32_t W, const float* im
     const size_t plane_all = (size_t)C * H * W;
     const float inv_n = 1.0f / (float)plane_all;
     float2* partial = (float2*)((char*)scratch + gsr_align(3 * plane_all * sizeof(float)));
-    const dim3 grid(gsr_div_up(W, SS_T), gsr_div_up(H, SS_T), C);
+    const dim3 grid(gsr_div_up(W, SS_T), gsr_div_up(H, SS_TY), C);
     hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(256), 0, s, H, W, img, gt, (float*)scratch, plane_all, partial);
     hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(256), 0, s, H, W, img, gt, (const float*)scratch, plane_all, (1.0f - lambda_dssim) * inv_n,
                        lambda_dssim * inv_n, dL_dimg);
@@ -243,14 +281,21 @@ extern "C" int gsr_loss_l1_ssim(int32_t C, int32_t H, int32_t W, const float* im
 // 2DGS geometric regularisers in ONE kernel (forward values, loss, and dL/dallmap):
 //   TwoDGSScene.render post-processing (gssr/scene/twodgs_scene.py:88-115), depth_to_normal (gssr/utils/point_utils.py:9-37),
 //   normal + distortion losses (twodgs_scene.py:25-35).  ~35 N-sized torch ops (+ autograd) in the reference.
-// 16x16 pixel tile per block; the 3x3 normal stencil and its adjoint (a 13-point diamond in depth) are staged through LDS:
-//   P   (20x20) = depth * ray                      halo 2
-//   g   (18x18) = d loss / d (dx, dy) per pixel    halo 1     (zero for non-interior pixels)
+// GEO_TX x GEO_TY pixel tile per block; the 3x3 normal stencil and its adjoint (a 13-point diamond in depth) are staged through LDS:
+//   P   (tile + 4) = depth * ray                   halo 2
+//   g   (tile + 2) = d loss / d (dx, dy) per pixel halo 1     (zero for non-interior pixels)
 // then every pixel gathers  dP = g_dx(y-1,x) - g_dx(y+1,x) + g_dy(y,x-1) - g_dy(y,x+1)  and chains it into allmap channels 0, 1, 5.
 // Algorithmic bytes: 7 channels read + 11 written (+ optional outputs) = 72 B per pixel.
-#define GEO_T 16
-#define GEO_P (GEO_T + 4)      // 20
-#define GEO_G (GEO_T + 2)      // 18
+#ifndef GEO_TX
+#define GEO_TX 64                      // 64 x 4 pixels: rows of whole 256-byte segments (16 x 16: 0.0567 ms, 32 x 8: 0.0526, 64 x 4: 0.0508; tools/ab_loss_tiles.sh)
+#define GEO_TY 4
+#endif
+#define GEO_PX (GEO_TX + 4)    // P tile, halo 2
+#define GEO_PY (GEO_TY + 4)
+#define GEO_GX (GEO_TX + 2)    // g tile, halo 1
+#define GEO_GY (GEO_TY + 2)
+#define GEO_NLD ((GEO_PX * GEO_PY + 255) / 256)
+static_assert(GEO_TX * GEO_TY == 256 && (GEO_TX & (GEO_TX - 1)) == 0, "one thread per pixel of the tile");
 
 struct GeoArgs {
     int H, W;
@@ -263,32 +308,43 @@ __device__ __forceinline__ float nan0(float v) { return (isnan(v) || isinf(v)) ?
 
 __global__ void __launch_bounds__(256) k_surfel_geo(GeoArgs p)
 {
-    __shared__ float sP[3][GEO_P][GEO_P + 1];
-    __shared__ float sG[6][GEO_G][GEO_G + 1];
-    __shared__ float sDot[GEO_G][GEO_G + 1];
-    __shared__ float sN[3][GEO_G][GEO_G + 1];
+    __shared__ float sP[3][GEO_PY][GEO_PX + 1];
+    __shared__ float sG[6][GEO_GY][GEO_GX + 1];
+    __shared__ float sDot[GEO_GY][GEO_GX + 1];
+    __shared__ float sN[3][GEO_GY][GEO_GX + 1];
     __shared__ float red[4];
     typedef const float __attribute__((address_space(4))) * cfp;
     float rm[9], nr[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) { rm[i] = ((cfp)p.ray_mat)[i]; nr[i] = ((cfp)p.normal_rot)[i]; }
-    const int H = p.H, W = p.W, x0 = blockIdx.x * GEO_T, y0 = blockIdx.y * GEO_T;
+    const int H = p.H, W = p.W, x0 = blockIdx.x * GEO_TX, y0 = blockIdx.y * GEO_TY;
     const size_t N = (size_t)H * W;
-    for (int e = threadIdx.x; e < GEO_P * GEO_P; e += 256) {
-        const int ly = e / GEO_P, lx = e % GEO_P, gy = y0 + ly - 2, gx = x0 + lx - 2;
-        float P0 = 0.f, P1 = 0.f, P2 = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const size_t o = (size_t)gy * W + gx;
-            const float a = p.allmap[N + o];
-            const float d = nan0(p.allmap[o] / a) * (1.0f - p.depth_ratio) + p.depth_ratio * nan0(p.allmap[5 * N + o]);
-            const float fx = (float)gx, fy = (float)gy;
-            P0 = d * (fx * rm[0] + fy * rm[3] + rm[6]); P1 = d * (fx * rm[1] + fy * rm[4] + rm[7]); P2 = d * (fx * rm[2] + fy * rm[5] + rm[8]);
+    {   // loads of every round first (clamped address + select instead of a branch), LDS writes after: see k_ssim_fwd
+        float va[GEO_NLD], v0[GEO_NLD], v5[GEO_NLD];
+#pragma unroll
+        for (int i = 0; i < GEO_NLD; i++) {
+            const int e = threadIdx.x + i * 256, ly = e / GEO_PX, lx = e % GEO_PX, gy = y0 + ly - 2, gx = x0 + lx - 2;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && e < GEO_PX * GEO_PY;
+            const size_t o = in ? (size_t)gy * W + gx : 0;
+            va[i] = p.allmap[N + o]; v0[i] = p.allmap[o]; v5[i] = p.allmap[5 * N + o];
         }
-        sP[0][ly][lx] = P0; sP[1][ly][lx] = P1; sP[2][ly][lx] = P2;
+#pragma unroll
+        for (int i = 0; i < GEO_NLD; i++) {
+            const int e = threadIdx.x + i * 256, ly = e / GEO_PX, lx = e % GEO_PX, gy = y0 + ly - 2, gx = x0 + lx - 2;
+            if (e < GEO_PX * GEO_PY) {
+                float P0 = 0.f, P1 = 0.f, P2 = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const float d = nan0(v0[i] / va[i]) * (1.0f - p.depth_ratio) + p.depth_ratio * nan0(v5[i]);
+                    const float fx = (float)gx, fy = (float)gy;
+                    P0 = d * (fx * rm[0] + fy * rm[3] + rm[6]); P1 = d * (fx * rm[1] + fy * rm[4] + rm[7]); P2 = d * (fx * rm[2] + fy * rm[5] + rm[8]);
+                }
+                sP[0][ly][lx] = P0; sP[1][ly][lx] = P1; sP[2][ly][lx] = P2;
+            }
+        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < GEO_G * GEO_G; e += 256) {
-        const int ly = e / GEO_G, lx = e % GEO_G, gy = y0 + ly - 1, gx = x0 + lx - 1;
+    for (int e = threadIdx.x; e < GEO_GX * GEO_GY; e += 256) {
+        const int ly = e / GEO_GX, lx = e % GEO_GX, gy = y0 + ly - 1, gx = x0 + lx - 1;
         float g[6] = {0, 0, 0, 0, 0, 0}, n[3] = {0, 0, 0}, dot = 0.f;
         if (gy >= 1 && gy <= H - 2 && gx >= 1 && gx <= W - 2) {
             const size_t o = (size_t)gy * W + gx;
@@ -323,7 +379,7 @@ __global__ void __launch_bounds__(256) k_surfel_geo(GeoArgs p)
         sDot[ly][lx] = dot;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, gx = x0 + lx, gy = y0 + ly;
+    const int lx = threadIdx.x % GEO_TX, ly = threadIdx.x / GEO_TX, gx = x0 + lx, gy = y0 + ly;
     float err = 0.f, dist = 0.f;
     if (gx < W && gy < H) {
         const size_t o = (size_t)gy * W + gx;
@@ -364,7 +420,13 @@ __global__ void __launch_bounds__(1024) k_geo_finish(const float2* __restrict__ 
 {
     __shared__ float r1[16], r2[16];
     float a = 0.f, b = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) { const float2 q = partial[i]; a += q.x; b += q.y; }
+    for (int i0 = 0; i0 < n; i0 += 8 * 1024) {           // eight loads in flight per thread, summed in index order
+        float2 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 1024 + threadIdx.x; q[u] = partial[i < n ? i : 0]; if (i >= n) q[u] = make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a += q[u].x; b += q[u].y; }
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); }
     if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = a; r2[threadIdx.x >> 6] = b; }
@@ -378,7 +440,7 @@ __global__ void __launch_bounds__(1024) k_geo_finish(const float2* __restrict__ 
 
 extern "C" size_t gsr_loss_surfel_geo_scratch_bytes(int32_t H, int32_t W)
 {
-    return (H > 0 && W > 0) ? (size_t)gsr_div_up(W, GEO_T) * gsr_div_up(H, GEO_T) * sizeof(float2) : 0;
+    return (H > 0 && W > 0) ? (size_t)gsr_div_up(W, GEO_TX) * gsr_div_up(H, GEO_TY) * sizeof(float2) : 0;
 }
 
 extern "C" int gsr_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, const float* ray_mat, const float* normal_rot, float depth_ratio,
@@ -395,7 +457,7 @@ extern "C" int gsr_loss_surfel_geo(int32_t H, int32_t W, const float* allmap, co
     a.H = H; a.W = W; a.allmap = allmap; a.ray_mat = ray_mat; a.normal_rot = normal_rot; a.depth_ratio = depth_ratio;
     a.wn = lambda_normal * inv_n; a.wd = lambda_dist * inv_n; a.partial = (float2*)scratch; a.dL = dL_dallmap;
     a.o_depth = out_surf_depth; a.o_nw = out_normal_world; a.o_sn = out_surf_normal;
-    const dim3 grid(gsr_div_up(W, GEO_T), gsr_div_up(H, GEO_T));
+    const dim3 grid(gsr_div_up(W, GEO_TX), gsr_div_up(H, GEO_TY));
     hipLaunchKernelGGL(k_surfel_geo, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_geo_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, (int)(grid.x * grid.y), loss_out, inv_n, lambda_normal,
                        lambda_dist);
@@ -418,29 +480,38 @@ __device__ __forceinline__ float sgn_(float v) { return v > 0.f ? 1.0f : (v < 0.
 
 __global__ void __launch_bounds__(256) k_plane_geo(PlaneGeoArgs p)
 {
-    __shared__ float sP[3][GEO_P][GEO_P + 1];
-    __shared__ float sG[6][GEO_G][GEO_G + 1];
-    __shared__ float sN[3][GEO_G][GEO_G + 1];
+    __shared__ float sP[3][GEO_PY][GEO_PX + 1];
+    __shared__ float sG[6][GEO_GY][GEO_GX + 1];
+    __shared__ float sN[3][GEO_GY][GEO_GX + 1];
     __shared__ float red[4];
     typedef const float __attribute__((address_space(4))) * cfp;
     float rm[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) rm[i] = ((cfp)p.ray_mat)[i];
-    const int H = p.H, W = p.W, x0 = blockIdx.x * GEO_T, y0 = blockIdx.y * GEO_T;
+    const int H = p.H, W = p.W, x0 = blockIdx.x * GEO_TX, y0 = blockIdx.y * GEO_TY;
     const size_t N = (size_t)H * W;
-    for (int e = threadIdx.x; e < GEO_P * GEO_P; e += 256) {
-        const int ly = e / GEO_P, lx = e % GEO_P, gy = y0 + ly - 2, gx = x0 + lx - 2;
-        float P0 = 0.f, P1 = 0.f, P2 = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float d = p.depth[(size_t)gy * W + gx];
-            const float fx = (float)gx, fy = (float)gy;
-            P0 = d * (fx * rm[0] + fy * rm[3] + rm[6]); P1 = d * (fx * rm[1] + fy * rm[4] + rm[7]); P2 = d * (fx * rm[2] + fy * rm[5] + rm[8]);
+    {
+        float vd[GEO_NLD];
+#pragma unroll
+        for (int i = 0; i < GEO_NLD; i++) {
+            const int e = threadIdx.x + i * 256, ly = e / GEO_PX, lx = e % GEO_PX, gy = y0 + ly - 2, gx = x0 + lx - 2;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W && e < GEO_PX * GEO_PY;
+            vd[i] = p.depth[in ? (size_t)gy * W + gx : 0];
+            if (!in) vd[i] = 0.0f;
         }
-        sP[0][ly][lx] = P0; sP[1][ly][lx] = P1; sP[2][ly][lx] = P2;
+#pragma unroll
+        for (int i = 0; i < GEO_NLD; i++) {
+            const int e = threadIdx.x + i * 256, ly = e / GEO_PX, lx = e % GEO_PX, gy = y0 + ly - 2, gx = x0 + lx - 2;
+            if (e < GEO_PX * GEO_PY) {
+                const float d = vd[i], fx = (float)gx, fy = (float)gy;
+                sP[0][ly][lx] = d * (fx * rm[0] + fy * rm[3] + rm[6]); sP[1][ly][lx] = d * (fx * rm[1] + fy * rm[4] + rm[7]);
+                sP[2][ly][lx] = d * (fx * rm[2] + fy * rm[5] + rm[8]);
+            }
+        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < GEO_G * GEO_G; e += 256) {
-        const int ly = e / GEO_G, lx = e % GEO_G, gy = y0 + ly - 1, gx = x0 + lx - 1;
+    for (int e = threadIdx.x; e < GEO_GX * GEO_GY; e += 256) {
+        const int ly = e / GEO_GX, lx = e % GEO_GX, gy = y0 + ly - 1, gx = x0 + lx - 1;
         float g[6] = {0, 0, 0, 0, 0, 0}, n[3] = {0, 0, 0};
         if (gy >= 1 && gy <= H - 2 && gx >= 1 && gx <= W - 2) {
             const size_t o = (size_t)gy * W + gx;
@@ -469,7 +540,7 @@ __global__ void __launch_bounds__(256) k_plane_geo(PlaneGeoArgs p)
         for (int c = 0; c < 3; c++) sN[c][ly][lx] = n[c];
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4, gx = x0 + lx, gy = y0 + ly;
+    const int lx = threadIdx.x % GEO_TX, ly = threadIdx.x / GEO_TX, gx = x0 + lx, gy = y0 + ly;
     float err = 0.f;
     if (gx < W && gy < H) {
         const size_t o = (size_t)gy * W + gx;
@@ -507,7 +578,7 @@ extern "C" int gsr_loss_plane_geo(int32_t H, int32_t W, const float* plane_depth
     const float inv_n = 1.0f / ((float)H * (float)W);
     a.H = H; a.W = W; a.depth = plane_depth; a.alpha = alpha; a.normal = normal; a.weight = weight; a.ray_mat = ray_mat;
     a.wl = lambda_normal * inv_n; a.partial = (float2*)scratch; a.dDepth = dL_ddepth; a.dNormal = dL_dnormal; a.o_dn = out_depth_normal;
-    const dim3 grid(gsr_div_up(W, GEO_T), gsr_div_up(H, GEO_T));
+    const dim3 grid(gsr_div_up(W, GEO_TX), gsr_div_up(H, GEO_TY));
     hipLaunchKernelGGL(k_plane_geo, grid, dim3(256), 0, s, a);
     // loss_out = {mean weighted L1, 0, lambda * mean}
     hipLaunchKernelGGL(k_geo_finish, dim3(1), dim3(1024), 0, s, (const float2*)scratch, (int)(grid.x * grid.y), loss_out, inv_n, lambda_normal, 0.0f);
