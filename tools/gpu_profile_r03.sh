@@ -43,4 +43,6 @@ for m in scaffold-2dgs octree-pgsr; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/it_$m -- python $R/tools/iter_breakdown.py --method $m > /dev/null 2>&1
   f=$(find $O/it_$m -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${m}_iteration_kernel_stats.csv; rm -rf $O/it_$m
 done
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/it_losses -- python $R/tools/bench_losses.py > $O/bench_losses.json 2>/dev/null
+f=$(find $O/it_losses -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/loss_kernel_stats.csv; rm -rf $O/it_losses
 ls -la $O | head -40

@@ -4,6 +4,7 @@ cp $O/bench_default.json profiles/r03_bench_default.json; cp $O/bench_ewa.json p
 for v in surfel ewa plane; do cp $O/${v}_kernel_stats.csv profiles/r03_${v}_kernel_stats.csv; done
 cp $O/timeline_surfel.json profiles/r03_timeline_surfel.json; cp $O/side_points.jsonl profiles/r03_side_points.jsonl; cp $O/tsdf_sparse.json profiles/r03_tsdf_sparse.json
 cp $O/scaffold-2dgs_iteration_kernel_stats.csv profiles/r03_scaffold2dgs_iteration_kernel_stats.csv; cp $O/octree-pgsr_iteration_kernel_stats.csv profiles/r03_octree_pgsr_iteration_kernel_stats.csv
+cp $O/loss_kernel_stats.csv profiles/r03_loss_kernel_stats.csv 2>/dev/null; cp $O/bench_losses.json profiles/r03_bench_losses.json 2>/dev/null
 cp $O/traffic.json profiles/traffic.json; python tools/kernel_resources.py > profiles/r03_kernel_resources.json 2>/dev/null
 python - <<PY
 import json
