@@ -151,6 +151,17 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     __shared__ uint32_t lds[17];
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // The block's keys (and, where the registers allow, values) are requested before the histogram rows below: the two sets of loads are
+    // independent, and a block pays their round trips once instead of one after the other.
+    constexpr bool EARLY_VALS = ITEMS <= 4;
+    const uint32_t base = blockIdx.x * (GSR_SORT_THREADS * ITEMS) + wave * (GSR_WAVE * ITEMS);
+    uint32_t key[ITEMS], rank[ITEMS], val[EARLY_VALS ? ITEMS : 1];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const uint32_t i = base + it * GSR_WAVE + lane;
+        key[it] = i < n ? keys_in[i] : 0xFFFFFFFFu;
+        if (EARLY_VALS) val[it] = (vals_in && i < n) ? vals_in[i] : i;
+    }
     for (int i = threadIdx.x; i < 4 * NB; i += GSR_SORT_THREADS) (&cnt[0][0])[i] = 0;
     {   // global base of digit d for this block = (#keys with a smaller digit) + (#keys with digit d in earlier blocks): the group
         // histograms of the earlier groups + the block histograms of the earlier blocks of this group (coalesced NB-word rows)
@@ -166,28 +177,40 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
             }
             ngroups = 0;
         }
-        // rows are requested eight at a time (independent loads in flight): a rolled loop would pay one L2 round trip per row
-        for (uint32_t g0 = 0; g0 < ngroups; g0 += 8) {
+        // rows are requested GB at a time (independent loads in flight): a rolled loop would pay one L2 round trip per row.  With one digit per
+        // thread the block histograms of this group's earlier blocks are requested first and summed last, under the group rows' round trips.
+        constexpr int GB = DPT == 1 ? 16 : 8;
+        uint32_t ch[DPT == 1 ? GSR_SORT_GROUP - 1 : 1];
+        const uint32_t b0 = grp * GSR_SORT_GROUP;
+        if (DPT == 1 && !digit_major_nblk) {
+#pragma unroll
+            for (int u = 0; u < GSR_SORT_GROUP - 1; u++) ch[u] = (threadIdx.x <= mask && b0 + u < blockIdx.x) ? H[(size_t)(b0 + u) * NB + threadIdx.x] : 0u;
+        }
+        for (uint32_t g0 = 0; g0 < ngroups; g0 += GB) {
 #pragma unroll
             for (int k = 0; k < DPT; k++) {
                 const uint32_t d = DPT * threadIdx.x + k;
-                uint32_t c[8];
+                uint32_t c[GB];
 #pragma unroll
-                for (int u = 0; u < 8; u++) c[u] = (d <= mask && g0 + u < ngroups) ? GH[(size_t)(g0 + u) * NB + d] : 0u;
+                for (int u = 0; u < GB; u++) c[u] = (d <= mask && g0 + u < ngroups) ? GH[(size_t)(g0 + u) * NB + d] : 0u;
 #pragma unroll
-                for (int u = 0; u < 8; u++) { t[k] += c[u]; if (g0 + u < grp) before[k] += c[u]; }
+                for (int u = 0; u < GB; u++) { t[k] += c[u]; if (g0 + u < grp) before[k] += c[u]; }
             }
         }
         if (!digit_major_nblk) {
-            const uint32_t b0 = grp * GSR_SORT_GROUP;
+            if (DPT == 1) {
 #pragma unroll
-            for (int k = 0; k < DPT; k++) {
-                const uint32_t d = DPT * threadIdx.x + k;
-                uint32_t c[GSR_SORT_GROUP - 1];
+                for (int u = 0; u < GSR_SORT_GROUP - 1; u++) before[0] += ch[u];
+            } else {
 #pragma unroll
-                for (int u = 0; u < GSR_SORT_GROUP - 1; u++) c[u] = (d <= mask && b0 + u < blockIdx.x) ? H[(size_t)(b0 + u) * NB + d] : 0u;
+                for (int k = 0; k < DPT; k++) {
+                    const uint32_t d = DPT * threadIdx.x + k;
+                    uint32_t c[GSR_SORT_GROUP - 1];
 #pragma unroll
-                for (int u = 0; u < GSR_SORT_GROUP - 1; u++) before[k] += c[u];
+                    for (int u = 0; u < GSR_SORT_GROUP - 1; u++) c[u] = (d <= mask && b0 + u < blockIdx.x) ? H[(size_t)(b0 + u) * NB + d] : 0u;
+#pragma unroll
+                    for (int u = 0; u < GSR_SORT_GROUP - 1; u++) before[k] += c[u];
+                }
             }
         }
         digit_excl_scan<NB>(t, ex, lds);
@@ -199,14 +222,11 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
     }
     __syncthreads();
 
-    const uint32_t base = blockIdx.x * (GSR_SORT_THREADS * ITEMS) + wave * (GSR_WAVE * ITEMS);
-    uint32_t key[ITEMS], rank[ITEMS];
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = base + it * GSR_WAVE + lane;
         const bool valid = i < n;
-        key[it] = valid ? keys_in[i] : 0xFFFFFFFFu;
         const uint32_t d = (key[it] >> shift) & mask;
         // lanes of this wave holding the same digit (invalid lanes form their own group and are ignored)
         uint64_t peers = __ballot(valid);
@@ -250,7 +270,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
             const uint32_t d = (key[it] >> shift) & mask;
             const uint32_t lp = lbase[d] + cnt[wave][d] + rank[it];
             skey[lp] = key[it];
-            sval[lp] = vals_in ? vals_in[i] : i;
+            sval[lp] = EARLY_VALS ? val[it] : (vals_in ? vals_in[i] : i);
         }
     }
     __syncthreads();
