@@ -690,25 +690,29 @@ __global__ void __launch_bounds__(64) k_wgrad(WgArgs p)
     // chunk c = anchors 64 c .. 64 c + 63 = tiles 4 c .. 4 c + 3; lane (i, kk) reads the 16 anchors of tile 4 c + kk for its column
     const float* colA = p.sc + ((size_t)kk * SC_COLS + pr.a_col + i) * 16;
     const float* colB = p.sc + ((size_t)kk * SC_COLS + pr.b_col + i) * 16;
+    // A wave walks ~4.5 chunks; every chunk's loads (A and up to three B column groups, 16 float4 per lane) go out together -- group by
+    // group behind the `nb < pr.nb` test they were four dependent round trips per chunk.  Groups beyond pr.nb re-read group 0 (a valid
+    // address) and their products are not formed.
     for (int c = blockIdx.x; c < p.n_chunks; c += gridDim.x) {
         const size_t o = (size_t)c * 4 * SC_COLS * 16;
-        float4 a4[4];
+        float4 a4[4], b4[3][4];
 #pragma unroll
         for (int q = 0; q < 4; q++) a4[q] = reinterpret_cast<const float4*>(colA + o)[q];
+#pragma unroll
+        for (int nb = 0; nb < 3; nb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) b4[nb][q] = reinterpret_cast<const float4*>(colB + (size_t)(16 * (nb < pr.nb ? nb : 0)) * 16 + o)[q];
 #pragma unroll
         for (int q = 0; q < 4; q++) bsum += (a4[q].x + a4[q].y) + (a4[q].z + a4[q].w);
 #pragma unroll
         for (int nb = 0; nb < 3; nb++) {
             if (nb < pr.nb) {
-                float4 b4[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) b4[q] = reinterpret_cast<const float4*>(colB + (size_t)(16 * nb) * 16 + o)[q];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].x, b4[q].x, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].y, b4[q].y, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].z, b4[q].z, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].w, b4[q].w, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].x, b4[nb][q].x, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].y, b4[nb][q].y, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].z, b4[nb][q].z, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q].w, b4[nb][q].w, acc[nb], 0, 0, 0);
                 }
             }
         }
