@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(256) k_loss_l1_linear(int64_t n4c, int64_t nc,
 {
     float acc = 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll 2
     for (int64_t i = t0; i < n4c; i += stride) {
         const float4 c = reinterpret_cast<const float4*>(color)[i], g = reinterpret_cast<const float4*>(gt)[i];
         const float d0 = c.x - g.x, d1 = c.y - g.y, d2 = c.z - g.z, d3 = c.w - g.w;
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(256) k_loss_l1_linear(int64_t n4c, int64_t nc,
         dcol[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);
     }
     acc *= inv_n;
+#pragma unroll 4
     for (int64_t i = t0; i < n4a; i += stride) {
         const float4 a = reinterpret_cast<const float4*>(aux)[i], w = reinterpret_cast<const float4*>(waux)[i];
         acc += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);

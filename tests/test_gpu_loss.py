@@ -153,6 +153,28 @@ def test_l1_plus_linear_root_flag_same_gradients():
     assert abs(grads[0][0] - ref.item()) < 1e-3 * abs(ref.item()) + 1e-5
 
 
+@pytest.mark.parametrize("shape, shift", [((540, 960), 0), ((67, 91), 0), ((67, 91), 1)], ids=["several-grid-strides", "ragged", "misaligned"])
+def test_l1_plus_linear_matches_torch(shape, shift):
+    """Value and dL/dcolor against the torch expression, at a size that takes the unrolled grid-stride loops through whole rounds and a
+    remainder (11 x 540 x 960 auxiliary values: 2.7 rounds of the 2048 x 256-thread grid), at a ragged size (tail elements after the float4
+    body), and on views that start one element into their storage (the 16-byte test fails: scalar path)."""
+    from gsrast.losses import l1_plus_linear
+    H, W = shape
+    g = torch.Generator().manual_seed(3)
+    def mk(ch, randn=False):
+        t = (torch.randn if randn else torch.rand)(ch * H * W + shift, generator=g).to(DEV)
+        return t[shift:].view(ch, H, W)
+    c, gt, a, w = mk(3), mk(3), mk(11), mk(11, True)
+    cc = c.detach().requires_grad_(True)
+    loss = l1_plus_linear(cc, gt, a, w)
+    loss.backward()
+    ref_c = c.detach().double().requires_grad_(True)
+    ref = (ref_c - gt.double()).abs().mean() + (a.double() * w.double()).sum()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-5 * max(abs(ref.item()), (a * w).abs().sum().item() * 1e-2) + 1e-6
+    assert torch.equal(cc.grad, ref_c.grad.float())
+
+
 def test_unit_upstream_flag_same_gradients_and_unused_loss_sends_none():
     """unit_upstream=True (the loss enters the total with weight 1, as in GS-SR's sum(loss_dict.values())) returns the stored gradient without the
     full-size multiply by the upstream scalar: bit-identical to the default path when that scalar is 1; and a loss value that is computed but
