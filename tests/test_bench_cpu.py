@@ -1,0 +1,81 @@
+"""Host logic of bench.py that the judged JSON line rests on (no GPU): the algorithmic-byte model of SURVEY §8(d), the mirror of the library's
+depth-order rule, the self-launcher's environment, and the argument defaults the driver relies on."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench   # noqa: E402
+
+
+def test_algorithmic_bytes_follow_the_survey_table():
+    # bytes staged per tile instance, read / written per pixel, gradient bytes per instance; + 8 B per tile range
+    R, N, T = 1_380_000, 1920 * 1080, 8160
+    for variant, (rec, pix_f, grad, pix_b) in {"ewa": (40, 20, 44, 20), "plane": (60, 44, 68, 64), "surfel": (76, 76, 72, 76)}.items():
+        fwd, bwd = bench.algorithmic_bytes(variant, R, N, T)
+        assert fwd == R * rec + N * pix_f + 8 * T
+        assert bwd == R * (rec + grad) + N * pix_b + 8 * T
+    # the headline kernel's figure in the committed bench line is this model at the R that run measured
+    import json
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")).read().strip().splitlines()[-1])
+    fwd, bwd = bench.algorithmic_bytes("surfel", line["config"]["tile_instances_R"], N, T)
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == bwd
+    assert abs(line["roofline"]["achieved"] - bwd / (line["roofline"]["avg_launch_ms"] * 1e-3) / 1e9) < 0.5
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-4
+
+
+def test_depth_order_rule_mirrors_the_library(monkeypatch):
+    src = open(os.path.join(ROOT, "gs-sr_amd", "csrc", "gsr_binning.hip")).read()
+    m = re.search(r"variant == GSR_EWA \? (\d+)ll : \(variant == GSR_PLANE \? (\d+)ll : (\d+)ll\)", src)
+    assert m, "gsr_depth_order_static_rule changed shape: update bench.depth_order_is_global and this test"
+    per_tile = {"ewa": int(m.group(1)), "plane": int(m.group(2)), "surfel": int(m.group(3))}
+    monkeypatch.delenv("GSR_DEPTH_ORDER", raising=False)
+    T = 8160
+    for v, k in per_tile.items():
+        assert bench.depth_order_is_global(k * T, T, v) is False          # P <= k T: per-tile sort inside the forward
+        assert bench.depth_order_is_global(k * T + 1, T, v) is True
+    monkeypatch.setenv("GSR_DEPTH_ORDER", "global")
+    assert bench.depth_order_is_global(1, T, "surfel") is True
+    monkeypatch.setenv("GSR_DEPTH_ORDER", "tile")
+    assert bench.depth_order_is_global(10 ** 9, T, "ewa") is False
+
+
+def test_stage_bytes_move_the_sort_into_the_forward_when_it_is_fused(monkeypatch):
+    monkeypatch.delenv("GSR_DEPTH_ORDER", raising=False)
+    P, R, N, T = 300_000, 1_380_000, 1920 * 1080, 8160
+    b = bench.stage_bytes("surfel", "precomp", P, R, N, T)
+    fwd, bwd = bench.algorithmic_bytes("surfel", R, N, T)
+    assert b["blend_bwd"] == bwd
+    assert b["blend_fwd"] == fwd + 12 * R          # per-tile mode: the prologue reads id + depth key and writes the id back
+    assert set(b) >= {"preprocess", "depth_order", "binning", "blend_fwd", "blend_bwd", "preprocess_bwd"}
+
+
+def test_helper_children_do_not_inherit_the_rendezvous(monkeypatch):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.setenv(k, "1")
+    monkeypatch.setenv("GSR_XCD_REMAP", "2")
+    env = bench.child_env()
+    assert not {"RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"} & set(env)
+    assert env["GSR_XCD_REMAP"] == "2"
+
+
+def test_self_launcher_refuses_shared_devices_unless_asked(monkeypatch):
+    import types
+    import pytest
+    from gsrast import launch_tiles
+    seen = {}
+
+    def fake_spawn(cmd_of_rank, world, ndev, port, pin_gpus=True, extra_env=None):
+        seen.update(world=world, ndev=ndev, port=port, pin=pin_gpus, env=dict(extra_env or {}), cmd=cmd_of_rank(0))
+        return 0
+    monkeypatch.setattr(launch_tiles, "spawn_ranks", fake_spawn)
+    monkeypatch.setenv("MASTER_PORT", "29577")
+    args = types.SimpleNamespace(gpus=4, oversubscribe=False, no_pin=False)
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(args, ndev=2)                       # two ranks on one device: RCCL would refuse the communicator
+    assert bench.launch_ranks(types.SimpleNamespace(gpus=2, oversubscribe=False, no_pin=False), ndev=8) == 0
+    assert seen["world"] == 2 and seen["ndev"] == 2 and seen["port"] == 29577 and seen["pin"] and seen["env"] == {"GSR_BENCH_BACKEND": "nccl"}
+    assert os.path.basename(seen["cmd"][1]) == "bench.py"
+    assert bench.launch_ranks(types.SimpleNamespace(gpus=4, oversubscribe=True, no_pin=False), ndev=2) == 0
+    assert seen["world"] == 4 and seen["ndev"] == 2 and seen["env"] == {"GSR_BENCH_BACKEND": "gloo"}
