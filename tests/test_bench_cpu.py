@@ -79,3 +79,22 @@ def test_self_launcher_refuses_shared_devices_unless_asked(monkeypatch):
     assert os.path.basename(seen["cmd"][1]) == "bench.py"
     assert bench.launch_ranks(types.SimpleNamespace(gpus=4, oversubscribe=True, no_pin=False), ndev=2) == 0
     assert seen["world"] == 4 and seen["ndev"] == 2 and seen["env"] == {"GSR_BENCH_BACKEND": "gloo"}
+
+
+def test_committed_rocprof_summary_agrees_with_the_bench_line():
+    """profiles/: the rocprofv3 --kernel-trace --stats average of the dominant kernel and the HIP-event average inside bench.py are two
+    measurements of the same launches (different boxes of the pool: a few per cent apart at most), and the PMC traffic figure quoted in the
+    line is the one in the committed counter summary."""
+    import csv
+    import json
+    prof = os.path.join(ROOT, "profiles")
+    line = json.loads(open(os.path.join(prof, "r03_bench_default.json")).read().strip().splitlines()[-1])
+    rows = [r for r in csv.DictReader(open(os.path.join(prof, "r03_surfel_kernel_stats.csv"))) if "k_blend_bwd_sp<1>" in r["Name"]]
+    assert len(rows) == 1
+    rocprof_ms = float(rows[0]["AverageNs"]) * 1e-6
+    assert abs(rocprof_ms - line["roofline"]["avg_launch_ms"]) < 0.03 * line["roofline"]["avg_launch_ms"]
+    pmc = json.load(open(os.path.join(prof, "r03_pmc_summary.json")))
+    assert abs(pmc["k_blend_bwd_sp<1>"]["hbm_bytes_per_launch"] - line["roofline"]["traffic"]) < 0.02 * line["roofline"]["traffic"]
+    assert line["roofline"]["traffic"] >= line["roofline"]["algorithmic_bytes_per_launch"]
+    assert line["metric"].startswith("train iters/sec") and line["unit"] == "iters/s" and line["n_gpus"] == 1 and line["scaling"] == "weak"
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
