@@ -283,10 +283,18 @@ def parity_full_size(variant, sc, og, device, color_mode):
     beside every figure -- the criterion of tests/test_gpu_parity.py::test_full_size_oracle_parity (tests/parity_truth.py), reported here."""
     import hiprun
     import parity_truth as pt
-    f32, fma, truth, ints = pt.run_oracles(sc, variant, og)
     st = hiprun.run_raw(variant, sc, device=device)
     res = hiprun.run(variant, sc, og, device=device)
-    cand = dict(color=st["color"], final_T=st["final_T"], n_contrib=st["n_contrib"], grads=res["grads"])
+    lists = "pass"
+    try:
+        # the library's tile-instance list (instances that can reach no pixel of their tile are not emitted, gsr_tile_cull.h) against the oracle's full
+        # list: subset in order, nothing contributing dropped (float32 and float64), the exact float64 region kept -- tests/tile_cull.py
+        f32, fma, truth, ints = pt.run_oracles(sc, variant, og, hip_state=st)
+    except AssertionError as e:
+        lists = "FAIL: " + str(e)[:300]
+        f32, fma, truth, ints = pt.run_oracles(sc, variant, og)
+    view = ints.get("view")
+    cand = dict(color=st["color"], final_T=st["final_T"], n_contrib=view["n_contrib"] if view else st["n_contrib"], grads=res["grads"])
     if variant == "surfel":
         cand["others"] = st["others"]
     if variant == "plane":
@@ -298,7 +306,8 @@ def parity_full_size(variant, sc, og, device, color_mode):
         verdict = "FAIL: " + str(e)[:300]
     rnd = lambda v: float(f"{v:.4g}") if isinstance(v, float) else v
     out = {"criterion": "tests/parity_truth.py vs float64 truth", "verdict": verdict,
-           "radii_equal": bool(np.array_equal(st["radii"], ints["radii"])), "point_list_equal": bool(np.array_equal(st["point_list"], ints["point_list"])),
+           "radii_equal": bool(np.array_equal(st["radii"], ints["radii"])), "instance_list_vs_oracle": lists,
+           "tile_instances": {k: (rnd(v) if isinstance(v, float) else v) for k, v in (view or {}).items() if k not in ("keep", "n_contrib")},
            "robust_pixel_fraction": rnd(rep.get("robust_pixel_fraction", 0.0)), "fragile_pixels_by_gate": rep.get("fragile_pixels_by_gate"),
            "robust_row_fraction": rnd(rep.get("robust_row_fraction", 0.0))}
     for k in ("n_contrib", "median_contributor", "median_splat", "observe"):

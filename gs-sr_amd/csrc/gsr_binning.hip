@@ -11,6 +11,7 @@
 // Stability of every pass makes the result identical to the reference's single 64-bit sort.
 #include "gsr_common.h"
 #include "gsr_tile_sort.h"
+#include "gsr_tile_cull.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------ wave helpers
@@ -455,9 +456,14 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
 // (binary search over the wave's 64 prefix values with shuffles), so the work per lane is even -- one thread per gaussian left a few
 // lanes looping over hundreds of tiles -- and the key/value stores are fully coalesced.  Order within a gaussian is (y outer, x inner),
 // as in the reference's nested loop.
+// CULLV (template argument): >= 0 = the variant whose region test applies, -1 = the reference's whole rect.  With culling, tiles_touched / offsets
+// count only the tiles the gaussian's cull record can reach (gsr_preprocess.hip pre_tile_count); the wave walks the UNCULLED rects of its 64
+// gaussians, repeats the region test per candidate tile (same function, same words: same answers) and writes the hits compacted, in walk order,
+// behind the wave's culled base.
+template <int CULLV>
 __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ block_prefix, const uint32_t* __restrict__ tiles_touched,
-                                                   const ushort4* __restrict__ rect, int gx,
+                                                   const ushort4* __restrict__ rect, const float4* __restrict__ cull, int gx,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t cap,
                                                    uint2* __restrict__ ranges, uint32_t T, uint32_t* __restrict__ zero_ptr, uint32_t zero_n,
                                                    uint32_t* __restrict__ order_valid, uint32_t scan_block,
@@ -498,6 +504,33 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
     ushort4 r = make_ushort4(0, 0, 1, 1);
     if (cnt) r = rect[g];
     const uint32_t wave_base = __shfl(incl - cnt, 0, 64);
+    if constexpr (CULLV >= 0) {
+        __shared__ float4 s_cull[2 * 256];
+        __shared__ ushort4 s_rect[256];
+        const uint32_t wbase = threadIdx.x & ~63u;
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = make_float4(0.f, -1.f, 0.f, 0.f);
+        if (cnt) { c0 = cull[2 * (size_t)g]; c1 = cull[2 * (size_t)g + 1]; }
+        s_cull[2 * threadIdx.x] = c0; s_cull[2 * threadIdx.x + 1] = c1; s_rect[threadIdx.x] = r;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the walk covers the rects of the gaussians that kept at least one tile (a gaussian whose every tile was dropped has nothing to emit)
+        const uint32_t area = cnt ? ((uint32_t)r.z - (uint32_t)r.x) * ((uint32_t)r.w - (uint32_t)r.y) : 0u;
+        const uint32_t ai = wave_incl_scan(area);
+        const uint32_t total = (uint32_t)__shfl((int)ai, 63, 64), excl = ai - area;
+        uint32_t run = wave_base;
+        for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+            const TcCand c = tc_candidate<CULLV>(k0 + lane, total, excl, s_cull + 2 * wbase, s_rect + wbase);
+            const uint64_t hits = __ballot(c.hit);
+            const uint32_t off = run + (uint32_t)__popcll(hits & lanemask_lt());
+            const uint32_t sg = (uint32_t)__shfl((int)g, (int)c.s, 64);
+            if (c.hit && off < cap) {                    // cap == R normally; smaller only when a speculative forward overflowed
+                keys[off] = c.ty * (uint32_t)gx + c.tx;
+                vals[off] = sg;
+            }
+            run += (uint32_t)__popcll(hits);
+        }
+        return;
+    }
     // lanes past P carry incl = 0: give them the wave's running total so the prefix stays monotone
     uint32_t last = __shfl(incl, 63, 64);
     {
@@ -738,6 +771,14 @@ __global__ void __launch_bounds__(256) k_tile_depth_sort(const uint2* __restrict
     }
 }
 
+// GSR_TILE_CULL=0: tiles_touched and the instance list cover the whole tile rect of every gaussian, like the reference's (gsr_tile_cull.h)
+bool gsr_tile_cull_enabled()
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("GSR_TILE_CULL"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
+
 // GSR_TILE_SORT=fused (default): k_blend_fwd orders its tile's list in its prologue (gsr_tile_sort.h); =kernel: the separate k_tile_depth_sort launch.
 bool gsr_tile_sort_is_fused()
 {
@@ -781,11 +822,19 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     const bool global_order = gsr_depth_order_is_global(cfg, g);
     (void)total_by_duplicate;
     const bool self_scan = gsr_prefix_in_preprocess(cfg, g) && gsr_duplicate_scans();      // the block sums are raw: every workgroup adds up the ones in front of it
-    hipLaunchKernelGGL(k_duplicate, dim3(gsr_div_up((uint32_t)max(cfg->P, T), 256)), dim3(256), 0, s, (uint32_t)cfg->P,
-                       global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr, g.offsets, g.scan_tmp,
-                       g.tiles_touched, g.rect, gx, k0, v0, R, im.ranges, (uint32_t)T, b.hist, gsr_sort_group_words(R, R >= big_from, 256), im.tile_order + T,
-                       gsr_prefix_in_preprocess(cfg, g) ? 256u : (uint32_t)GSR_SCAN_BLOCK,
-                       self_scan ? gsr_div_up((uint32_t)cfg->P, 256u) : 0u, g.counters, host_word_dev);
+    {
+        const dim3 dg(gsr_div_up((uint32_t)max(cfg->P, T), 256)), db(256);
+        const uint32_t* sidx = global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr;
+        const uint32_t zn = gsr_sort_group_words(R, R >= big_from, 256);
+        const uint32_t sblk = gsr_prefix_in_preprocess(cfg, g) ? 256u : (uint32_t)GSR_SCAN_BLOCK;
+        const uint32_t snb = self_scan ? gsr_div_up((uint32_t)cfg->P, 256u) : 0u;
+#define GSR_DUP(CV) hipLaunchKernelGGL(k_duplicate<CV>, dg, db, 0, s, (uint32_t)cfg->P, sidx, g.offsets, g.scan_tmp, g.tiles_touched, g.rect, g.cull, gx, k0, v0, R, \
+                                       im.ranges, (uint32_t)T, b.hist, zn, im.tile_order + T, sblk, snb, g.counters, host_word_dev)
+        if (!gsr_tile_cull_enabled()) GSR_DUP(-1);
+        else if (cfg->variant == GSR_SURFEL) GSR_DUP(GSR_SURFEL);
+        else GSR_DUP(GSR_EWA);
+#undef GSR_DUP
+    }
     bool in_b = false;
     // tile ranges: k_tile_ranges over the sorted keys (default), or written by the last scatter pass (GSR_TILE_RANGES=scatter).  MEASURED (round 3,
     // P = 300k, 1080p): the fold loses -- binning 0.0847 ms against 0.0748 with the separate 5 us kernel: two more LDS reads, a compare and

@@ -110,6 +110,7 @@ bool gsr_depth_order_static_rule(int P, int T, bool* forced, int variant = GSR_S
 // call of a two-stage forward -- finds it (gsr_api.hip).
 void gsr_forward_begin(const gsr_cfg* cfg, const GeomView& g);
 bool gsr_depth_order_is_global(const gsr_cfg* cfg, const GeomView& g);
+bool gsr_tile_cull_enabled();         // GSR_TILE_CULL=0|1 (default 1): tile instances culled at emission (gsr_tile_cull.h, gsr_binning.hip)
 bool gsr_tile_sort_is_fused();        // GSR_TILE_SORT=fused|kernel: who orders a tile's list by depth when the depth order is per tile (gsr_binning.hip)
 bool gsr_tile_order_wanted();         // GSR_TILE_ORDER=0|1, default auto: on while recent forwards reported long tile lists (gsr_api.hip); once per forward
 const uint32_t* gsr_static_tile_map(int gx, int gy, hipStream_t s);     // device [gx*gy] blockIdx -> tile, block-cyclic over the XCDs; cached per device and grid; nullptr if unavailable (gsr_api.hip)

@@ -5,6 +5,7 @@
 // Built with -ffp-contract=off (see gsr_math.h).  Reference behaviour cited per kernel.
 #include "gsr_common.h"
 #include "gsr_tile_sort.h"
+#include "gsr_tile_cull.h"
 #include <stdlib.h>
 #include "gsr_math.h"
 
@@ -27,7 +28,10 @@ struct PreParams {
     // although prefiltered is set" and traps the device (auxiliary.h:156-160); here the kernel stores 1 into this mapped word and the forward call
     // that owns it fails with that message.  nullptr: not checked.
     uint32_t* prefiltered_err;
+    int tile_cull;            // 1 (default): tiles_touched counts only the tiles of the rect the cull record can reach (gsr_tile_cull.h); 0 (GSR_TILE_CULL=0): the whole rect
 };
+// what the tile-instance count needs from the per-gaussian pass: the unculled tile count, the rect and the cull record (also stored in the geom arena)
+struct PreTc { uint32_t tiles; ushort4 rect; float4 c0, c1; };
 
 __device__ __forceinline__ void load16(const float* p, float* m)
 {
@@ -47,9 +51,10 @@ __device__ __forceinline__ float two_tau(float o)
 // ------------------------------------------------------------------------------------------------ EWA / PLANE
 // 3DGS forward.cu:156-256 (PLANE forward.cu:156-268 is identical); FILTER forward.cu:268-340 when FILTER_ONLY.
 template <bool FILTER_ONLY>
-__device__ __forceinline__ uint32_t pre_ewa_one(const PreParams& p, const int idx, const float* sh_staged = nullptr)      // -> tiles_touched
+__device__ __forceinline__ PreTc pre_ewa_one(const PreParams& p, const int idx, const float* sh_staged = nullptr)      // -> rect tiles, rect, cull record
 {
-    if (FILTER_ONLY && p.in_mask && !p.in_mask[idx]) { p.radii[idx] = 0; return 0u; }
+    PreTc tc; tc.tiles = 0u; tc.rect = make_ushort4(0, 0, 0, 0); tc.c0 = make_float4(0, 0, 0, 0); tc.c1 = make_float4(0, -1, 0, 0);
+    if (FILTER_ONLY && p.in_mask && !p.in_mask[idx]) { p.radii[idx] = 0; return tc; }
     float view[16], proj[16];
     load16(p.view, view); load16(p.proj, proj);
 
@@ -120,10 +125,10 @@ __device__ __forceinline__ uint32_t pre_ewa_one(const PreParams& p, const int id
     } while (0);
 
     p.radii[idx] = radius_out;
-    if (FILTER_ONLY) return 0u;
+    if (FILTER_ONLY) return tc;
     p.g.depth_key[idx] = key;
-    p.g.tiles_touched[idx] = tiles;
-    p.g.rect[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+    tc.tiles = tiles; tc.rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1); tc.c0 = cull0; tc.c1 = cull1;
+    p.g.rect[idx] = tc.rect;
     p.g.cull[2 * (size_t)idx] = cull0;
     p.g.cull[2 * (size_t)idx + 1] = cull1;
     p.g.clamped[idx] = clamped;
@@ -131,6 +136,38 @@ __device__ __forceinline__ uint32_t pre_ewa_one(const PreParams& p, const int id
     float4* rec = p.g.rec + (size_t)idx * st;
     rec[0] = q0; rec[1] = q1; rec[2] = q2;
     if (p.variant == GSR_PLANE) rec[3] = q3;
+    return tc;
+}
+// tiles_touched of the wave's 64 gaussians with the tiles their cull record cannot reach left out (gsr_tile_cull.h): the wave walks the rects of its
+// gaussians 64 candidate tiles at a time (lane = candidate), one region test each, and every gaussian counts the hits inside its own span of the
+// ballot.  k_duplicate (gsr_binning.hip) repeats the same walk with the same function on the same words when it emits the instances.
+template <int V>
+__device__ __forceinline__ uint32_t pre_tile_count(const PreParams& p, const int idx, const PreTc& tc)
+{
+    uint32_t tiles = tc.tiles;
+    if (p.tile_cull) {                                // kernel-uniform
+        __shared__ float4 s_cull[2 * 256];
+        __shared__ ushort4 s_rect[256];
+        const uint32_t lane = tds_lane(), wbase = threadIdx.x & ~63u;
+        s_cull[2 * threadIdx.x] = tc.c0; s_cull[2 * threadIdx.x + 1] = tc.c1; s_rect[threadIdx.x] = tc.rect;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t incl = tds_wave_incl_scan(tc.tiles);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64), excl = incl - tc.tiles;
+        uint32_t kept = 0u;
+        for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+            const TcCand c = tc_candidate<V>(k0 + lane, total, excl, s_cull + 2 * wbase, s_rect + wbase);
+            const uint64_t hits = __ballot(c.hit);
+            // this gaussian's candidates occupy [excl, incl) of the walk: bits [lo, hi) of this batch
+            const uint32_t lo = max(excl, k0) - k0, hi = min(incl, k0 + 64u) > k0 ? min(incl, k0 + 64u) - k0 : 0u;
+            if (hi > lo) {
+                const uint64_t span = (hi >= 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                kept += (uint32_t)__popcll(hits & span);
+            }
+        }
+        tiles = kept;
+    }
+    if (idx < p.P) p.g.tiles_touched[idx] = tiles;
     return tiles;
 }
 // the prefix of tiles_touched the id-order binning needs, block part: inclusive scan over the block's 256 gaussians + the block total
@@ -148,9 +185,9 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
 {
     for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t tiles = 0u;
-    if (idx < p.P) tiles = pre_ewa_one<FILTER_ONLY>(p, idx);
-    if (!FILTER_ONLY) pre_block_scan(p, idx, tiles);
+    PreTc tc; tc.tiles = 0u; tc.rect = make_ushort4(0, 0, 0, 0); tc.c0 = make_float4(0, 0, 0, 0); tc.c1 = make_float4(0, -1, 0, 0);
+    if (idx < p.P) tc = pre_ewa_one<FILTER_ONLY>(p, idx);
+    if (!FILTER_ONLY) pre_block_scan(p, idx, pre_tile_count<GSR_EWA>(p, idx, tc));
 }
 
 // The same with the SH coefficients (16 x 3 floats = 192 B per gaussian) staged through LDS.  Read straight from global memory, lane l's 48 floats
@@ -197,15 +234,16 @@ __global__ void __launch_bounds__(256) k_preprocess_ewa_sh16(PreParams p)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* my = s_sh + wave * 64 * GSR_SH_ROW;
     sh_rows_load(my, p.shs, (size_t)(idx - lane), lane, (size_t)p.P * 48);
-    uint32_t tiles = 0u;
-    if (idx < p.P) tiles = pre_ewa_one<false>(p, idx, my + lane * GSR_SH_ROW);
-    pre_block_scan(p, idx, tiles);
+    PreTc tc; tc.tiles = 0u; tc.rect = make_ushort4(0, 0, 0, 0); tc.c0 = make_float4(0, 0, 0, 0); tc.c1 = make_float4(0, -1, 0, 0);
+    if (idx < p.P) tc = pre_ewa_one<false>(p, idx, my + lane * GSR_SH_ROW);
+    pre_block_scan(p, idx, pre_tile_count<GSR_EWA>(p, idx, tc));
 }
 
 // ------------------------------------------------------------------------------------------------ SURFEL
 // SURFEL forward.cu:149-251
-__device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int idx, const float* sh_staged = nullptr)      // -> tiles_touched
+__device__ __forceinline__ PreTc pre_surfel_one(const PreParams& p, const int idx, const float* sh_staged = nullptr)      // -> rect tiles, rect, cull record
 {
+    PreTc tc;
     float view[16], proj[16];
     load16(p.view, view); load16(p.proj, proj);
 
@@ -299,8 +337,8 @@ __device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int
 
     p.radii[idx] = radius_out;
     p.g.depth_key[idx] = key;
-    p.g.tiles_touched[idx] = tiles;
-    p.g.rect[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+    tc.tiles = tiles; tc.rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1); tc.c0 = cull0; tc.c1 = cull1;
+    p.g.rect[idx] = tc.rect;
     p.g.cull[2 * (size_t)idx] = cull0;
     p.g.cull[2 * (size_t)idx + 1] = cull1;
     p.g.clamped[idx] = clamped;
@@ -310,7 +348,7 @@ __device__ __forceinline__ uint32_t pre_surfel_one(const PreParams& p, const int
     rec[2] = make_float4(T[8], pix, piy, o);
     rec[3] = make_float4(normal.x, normal.y, normal.z, rgb.x);
     rec[4] = make_float4(rgb.y, rgb.z, 0.f, 0.f);
-    return tiles;
+    return tc;
 }
 template <bool SH16>
 __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
@@ -325,9 +363,9 @@ __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
         sh_rows_load(my, p.shs, (size_t)(idx - lane), lane, (size_t)p.P * 48);
         sh_row = my + lane * GSR_SH_ROW;
     }
-    uint32_t tiles = 0u;
-    if (idx < p.P) tiles = pre_surfel_one(p, idx, sh_row);
-    pre_block_scan(p, idx, tiles);
+    PreTc tc; tc.tiles = 0u; tc.rect = make_ushort4(0, 0, 0, 0); tc.c0 = make_float4(0, 0, 0, 0); tc.c1 = make_float4(0, -1, 0, 0);
+    if (idx < p.P) tc = pre_surfel_one(p, idx, sh_row);
+    pre_block_scan(p, idx, pre_tile_count<GSR_SURFEL>(p, idx, tc));
 }
 
 // 3DGS rasterizer_impl.cu:54-66
@@ -356,6 +394,7 @@ static PreParams make_params(const gsr_cfg* cfg, const gsr_inputs* in, GeomView 
     { const char* e = getenv("GSR_NO_CULL"); p.no_cull = (e && atoi(e) != 0) ? 1 : 0; }
     p.in_mask = nullptr; p.scale_stride = 3;
     p.scan_offsets = nullptr; p.scan_sums = nullptr; p.prefiltered_err = nullptr;
+    p.tile_cull = gsr_tile_cull_enabled() ? 1 : 0;
     p.radii = radii; p.g = g;
     p.zero_ptr = nullptr; p.zero_n = 0;
     return p;

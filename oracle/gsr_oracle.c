@@ -786,6 +786,59 @@ blend:;
     return st;
 }
 
+/* ------------------------------------------------------------------ which tile instances can contribute at all
+   For every instance k of the sorted list (tile = the range it lies in) the largest alpha the reference's per-pixel gates let through on any
+   pixel of that tile that lies inside the image -- the same statements as blend_pixel_fwd above (EWA 3DGS forward.cu:330-345, SURFEL
+   forward.cu:351-392: power > 0, p.z == 0, depth < near skip the pair), without the transmittance state: an instance whose value stays below
+   1/255 fails the alpha gate (3DGS forward.cu:346, SURFEL :393) on every pixel, whatever lies in front of it.  The HIP library drops such
+   instances when it emits the list (gsr_tile_cull.h); tests hold its filtered list against this. */
+static real pair_alpha(const ref_state* st, const ref_inputs* in, uint32_t id, real pixfx, real pixfy)
+{
+    const real* nor_o = st->conic_opacity + 4*id;
+    if (st->variant != REF_SURFEL) {
+        real dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
+        real power = -0.5f * (nor_o[0] * dx * dx + nor_o[2] * dy * dy) - nor_o[1] * dx * dy;
+        if (power > 0.0f) return 0;
+        return R_fmin(0.99f, nor_o[3] * R_exp(power));
+    }
+    const real* Tm = (in->cov3D_precomp ? in->cov3D_precomp : st->cov3D) + 9*id;
+    const real* Tu = Tm; const real* Tv = Tm + 3; const real* Tw = Tm + 6;
+    real kx = pixfx*Tw[0] - Tu[0], ky = pixfx*Tw[1] - Tu[1], kz = pixfx*Tw[2] - Tu[2];
+    real lx = pixfy*Tw[0] - Tv[0], ly = pixfy*Tw[1] - Tv[1], lz = pixfy*Tw[2] - Tv[2];
+    real ppx = ky*lz - kz*ly, ppy = kz*lx - kx*lz, ppz = kx*ly - ky*lx;
+    if (ppz == 0.0f) return 0;
+    real sx = ppx / ppz, sy = ppy / ppz;
+    real rho3d = (sx*sx + sy*sy);
+    real dx = st->means2D[2*id] - pixfx, dy = st->means2D[2*id+1] - pixfy;
+    real rho2d = FilterInvSquare * (dx*dx + dy*dy);
+    real rho = R_fmin(rho3d, rho2d);
+    real depth = (rho3d <= rho2d) ? (sx*Tw[0] + sy*Tw[1]) + Tw[2] : Tw[2];
+    if (depth < near_n) return 0;
+    real power = -0.5f * rho;
+    if (power > 0.0f) return 0;
+    return R_fmin(0.99f, nor_o[3] * R_exp(power));
+}
+void ref_instance_max_alpha(const ref_state* st, const ref_inputs* in, real* out)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int tile = 0; tile < st->T; tile++) {
+        const uint32_t tx = (uint32_t)(tile % st->gx), ty = (uint32_t)(tile / st->gx);
+        const uint32_t r0 = st->ranges[2*tile], r1 = st->ranges[2*tile+1];
+        for (uint32_t k = r0; k < r1; k++) {
+            const uint32_t id = st->point_list[k];
+            real best = 0;
+            for (uint32_t ly = 0; ly < BLOCK_Y; ly++)
+                for (uint32_t lx = 0; lx < BLOCK_X; lx++) {
+                    const uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                    if (px < (uint32_t)st->W && py < (uint32_t)st->H) best = R_fmax(best, pair_alpha(st, in, id, (real)px, (real)py));
+                }
+            out[k] = best;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ backward */
 static void atomic_addf(real* p, real v)
 {

@@ -117,6 +117,8 @@ void     ref_get_pair_counts(const ref_state* st, uint64_t* evaluated, uint64_t*
 /* measurement controls of bench.py's cpu_baseline leg: OpenMP thread count, and "every n-th tile only" in the blend loops */
 void     ref_set_threads(int32_t n);
 void     ref_set_tile_stride(int32_t n);
+/* out[k], k < R: the largest alpha any in-image pixel of instance k's tile sees from that gaussian under the reference's per-pixel gates (0: none) */
+void     ref_instance_max_alpha(const ref_state* st, const ref_inputs* in, real* out);
 void     ref_get_point_list(const ref_state* st, uint32_t* out /*[R]*/);
 void     ref_get_keys(const ref_state* st, uint64_t* out /*[R] sorted keys*/);
 void     ref_get_ranges(const ref_state* st, uint32_t* out /*[T,2]*/);

@@ -221,6 +221,13 @@ class Forward:
         f(self.st, C.byref(a), C.byref(b))
         return int(a.value), int(b.value)
 
+    def instance_max_alpha(self):
+        """[R] float32: per instance of the sorted list, the largest alpha any in-image pixel of its tile sees under the reference's per-pixel gates."""
+        out = np.zeros((max(self.R, 1),), np.float32)
+        fn = lib().ref_instance_max_alpha; fn.argtypes = [C.c_void_p, C.POINTER(RefInputs), C.c_void_p]; fn.restype = None
+        fn(self.st, C.byref(self.ri), out.ctypes.data)
+        return out[:self.R]
+
     def keys(self):
         out = np.zeros((self.R,), np.uint64); lib().ref_get_keys(self.st, out.ctypes.data); return out
 
@@ -334,6 +341,14 @@ class Truth:
         if M == 0:
             g["dL_dsh"] = z(P, 0, 3)
         return g
+
+    def instance_max_alpha(self):
+        """[R] float64: as oracle.Forward.instance_max_alpha, evaluated by the float64 build over the float32 run's list."""
+        R = int(self._ov[1].shape[0])
+        out = np.zeros((max(R, 1),), np.float64)
+        fn = lib64().ref_instance_max_alpha; fn.argtypes = [C.c_void_p, C.POINTER(RefInputs64), C.c_void_p]; fn.restype = None
+        fn(self.st, C.byref(self.ri), out.ctypes.data)
+        return out[:R]
 
     def fragile(self):
         """[H,W] bool: pixels where some gate decision is within its float32 error bound of flipping."""

