@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
     const int px = ox + (lane & 7), py = oy + (lane >> 3);
     const bool inside = px < p.W && py < p.H;
     const float pxf = (float)px, pyf = (float)py;
+    const float fdx = (float)(lane & 7), fdy = (float)(lane >> 3);      // SURFEL: pixel offset inside the sub-tile
     const size_t HW = (size_t)p.W * p.H;
     const uint32_t pix_id = (uint32_t)p.W * py + px;
 
@@ -77,8 +78,27 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         // two-SGPR fmas of the surfel intersection needed are gone.  Measured: surfel 0.234 -> 0.201 ms, EWA 0.233 -> 0.189, PLANE 0.199 -> 0.176.
         if (hit) {
             const float4* __restrict__ rr = p.rec + (size_t)id * ST;
+            if constexpr (V == GSR_SURFEL) {
+                // SURFEL: the staging lane also does the per-(splat, sub-tile) part of the ray-splat intersection.  p = k x l (k = px Tw - Tu, l = py Tw - Tv,
+                // SURFEL forward.cu:351-357) is affine in the pixel: with (ox, oy) the sub-tile's first pixel, k0 = ox Tw - Tu, l0 = oy Tw - Tv,
+                //     p(ox + dx, oy + dy) = k0 x l0 + dx (Tw x l0) + dy (k0 x Tw),
+                // and the depth s . Tw.xy + Tw.z equals det[Tu Tv Tw] / p.z (record word D, gsr_preprocess.hip).  Staged: {P0, Px, Py, D, Tw.z, opacity,
+                // centre - origin, normal, rgb} = 20 floats, so that a pixel pays 6 FMAs + 1 multiply for p and the depth instead of 15 instructions.
+                const float4 r0 = rr[0], r1 = rr[1], r2 = rr[2], r3 = rr[3], r4 = rr[4];
+                const float fox = (float)ox, foy = (float)oy;
+                const float Tw0 = r1.z, Tw1 = r1.w, Tw2 = r2.x;
+                const float kx = fox * Tw0 - r0.x, ky = fox * Tw1 - r0.y, kz = fox * Tw2 - r0.z;
+                const float lx = foy * Tw0 - r0.w, ly = foy * Tw1 - r1.x, lz = foy * Tw2 - r1.y;
+                float4* dst = s_rec + wave * ST * 64 + lane;
+                dst[0 * 64] = make_float4(ky * lz - kz * ly, kz * lx - kx * lz, kx * ly - ky * lx, Tw1 * lz - Tw2 * ly);
+                dst[1 * 64] = make_float4(Tw2 * lx - Tw0 * lz, Tw0 * ly - Tw1 * lx, ky * Tw2 - kz * Tw1, kz * Tw0 - kx * Tw2);
+                dst[2 * 64] = make_float4(kx * Tw1 - ky * Tw0, r4.z, Tw2, r2.w);
+                dst[3 * 64] = make_float4(r2.y - fox, r2.z - foy, r3.x, r3.y);
+                dst[4 * 64] = make_float4(r3.z, r3.w, r4.x, r4.y);
+            } else {
 #pragma unroll
-            for (int k = 0; k < ST; k++) s_rec[(wave * ST + k) * 64 + lane] = rr[k];      // [wave][k][slot]: lane-contiguous 16-byte stores
+                for (int k = 0; k < ST; k++) s_rec[(wave * ST + k) * 64 + lane] = rr[k];      // [wave][k][slot]: lane-contiguous 16-byte stores
+            }
         }
         while (m) {
             const int j = __ffsll((unsigned long long)m) - 1;
@@ -113,18 +133,15 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 }
             } else {
                 const float4 q0 = FWD_LD(0), q1 = FWD_LD(1), q2 = FWD_LD(2), q3 = FWD_LD(3), q4 = FWD_LD(4);
-                const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
-                const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
-                const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
-                const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
-                const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
+                // p = P0 + dx Px + dy Py, (dx, dy) = this lane's pixel inside the sub-tile (staged layout: see the staging block above)
+                const float ppx = fmaf(fdy, q1.z, fmaf(fdx, q0.w, q0.x)), ppy = fmaf(fdy, q1.w, fmaf(fdx, q1.x, q0.y)), ppz = fmaf(fdy, q2.x, fmaf(fdx, q1.y, q0.z));
                 const float rpz = rcp_nr(ppz);
                 const float sx = ppx * rpz, sy = ppy * rpz;
                 const float rho3d = sx * sx + sy * sy;
-                const float dx = q2.y - pxf, dy = q2.z - pyf;
+                const float dx = q3.x - fdx, dy = q3.y - fdy;
                 const float rho2d = FILTER_INV_SQ * (dx * dx + dy * dy);
                 const float rho = fminf(rho3d, rho2d);
-                const float depth = (rho3d <= rho2d) ? (sx * Tw0 + sy * Tw1) + Tw2 : Tw2;
+                const float depth = (rho3d <= rho2d) ? q2.y * rpz : q2.z;
                 const float power = -0.5f * rho;
                 const float alpha = fminf(0.99f, q2.w * __expf(power));
                 bool ok = !done && !(ppz == 0.0f) && !(depth < NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
@@ -140,11 +157,11 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                     Dd += depth * w; M1 += mm * w; M2 += mm * mm * w;
                     if (T > 0.5f) {
                         median_depth = depth; surf_idx = (int)gid;
-                        mn0 = q3.x; mn1 = q3.y; mn2 = q3.z;
+                        mn0 = q3.z; mn1 = q3.w; mn2 = q4.x;
                         median_contributor = contributor;
                     }
-                    N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
-                    C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
+                    N0 += q3.z * w; N1 += q3.w * w; N2 += q4.x * w;
+                    C0 += q4.y * w; C1 += q4.z * w; C2 += q4.w * w;
                     T = test_T;
                     last_contributor = contributor;
                 }

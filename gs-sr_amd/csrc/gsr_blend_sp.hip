@@ -60,9 +60,11 @@ template <int V> struct SpOcc { static constexpr int WPE = (V == GSR_EWA) ? SP_W
 #endif
 
 template <int V> struct SpTraits;
-template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10; };
-template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = 16; };
-template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 18; };
+// NACC: gradient components per splat, TS: floats per table row, NREG: per-lane register accumulators of a load (SURFEL: the nine transMat components
+// are accumulated as three moments of dL/dp over the load's 16 pixels plus three depth terms and turned into dL/dTu, dL/dTv, dL/dTw once per load)
+template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10, NREG = 10, NPIN = 9; };
+template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = 16, NREG = 16, NPIN = 16; };
+template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 18, NREG = 21, NPIN = 21; };
 
 // inclusive scans along the 16 lanes of each DPP row, lane 0 first, in place.  A lane whose source would lie outside the row is
 // disabled by the hardware (bound_ctrl off) and keeps its value -- exactly the Hillis-Steele step.  s_nop 1 = the two wait states
@@ -139,6 +141,7 @@ template <int N> __device__ __forceinline__ void sp_pin(float* a)
     asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]));
     if constexpr (N > 9) asm volatile("" : "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
     if constexpr (N > 16) asm volatile("" : "+v"(a[16]), "+v"(a[17]));
+    if constexpr (N > 18) asm volatile("" : "+v"(a[18]), "+v"(a[19]), "+v"(a[20]));
 }
 
 // per-pixel constants, lane j of a row holds those of pixel j of the row's 4x4 block
@@ -150,9 +153,55 @@ template <> struct SpPix<GSR_SURFEL> {
     uint32_t last, med;
 };
 
+// SURFEL, per (splat, 4x4 block) load.  The ray-splat vector p = k x l, k = px Tw - Tu, l = py Tw - Tv (SURFEL forward.cu:351-357), is AFFINE in the
+// pixel: with (x0, y0) the block's first pixel, k0 = x0 Tw - Tu, l0 = y0 Tw - Tv,
+//     p(x0 + dx, y0 + dy) = k0 x l0 + dx (Tw x l0) + dy (k0 x Tw)          (the dx dy term is Tw x Tw = 0).
+// The cancellation of px Tw against Tu happens once, in k0 / l0, as it does per pixel in the reference's form; the three cross products are formed
+// once per load and a pixel step evaluates p with <= 6 FMAs instead of 12 instructions.  The depth s . Tw.xy + Tw.z equals (p . Tw) / p.z and
+// p . Tw = det[Tu Tv Tw] =: D for every pixel (k, l differ from -Tu, -Tv by multiples of Tw), so depth = D / p.z with D from the record.
+struct SpSurf { float P0x, P0y, P0z, Pxx, Pxy, Pxz, Pyx, Pyy, Pyz, Tw0, Tw1, Tw2, D, cdx, cdy; };
+__device__ __forceinline__ SpSurf sp_surf_setup(const float4& q0, const float4& q1, const float4& q2, const float4& q4, float x0, float y0)
+{
+    SpSurf S;
+    const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y, Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
+    const float kx = x0 * Tw0 - Tu0, ky = x0 * Tw1 - Tu1, kz = x0 * Tw2 - Tu2;
+    const float lx = y0 * Tw0 - Tv0, ly = y0 * Tw1 - Tv1, lz = y0 * Tw2 - Tv2;
+    S.P0x = ky * lz - kz * ly; S.P0y = kz * lx - kx * lz; S.P0z = kx * ly - ky * lx;              // k0 x l0
+    S.Pxx = Tw1 * lz - Tw2 * ly; S.Pxy = Tw2 * lx - Tw0 * lz; S.Pxz = Tw0 * ly - Tw1 * lx;        // Tw x l0
+    S.Pyx = ky * Tw2 - kz * Tw1; S.Pyy = kz * Tw0 - kx * Tw2; S.Pyz = kx * Tw1 - ky * Tw0;        // k0 x Tw
+    S.Tw0 = Tw0; S.Tw1 = Tw1; S.Tw2 = Tw2; S.D = q4.z;
+    S.cdx = q2.y - x0; S.cdy = q2.z - y0;
+    return S;
+}
+// end of a load: the moments M0 = sum dp, Mx = sum dx dp, My = sum dy dp (dp = dL/dp of a pixel step, dx, dy its offset inside the block) and
+// Z = sum dL_dz (sx, sy, 1) -> the nine transMat gradient components of SURFEL backward.cu:403-433 summed over the load's pixels:
+//     sum dL/dTu = sum dp x l           = M0 x l0 + My x Tw
+//     sum dL/dTv = sum k x dp           = k0 x M0 + Tw x Mx
+//     sum dL/dTw = Z - sum (px dL/dTu + py dL/dTv) = Z - (x0 SdTu + y0 SdTv + Mx x l0 + k0 x My)      (the dx dy moments cancel: Mxy x Tw + Tw x Mxy = 0)
+__device__ __forceinline__ void sp_surf_finish(const float4& t0, const float4& t1, float Tw2, float x0, float y0, const float* a /* NREG */, float* g /* 9 */)
+{
+    const float Tu0 = t0.x, Tu1 = t0.y, Tu2 = t0.z, Tv0 = t0.w, Tv1 = t1.x, Tv2 = t1.y, Tw0 = t1.z, Tw1 = t1.w;
+    const float kx = x0 * Tw0 - Tu0, ky = x0 * Tw1 - Tu1, kz = x0 * Tw2 - Tu2;
+    const float lx = y0 * Tw0 - Tv0, ly = y0 * Tw1 - Tv1, lz = y0 * Tw2 - Tv2;
+    const float m0x = a[7], m0y = a[8], m0z = a[9], mxx = a[10], mxy = a[11], mxz = a[12], myx = a[13], myy = a[14], myz = a[15];
+    const float ux = (m0y * lz - m0z * ly) + (myy * Tw2 - myz * Tw1);
+    const float uy = (m0z * lx - m0x * lz) + (myz * Tw0 - myx * Tw2);
+    const float uz = (m0x * ly - m0y * lx) + (myx * Tw1 - myy * Tw0);
+    const float vx = (ky * m0z - kz * m0y) + (Tw1 * mxz - Tw2 * mxy);
+    const float vy = (kz * m0x - kx * m0z) + (Tw2 * mxx - Tw0 * mxz);
+    const float vz = (kx * m0y - ky * m0x) + (Tw0 * mxy - Tw1 * mxx);
+    const float cx = (mxy * lz - mxz * ly) + (ky * myz - kz * myy);
+    const float cy = (mxz * lx - mxx * lz) + (kz * myx - kx * myz);
+    const float cz = (mxx * ly - mxy * lx) + (kx * myy - ky * myx);
+    g[0] = ux; g[1] = uy; g[2] = uz; g[3] = vx; g[4] = vy; g[5] = vz;
+    g[6] = a[18] - ((x0 * ux + y0 * vx) + cx);
+    g[7] = a[19] - ((x0 * uy + y0 * vy) + cy);
+    g[8] = a[20] - ((x0 * uz + y0 * vz) + cz);
+}
+
 // one pixel step of a row: pixel I of the block against the 16 splats held by the row's lanes
 template <int V, int I, int NACC>
-__device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
+__device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4, const SpSurf& S,
                                         bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc, bool mn_live)
 {
     const float pxf = K.rowx + (float)(I & 3), pyf = K.rowy + (float)(I >> 2);
@@ -209,20 +258,19 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
             }
         }
     } else {
-        const float Tu0 = q0.x, Tu1 = q0.y, Tu2 = q0.z, Tv0 = q0.w, Tv1 = q1.x, Tv2 = q1.y;
-        const float Tw0 = q1.z, Tw1 = q1.w, Tw2 = q2.x;
         const float opa = q2.w;
-        const float kx = pxf * Tw0 - Tu0, ky = pxf * Tw1 - Tu1, kz = pxf * Tw2 - Tu2;
-        const float lx = pyf * Tw0 - Tv0, ly = pyf * Tw1 - Tv1, lz = pyf * Tw2 - Tv2;
-        const float ppx = ky * lz - kz * ly, ppy = kz * lx - kx * lz, ppz = kx * ly - ky * lx;
+        constexpr int DX = I & 3, DY = I >> 2;
+        float ppx = S.P0x, ppy = S.P0y, ppz = S.P0z;
+        if constexpr (DX != 0) { ppx = fmaf((float)DX, S.Pxx, ppx); ppy = fmaf((float)DX, S.Pxy, ppy); ppz = fmaf((float)DX, S.Pxz, ppz); }
+        if constexpr (DY != 0) { ppx = fmaf((float)DY, S.Pyx, ppx); ppy = fmaf((float)DY, S.Pyy, ppy); ppz = fmaf((float)DY, S.Pyz, ppz); }
         const float rpz = (ppz == 0.0f) ? 0.0f : rcp_nr(ppz);
         const float sx = ppx * rpz, sy = ppy * rpz;
         const float rho3d = sx * sx + sy * sy;
-        const float dx = q2.y - pxf, dy = q2.z - pyf;
+        const float dx = S.cdx - (float)DX, dy = S.cdy - (float)DY;
         const float rho2d = FILTER_INV_SQ * (dx * dx + dy * dy);
         const float rho = fminf(rho3d, rho2d);
         const bool b3 = rho3d <= rho2d;
-        const float c_d = b3 ? (sx * Tw0 + sy * Tw1) + Tw2 : Tw2;
+        const float c_d = b3 ? S.D * rpz : S.Tw2;
         const float power = -0.5f * rho;
         const float G = __expf(power);
         const float alpha = fminf(0.99f, opa * G);
@@ -269,19 +317,17 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         dL_dz = bc_fmac<I>(dL_dz, K.dLd, w);
         const float dL_dG = opa * dL_dalpha;
         const float dL_dG3 = b3 ? dL_dG : 0.0f, dL_dG2 = b3 ? 0.0f : dL_dG, dL_dz3 = b3 ? dL_dz : 0.0f;
-        const float dL_dsx = dL_dG3 * -G * sx + dL_dz3 * Tw0;
-        const float dL_dsy = dL_dG3 * -G * sy + dL_dz3 * Tw1;
+        const float dL_dsx = dL_dG3 * -G * sx + dL_dz3 * S.Tw0;
+        const float dL_dsy = dL_dG3 * -G * sy + dL_dz3 * S.Tw1;
         const float dpx = dL_dsx * rpz, dpy = dL_dsy * rpz, dpz = -(dpx * sx + dpy * sy);
-        const float tux = dpy * lz - dpz * ly, tuy = dpz * lx - dpx * lz, tuz = dpx * ly - dpy * lx;
-        const float tvx = ky * dpz - kz * dpy, tvy = kz * dpx - kx * dpz, tvz = kx * dpy - ky * dpx;
-        // accumulator layout (SURFEL): 0-2 colour, 3 opacity, 4-6 normal, 7-15 transMat, 16-17 mean2D
+        // register accumulators (SURFEL): 0-2 colour, 3 opacity, 4-6 normal, 7-9 M0, 10-12 Mx, 13-15 My, 16-17 mean2D, 18-20 Z (sp_surf_finish)
         acc[0] = bc_fmac<I>(acc[0], K.dLp0, w); acc[1] = bc_fmac<I>(acc[1], K.dLp1, w); acc[2] = bc_fmac<I>(acc[2], K.dLp2, w);
         acc[3] += G * dL_dalpha;
         acc[4] = bc_fmac<I>(acc[4], K.dN0, w); acc[5] = bc_fmac<I>(acc[5], K.dN1, w); acc[6] = bc_fmac<I>(acc[6], K.dN2, w);
-        acc[7] += tux; acc[8] += tuy; acc[9] += tuz; acc[10] += tvx; acc[11] += tvy; acc[12] += tvz;
-        acc[13] += dL_dz3 * sx - (pxf * tux + pyf * tvx);
-        acc[14] += dL_dz3 * sy - (pxf * tuy + pyf * tvy);
-        acc[15] += dL_dz - (pxf * tuz + pyf * tvz);
+        acc[7] += dpx; acc[8] += dpy; acc[9] += dpz;
+        if constexpr (DX != 0) { acc[10] = fmaf((float)DX, dpx, acc[10]); acc[11] = fmaf((float)DX, dpy, acc[11]); acc[12] = fmaf((float)DX, dpz, acc[12]); }
+        if constexpr (DY != 0) { acc[13] = fmaf((float)DY, dpx, acc[13]); acc[14] = fmaf((float)DY, dpy, acc[14]); acc[15] = fmaf((float)DY, dpz, acc[15]); }
+        acc[18] = fmaf(dL_dz3, sx, acc[18]); acc[19] = fmaf(dL_dz3, sy, acc[19]); acc[20] += dL_dz;
         acc[16] += dL_dG2 * (-G * FILTER_INV_SQ * dx);
         acc[17] += dL_dG2 * (-G * FILTER_INV_SQ * dy);
         // median-normal quirk (backward.cu:381): every contributor receives dL/d(median normal).  The 2DGS scenes send no gradient to those channels
@@ -296,7 +342,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     using TR = SpTraits<V>;
     constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
     constexpr int AS = (V == GSR_EWA) ? GSR_ACC_EWA : (V == GSR_PLANE ? GSR_ACC_PLANE : GSR_ACC_SURFEL);
-    constexpr int NACC = TR::NACC, TS = TR::TS;
+    constexpr int NACC = TR::NACC, TS = TR::TS, NREG = TR::NREG;
 
     constexpr int CAPV = (V == GSR_EWA) ? SP_CAP_EWA : (V == GSR_PLANE ? SP_CAP_PLANE : SP_CAP_SURFEL);      // table rows per wave
     __shared__ float2 s_wtab[4 * CAPV * (TS / 2)];        // [wave][compact entry][component pair]: PRIVATE to the wave, plain read-add-write
@@ -466,17 +512,29 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             float4 q3 = z4, q4 = z4;
             if (V != GSR_EWA) q3 = valid ? r[3] : z4;
             if (V == GSR_SURFEL) q4 = valid ? r[4] : z4;
-            float acc[TS];
+            float acc[NREG];
 #pragma unroll
-            for (int c = 0; c < TS; c++) acc[c] = 0.f;
+            for (int c = 0; c < NREG; c++) acc[c] = 0.f;
+            SpSurf S = {};
+            if constexpr (V == GSR_SURFEL) S = sp_surf_setup(q0, q1, q2, q4, K.rowx, K.rowy);
             // `never` is a wave-uniform, never-true condition the compiler cannot fold: the (untaken) scalar branch after every step ends
             // the basic block, so the 16 unrolled steps are scheduled one at a time -- as ONE block the scheduler overlaps them and the
             // kernel needs 280+ VGPRs (one wave per SIMD); split, every step's temporaries die inside the step.
             const bool never = p.gx == 0x7fffffff;
-#define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc, mn_live); sp_pin<NACC>(acc); if (never) asm volatile("s_nop 0");
+#define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, S, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc, mn_live); sp_pin<TR::NPIN>(acc); if (never) asm volatile("s_nop 0");
             SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6) SP_STEP(7)
-            SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11) SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
+            SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11)
+            // SURFEL: Tu, Tv (dead since sp_surf_setup) come back for sp_surf_finish; requested here, four steps ahead of their use
+            float4 t0 = z4, t1 = z4;
+            if constexpr (V == GSR_SURFEL) { t0 = r[0]; t1 = r[1]; }
+            SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
 #undef SP_STEP
+            if constexpr (V == GSR_SURFEL) {
+                float g9[9];
+                sp_surf_finish(t0, t1, S.Tw2, K.rowx, K.rowy, acc, g9);
+#pragma unroll
+                for (int c = 0; c < 9; c++) acc[7 + c] = g9[c];
+            }
             // Add the 16 x 4 (block, splat) partials of this load into the wave's table.  The same splat can sit in several ROWS of one
             // load (it reaches several blocks), never twice in one row: the four rows go one after the other, each a plain
             // read-add-write (DS operations of a wave execute in order) -- no LDS float atomics, which cost ~2 cycles per LANE

@@ -347,7 +347,12 @@ __device__ __forceinline__ PreTc pre_surfel_one(const PreParams& p, const int id
     rec[1] = make_float4(T[4], T[5], T[6], T[7]);
     rec[2] = make_float4(T[8], pix, piy, o);
     rec[3] = make_float4(normal.x, normal.y, normal.z, rgb.x);
-    rec[4] = make_float4(rgb.y, rgb.z, 0.f, 0.f);
+    // D = det[Tu Tv Tw] = p . Tw for every pixel's ray-splat vector p = k x l (k, l differ from -Tu, -Tv by multiples of Tw): the blend kernels take the
+    // depth s . Tw.xy + Tw.z of SURFEL forward.cu:367 as D / p.z (gsr_blend_sp.hip sp_surf_setup).  Its terms are of size |Tu.z Tv.z Tw| ~ 1e7 against a
+    // result of ~1e4, so it is formed in float64 from the float32 T (9 DP multiplies per visible surfel).
+    const double detT = (double)T[0] * ((double)T[4] * T[8] - (double)T[5] * T[7]) - (double)T[1] * ((double)T[3] * T[8] - (double)T[5] * T[6])
+                        + (double)T[2] * ((double)T[3] * T[7] - (double)T[4] * T[6]);
+    rec[4] = make_float4(rgb.y, rgb.z, (float)detT, 0.f);
     return tc;
 }
 template <bool SH16>
