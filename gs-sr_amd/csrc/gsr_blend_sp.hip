@@ -202,7 +202,7 @@ __device__ __forceinline__ void sp_surf_finish(const float4& t0, const float4& t
 // one pixel step of a row: pixel I of the block against the 16 splats held by the row's lanes
 template <int V, int I, int NACC>
 __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4, const SpSurf& S,
-                                        bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc, bool mn_live)
+                                        bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc, uint32_t& okbits)
 {
     const float pxf = K.rowx + (float)(I & 3), pyf = K.rowy + (float)(I >> 2);
     const uint32_t last = bc_movu<I>(K.last);
@@ -275,7 +275,8 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float G = __expf(power);
         const float alpha = fminf(0.99f, opa * G);
         const bool ok = valid & (idx0 < last) & !(ppz == 0.0f) & !(c_d < NEAR_N) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
-        const float al = ok ? alpha : 0.0f, cd = ok ? c_d : 1.0f, okf = ok ? 1.0f : 0.0f;
+        const float al = ok ? alpha : 0.0f, cd = ok ? c_d : 1.0f;
+        okbits |= ok ? (1u << I) : 0u;              // which of the load's 16 pixels this splat contributed to (the median-normal pass below)
         const float om = 1.f - al;
         // T_j = T_carry / prod_{k <= j} (1 - alpha_k): the row scan runs on the reciprocals 1 / (1 - alpha_k), which the dL/dalpha term needs anyway --
         // one v_rcp_f32 (8 issue cycles) per step instead of two
@@ -330,10 +331,17 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         acc[18] = fmaf(dL_dz3, sx, acc[18]); acc[19] = fmaf(dL_dz3, sy, acc[19]); acc[20] += dL_dz;
         acc[16] += dL_dG2 * (-G * FILTER_INV_SQ * dx);
         acc[17] += dL_dG2 * (-G * FILTER_INV_SQ * dy);
-        // median-normal quirk (backward.cu:381): every contributor receives dL/d(median normal).  The 2DGS scenes send no gradient to those channels
-        // (twodgs_scene.py:88-105), so the three DPP fmacs are skipped -- wave-uniformly -- when none of the wave's 64 pixels has one.
-        if (mn_live) { acc[4] = bc_fmac<I>(acc[4], K.dMN0, okf); acc[5] = bc_fmac<I>(acc[5], K.dMN1, okf); acc[6] = bc_fmac<I>(acc[6], K.dMN2, okf); }
     }
+}
+
+// median-normal quirk (SURFEL backward.cu:381): EVERY contributor of a pixel receives dL/d(median normal).  The 2DGS scenes send no gradient to those
+// channels (twodgs_scene.py:88-105), so this runs -- once per load, wave-uniformly -- only when some pixel of the wave has one: the pixel steps just
+// record which pixels each splat contributed to (one bit per step), instead of three DPP fmacs behind a branch in every step (round 3: the branch's
+// two register assignments for the accumulators were reconciled with ~10 v_mov per step).
+template <int I> __device__ __forceinline__ void sp_mn_pixel(const SpPix<GSR_SURFEL>& K, uint32_t okbits, float* acc)
+{
+    const float okf = (float)((okbits >> I) & 1u);
+    acc[4] = bc_fmac<I>(acc[4], K.dMN0, okf); acc[5] = bc_fmac<I>(acc[5], K.dMN1, okf); acc[6] = bc_fmac<I>(acc[6], K.dMN2, okf);
 }
 
 template <int V>
@@ -516,12 +524,13 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
 #pragma unroll
             for (int c = 0; c < NREG; c++) acc[c] = 0.f;
             SpSurf S = {};
+            uint32_t okbits = 0u;
             if constexpr (V == GSR_SURFEL) S = sp_surf_setup(q0, q1, q2, q4, K.rowx, K.rowy);
             // `never` is a wave-uniform, never-true condition the compiler cannot fold: the (untaken) scalar branch after every step ends
             // the basic block, so the 16 unrolled steps are scheduled one at a time -- as ONE block the scheduler overlaps them and the
             // kernel needs 280+ VGPRs (one wave per SIMD); split, every step's temporaries die inside the step.
             const bool never = p.gx == 0x7fffffff;
-#define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, S, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc, mn_live); sp_pin<TR::NPIN>(acc); if (never) asm volatile("s_nop 0");
+#define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, S, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc, okbits); sp_pin<TR::NPIN>(acc); if (never) asm volatile("s_nop 0");
             SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6) SP_STEP(7)
             SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11)
             // SURFEL: Tu, Tv (dead since sp_surf_setup) come back for sp_surf_finish; requested here, four steps ahead of their use
@@ -530,6 +539,11 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
 #undef SP_STEP
             if constexpr (V == GSR_SURFEL) {
+                if (mn_live) {
+#define SP_MN(I) sp_mn_pixel<I>(K, okbits, acc);
+                    SP_MN(0) SP_MN(1) SP_MN(2) SP_MN(3) SP_MN(4) SP_MN(5) SP_MN(6) SP_MN(7) SP_MN(8) SP_MN(9) SP_MN(10) SP_MN(11) SP_MN(12) SP_MN(13) SP_MN(14) SP_MN(15)
+#undef SP_MN
+                }
                 float g9[9];
                 sp_surf_finish(t0, t1, S.Tw2, K.rowx, K.rowy, acc, g9);
 #pragma unroll
