@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 const float depth = (rho3d <= rho2d) ? q2.y * rpz : q2.z;
                 const float power = -0.5f * rho;
                 const float alpha = fminf(0.99f, q2.w * __expf(power));
-                bool ok = !done && !(ppz == 0.0f) && !(depth < NEAR_N) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                // (the reference's `power > 0` gate, forward.cu:389, cannot fire: rho is a minimum of two sums of squares)
+                bool ok = !done && !(ppz == 0.0f) && !(depth < NEAR_N) && !(alpha < 1.0f / 255.0f);
                 const float test_T = T * (1 - alpha);
                 const bool stop = ok && (test_T < 0.0001f);
                 done = done || stop;
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 if (ok) {
                     const float w = alpha * T;
                     const float A = 1 - T;
-                    const float mm = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcp_(depth));
+                    const float mm = fmaf(-(FAR_N * NEAR_N) / (FAR_N - NEAR_N), rcp_(depth), FAR_N / (FAR_N - NEAR_N));      // far / (far - near) (1 - near / depth)
                     distortion += (mm * mm * A + M2 - 2 * mm * M1) * w;
                     Dd += depth * w; M1 += mm * w; M2 += mm * mm * w;
                     if (T > 0.5f) {

@@ -149,7 +149,9 @@ template <int V> struct SpPix;
 template <> struct SpPix<GSR_EWA> { float dLp0, dLp1, dLp2, Tc, Sc, rowx, rowy; uint32_t last; };
 template <> struct SpPix<GSR_PLANE> { float dLp0, dLp1, dLp2, dA0, dA1, dA2, dA3, dA4, Tc, Sc, rowx, rowy; uint32_t last; };
 template <> struct SpPix<GSR_SURFEL> {
-    float dLp0, dLp1, dLp2, dLd, dLa, dLr, dN0, dN1, dN2, dLmd, dMN0, dMN1, dMN2, fA, fD, fD2, Tc, Sc, rowx, rowy;
+    // c0, c1, c2: the distortion terms of a pixel as a quadratic in the splat's mapped depth m (SURFEL backward.cu:347-364, with the final A, M1, M2
+    // of the pixel): dL_daccum + dL_dweight = c0 + c1 m + c2 m^2 with c0 = dL_daccum + dL_dreg M2, c1 = -2 dL_dreg M1, c2 = dL_dreg A, and dL_dmd = w (2 c2 m + c1)
+    float dLp0, dLp1, dLp2, dLd, c0, c1, c2, dN0, dN1, dN2, dLmd, dMN0, dMN1, dMN2, Tc, Sc, rowx, rowy;
     uint32_t last, med;
 };
 
@@ -274,7 +276,8 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float power = -0.5f * rho;
         const float G = __expf(power);
         const float alpha = fminf(0.99f, opa * G);
-        const bool ok = valid & (idx0 < last) & !(ppz == 0.0f) & !(c_d < NEAR_N) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
+        // the reference's `power > 0` gate (forward.cu:389) cannot fire here: rho = min of two sums of squares, power = -rho / 2 <= 0 (NaN passes it as well)
+        const bool ok = valid & (idx0 < last) & !(ppz == 0.0f) & !(c_d < NEAR_N) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
         const float al = ok ? alpha : 0.0f, cd = ok ? c_d : 1.0f;
         okbits |= ok ? (1u << I) : 0u;              // which of the load's 16 pixels this splat contributed to (the median-normal pass below)
         const float om = 1.f - al;
@@ -284,15 +287,11 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float Tj = bc_fresh<I>(K.Tc) * row_scan_mul(r1a);
         const float w = al * Tj;
         const float rcd = rcp_(cd);
-        const float m_d = (FAR_N / (FAR_N - NEAR_N)) * (1 - NEAR_N * rcd);
+        const float m_d = fmaf(-(FAR_N * NEAR_N) / (FAR_N - NEAR_N), rcd, FAR_N / (FAR_N - NEAR_N));      // far / (far - near) (1 - near / depth)
         const float dmd_dd = ((FAR_N * NEAR_N) / (FAR_N - NEAR_N)) * rcd * rcd;
-        // dL_dweight = (M2 + m^2 A - 2 m M1) dL_dreg  (SURFEL backward.cu:347-364, with the final A, M1, M2 of the pixel)
-        float t1 = bc_mul<I>(K.fA, m_d * m_d);
-        t1 = bc_add<I>(K.fD2, t1);
-        const float t2 = bc_mul<I>(K.fD, m_d);
-        t1 = fmaf(-2.0f, t2, t1);
-        const float dL_dweight = bc_mul<I>(K.dLr, t1);
-        float u = bc_add<I>(K.dLa, dL_dweight);
+        float u = bc_mul<I>(K.c2, m_d * m_d);
+        u = bc_fmac<I>(u, K.c1, m_d);
+        u = bc_add<I>(K.c0, u);
         u = bc_fmac<I>(u, K.dLd, cd);
         u = bc_fmac<I>(u, K.dLp0, q3.w); u = bc_fmac<I>(u, K.dLp1, q4.x); u = bc_fmac<I>(u, K.dLp2, q4.y);
         u = bc_fmac<I>(u, K.dN0, q3.x); u = bc_fmac<I>(u, K.dN1, q3.y); u = bc_fmac<I>(u, K.dN2, q3.z);
@@ -312,8 +311,7 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float dLmd = bc_mov<I>(K.dLmd);
         float dL_dz = (ok & (idx0 + 1u == med)) ? dLmd : 0.0f;      // contributor == median_contributor-1
         // dL_dmd = 2 w (m A - M1) dL_dreg
-        const float t3 = bc_mul<I>(K.fA, m_d) - bc_mov<I>(K.fD);
-        const float dL_dmd = bc_mul<I>(K.dLr, 2.0f * w * t3);
+        const float dL_dmd = w * bc_add<I>(K.c1, bc_mul<I>(K.c2, m_d + m_d));      // 2 w (m A - M1) dL_dreg
         dL_dz += dL_dmd * dmd_dd;
         dL_dz = bc_fmac<I>(dL_dz, K.dLd, w);
         const float dL_dG = opa * dL_dalpha;
@@ -401,16 +399,18 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
         K.dA0 = dA[0]; K.dA1 = dA[1]; K.dA2 = dA[2]; K.dA3 = dA[3]; K.dA4 = dA[4];
     }
     if constexpr (V == GSR_SURFEL) {
-        K.dLd = K.dLa = K.dLr = K.dN0 = K.dN1 = K.dN2 = K.dLmd = K.dMN0 = K.dMN1 = K.dMN2 = K.fD = K.fD2 = 0.f;
-        K.med = 0; K.fA = 1.f - T_final;
+        K.dLd = K.c0 = K.c1 = K.c2 = K.dN0 = K.dN1 = K.dN2 = K.dLmd = K.dMN0 = K.dMN1 = K.dMN2 = 0.f;
+        K.med = 0;
         if (inside) {                                        // SURFEL backward.cu:205-243
+            float dLa = 0.f, dLr = 0.f;
             K.med = p.n_contrib[pix_id + HW];
             if (p.dL_dothers) {
                 const float* g = p.dL_dothers;
-                K.dLd = g[0 * HW + pix_id]; K.dLa = g[1 * HW + pix_id]; K.dN0 = g[2 * HW + pix_id]; K.dN1 = g[3 * HW + pix_id]; K.dN2 = g[4 * HW + pix_id];
-                K.dLmd = g[5 * HW + pix_id]; K.dLr = g[6 * HW + pix_id]; K.dMN0 = g[8 * HW + pix_id]; K.dMN1 = g[9 * HW + pix_id]; K.dMN2 = g[10 * HW + pix_id];
+                K.dLd = g[0 * HW + pix_id]; dLa = g[1 * HW + pix_id]; K.dN0 = g[2 * HW + pix_id]; K.dN1 = g[3 * HW + pix_id]; K.dN2 = g[4 * HW + pix_id];
+                K.dLmd = g[5 * HW + pix_id]; dLr = g[6 * HW + pix_id]; K.dMN0 = g[8 * HW + pix_id]; K.dMN1 = g[9 * HW + pix_id]; K.dMN2 = g[10 * HW + pix_id];
             }
-            K.fD = p.final_T[pix_id + HW]; K.fD2 = p.final_T[pix_id + 2 * HW];
+            const float fD = p.final_T[pix_id + HW], fD2 = p.final_T[pix_id + 2 * HW];
+            K.c0 = fmaf(dLr, fD2, dLa); K.c1 = -2.0f * dLr * fD; K.c2 = dLr * (1.f - T_final);
         }
     }
     bool mn_live = false;
