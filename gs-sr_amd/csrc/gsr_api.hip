@@ -102,7 +102,9 @@ extern "C" int gsr_profile_enable(int32_t enable)
     // enable: 0 = off, 1 = every stage (the original meaning), otherwise bit (8 + i) selects stage i alone -- an event pair costs ~10 us of
     // stream idle time per stage boundary (profiles/r03_timeline.json), so a caller that wants ONE kernel's duration inside a timed
     // region enables only that stage
-    g_prof_on = enable == 0 ? 0u : (enable == 1 ? 0xFFu : (((uint32_t)enable >> 8) & 0xFFu));
+    // any other non-zero value whose stage mask is empty (2, -1 & 0xFF, ...) keeps the pre-round-3 meaning "on" = every stage
+    const uint32_t mask = ((uint32_t)enable >> 8) & 0xFFu;
+    g_prof_on = enable == 0 ? 0u : ((enable == 1 || mask == 0u) ? 0xFFu : mask);
     for (int i = 0; i < GSR_PROF_LABELS; i++) { g_prof_ms[i] = 0; g_prof_n[i] = 0; }
     return 0;
 }
@@ -140,7 +142,7 @@ GeomView gsr_carve_geom(int variant, int P, void* base)
     g.keys_b = take<uint32_t>(p, n);
     g.vals_b = take<uint32_t>(p, n);
     g.sorted_idx = g.vals_a;                 // four sort passes: identity -> vals_b -> vals_a -> vals_b -> vals_a (gsr_launch_depth_order)
-    g.hist = take<uint32_t>(p, gsr_sort_hist_words(nblk, gsr_depth_sort_digit_bins()));   // 256-bin digits (2048 only under GSR_DEPTH_BITS=11: the size query and the carve run in one process, after the environment is read)
+    g.hist = take<uint32_t>(p, gsr_sort_hist_words(nblk, 256));   // 256-bin digits
     g.scan_tmp = take<uint32_t>(p, gsr_div_up((uint32_t)n, 256) + 64);       // block sums of the prefix: 256-gaussian blocks when the preprocess writes them
     g.counters = take<uint32_t>(p, 64);
     g.bytes = (size_t)(p - reinterpret_cast<char*>(base));
@@ -221,7 +223,7 @@ static int check_cfg(const gsr_cfg* cfg, const gsr_inputs* in)
 // a word (round 1 used an unsynchronised `next++`); with more than GSR_MAIL_SLOTS forwards in flight the caller spins for a free slot.
 #define GSR_MAIL_SLOTS 64
 struct Mailbox {
-    uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev[GSR_MAIL_SLOTS] = {};
+    uint32_t* host = nullptr; uint32_t* dev = nullptr;
     std::atomic<unsigned> next{0};
     std::atomic<int> busy[GSR_MAIL_SLOTS];
     std::atomic<int> order_ttl{0};          // forwards for which the longest-first launch order stays on after the last long-list report
@@ -249,10 +251,7 @@ static Mailbox* mailbox()
         if (hipHostMalloc(&h, (GSR_MAIL_SLOTS + 1) * 64, hipHostMallocMapped) != hipSuccess) return nullptr;     // one cache line per slot + the long-list feedback word
         ((uint32_t*)h)[16 * GSR_MAIL_SLOTS] = 0u;
         if (hipHostGetDevicePointer(&dp, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
-        for (int i = 0; i < GSR_MAIL_SLOTS; i++) {
-            m.busy[i].store(0);
-            if (hipEventCreateWithFlags(&m.ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
-        }
+        for (int i = 0; i < GSR_MAIL_SLOTS; i++) m.busy[i].store(0);
         m.host = (uint32_t*)h; m.dev = (uint32_t*)dp;
     }
     return &m;
@@ -271,18 +270,15 @@ bool gsr_tile_order_wanted()
     if (mode == -2) { const char* e = getenv("GSR_TILE_ORDER"); mode = (!e || e[0] == 'a') ? -1 : (atoi(e) != 0 ? 1 : 0); }
     if (mode >= 0) return mode != 0;
     Mailbox* mb = mailbox();
-    return mb && mb->order_ttl.load(std::memory_order_relaxed) > 0;      // set by gsr_forward_begin, once per forward
+    return mb && mb->order_ttl.load(std::memory_order_relaxed) > 0;      // set by gsr_decide_depth_order, once per forward
 }
 
 // Once per forward: read the long-list word the previous forwards' blend kernels stored into, refresh the two counters it drives -- longest-first
 // launch order for 64 forwards after a list beyond max(1024, 4 x mean); GLOBAL depth order for 64 forwards after a list beyond 6000 entries, where
 // the prologue's global-memory radix path loses to it (816 vs 780 it/s at 12 633 entries, a tie at 3800: profiles/r03_skewed_density.txt) --
-// and remember the depth order of this forward under the geom arena's address.
-struct DepthModeEnt { const void* key; int global; };
-static DepthModeEnt g_depth_mode[256];
-static unsigned g_depth_mode_next = 0;
-static std::mutex g_depth_mode_mu;
-void gsr_forward_begin(const gsr_cfg* cfg, const GeomView& g)
+// and return the depth order of THIS forward.  The caller hands it to every stage launcher; the preprocess kernel records it in the geom arena
+// (GeomView::counters[GSR_CNT_MODE]) for later calls on that arena (gsr_forward_stage2).  GSR_DEPTH_FEEDBACK=0: the static rule only.
+bool gsr_decide_depth_order(const gsr_cfg* cfg)
 {
     const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
     bool forced = false;
@@ -302,22 +298,11 @@ void gsr_forward_begin(const gsr_cfg* cfg, const GeomView& g)
             t = mb->global_ttl.load(std::memory_order_relaxed);
             if (t > 0) mb->global_ttl.store(t - 1, std::memory_order_relaxed);
         }
-        static int fb = -1;                     // GSR_DEPTH_FEEDBACK=0: the static rule only
+        static int fb = -1;
         if (fb < 0) { const char* e = getenv("GSR_DEPTH_FEEDBACK"); fb = e ? (atoi(e) != 0) : 1; }
         if (fb && !forced && mb->global_ttl.load(std::memory_order_relaxed) > 0) global = true;
     }
-    std::lock_guard<std::mutex> lk(g_depth_mode_mu);
-    for (DepthModeEnt& e : g_depth_mode) if (e.key == (const void*)g.depth_key) { e.global = global ? 1 : 0; return; }
-    g_depth_mode[g_depth_mode_next++ & 255u] = DepthModeEnt{(const void*)g.depth_key, global ? 1 : 0};
-}
-bool gsr_depth_order_is_global(const gsr_cfg* cfg, const GeomView& g)
-{
-    {
-        std::lock_guard<std::mutex> lk(g_depth_mode_mu);
-        for (const DepthModeEnt& e : g_depth_mode) if (e.key == (const void*)g.depth_key && e.key) return e.global != 0;
-    }
-    const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
-    return gsr_depth_order_static_rule(cfg->P, T, nullptr, cfg->variant);      // a geom arena this process has not run a preprocess on
+    return global;
 }
 uint32_t* gsr_long_list_word()
 {
@@ -381,8 +366,9 @@ extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void
     const unsigned slot = mb ? take_slot(mb) : 0u;
     struct SlotGuard { Mailbox* m; unsigned s; ~SlotGuard() { if (m) release_slot(m, s); } } guard{mb, slot};
     if (mb) mb->host[16 * slot + 1] = 0u;                      // "a gaussian failed the frustum test although prefiltered is set"
-    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s, mb ? mb->dev + 16 * slot + 1 : nullptr)) return 1; }
-    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb ? mb->dev + 16 * slot : nullptr, s)) return 1; }
+    const bool global_order = gsr_decide_depth_order(cfg);      // recorded in the geom arena by the preprocess kernel; stage 2 reads it back
+    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s, global_order, mb ? mb->dev + 16 * slot + 1 : nullptr)) return 1; }
+    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb ? mb->dev + 16 * slot : nullptr, s, global_order, true)) return 1; }
     // the one host<->device sync of the forward (reference: cudaMemcpy of point_offsets[P-1], rasterizer_impl.cu:281)
     if (mb) {
         GSR_CHECK(hipStreamSynchronize(s), "stage1 sync");
@@ -413,8 +399,19 @@ extern "C" int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void
         // the reference returns the zero-initialised outputs untouched when P == 0 (rasterize_points.cu:79-113)
         return 0;
     }
-    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, num_rendered, nullptr, s)) return 1; }
-    { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1; }
+    // The depth order the geom arena was laid out for (which of sorted_idx / offsets / scan_tmp mean what): recorded there by the preprocess kernel of
+    // the stage-1 call -- or of the gsr_forward whose overflow this call repairs.  Read back (the stream is idle: the caller has synchronised to learn
+    // num_rendered); an arena without the record is refused instead of being binned on a guess.
+    uint32_t mode = 0u;
+    GSR_CHECK(hipMemcpyAsync(&mode, g.counters + GSR_CNT_MODE, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read depth-order record");
+    GSR_CHECK(hipStreamSynchronize(s), "stage2 sync");
+    if (mode != GSR_MODE_TILE && mode != GSR_MODE_GLOBAL) {
+        gsr_set_error("geom buffer carries no depth-order record (0x%08x): it must come from gsr_forward_stage1 / gsr_forward of this library, unmodified", mode);
+        return 1;
+    }
+    const bool global_order = mode == GSR_MODE_GLOBAL;
+    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, num_rendered, nullptr, s, global_order)) return 1; }
+    { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s, global_order)) return 1; }
     return 0;
 }
 
@@ -453,23 +450,20 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
     if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
     const unsigned slot = take_slot(mb);
     struct SlotGuard { Mailbox* m; unsigned s; ~SlotGuard() { release_slot(m, s); } } guard{mb, slot};
-    // How the host learns num_rendered while stage 2 is already queued: the scan kernel stores it into the slot's mapped pinned word (system-scope
-    // store) and the host POLLS that word -- preset to a sentinel -- instead of waiting on an event recorded behind stage 1: the event record is a
-    // packet of its own and left ~6 us of stream idle time between the prefix and k_duplicate in every forward (profiles/r03_timeline_surfel.json).
-    // GSR_MAILBOX_POLL=0: the event.  The poll gives up after 2 s and synchronises the stream instead.
-    static int poll = -1;
-    if (poll < 0) { const char* e = getenv("GSR_MAILBOX_POLL"); poll = e ? (atoi(e) != 0) : 1; }
+    // How the host learns num_rendered while stage 2 is already queued: k_duplicate (per-tile order) or the scan kernel (global order) stores it into
+    // the slot's mapped pinned word (system-scope store) and the host POLLS that word -- preset to a sentinel -- instead of waiting on an event recorded
+    // behind stage 1: the event record is a packet of its own and left ~6 us of stream idle time in every forward (profiles/r03_timeline_surfel.json).
+    // The poll gives up after 2 s and synchronises the stream instead.
     volatile uint32_t* word = mb->host + 16 * slot;
     mb->host[16 * slot + 1] = 0u;                              // "a gaussian failed the frustum test although prefiltered is set"
-    if (poll) { *word = 0xFFFFFFFFu; std::atomic_thread_fence(std::memory_order_seq_cst); }
-    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s, mb->dev + 16 * slot + 1)) return 1; }
-    // with the mailbox polled the total (num_rendered) may arrive a kernel later: k_duplicate adds up the block sums and publishes it
-    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s, poll != 0)) return 1; }
-    if (!poll) GSR_CHECK(hipEventRecord(mb->ev[slot], s), "event record");
-    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s, poll != 0, mb->dev + 16 * slot)) return 1; }
-    { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1; }
+    *word = 0xFFFFFFFFu; std::atomic_thread_fence(std::memory_order_seq_cst);
+    const bool global_order = gsr_decide_depth_order(cfg);
+    { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s, global_order, mb->dev + 16 * slot + 1)) return 1; }
+    { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s, global_order, false)) return 1; }
+    { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s, global_order, mb->dev + 16 * slot)) return 1; }
+    { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s, global_order)) return 1; }
     uint32_t R;
-    if (poll) {
+    {
         const auto t0 = std::chrono::steady_clock::now();
         uint64_t spins = 0;
         while ((R = *word) == 0xFFFFFFFFu) {
@@ -481,9 +475,6 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
                 break;
             }
         }
-    } else {
-        GSR_CHECK(hipEventSynchronize(mb->ev[slot]), "stage1 event sync");
-        R = *word;
     }
     *num_rendered_host = R;
     *overflow_host = (R > cap) ? 1 : 0;
@@ -508,6 +499,8 @@ extern "C" int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void*
     if (!status_dev) { gsr_set_error("gsr_forward_async: status_dev must be provided"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     if (cfg->P == 0) { if (gsr_memset_async(status_dev, 0, sizeof(uint32_t), s)) { gsr_set_error("status"); return 1; }; return 0; }
+    // cfg->prefiltered: a gaussian that fails the frustum test sets status_dev[2] (sticky, like the overflow word): the reference traps the device
+    // (auxiliary.h:156-160), the synchronous forwards fail the call, this one reports it where the caller looks when it synchronises
     GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
     if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
     const uint32_t cap = gsr_binning_capacity(cfg->variant, binning_bytes, cfg->W, cfg->H);
@@ -515,11 +508,12 @@ extern "C" int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void*
     BinView b = gsr_carve_bin(cfg->variant, cap, cfg->W, cfg->H, binning);
     ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, img);
     if (im.bytes > img_bytes) { gsr_set_error("img buffer too small: %zu < %zu", img_bytes, im.bytes); return 1; }
-    if (gsr_launch_preprocess(cfg, in, g, radii, s)) return 1;
-    if (gsr_launch_depth_order(cfg, g, nullptr, s, true)) return 1;
-    if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s, true, nullptr)) return 1;
+    const bool global_order = gsr_decide_depth_order(cfg);      // a recorded graph replays the decision of its capture
+    if (gsr_launch_preprocess(cfg, in, g, radii, s, global_order, status_dev + 2)) return 1;
+    if (gsr_launch_depth_order(cfg, g, nullptr, s, global_order, false)) return 1;
+    if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s, global_order, nullptr)) return 1;
     hipLaunchKernelGGL(k_forward_status, dim3(1), dim3(1), 0, s, g.counters, cap, status_dev);      // after the binning: k_duplicate may be the one that publishes the total
-    if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s)) return 1;
+    if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s, global_order)) return 1;
     return 0;
 }
 

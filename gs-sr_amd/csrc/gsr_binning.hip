@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                     uint32_t n, const uint32_t* __restrict__ n_dev, int shift, int bits,
                                                                     const uint32_t* __restrict__ H, const uint32_t* __restrict__ GH, uint32_t ngroups,
-                                                                    uint32_t* __restrict__ GH_next, uint32_t digit_major_nblk, uint2* __restrict__ ranges_out)
+                                                                    uint32_t* __restrict__ GH_next, uint32_t digit_major_nblk)
 {
     constexpr int DPT = NB / GSR_SORT_THREADS;
     if (n_dev) n = min(n, *n_dev);
@@ -282,30 +282,19 @@ __global__ void __launch_bounds__(GSR_SORT_THREADS) k_radix_scatter(const uint32
         const uint32_t pos = gbase[d] + (q - lbase[d]);
         keys_out[pos] = k;
         vals_out[pos] = sval[q];
-        if (ranges_out) {
-            // identifyTileRanges (3DGS rasterizer_impl.cu:116-138) folded into the LAST pass of the tile sort, whose keys are the tile ids: a key
-            // change inside this block's run of digit d is a tile boundary of the output (the run lands contiguously); at the two ends of the run
-            // the neighbour belongs to another block, so the candidates are merged with atomicMin / atomicMax (the tile's true first / last
-            // position is among them).  ranges was initialised to (0xFFFFFFFF, 0) by k_duplicate: an untouched tile reads as x > y = empty.
-            const uint32_t run_end = (d == mask) ? nb : lbase[d + 1];
-            if (q == lbase[d]) atomicMin(&ranges_out[k].x, pos);
-            else if (skey[q - 1] != k) ranges_out[k].x = pos;
-            if (q + 1 == run_end) atomicMax(&ranges_out[k].y, pos + 1u);
-            else if (skey[q + 1] != k) ranges_out[k].y = pos + 1u;
-        }
     }
 }
 
-// hist must hold gsr_sort_hist_words(nblk for the 1024-key geometry, NB) words, NB = 256 (digits <= 8 bits) or 2048
+// hist must hold gsr_sort_hist_words(nblk for the 1024-key geometry, 256) words; digits of at most 8 bits
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
-                         bool* result_in_b, hipStream_t s, bool big_blocks, bool group0_zeroed, uint2* ranges_out)
+                         bool* result_in_b, hipStream_t s, bool big_blocks, bool group0_zeroed)
 {
     // keys per block: 1024 (many blocks: small inputs are latency-bound) or 4096 (longer digit runs -> full-line writes on big inputs).
     // The histogram area is always sized for the 1024-key geometry, the larger upper bound.
     const uint32_t nblk = gsr_sort_blocks(n, big_blocks);
-    const bool wide = bits_per_pass > 8;      // 2048-bin kernels
-    const uint32_t NB = wide ? 2048u : 256u;
+    const uint32_t NB = 256u;
+    if (bits_per_pass > 8) bits_per_pass = 8;
     const uint32_t ngroups = gsr_div_up(nblk, GSR_SORT_GROUP);
     uint32_t* GH[2] = { hist, hist + (size_t)NB * ngroups };
     uint32_t* H = hist + 2 * (size_t)NB * ngroups;
@@ -327,20 +316,11 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         const dim3 g(nblk), b(GSR_SORT_THREADS);
         uint32_t* gh = dm ? GH[0] : GH[pass & 1];
         uint32_t* gh_next = (!dm && passes_left > 1) ? GH[(pass + 1) & 1] : nullptr;
-        uint2* ro = (passes_left == 1) ? ranges_out : nullptr;      // tile ranges from the last pass (keys == tile ids), see k_radix_scatter
-        if (wide) {
-            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
-            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
-            if (dm) hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, H, nblk, gh);
-            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm, ro);
-            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 2048>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm, ro);
-        } else {
-            if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
-            else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
-            if (dm) hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, H, nblk, gh);
-            if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm, ro);
-            else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm, ro);
-        }
+        if (big_blocks) hipLaunchKernelGGL((k_radix_hist<16, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
+        else hipLaunchKernelGGL((k_radix_hist<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, n, n_dev, shift, mask, H, gh, dm);
+        if (dm) hipLaunchKernelGGL(k_scan_rows, dim3(mask + 1), dim3(256), 0, s, H, nblk, gh);
+        if (big_blocks) hipLaunchKernelGGL((k_radix_scatter<16, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
+        else hipLaunchKernelGGL((k_radix_scatter<GSR_SORT_ITEMS, 256>), g, b, 0, s, kin, vin, kout, vout, n, n_dev, shift, bits, H, gh, ngroups, gh_next, dm);
         uint32_t* t;
         t = kin; kin = kout; kout = t;
         if (vin == nullptr) { vin = vout; vout = vals_a; }     // first pass generated identity values into vals_b
@@ -365,39 +345,18 @@ __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_local(const uint32_t
     if (i < P) offsets[i] = incl;
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
-uint32_t gsr_depth_sort_digit_bins()
-{
-    static int depth_bits = -1;
-    if (depth_bits < 0) { const char* e = getenv("GSR_DEPTH_BITS"); depth_bits = (e && atoi(e) == 11) ? 11 : 8; }
-    return depth_bits == 11 ? 2048u : 256u;
-}
-
 // Where the depth order of a tile's list comes from.
 //   "tile" (default, round 3): no global depth sort.  Instances are emitted in ID order, the stable tile sort bins them, and every tile's list is put
 //           in (depth bits, id) order in LDS -- in k_blend_fwd's prologue (gsr_tile_sort.h, GSR_TILE_SORT=fused) or by k_tile_depth_sort (=kernel) --
 //           instead of the eight launches of a 4-pass radix sort over P keys, each of which costs its ~5-10 us latency floor whatever P is
-//           (profiles/r03_timeline_surfel.json).
+//           (profiles/r03_timeline_surfel.json).  The block-local prefix of tiles_touched is written by the preprocess kernel, k_duplicate adds up
+//           the block sums in front of its own and publishes num_rendered: no prefix launch at all in the single-call forwards.
 //   "global" (GSR_DEPTH_ORDER=global, rounds 1-2): stable LSD sort of the P gaussians by depth bits first, instances emitted in that order.
 // Both give the reference's order: by tile, then depth bits, then gaussian id (3DGS rasterizer_impl.cu:70-111, 300-308).
 // Measured with the fused per-tile sort (MI355X, 1080p, surfel, tools/ab_depth_order.sh): depth_order + binning + blend_fwd, tile / global, in ms:
 //   P = 600k (337 entries per tile) 0.548 / 0.582;  800k (450) 0.698 / 0.742;  1M (562) 0.878 / 0.889;  1.5M (845) 1.008 / 1.050;
 //   2M (1125) 1.197 / 1.165;  3M (1688) 1.317 / 1.381 -- a tie above ~1.5M (rank by counting is O(n^2) up to 512 entries, a bitonic network above).
-// "auto" (default) takes the per-tile path while P <= 192 tiles' worth of gaussians (1.57M at 1080p).  (With the separate k_tile_depth_sort launch
-// the crossover was at ~96 T: profiles/r03_depth_order_ab.txt.)
-// The preprocess kernel also writes the block-local prefix of tiles_touched (per-tile depth order only: the global order needs the prefix in
-// depth-sorted order).  GSR_PREFIX=kernel keeps the separate k_offsets_local launch.
-bool gsr_prefix_in_preprocess(const gsr_cfg* cfg, const GeomView& g)
-{
-    static int fused = -1;
-    if (fused < 0) { const char* e = getenv("GSR_PREFIX"); fused = (e && e[0] == 'k') ? 0 : 1; }
-    return fused != 0 && !gsr_depth_order_is_global(cfg, g);
-}
-bool gsr_duplicate_scans()      // GSR_SCAN=kernel keeps k_scan_small in the single-call forwards too
-{
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("GSR_SCAN"); on = (e && e[0] == 'k') ? 0 : 1; }
-    return on != 0;
-}
+// "auto" (default) takes the per-tile path while P <= 192 tiles' worth of gaussians (1.57M at 1080p).
 // The rule without feedback: GSR_DEPTH_ORDER=global|tile forces one (the returned flag says so), otherwise per tile while P <= 192 T.
 bool gsr_depth_order_static_rule(int P, int T, bool* forced, int variant)
 {
@@ -412,36 +371,21 @@ bool gsr_depth_order_static_rule(int P, int T, bool* forced, int variant)
     return (long long)P > per_tile * (long long)T;
 }
 
-int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s, bool total_by_duplicate)
+int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s, bool global_order, bool need_total)
 {
     const uint32_t P = (uint32_t)cfg->P;
-    const int T_tiles = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);
-    (void)T_tiles;
-    if (!gsr_depth_order_is_global(cfg, g)) {
-        // id order: only the prefix sum of tiles_touched (block-local + block sums; k_duplicate adds the two) and num_rendered.  The block-local
-        // part is written by the preprocess kernel itself (256-gaussian blocks, gsr_prefix_in_preprocess) unless GSR_PREFIX=kernel.
-        const bool fused = gsr_prefix_in_preprocess(cfg, g);
-        const uint32_t nb = gsr_div_up(P, fused ? 256u : (uint32_t)GSR_SCAN_BLOCK);
-        if (!fused) hipLaunchKernelGGL(k_offsets_local, dim3(nb), dim3(GSR_SCAN_BLOCK), 0, s, (const uint32_t*)nullptr, g.tiles_touched, P, g.offsets, g.scan_tmp);
-        // total_by_duplicate (single-call forwards, where the binning follows at once): k_duplicate adds up the block sums itself and publishes
-        // num_rendered -- nothing to launch here (gsr_duplicate_scans)
-        // with gsr_duplicate_scans() the block sums are left RAW in either case (a redo of the binning after an overflowed speculative forward finds
-        // them as the first one did); two-stage forwards still need the total now: k_scan_small in its total-only form
-        const bool raw = fused && gsr_duplicate_scans();
-        if (!(raw && total_by_duplicate))
-            hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, nb, g.counters, host_word_dev, raw ? 1 : 0);
+    if (!global_order) {
+        // id order: the block-local prefix and the RAW block sums were written by the preprocess kernel; k_duplicate adds up the sums in front of each
+        // workgroup and publishes num_rendered.  A two-stage forward needs the total NOW (the host sizes the binning arena from it): one single-block
+        // kernel in its total-only form -- the sums stay raw, so a redo of the binning finds them as the first run did.
+        if (need_total)
+            hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(GSR_SCAN_BLOCK), 0, s, g.scan_tmp, gsr_div_up(P, 256u), g.counters, host_word_dev, 1);
         return gsr_check_launch("depth_order", s, cfg->debug);
     }
     bool in_b = false;
     // Four 8-bit passes: keys depth_key (A) <-> keys_b end in A, ids: identity -> vals_b -> vals_a -> vals_b -> vals_a (= sorted_idx).
-    // GSR_DEPTH_BITS=11 selects three 11-bit passes instead (33 >= 32 bits, bit-identical result, kept for A/B): MEASURED SLOWER on
-    // MI355X at P = 300k -- depth_order 0.080 -> 0.106 ms.  A pass costs ~14 us of launch latency + ~2 us per 256 bins (the
-    // digit-major histogram matrix is written / scanned / read with a block-count stride), so 2048 bins cost more than the pass saved.
-    const int depth_bits = gsr_depth_sort_digit_bins() == 2048 ? 11 : 8;
     // the preprocess kernel cleared the first group-histogram buffer (gsr_preprocess.hip: PreParams::zero_ptr)
-    if (gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, depth_bits, true, g.hist, &in_b, s, false, true)) return 1;
-    if (depth_bits == 11)      // odd pass count: the ids ended in vals_b, bring them to sorted_idx (= vals_a)
-        GSR_CHECK(hipMemcpyAsync(g.sorted_idx, g.vals_b, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, s), "copy sorted ids");
+    if (gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, 8, true, g.hist, &in_b, s, false, true)) return 1;
     const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
     hipLaunchKernelGGL(k_offsets_local, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, g.sorted_idx, g.tiles_touched, P, g.offsets, g.scan_tmp);
     // the single-block scan of the block sums also publishes num_rendered (device word + mapped pinned host word): k_duplicate adds the
@@ -798,7 +742,7 @@ int gsr_tile_sort_passes(int T) { return (tile_bits(T) + 7) / 8; }
 // R is the exact instance count, or -- when n_dev != nullptr -- the CAPACITY of the binning arena while the exact count
 // is read on the device from *n_dev (speculative forward: the host has not seen it yet).
 int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s,
-                       bool total_by_duplicate, uint32_t* host_word_dev)
+                       bool global_order, uint32_t* host_word_dev)
 {
     const int gx = (cfg->W + GSR_TILE - 1) / GSR_TILE, gy = (cfg->H + GSR_TILE - 1) / GSR_TILE;
     const int T = gx * gy;
@@ -813,21 +757,20 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     uint32_t *k0 = (passes & 1) ? b.keys_b : b.tile_keys, *v0 = (passes & 1) ? b.vals_b : b.point_list;
     uint32_t *k1 = (passes & 1) ? b.tile_keys : b.keys_b, *v1 = (passes & 1) ? b.point_list : b.vals_b;
     // 4096-key blocks for the tile sort from this many instances on, 1024-key blocks below (GSR_SORT_BIG_FROM overrides for A/B).  Re-measured at the end of
-    // round 3, binning stage small / big blocks in ms: R = 0.92 M 0.057 / 0.069; 1.38 M (the headline scene) 0.069 / 0.076; 1.60 M 0.0757 / 0.0771;
+    // round 3, binning stage small / big blocks in ms: R = 0.92 M 0.057 / 0.069; 1.38 M 0.069 / 0.076; 1.60 M 0.0757 / 0.0771;
     // 1.83 M 0.0798 / 0.0785; 2.06 M 0.087 / 0.080; 4.6 M 0.157 / 0.144; 17.5 M 0.587 / 0.495 -- the round-2 threshold of 2^19 was half a size class early.
     static uint32_t big_from0 = 0;
     if (!big_from0) { const char* e = getenv("GSR_SORT_BIG_FROM"); big_from0 = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 1700000u; }
     // R is the CAPACITY of the arena when the count is read on the device (speculative / sync-free forwards: 1.25 x the last count + 16384)
     const uint32_t big_from = n_dev ? big_from0 + big_from0 / 4 : big_from0;
-    const bool global_order = gsr_depth_order_is_global(cfg, g);
-    (void)total_by_duplicate;
-    const bool self_scan = gsr_prefix_in_preprocess(cfg, g) && gsr_duplicate_scans();      // the block sums are raw: every workgroup adds up the ones in front of it
     {
         const dim3 dg(gsr_div_up((uint32_t)max(cfg->P, T), 256)), db(256);
         const uint32_t* sidx = global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr;
         const uint32_t zn = gsr_sort_group_words(R, R >= big_from, 256);
-        const uint32_t sblk = gsr_prefix_in_preprocess(cfg, g) ? 256u : (uint32_t)GSR_SCAN_BLOCK;
-        const uint32_t snb = self_scan ? gsr_div_up((uint32_t)cfg->P, 256u) : 0u;
+        // per-tile order: 256-gaussian blocks, RAW block sums (every workgroup adds up the ones in front of its own, the last one publishes the
+        // total); global order: GSR_SCAN_BLOCK-gaussian blocks, block sums already scanned by k_scan_small
+        const uint32_t sblk = global_order ? (uint32_t)GSR_SCAN_BLOCK : 256u;
+        const uint32_t snb = global_order ? 0u : gsr_div_up((uint32_t)cfg->P, 256u);
 #define GSR_DUP(CV) hipLaunchKernelGGL(k_duplicate<CV>, dg, db, 0, s, (uint32_t)cfg->P, sidx, g.offsets, g.scan_tmp, g.tiles_touched, g.rect, g.cull, gx, k0, v0, R, \
                                        im.ranges, (uint32_t)T, b.hist, zn, im.tile_order + T, sblk, snb, g.counters, host_word_dev)
         if (!gsr_tile_cull_enabled()) GSR_DUP(-1);
@@ -836,13 +779,9 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
 #undef GSR_DUP
     }
     bool in_b = false;
-    // tile ranges: k_tile_ranges over the sorted keys (default), or written by the last scatter pass (GSR_TILE_RANGES=scatter).  MEASURED (round 3,
-    // P = 300k, 1080p): the fold loses -- binning 0.0847 ms against 0.0748 with the separate 5 us kernel: two more LDS reads, a compare and
-    // ~22k global atomics at the ends of the digit runs lengthen the tail of every scatter block by more than the launch they save.
-    static int ranges_fused = -1;
-    if (ranges_fused < 0) { const char* e = getenv("GSR_TILE_RANGES"); ranges_fused = (e && e[0] == 's') ? 1 : 0; }
-    if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= big_from, true, ranges_fused ? im.ranges : nullptr)) return 1;
-    if (!ranges_fused) hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
+    // (tile ranges written by the last scatter pass instead of k_tile_ranges were measured in round 3 and lost: binning 0.0847 vs 0.0748 ms, DESIGN Appendix A (42))
+    if (gsr_radix_sort_pairs(k0, v0, k1, v1, R, n_dev, 0, tile_bits(T), 8, false, b.hist, &in_b, s, R >= big_from, true)) return 1;
+    hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
     if (!global_order && !gsr_tile_sort_is_fused())
         hipLaunchKernelGGL(k_tile_depth_sort, dim3(gsr_div_up((uint32_t)T, 4u)), dim3(256), 0, s, im.ranges, (uint32_t)T, R, g.depth_key, b.point_list, b.tile_keys,
                            b.keys_b, b.vals_b);

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         if (lane == 63) atomic_addf(accg + (slot), s_);                   \
     } while (0)
 
-template <int V, bool MFMA_RED>
+template <int V>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_blend_bwd(BlendParams p)
 {
     constexpr int ST = (V == GSR_EWA) ? GSR_REC_EWA : (V == GSR_PLANE ? GSR_REC_PLANE : GSR_REC_SURFEL);
@@ -335,21 +335,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 const float g_cc = -0.5f * gdy * dy * dL_dG;
                 const float g_op = Gm * dL_dalpha;
                 if (V == GSR_EWA) {
-                    if (MFMA_RED) {
-                        const float v9[9] = { g_c0, g_c1, g_c2, g_op, g_mx, g_my, g_ca, g_cb, g_cc };
-                        const float w9 = reduce_mfma<9>(v9, lane);
-                        if (lane >= 48 && lane < 57 && w9 != 0.f) atomic_addf(accg + (lane - 48), w9);
-                    } else {
-                        const float v8[8] = { g_c0, g_c1, g_c2, g_op, g_mx, g_my, g_ca, g_cb };
-                        const float w8 = reduce8(v8, lane);
-                        const float w1 = wave_sum_to_lane63(g_cc);
-                        if (lane >= 56 && w8 != 0.f) atomic_addf(accg + (lane - 56), w8);
-                        if (lane == 63 && w1 != 0.f) atomic_addf(accg + 8, w1);
-                    }
+                    const float v8[8] = { g_c0, g_c1, g_c2, g_op, g_mx, g_my, g_ca, g_cb };
+                    const float w8 = reduce8(v8, lane);
+                    const float w1 = wave_sum_to_lane63(g_cc);
+                    if (lane >= 56 && w8 != 0.f) atomic_addf(accg + (lane - 56), w8);
+                    if (lane == 63 && w1 != 0.f) atomic_addf(accg + 8, w1);
                 } else {
                     const float v16[16] = { g_c0, g_c1, g_c2, g_op, g_mx, g_my, g_ca, g_cb, g_cc, g_ax, g_ay,
                                             g_am[0], g_am[1], g_am[2], g_am[3], g_am[4] };
-                    const float w16 = MFMA_RED ? (geo ? reduce_mfma<16>(v16, lane) : reduce_mfma<11>(v16, lane)) : reduce16(v16, lane);
+                    const float w16 = reduce16(v16, lane);
                     if (lane >= 48 && w16 != 0.f) atomic_addf(accg + (lane - 48), w16);
                 }
             } else {
@@ -419,7 +413,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 // accumulator layout (SURFEL): 0-2 colour, 3 opacity, 4-6 normal, 7-15 transMat, 16-17 mean2D
                 const float v16[16] = { g_c0, g_c1, g_c2, g_op, g_n0, g_n1, g_n2, g_T[0], g_T[1], g_T[2], g_T[3], g_T[4],
                                         g_T[5], g_T[6], g_T[7], g_T[8] };
-                const float w16 = MFMA_RED ? reduce_mfma<16>(v16, lane) : reduce16(v16, lane);
+                const float w16 = reduce16(v16, lane);
                 if (lane >= 48 && w16 != 0.f) atomic_addf(accg + (lane - 48), w16);
                 if (__ballot(ok && !b3) != 0) {      // wave-uniform: any pair on the screen-space filter branch
                     const float w2 = reduce2(g_mx, g_my, lane);
@@ -453,25 +447,20 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
     p.fx = cfg->W / (2.0f * cfg->tanfovx);
     p.tile_order = im.tile_order;         // used when its word T is set: decided per forward (gsr_tile_order_wanted, gsr_api.hip)
     p.long_word = nullptr; p.long_len = 0xFFFFFFFFu;
-    {
-        // GSR_CULL_REUSE=0: the backward re-tests every entry against the four 8x8 quadrants (round 2) instead of reading the forward's ballots
-        static int reuse = -1;
-        if (reuse < 0) { const char* e = getenv("GSR_CULL_REUSE"); reuse = e ? (atoi(e) != 0) : 1; }
-        p.qmask = reuse ? b.qmask : nullptr;
-    }
+    p.qmask = b.qmask;                    // the forward's per-(batch, quadrant) cull ballots, read by the splat-parallel backward
     p.ranges = im.ranges; p.point_list = b.point_list; p.cull = g.cull; p.rec = g.rec; p.bg = cfg->bg;
     p.depth_key = nullptr; p.list_rw = nullptr; p.tile_keys = nullptr; p.scratch_keys = nullptr; p.scratch_ids = nullptr;
-    { static int bk = -1; if (bk < 0) { const char* e = getenv("GSR_TILE_RANK"); bk = (e && e[0] == 'p') ? 0 : 1; } p.sort_buckets = bk; }
+    p.sort_buckets = 1;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib;
     return p;
 }
 
 int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
-                         const gsr_outputs* out, hipStream_t s)
+                         const gsr_outputs* out, hipStream_t s, bool global_order)
 {
     (void)in;
     BlendParams p = make_bp(cfg, g, b, im, s);
-    if (!gsr_depth_order_is_global(cfg, g) && gsr_tile_sort_is_fused()) {
+    if (!global_order && gsr_tile_sort_is_fused()) {
         p.depth_key = g.depth_key; p.list_rw = b.point_list; p.tile_keys = b.tile_keys; p.scratch_keys = b.keys_b; p.scratch_ids = b.vals_b;
     }
     {   // long-list feedback for the launch order of the forwards that follow (gsr_tile_order_wanted): "long" = beyond max(1024, ~4 x the mean list,
@@ -516,22 +505,12 @@ int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
         return gsr_check_launch("blend_bwd_sp", s, cfg->debug);
     }
     dim3 grid(p.gx * p.gy), block(256);
-    static int mfma_red = -1;
-    // MEASURED (MI355X, 300k splats 1080p): MFMA reduction 1.65 ms vs DPP tree 1.04 ms (surfel), 1.08 vs 0.67 (EWA):
-    // the fp32 16x16x4 MFMA issues at 32 cycles/SIMD and its dependent chain stalls the in-order wave.  Off by default.
-    if (mfma_red < 0) { const char* e = getenv("GSR_MFMA_REDUCE"); mfma_red = e ? (atoi(e) != 0) : 0; }
-    if (mfma_red) {
-        switch (cfg->variant) {
-        case GSR_EWA: hipLaunchKernelGGL((k_blend_bwd<GSR_EWA, true>), grid, block, 0, s, p); break;
-        case GSR_PLANE: hipLaunchKernelGGL((k_blend_bwd<GSR_PLANE, true>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((k_blend_bwd<GSR_SURFEL, true>), grid, block, 0, s, p); break;
-        }
-    } else {
-        switch (cfg->variant) {
-        case GSR_EWA: hipLaunchKernelGGL((k_blend_bwd<GSR_EWA, false>), grid, block, 0, s, p); break;
-        case GSR_PLANE: hipLaunchKernelGGL((k_blend_bwd<GSR_PLANE, false>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((k_blend_bwd<GSR_SURFEL, false>), grid, block, 0, s, p); break;
-        }
+    // (the 16-component reduction on the matrix pipe, v_mfma_f32_16x16x4_f32 with a one-hot selector, was measured in round 1 and removed in round 4:
+    // 1.65 ms vs 1.04 ms for the DPP tree -- DESIGN Appendix A)
+    switch (cfg->variant) {
+    case GSR_EWA: hipLaunchKernelGGL(k_blend_bwd<GSR_EWA>, grid, block, 0, s, p); break;
+    case GSR_PLANE: hipLaunchKernelGGL(k_blend_bwd<GSR_PLANE>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(k_blend_bwd<GSR_SURFEL>, grid, block, 0, s, p); break;
     }
     return gsr_check_launch("blend_bwd", s, cfg->debug);
 }

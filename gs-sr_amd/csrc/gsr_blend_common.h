@@ -128,28 +128,6 @@ __device__ __forceinline__ float reduce8(const float* v, int lane)
     w += dpp_f<0x128, 0xF>(w);   // row_ror:8 -> sum over the row, component = lane & 7
     return rows_to_row3(w);
 }
-// ---- the same reduction on the MATRIX pipe (idle in this VALU-bound kernel).  v_mfma_f32_16x16x4_f32 computes
-// D[i][j] += sum_k A[i][k] * B[k][j] with lane l holding A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15].  Feeding the
-// per-lane gradient term of component c as A and the one-hot column selector B_c[k][j] = (j == c) accumulates
-// D[i][c] = sum_k v_c[lane i + 16k]; after N such MFMAs lane l holds, for component l&15, four partial rows
-// (D[4(l>>4)+r][l&15], r = 0..3): three adds and the two row swaps finish the sum.  Exact fp32 (an FMA chain with
-// multiplier 1.0), deterministic order, ~22 VALU + N MFMAs instead of ~55 VALU for 16 components.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <int N>
-__device__ __forceinline__ float reduce_mfma(const float* v, int lane)
-{
-    f32x4_t acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
-    float sel = ((lane & 15) == 0) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int c = 0; c < N; c++) {
-        if (c & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c], sel, acc1, 0, 0, 0);
-        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c], sel, acc0, 0, 0, 0);
-        if (c + 1 < N) sel = dpp_f<0x111, 0xF>(sel);      // row_shr:1 -> selector of column c+1
-    }
-    const f32x4_t a = acc0 + acc1;
-    return rows_to_row3((a.x + a.y) + (a.z + a.w));        // every lane l: total of component l & 15
-}
-
 // lane 62 <- total of a, lane 63 <- total of b
 __device__ __forceinline__ float reduce2(float a, float b, int lane)
 {

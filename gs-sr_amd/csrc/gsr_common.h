@@ -89,13 +89,22 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug);
     } while (0)
 
 // ---- stage launchers (each in its own .hip) ------------------------------------------------------------------
-int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s, uint32_t* prefiltered_err = nullptr);
-int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s, bool total_by_duplicate = false);   // sorted_idx, offsets, counters[0]
-bool gsr_duplicate_scans();
+// Depth order of a forward (global stable sort of the gaussians by depth, or every tile's list sorted in the blend forward's prologue): decided ONCE
+// per forward by its entry point (gsr_decide_depth_order, gsr_api.hip) and handed to every stage launcher as `global_order`.  It also fixes the layout of
+// offsets / scan_tmp / sorted_idx in the geom arena, so the preprocess kernel records it IN the arena (GeomView::counters[GSR_CNT_MODE]); a later call
+// on that arena (gsr_forward_stage2, also the redo after an overflowed gsr_forward) reads it back and refuses an arena that carries none.
+#define GSR_CNT_MODE 1
+#define GSR_MODE_TILE 0x47530001u
+#define GSR_MODE_GLOBAL 0x47530002u
+bool gsr_decide_depth_order(const gsr_cfg* cfg);          // static rule (GSR_DEPTH_ORDER, P <= ~192 T) + the long-list feedback; polls the feedback word: call once per forward
+int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s, bool global_order, uint32_t* prefiltered_err = nullptr);
+// global order: sorted_idx, offsets, the scanned block sums and counters[0]; per-tile order: nothing unless `need_total` (two-stage forward: the host
+// sizes the binning arena from num_rendered) -- otherwise k_duplicate adds up the raw block sums and publishes the total itself
+int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_dev, hipStream_t s, bool global_order, bool need_total);
 int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s,
-                       bool total_by_duplicate = false, uint32_t* host_word_dev = nullptr);
+                       bool global_order, uint32_t* host_word_dev = nullptr);
 int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
-                         const gsr_outputs* out, hipStream_t s);
+                         const gsr_outputs* out, hipStream_t s, bool global_order);
 int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_out_grads* og, float* acc, hipStream_t s);
 bool gsr_blend_bwd_is_sp();            // GSR_BWD=sp (default) | px (gsr_blend.hip)
@@ -103,13 +112,7 @@ void gsr_blend_bwd_attach_events(hipEvent_t start, hipEvent_t stop);     // spla
 // hipMemsetAsync that is safe to record into a HIP graph: on ROCm 7.2 a memset NODE replays with a corrupted fill value from the second replay
 // on (measured round 3: vis_idx filled with 0x5A5A5A5A instead of 0xFF...), so while `s` is being captured the fill is a kernel; eagerly it is
 // the runtime's memset.  nbytes must be a multiple of 4.
-bool gsr_prefix_in_preprocess(const gsr_cfg* cfg, const GeomView& g);      // the preprocess kernel writes the block-local prefix of tiles_touched (gsr_binning.hip)
 bool gsr_depth_order_static_rule(int P, int T, bool* forced, int variant = GSR_SURFEL);   // GSR_DEPTH_ORDER=tile|global|auto and the P <= 192 T rule (gsr_binning.hip)
-// The depth order (global sort of the gaussians or per-tile sort) is decided ONCE per forward, in gsr_forward_begin (called by gsr_launch_preprocess, the
-// first launcher of every forward path) and remembered under the geom arena's address, where every later stage of the same forward -- and the second
-// call of a two-stage forward -- finds it (gsr_api.hip).
-void gsr_forward_begin(const gsr_cfg* cfg, const GeomView& g);
-bool gsr_depth_order_is_global(const gsr_cfg* cfg, const GeomView& g);
 bool gsr_tile_cull_enabled();         // GSR_TILE_CULL=0|1 (default 1): tile instances culled at emission (gsr_tile_cull.h, gsr_binning.hip)
 bool gsr_tile_sort_is_fused();        // GSR_TILE_SORT=fused|kernel: who orders a tile's list by depth when the depth order is per tile (gsr_binning.hip)
 bool gsr_tile_order_wanted();         // GSR_TILE_ORDER=0|1, default auto: on while recent forwards reported long tile lists (gsr_api.hip); once per forward
@@ -131,5 +134,4 @@ static inline uint32_t gsr_sort_group_words(uint32_t n, bool big_blocks, uint32_
 static inline size_t gsr_sort_hist_words(uint32_t nblk_1024, uint32_t NB) { return (size_t)NB * nblk_1024 + 2 * (size_t)NB * (nblk_1024 / GSR_SORT_GROUP + 1); }
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,
-                         bool* result_in_b, hipStream_t s, bool big_blocks = false, bool group0_zeroed = false, uint2* ranges_out = nullptr);
-uint32_t gsr_depth_sort_digit_bins();      // 256, or 2048 with GSR_DEPTH_BITS=11 (gsr_binning.hip)
+                         bool* result_in_b, hipStream_t s, bool big_blocks = false, bool group0_zeroed = false);

@@ -28,6 +28,7 @@ struct PreParams {
     // although prefiltered is set" and traps the device (auxiliary.h:156-160); here the kernel stores 1 into this mapped word and the forward call
     // that owns it fails with that message.  nullptr: not checked.
     uint32_t* prefiltered_err;
+    uint32_t* mode_word; uint32_t mode;      // GeomView::counters[GSR_CNT_MODE] <- GSR_MODE_TILE / GSR_MODE_GLOBAL: the depth order this arena is being laid out for
     int tile_cull;            // 1 (default): tiles_touched counts only the tiles of the rect the cull record can reach (gsr_tile_cull.h); 0 (GSR_TILE_CULL=0): the whole rect
 };
 // what the tile-instance count needs from the per-gaussian pass: the unculled tile count, the rect and the cull record (also stored in the geom arena)
@@ -183,6 +184,7 @@ __device__ __forceinline__ void pre_block_scan(const PreParams& p, const int idx
 template <bool FILTER_ONLY>
 __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
 {
+    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) *p.mode_word = p.mode;
     for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     PreTc tc; tc.tiles = 0u; tc.rect = make_ushort4(0, 0, 0, 0); tc.c0 = make_float4(0, 0, 0, 0); tc.c1 = make_float4(0, -1, 0, 0);
@@ -228,6 +230,7 @@ __device__ __forceinline__ void sh_rows_store(const float* my, float* __restrict
 }
 __global__ void __launch_bounds__(256) k_preprocess_ewa_sh16(PreParams p)
 {
+    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) *p.mode_word = p.mode;
     __shared__ float s_sh[4 * 64 * GSR_SH_ROW];
     for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -358,6 +361,7 @@ __device__ __forceinline__ PreTc pre_surfel_one(const PreParams& p, const int id
 template <bool SH16>
 __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
 {
+    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) *p.mode_word = p.mode;
     for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const float* sh_row = nullptr;
@@ -398,24 +402,24 @@ static PreParams make_params(const gsr_cfg* cfg, const gsr_inputs* in, GeomView 
     p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
     { const char* e = getenv("GSR_NO_CULL"); p.no_cull = (e && atoi(e) != 0) ? 1 : 0; }
     p.in_mask = nullptr; p.scale_stride = 3;
-    p.scan_offsets = nullptr; p.scan_sums = nullptr; p.prefiltered_err = nullptr;
+    p.scan_offsets = nullptr; p.scan_sums = nullptr; p.prefiltered_err = nullptr; p.mode_word = nullptr; p.mode = 0u;
     p.tile_cull = gsr_tile_cull_enabled() ? 1 : 0;
     p.radii = radii; p.g = g;
     p.zero_ptr = nullptr; p.zero_n = 0;
     return p;
 }
 
-int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s, uint32_t* prefiltered_err)
+int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, int32_t* radii, hipStream_t s, bool global_order, uint32_t* prefiltered_err)
 {
     PreParams p = make_params(cfg, in, g, radii);
     p.prefiltered_err = cfg->prefiltered ? prefiltered_err : nullptr;
-    p.zero_ptr = g.hist; p.zero_n = gsr_sort_group_words((uint32_t)cfg->P, false, gsr_depth_sort_digit_bins());
-    gsr_forward_begin(cfg, g);          // the one place per forward where the feedback is polled and the depth order of THIS forward is decided
-    if (gsr_prefix_in_preprocess(cfg, g)) { p.scan_offsets = g.offsets; p.scan_sums = g.scan_tmp; }
+    p.zero_ptr = g.hist; p.zero_n = gsr_sort_group_words((uint32_t)cfg->P, false, 256);      // first group histogram of the global depth sort
+    p.mode_word = g.counters + GSR_CNT_MODE; p.mode = global_order ? GSR_MODE_GLOBAL : GSR_MODE_TILE;
+    // per-tile depth order: instances are emitted in id order, the block-local prefix of tiles_touched is written here (256-gaussian blocks)
+    if (!global_order) { p.scan_offsets = g.offsets; p.scan_sums = g.scan_tmp; }
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);
-    static int stage_sh = -1;                  // GSR_SH_STAGE=0: SH coefficients read straight from global memory (rounds 1-3)
-    if (stage_sh < 0) { const char* e = getenv("GSR_SH_STAGE"); stage_sh = e ? (atoi(e) != 0) : 1; }
-    const bool sh16 = stage_sh && p.shs && !p.colors && cfg->M == 16 && (((uintptr_t)p.shs) & 15) == 0;
+    // SH colours of degree-3 models: the 16 x 3 coefficients go through LDS (coalesced 16-byte loads); other shapes read them directly
+    const bool sh16 = p.shs && !p.colors && cfg->M == 16 && (((uintptr_t)p.shs) & 15) == 0;
     if (cfg->variant == GSR_SURFEL) { if (sh16) hipLaunchKernelGGL(k_preprocess_surfel<true>, grid, block, 0, s, p); else hipLaunchKernelGGL(k_preprocess_surfel<false>, grid, block, 0, s, p); }
     else if (sh16) hipLaunchKernelGGL(k_preprocess_ewa_sh16, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_preprocess_ewa<false>, grid, block, 0, s, p);
@@ -861,9 +865,7 @@ int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const in
     p.view = cfg->viewmatrix; p.proj = cfg->projmatrix; p.campos = cfg->campos;
     p.radii = radii; p.clamped = g.clamped; p.rec = g.rec; p.acc = acc; p.acc_clear = leave_zero ? acc : nullptr; p.ig = *ig;
     dim3 grid(gsr_div_up(cfg->P, 256)), block(256);
-    static int stage_sh = -1;                  // GSR_SH_STAGE=0: SH coefficients and their gradients straight from / to global memory (rounds 1-3)
-    if (stage_sh < 0) { const char* e = getenv("GSR_SH_STAGE"); stage_sh = e ? (atoi(e) != 0) : 1; }
-    const bool sh16 = stage_sh && p.shs && p.ig.dL_dsh && cfg->M == 16 && ((((uintptr_t)p.shs) | ((uintptr_t)p.ig.dL_dsh)) & 15) == 0;
+    const bool sh16 = p.shs && p.ig.dL_dsh && cfg->M == 16 && ((((uintptr_t)p.shs) | ((uintptr_t)p.ig.dL_dsh)) & 15) == 0;
     if (cfg->variant == GSR_SURFEL) { if (sh16) hipLaunchKernelGGL(k_preprocess_bwd_surfel<true>, grid, block, 0, s, p); else hipLaunchKernelGGL(k_preprocess_bwd_surfel<false>, grid, block, 0, s, p); }
     else if (sh16) hipLaunchKernelGGL(k_preprocess_bwd_ewa<true>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(k_preprocess_bwd_ewa<false>, grid, block, 0, s, p);

@@ -220,7 +220,9 @@ def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_co
     `static_rows=True` (round 3; implies a padded visible list): NO host synchronisation at all and STATIC output shapes -- the form a HIP graph can
     record.  The five Gaussian tensors keep all Nv * k rows: the P emitted Gaussians first, the rest parked at the camera centre with zero opacity
     (every rasterizer of this library culls them: radii 0, no tile instance, zero gradients), and an eighth value `count` (int32 device tensor,
-    shape (1,)) = P is returned for consumers that average over the Gaussians (the reference's scaling loss: use sum() / count)."""
+    shape (1,)) = P is returned for consumers that average over the Gaussians (the reference's scaling loss: use sum() / count).  The parked rows
+    sit at view depth 0, i.e. they FAIL the frustum test by construction: rasterize them with `prefiltered=False` (what every scene of the reference
+    passes, e.g. scaffold_scene.py:101) -- with `prefiltered=True` the rasterizer reports them as the reference does ("Point is filtered ...")."""
     if use_feat_bank and mlp_feature_bank is None:
         raise RuntimeError("gsrast.decode: use_feat_bank=True needs mlp_feature_bank (get_featurebank_mlp of the gaussian model)")
     if feat.shape[1] != 32:

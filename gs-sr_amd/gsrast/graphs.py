@@ -53,6 +53,9 @@ class GraphedStep:
         for st, cap in self.status:
             h = st.cpu()
             res.append((int(h[0]), bool(h[1]), cap))
+            if bool(h[2]):
+                st.zero_()
+                raise RuntimeError(rasterize.PREFILTERED_MSG)
             if bool(h[1]):
                 st.zero_()
                 raise RuntimeError(f"gsrast.graphs: a recorded rasterizer forward overflowed its binning arena ({int(h[0])} instances, capacity {cap})")

@@ -41,7 +41,9 @@ def _bytes(n, device):
 # to a registry the caller inspects whenever it synchronises anyway: status[0] = instances of the last run, status[1] != 0 = a run
 # overflowed the capacity (outputs of that run were incomplete -> raise the capacity and re-run / re-capture; gsrast.graphs does that).
 _ASYNC = threading.local()
-_ASYNC_STATUS = []            # [(status int32[2] tensor, capacity)] of the async forwards issued since async_status_reset()
+PREFILTERED_MSG = "Point is filtered although prefiltered is set. This shouldn't happen!"      # auxiliary.h:157; status word 2 of a sync-free forward
+PREFILTERED_MSG = "Point is filtered although prefiltered is set. This shouldn't happen!"      # auxiliary.h:157; status word 2 of a sync-free forward
+_ASYNC_STATUS = []            # [(status int32[3] tensor, capacity)] of the async forwards issued since async_status_reset()
 
 
 class static_capacity:
@@ -61,9 +63,13 @@ class static_capacity:
 
 def async_status(reset=False):
     """-> list of (num_rendered, overflowed, capacity) for the sync-free forwards recorded so far (reads the device words: synchronises)."""
-    out = [(int(st[0]), bool(st[1]), cap) for st, cap in ((t.cpu(), c) for t, c in _ASYNC_STATUS)]
+    host = [(t.cpu(), c) for t, c in _ASYNC_STATUS]
+    out = [(int(st[0]), bool(st[1]), cap) for st, cap in host]
+    bad = any(bool(st[2]) for st, _ in host)
     if reset:
         _ASYNC_STATUS.clear()
+    if bad:
+        raise RuntimeError(PREFILTERED_MSG)
     return out
 
 
@@ -169,7 +175,7 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
                 raise RuntimeError("gsrast: a sync-free forward needs a capacity: pass static_capacity(cap) or run the call once eagerly first")
             acap = int(h * 1.25) + 16384
         binning = _bytes(L.gsr_binning_bytes(variant, int(acap), W, H), dev)
-        status = torch.zeros((2,), dtype=torch.int32, device=dev)
+        status = torch.zeros((3,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             check(L.gsr_forward_async(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(), ptr(img),
                                       img.numel(), ptr(radii), C.byref(o), ptr(status), s), "forward_async")

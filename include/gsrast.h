@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 
 enum gsr_variant {
     GSR_EWA = 0,     /* diff_gaussian_rasterization : 3DGS EWA splats, RGB only                          */
@@ -162,11 +162,13 @@ int gsr_backward_ex(const gsr_cfg* cfg, const gsr_inputs* in, const int32_t* rad
 /* ---- forward with NO host synchronisation at all (round 3): the form that can be recorded into a HIP graph (hipStreamBeginCapture /
  * torch.cuda.graph) and replayed.  Like gsr_forward it runs against a binning arena of fixed capacity and the kernels read the instance
  * count on the device; unlike gsr_forward the host never learns it: status_dev[0] <- num_rendered, status_dev[1] <- 1 if it exceeded the
- * capacity (outputs then incomplete; status_dev[1] is sticky: the library only ever sets it, the caller clears it), both DEVICE words the
- * caller reads whenever it synchronises anyway.  gsr_backward[_ex] of such a call takes num_rendered = the capacity. */
+ * capacity (outputs then incomplete; status_dev[1] is sticky: the library only ever sets it, the caller clears it), status_dev[2] <- 1 (sticky)
+ * if cfg->prefiltered is set and a gaussian failed the frustum test (the reference traps the device, auxiliary.h:156-160; the synchronous forwards
+ * fail the call) -- three DEVICE words the caller reads whenever it synchronises anyway.  gsr_backward[_ex] of such a call takes num_rendered =
+ * the capacity. */
 int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
                       void* binning, size_t binning_bytes, void* img, size_t img_bytes, int32_t* radii /*[P]*/,
-                      const gsr_outputs* out, uint32_t* status_dev /*[2]*/, void* stream);
+                      const gsr_outputs* out, uint32_t* status_dev /*[3]*/, void* stream);
 
 /* ---- helpers of the same extensions */
 int gsr_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -591,41 +591,17 @@ def test_long_tile_lists_sort_paths(variant, P, monkeypatch):
         _ncontrib_close(view["n_contrib"][0], nc[0], st["final_T"][0], ft[0])
 
 
-def test_tile_ranges_from_the_last_scatter_pass():
-    """GSR_TILE_RANGES=scatter (the tile ranges written by the last scatter pass of the tile sort instead of k_tile_ranges; measured slower, kept
-    for A/B): the integer checks (ranges == histogram of the tile keys, bit-exact lists, empty tiles) re-run in a child process with the switch set."""
-    import subprocess
-    import sys
-    env = dict(os.environ, GSR_TILE_RANGES="scatter")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity or test_full_size_properties or test_edge_cases or test_speculative_forward",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
-
-
-@pytest.mark.parametrize("env", [{"GSR_SH_STAGE": "0"}, {"GSR_PREFIX": "kernel"}, {"GSR_SCAN": "kernel"}, {"GSR_MAILBOX_POLL": "0"}, {"GSR_XCD_REMAP": "0"},
-                                 {"GSR_XCD_REMAP": "1"}])
-def test_round3_switches_keep_the_results(env):
-    """The A/B switches of the round-3 changes (SH rows straight from global memory, the prefix / scan kernels as launches of their own, the event
-    instead of the polled mailbox, raster / banded launch order): the parity cases incl. SH colours, the speculative forward with its overflow
-    redo and the edge cases re-run in a child process with each switch set."""
+@pytest.mark.parametrize("env", [{"GSR_XCD_REMAP": "0"}, {"GSR_XCD_REMAP": "1"}, {"GSR_TILE_CULL": "0"}])
+def test_kept_switches_keep_the_results(env):
+    """The switches that stay (raster / banded launch order of the blend workgroups; GSR_TILE_CULL=0 = the reference-shaped instance list, every tile
+    of every rect emitted): the parity cases incl. SH colours, the speculative forward with its overflow redo and the edge cases re-run in a child
+    process with each switch set.  With GSR_TILE_CULL=0 test_forward_backward_parity also holds R, tiles_touched, point_list, tile keys and ranges
+    bit-exactly against the oracle's."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_forward_backward_parity or test_speculative_forward or test_edge_cases or test_full_size_properties", "-p", "no:cacheprovider"],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
-
-
-def test_eleven_bit_depth_sort_kept_switchable():
-    """GSR_DEPTH_BITS=11 (three 2048-bin passes instead of four 256-bin ones, kept for A/B) has to give the same bit-exact lists: the integer
-    checks of the parity cases are re-run in a child process with the switch set."""
-    import subprocess
-    import sys
-    env = dict(os.environ, GSR_DEPTH_BITS="11", GSR_DEPTH_ORDER="global")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 

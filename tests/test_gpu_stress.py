@@ -177,12 +177,12 @@ def test_concurrent_forwards_on_two_threads_and_streams():
 
 @pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
 def test_dense_tile_lists_backward_through_the_chunk_halving_path(variant):
-    """Every splat reaches every quadrant of every tile and every tile list holds all 420 of them: a 256-entry chunk overflows the 112-row
+    """Every splat reaches (nearly) every quadrant of every tile and every tile list holds hundreds of them: a 256-entry chunk overflows the 112-row
     per-wave gradient table of the splat-parallel backward, so each chunk is re-staged at half length (twice).  All gradients against the
     oracle, for the three variants."""
     hr = _hr()
     W, H = 160, 96
-    P, sigma = (900, 60.0) if variant == "surfel" else (420, 260.0)      # surfels that large would cross the camera plane and be dropped
+    P, sigma = (1600, 60.0) if variant == "surfel" else (420, 260.0)     # surfels that large would cross the camera plane and be dropped
     sc = scenes.make_scene(variant, P, W, H, seed=53, sigma_px=sigma)
     sc["opacities"][:] = 0.015                      # transmittance stays alive to the end of every list
     og = scenes.random_out_grads(variant, W, H, seed=53, scale=1.0)
@@ -190,7 +190,9 @@ def test_dense_tile_lists_backward_through_the_chunk_halving_path(variant):
         g = f.backward(**og)
         st = hr.run_raw(variant, sc)
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        assert st["R"] == f.R and f.R > (0.35 if variant == "surfel" else 0.8) * P * T
+        import tile_cull
+        tile_cull.reference_view(st, f, variant=variant)
+        assert st["R"] > (0.2 if variant == "surfel" else 0.8) * P * T          # (surfel: the tile-level cull drops a third of the rect instances)
         assert (st["n_contrib"][0] > 256).mean() > 0.5, (st["n_contrib"][0] > 256).mean()      # most pixels replay more than one 256-entry chunk
         res = hr.run(variant, sc, og)
     names = [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"), ("dL_dopacities", "dL_dopacity"),
