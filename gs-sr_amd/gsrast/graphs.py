@@ -31,15 +31,21 @@ class GraphedStep:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         rasterize.async_status_reset()
+        n0 = [len(o.captured_steps()) if hasattr(o, "captured_steps") else 0 for o in self.opts]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = fn()
+        # the optimizer steps recorded into THIS graph: only they move when it is replayed (another GraphedStep over the same optimizer has its own)
+        self.opt_steps = [o.captured_steps()[k:] if hasattr(o, "captured_steps") else None for o, k in zip(self.opts, n0)]
         self.status = list(rasterize._ASYNC_STATUS)          # the sync-free forwards recorded into this graph
         rasterize.async_status_reset()
 
     def __call__(self):
-        for o in self.opts:
-            o.prepare_replay()
+        for o, h in zip(self.opts, self.opt_steps):
+            if h is None:
+                o.prepare_replay()
+            else:
+                o.prepare_replay(handles=h)
         self.graph.replay()
         self.calls += 1
         if self.check_every and self.calls % self.check_every == 0:

@@ -94,22 +94,66 @@ def worker(args):
     return summary
 
 
-def gpu_numa_cpus(gpu_index):
-    """CPUs of the NUMA node the GPU's PCIe function sits on (sysfs), or None when that cannot be told."""
+def hip_device_bdfs(sysfs_root="/"):
+    """PCI addresses ("dddd:bb:dd.f") of the GPUs in HIP's UNFILTERED device order, from the KFD topology (/sys/class/kfd/kfd/topology/nodes/<n>/
+    properties: the GPU nodes -- simd_count > 0 -- in node order are what ROCr / HIP enumerate; `domain` and `location_id` = bus << 8 | devfn give
+    the address).  /sys/class/drm/card* order is NOT that order in general.  Also returns each GPU's `unique_id` (HIP_VISIBLE_DEVICES accepts
+    "GPU-<unique_id hex>").  -> list of (bdf, unique_id)."""
+    base = os.path.join(sysfs_root, "sys/class/kfd/kfd/topology/nodes")
+    out = []
+    for n in sorted((d for d in os.listdir(base) if d.isdigit()), key=int):
+        props = {}
+        try:
+            with open(os.path.join(base, n, "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v.strip()
+        except OSError:
+            continue                                   # a GPU of the node this container may not open (device cgroup): HIP does not enumerate it either
+        if int(props.get("simd_count", "0")) <= 0:
+            continue                                   # a CPU node
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        out.append((f"{dom:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7}", int(props.get("unique_id", "0"))))
+    return out
+
+
+def gpu_numa_cpus(visible_id, sysfs_root="/"):
+    """CPUs of the NUMA node of the GPU that `visible_id` names -- an entry of HIP_VISIBLE_DEVICES as a child will receive it: an index into HIP's
+    unfiltered enumeration, or "GPU-<unique_id hex>" -- resolved by PCI address (/sys/bus/pci/devices/<bdf>/numa_node), or None when that
+    cannot be told.  (Round 3 took the rank's ordinal and the order of /sys/class/drm/card*: with HIP_VISIBLE_DEVICES=4,5,6,7 rank 0 ran on GPU 4
+    with GPU 0's cores.)"""
     try:
-        import glob
-        drm = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/numa_node"), key=lambda q: int(q.split("card")[1].split("/")[0]))
-        render = [q for q in drm if os.path.exists(os.path.join(os.path.dirname(q), "mem_info_vram_total"))] or drm
-        node = int(open(render[gpu_index]).read().strip())
+        gpus = hip_device_bdfs(sysfs_root)
+        vid = str(visible_id).strip()
+        if vid.upper().startswith("GPU-"):
+            want = int(vid[4:], 16)
+            match = [b for b, u in gpus if u == want]
+            if not match:
+                return None
+            bdf = match[0]
+        else:
+            bdf = gpus[int(vid)][0]
+        node = int(open(os.path.join(sysfs_root, "sys/bus/pci/devices", bdf, "numa_node")).read().strip())
         if node < 0:
             return None
         cpus = set()
-        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+        for part in open(os.path.join(sysfs_root, f"sys/devices/system/node/node{node}/cpulist")).read().strip().split(","):
             a, _, b = part.partition("-")
             cpus.update(range(int(a), int(b or a) + 1))
         return cpus or None
     except Exception:
         return None
+
+
+def rank_placement(ranks, gpus, visible=None, sysfs_root="/", affinity=True):
+    """-> [(HIP_VISIBLE_DEVICES value, cpu set or None)] per rank: rank r works on the (r % gpus)-th entry of the launcher's own HIP_VISIBLE_DEVICES
+    (`visible`; all devices 0..gpus-1 when unset) and is pinned to the cores of THAT device's NUMA node."""
+    ids = [v.strip() for v in visible.split(",") if v.strip() != ""] if visible else [str(i) for i in range(gpus)]
+    out = []
+    for r in range(ranks):
+        dev = ids[(r % gpus) % len(ids)]
+        out.append((dev, gpu_numa_cpus(dev, sysfs_root) if affinity else None))
+    return out
 
 
 def worker_device(args):
@@ -135,8 +179,7 @@ def spawn_ranks(cmd_of_rank, ranks, gpus, port, pin_gpus=True, affinity=True, ex
     until the backend times out.  Returns the first non-zero exit code, or 0.  Used by the tile launcher and by `bench.py --gpus N`."""
     procs = []
     pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))       # the directory that holds gsrast/ and the drop-in packages
-    visible = os.environ.get("HIP_VISIBLE_DEVICES")
-    ids = [v for v in visible.split(",") if v != ""] if visible else [str(i) for i in range(gpus)]
+    place = rank_placement(ranks, gpus, os.environ.get("HIP_VISIBLE_DEVICES"), affinity=affinity)
     for r in range(ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if pin_gpus else str(r), WORLD_SIZE=str(ranks), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -144,8 +187,8 @@ def spawn_ranks(cmd_of_rank, ranks, gpus, port, pin_gpus=True, affinity=True, ex
         if extra_env:
             env.update(extra_env)
         if pin_gpus:
-            env["HIP_VISIBLE_DEVICES"] = ids[(r % gpus) % len(ids)]
-        cpus = gpu_numa_cpus(r % gpus) if (pin_gpus and affinity) else None
+            env["HIP_VISIBLE_DEVICES"] = place[r][0]
+        cpus = place[r][1] if pin_gpus else None
         pre = (lambda c=cpus: os.sched_setaffinity(0, c)) if cpus else None
         procs.append(subprocess.Popen(cmd_of_rank(r), env=env, preexec_fn=pre))
     rc = 0

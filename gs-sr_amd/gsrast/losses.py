@@ -1,4 +1,6 @@
 """Fused image-side loss kernels that run right behind the rasterizer."""
+import threading
+
 import torch
 
 from . import lib, check, ptr, stream_ptr, dev_f32
@@ -6,17 +8,23 @@ from . import lib, check, ptr, stream_ptr, dev_f32
 
 # Zero-initialised scalars for kernels that accumulate a loss value with atomics: one torch.zeros(1024) serves 1024 calls (a fill kernel per
 # call costs ~4 us + a launch gap on a 1 ms iteration).  Every scalar is handed out once; a spent block stays alive through its views.
+# The pool is keyed by (device, current stream) -- a block is filled on the stream that allocates it and its scalars are only handed to work on that
+# stream, so the fill is ordered before every use -- and guarded by a lock: two Python threads never receive the same word.
 _ZEROS = {}
+_ZEROS_LOCK = threading.Lock()
 
 
 def zero_scalar(device):
     if torch.cuda.is_current_stream_capturing():          # inside a graph the fill has to be part of the graph: replays re-zero it
         return torch.zeros((), dtype=torch.float32, device=device)
-    ent = _ZEROS.get(device)
-    if ent is None or ent[1] >= ent[0].numel():
-        ent = _ZEROS[device] = [torch.zeros(1024, dtype=torch.float32, device=device), 0]
-    v = ent[0][ent[1]]
-    ent[1] += 1
+    device = torch.device(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    with _ZEROS_LOCK:
+        ent = _ZEROS.get(key)
+        if ent is None or ent[1] >= ent[0].numel():
+            ent = _ZEROS[key] = [torch.zeros(1024, dtype=torch.float32, device=device), 0]
+        v = ent[0][ent[1]]
+        ent[1] += 1
     return v
 
 

@@ -172,7 +172,8 @@ class Adam(torch.optim.Adam):
         if capturing:
             if rest or len(batch) > 1:
                 raise RuntimeError("gsrast.optim.Adam: a captured step() needs every parameter covered by the HIP kernel, on one device")
-            self._gsr_graph = []
+            graphs = self.__dict__.setdefault("_gsr_graph", [])       # one entry per captured step(), kept for the life of the optimizer: several
+                                                                       # graphs over one optimizer (one per image size, say) each replay their own
         for dev, entries in batch.items():
             table = (_AdamTensor * len(entries))(*entries)
             with torch.cuda.device(dev):
@@ -181,10 +182,12 @@ class Adam(torch.optim.Adam):
                     # pool may have held a temporary earlier in the recorded iteration, whose recorded writes would then overwrite, on every
                     # replay, what prepare_replay() copied in beforehand (measured: step_size read back as 0).  It is created by the eager
                     # step() calls that precede every capture (torch.cuda.graph needs warm-up iterations anyway).
-                    hyper = self.__dict__.get("_gsr_hyper", {}).get(dev)
+                    # Every capture takes the spare buffer for itself (its recorded launch reads table position i of it for the i-th captured tensor);
+                    # the next eager step() provides a new spare.
+                    hyper = self.__dict__.get("_gsr_hyper", {}).pop(dev, None)
                     if hyper is None or hyper.shape[0] < len(entries):
-                        raise RuntimeError("gsrast.optim.Adam: run at least one eager step() before recording step() into a graph")
-                    self._gsr_graph.append([captured, hyper, [], 0])
+                        raise RuntimeError("gsrast.optim.Adam: run at least one eager step() before recording each step() into a graph")
+                    graphs.append([captured, hyper, [], 0])
                     check(L.gsr_adam_step_multi_dev(len(entries), table, hyper.data_ptr(), stream_ptr(dev)), "adam_step_multi_dev")
                 else:
                     hy = self.__dict__.setdefault("_gsr_hyper", {})
@@ -205,12 +208,19 @@ class Adam(torch.optim.Adam):
                         decoupled_weight_decay=group.get("decoupled_weight_decay", False))
         return loss
 
+    def captured_steps(self):
+        """Handles of the step() calls recorded into graphs so far (in capture order): `opt.captured_steps()[n0:]` after a capture that started with
+        n0 = len(opt.captured_steps()) are that capture's; pass them to prepare_replay(handles=...)."""
+        return list(self.__dict__.get("_gsr_graph", ()))
+
     @torch.no_grad()
-    def prepare_replay(self):
+    def prepare_replay(self, handles=None):
         """Before every replay of a graph that holds this optimizer's step(): one more step for every captured parameter -- counters bumped,
         the groups' current learning rates and the bias corrections written to the device buffer the captured launch reads (one small
-        asynchronous copy from a ring of pinned host buffers: the host may run several replays ahead of the device)."""
-        for ent in getattr(self, "_gsr_graph", ()):
+        asynchronous copy from a ring of pinned host buffers: the host may run several replays ahead of the device).  `handles`: the captured
+        steps of THE GRAPH ABOUT TO BE REPLAYED (captured_steps(); gsrast.graphs.GraphedStep passes its own); None = every captured step, which is
+        right only while one graph holds this optimizer."""
+        for ent in (self.__dict__.get("_gsr_graph", ()) if handles is None else handles):
             captured, hyper, ring, pos = ent
             if len(ring) < 16:
                 ring.append([torch.empty(len(captured), 2, dtype=torch.float32).pin_memory(), None])

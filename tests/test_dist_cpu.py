@@ -195,3 +195,36 @@ def test_launch_tiles_two_workers_per_gpu_gloo():
         assert summary["tiles"] == 5 and summary["workers"] == 4 and summary["iterations"] == 35
         ranks = [open(os.path.join(out, f"tile_{k:04d}", "chkpnt", "done.txt")).read().split()[3] for k in range(5)]
         assert set(ranks) == {"rank0", "rank1", "rank2", "rank3"}
+
+
+def test_rank_placement_follows_the_visible_device_list_by_pci_address(tmp_path):
+    """spawn_ranks pins rank r to the (r % gpus)-th entry of the launcher's HIP_VISIBLE_DEVICES and to the cores of THAT device's NUMA node, resolved by
+    PCI address from the KFD topology -- not by the rank's ordinal or the order of /sys/class/drm/card* (VERDICT r3 weak #7).  A fake sysfs root: an
+    8-GPU node whose KFD order differs from its PCI order, two NUMA nodes, HIP_VISIBLE_DEVICES=4,5,6,7 and a device named by its unique id."""
+    from gsrast import launch_tiles
+    root = tmp_path
+    buses = [0x0c, 0x22, 0x38, 0x5c, 0x9f, 0xaf, 0xbf, 0xdf]         # KFD GPU order -> PCI bus
+    nodes = root / "sys/class/kfd/kfd/topology/nodes"
+    for cpu in (0, 1):                                                 # two CPU nodes first, as on a real 2-socket box
+        d = nodes / str(cpu); d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\nunique_id 0\n")
+    for k, bus in enumerate(buses):
+        d = nodes / str(2 + k); d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\nunique_id {0xabc000 + k}\n")
+        pd = root / "sys/bus/pci/devices" / f"0000:{bus:02x}:00.0"; pd.mkdir(parents=True)
+        (pd / "numa_node").write_text(f"{0 if k < 4 else 1}\n")
+    for node, cl in ((0, "0-63,128-191"), (1, "64-127,192-255")):
+        nd = root / f"sys/devices/system/node/node{node}"; nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cl + "\n")
+    assert [b for b, _ in launch_tiles.hip_device_bdfs(str(root))] == [f"0000:{b:02x}:00.0" for b in buses]
+    place = launch_tiles.rank_placement(4, 4, "4,5,6,7", sysfs_root=str(root))
+    assert [d for d, _ in place] == ["4", "5", "6", "7"]
+    assert all(c is not None and min(c) == 64 and max(c) == 255 and 0 not in c for _, c in place)           # GPUs 4..7 sit on node 1
+    place = launch_tiles.rank_placement(8, 8, None, sysfs_root=str(root))
+    assert [min(c) for _, c in place] == [0, 0, 0, 0, 64, 64, 64, 64]
+    place = launch_tiles.rank_placement(2, 2, f"GPU-{0xabc006:x},1", sysfs_root=str(root))
+    assert min(place[0][1]) == 64 and min(place[1][1]) == 0                                                 # by unique id, then by index
+    place = launch_tiles.rank_placement(4, 2, "6,1", sysfs_root=str(root))                                  # two workers per GPU share a placement
+    assert [d for d, _ in place] == ["6", "1", "6", "1"]
+    assert launch_tiles.gpu_numa_cpus("11", str(root)) is None and launch_tiles.gpu_numa_cpus("GPU-dead", str(root)) is None
+    assert all(c is None for _, c in launch_tiles.rank_placement(2, 2, "0,1", sysfs_root=str(root), affinity=False))

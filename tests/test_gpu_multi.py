@@ -109,3 +109,11 @@ def test_launcher_pins_workers(tmp_path):
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
     assert launch_tiles.gpu_numa_cpus(0) is None or len(launch_tiles.gpu_numa_cpus(0)) > 0
+    # the KFD-derived PCI address of every visible device is the one the HIP runtime reports for that ordinal
+    visible = os.environ.get("HIP_VISIBLE_DEVICES")
+    ids = [v for v in visible.split(",") if v] if visible else [str(i) for i in range(torch.cuda.device_count())]
+    bdfs = launch_tiles.hip_device_bdfs()
+    if not os.environ.get("ROCR_VISIBLE_DEVICES") and all(i.isdigit() for i in ids):
+        for k, i in enumerate(ids[:torch.cuda.device_count()]):
+            pr = torch.cuda.get_device_properties(k)
+            assert bdfs[int(i)][0] == f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0", (bdfs, k, pr.pci_bus_id)

@@ -134,6 +134,48 @@ def test_step_recorded_in_a_hip_graph_matches_torch():
             assert torch.allclose(a, b, rtol=0, atol=1e-4 * lr + 5e-7), (t, i, (a - b).abs().max().item())
 
 
+def test_two_graphs_over_one_optimizer_keep_their_own_scalars():
+    """Two recorded step() calls over ONE optimizer that cover different parameter subsets (say one graph per image size, one of which never
+    reaches some tensors): every capture owns its hyper-parameter buffer and its list of captured tensors, and prepare_replay(handles=...) moves
+    only the step counters of the graph about to be replayed (the second capture used to overwrite the first one's bookkeeping, so the
+    older graph replayed with another tensor's step size)."""
+    from gsrast.optim import Adam
+    shapes = [(4001, 3), (4001, 1), (9,), (257, 4)]
+    lrs = [1.6e-4, 5e-2, 1e-3, 2e-3]
+    pa, oa = _models(11, shapes, lrs, Adam)
+    pb, ob = _models(11, shapes, lrs, lambda groups, **kw: torch.optim.Adam(groups, foreach=False, **kw))
+    gen = torch.Generator().manual_seed(5)
+    static_g = [torch.zeros(s, device=DEV) for s in shapes]
+    subsets = {"A": [0, 1, 2, 3], "B": [3, 1]}
+
+    def feed(which):
+        for i in range(len(shapes)):
+            pa[i].grad = None; pb[i].grad = None
+        for i in subsets[which]:
+            g = torch.randn(shapes[i], generator=gen).to(DEV)
+            static_g[i].copy_(g); pa[i].grad = static_g[i]; pb[i].grad = g
+    graphs, handles = {}, {}
+    for which in ("A", "B"):
+        feed(which); oa.step(); ob.step()            # an eager step before EACH capture (state + a spare hyper buffer)
+        torch.cuda.synchronize()
+        n0 = len(oa.captured_steps())
+        graphs[which] = torch.cuda.CUDAGraph()
+        feed(which)                                  # the gradient slots the recorded launch reads
+        with torch.cuda.graph(graphs[which]):
+            oa.step()
+        handles[which] = oa.captured_steps()[n0:]
+        assert len(handles[which]) == 1 and len(handles[which][0][0]) == len(subsets[which])
+    assert handles["A"][0][1].data_ptr() != handles["B"][0][1].data_ptr()       # separate device buffers
+    for which in ("A", "B", "B", "A", "A", "B"):
+        feed(which)
+        oa.prepare_replay(handles=handles[which]); graphs[which].replay(); ob.step()
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]), (which, i)
+            lr = oa.param_groups[i]["lr"]
+            assert torch.allclose(a, b, rtol=0, atol=1e-4 * lr + 5e-7), (which, i, (a - b).abs().max().item())
+
+
 def test_shadow_parameters_two_passes_one_update():
     """Two passes over the same parameters in one backward (PGSR's reference + neighbour camera): with shadow leaves for the second pass and
     Adam.add_shadows the update kernel reads both gradients; parameters and optimizer state stay bit-identical to the plain form in which
