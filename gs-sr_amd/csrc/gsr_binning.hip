@@ -450,11 +450,12 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
     const uint32_t wave_base = __shfl(incl - cnt, 0, 64);
     if constexpr (CULLV >= 0) {
         __shared__ float4 s_cull[2 * 256];
+        __shared__ float2 s_slope[256];
         __shared__ ushort4 s_rect[256];
         const uint32_t wbase = threadIdx.x & ~63u;
         float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = make_float4(0.f, -1.f, 0.f, 0.f);
         if (cnt) { c0 = cull[2 * (size_t)g]; c1 = cull[2 * (size_t)g + 1]; }
-        s_cull[2 * threadIdx.x] = c0; s_cull[2 * threadIdx.x + 1] = c1; s_rect[threadIdx.x] = r;
+        s_cull[2 * threadIdx.x] = c0; s_cull[2 * threadIdx.x + 1] = c1; s_slope[threadIdx.x] = tc_slopes(c0, c1); s_rect[threadIdx.x] = r;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the walk covers the rects of the gaussians that kept at least one tile (a gaussian whose every tile was dropped has nothing to emit)
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
         const uint32_t total = (uint32_t)__shfl((int)ai, 63, 64), excl = ai - area;
         uint32_t run = wave_base;
         for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
-            const TcCand c = tc_candidate<CULLV>(k0 + lane, total, excl, s_cull + 2 * wbase, s_rect + wbase);
+            const TcCand c = tc_candidate<CULLV>(k0 + lane, total, excl, s_cull + 2 * wbase, s_slope + wbase, s_rect + wbase);
             const uint64_t hits = __ballot(c.hit);
             const uint32_t off = run + (uint32_t)__popcll(hits & lanemask_lt());
             const uint32_t sg = (uint32_t)__shfl((int)g, (int)c.s, 64);

@@ -54,7 +54,12 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0;
-    bool done = !inside;
+    // Which pixels still blend, and every gate of the pair loop, are kept as 64-bit wave masks in SCALAR registers: the compares write them directly
+    // (v_cmp -> SGPR pair, __builtin_amdgcn_fcmpf), they are combined on the scalar unit, and the lanes that apply the splat are selected through
+    // inverse_ballot.  With `done` as a loop-carried bool the early-exit test __ballot(!done) cost a v_cndmask + v_cmp per pair on top of the
+    // scalar bookkeeping of the bool's phi.  Predicates (LLVM fcmp numbering): 2 ogt, 4 olt, 5 ole, 11 uge, 13 ule, 14 une -- the unordered
+    // forms reproduce the reference's negated tests (`!(a < b)` is true for NaN).
+    uint64_t live = __ballot(inside);
     // SURFEL
     float N0 = 0, N1 = 0, N2 = 0, Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
     uint32_t median_contributor = 0; int surf_idx = -1;
@@ -63,7 +68,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
     float A0 = 0, A1 = 0, A2 = 0, A3 = 0, A4 = 0;
 
     for (uint32_t base = range.x; base < range.y; base += GSR_WAVE) {
-        if (__ballot(!done) == 0) break;
+        if (live == 0) break;
         const uint32_t i = base + lane;
         const bool v = i < range.y;
         const uint32_t id = v ? p.point_list[i] : 0u;
@@ -112,15 +117,15 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
                 const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
                 const float alpha = fminf(0.99f, q1.y * __expf(power));
-                bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                uint64_t okm = live & __builtin_amdgcn_fcmpf(power, 0.0f, 13) & __builtin_amdgcn_fcmpf(alpha, 1.0f / 255.0f, 11);
                 const float test_T = T * (1 - alpha);
-                const bool stop = ok && (test_T < 0.0001f);
-                done = done || stop;
-                ok = ok && !stop;
+                const uint64_t stopm = okm & __builtin_amdgcn_fcmpf(test_T, 0.0001f, 4);
+                live &= ~stopm; okm &= ~stopm;
                 if (V == GSR_PLANE) {
-                    const uint64_t ob = __ballot(ok && T > 0.5f);
+                    const uint64_t ob = okm & __builtin_amdgcn_fcmpf(T, 0.5f, 2);
                     if (ob != 0 && lane == 0) atomicAdd(&p.out_observe[gid], (int)__popcll(ob));
                 }
+                const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
                 if (ok) {
                     const float w = alpha * T;
                     C0 += q1.z * w; C1 += q1.w * w; C2 += q2.x * w;
@@ -145,11 +150,11 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 const float power = -0.5f * rho;
                 const float alpha = fminf(0.99f, q2.w * __expf(power));
                 // (the reference's `power > 0` gate, forward.cu:389, cannot fire: rho is a minimum of two sums of squares)
-                bool ok = !done && !(ppz == 0.0f) && !(depth < NEAR_N) && !(alpha < 1.0f / 255.0f);
+                uint64_t okm = live & __builtin_amdgcn_fcmpf(ppz, 0.0f, 14) & __builtin_amdgcn_fcmpf(depth, NEAR_N, 11) & __builtin_amdgcn_fcmpf(alpha, 1.0f / 255.0f, 11);
                 const float test_T = T * (1 - alpha);
-                const bool stop = ok && (test_T < 0.0001f);
-                done = done || stop;
-                ok = ok && !stop;
+                const uint64_t stopm = okm & __builtin_amdgcn_fcmpf(test_T, 0.0001f, 4);
+                live &= ~stopm; okm &= ~stopm;
+                const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
                 if (ok) {
                     const float w = alpha * T;
                     const float A = 1 - T;
@@ -167,7 +172,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                     last_contributor = contributor;
                 }
             }
-            if (__ballot(!done) == 0) break;
+            if (live == 0) break;
         }
     }
 

@@ -161,7 +161,7 @@ template <> struct SpPix<GSR_SURFEL> {
 // The cancellation of px Tw against Tu happens once, in k0 / l0, as it does per pixel in the reference's form; the three cross products are formed
 // once per load and a pixel step evaluates p with <= 6 FMAs instead of 12 instructions.  The depth s . Tw.xy + Tw.z equals (p . Tw) / p.z and
 // p . Tw = det[Tu Tv Tw] =: D for every pixel (k, l differ from -Tu, -Tv by multiples of Tw), so depth = D / p.z with D from the record.
-struct SpSurf { float P0x, P0y, P0z, Pxx, Pxy, Pxz, Pyx, Pyy, Pyz, Tw0, Tw1, Tw2, D, cdx, cdy; };
+struct SpSurf { float P0x, P0y, P0z, Pxx, Pxy, Pxz, Pyx, Pyy, Pyz, Tw0, Tw1, Tw2, D, cdx, cdy, oh; };      // EWA / PLANE use cdx, cdy (centre - block origin) and oh = -opacity / 2
 __device__ __forceinline__ SpSurf sp_surf_setup(const float4& q0, const float4& q1, const float4& q2, const float4& q4, float x0, float y0)
 {
     SpSurf S;
@@ -206,11 +206,21 @@ template <int V, int I, int NACC>
 __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4, const SpSurf& S,
                                         bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc, uint32_t& okbits)
 {
-    const float pxf = K.rowx + (float)(I & 3), pyf = K.rowy + (float)(I >> 2);
     const uint32_t last = bc_movu<I>(K.last);
     if constexpr (V != GSR_SURFEL) {
-        const float dx = q0.x - pxf, dy = q0.y - pyf;
-        const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+        constexpr int DX = I & 3, DY = I >> 2;
+        // centre - pixel.  EWA: from the block-relative centre of the load, squares shared by the exponent and the conic gradients.  PLANE keeps the
+        // round-3 expressions: the same rewrite measured SLOWER there (0.294 vs 0.285 ms at 5 waves / 96 VGPRs: the per-load values the compiler
+        // hoists out of the 16 steps push two more registers into scratch).
+        float dx, dy, dxx = 0.f, dxy = 0.f, dyy = 0.f, power;
+        if constexpr (V == GSR_EWA) {
+            dx = S.cdx - (float)DX; dy = S.cdy - (float)DY;
+            dxx = dx * dx; dxy = dx * dy; dyy = dy * dy;
+            power = fmaf(-0.5f, fmaf(q1.x, dyy, q0.z * dxx), -(q0.w * dxy));
+        } else {
+            dx = q0.x - (K.rowx + (float)DX); dy = q0.y - (K.rowy + (float)DY);
+            power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+        }
         const float G = __expf(power);
         const float alpha = fminf(0.99f, q1.y * G);
         const bool ok = valid & (idx0 < last) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
@@ -240,19 +250,29 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
             const bool mine = (j == I);
             K.Tc = mine ? nT : K.Tc; K.Sc = mine ? nS : K.Sc;
         }
-        const float dL_dG = q1.y * dL_dalpha;
-        const float gdx = Gm * dx, gdy = Gm * dy;
-        const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-        const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-        const float g_mx = dL_dG * dG_ddelx * ddelx_dx;
-        const float g_my = dL_dG * dG_ddely * ddely_dy;
+        // Gradients of this pair (3DGS backward.cu:520-545) with gG = G dL_dalpha and h = -opacity gG / 2 = -G dL_dG / 2:
+        //   opacity += gG;  conic (xx, xy, yy) += h (dx^2, dx dy, dy^2);  mean2D.x += 2 h (A dx + B dy) W/2,  mean2D.y += 2 h (C dy + B dx) H/2.
+        // EWA accumulates the two moments sum h dx, sum h dy and applies A, B, C and the NDC factors once per load (end of the load loop); PLANE needs
+        // |mean2D term| per pixel (PLANE backward.cu:552-553) and keeps the literal per-pixel terms.
         acc[0] = bc_fmac<I>(acc[0], K.dLp0, w); acc[1] = bc_fmac<I>(acc[1], K.dLp1, w); acc[2] = bc_fmac<I>(acc[2], K.dLp2, w);
-        acc[3] += Gm * dL_dalpha;
-        acc[4] += g_mx; acc[5] += g_my;
-        acc[6] += -0.5f * gdx * dx * dL_dG;
-        acc[7] += -0.5f * gdx * dy * dL_dG;
-        acc[8] += -0.5f * gdy * dy * dL_dG;
-        if constexpr (V == GSR_PLANE) {
+        if constexpr (V == GSR_EWA) {
+            const float gG = Gm * dL_dalpha;
+            const float h = gG * S.oh;
+            acc[3] += gG;
+            acc[6] = fmaf(h, dxx, acc[6]); acc[7] = fmaf(h, dxy, acc[7]); acc[8] = fmaf(h, dyy, acc[8]);
+            acc[4] = fmaf(h, dx, acc[4]); acc[5] = fmaf(h, dy, acc[5]);
+        } else {
+            const float dL_dG = q1.y * dL_dalpha;
+            const float gdx = Gm * dx, gdy = Gm * dy;
+            const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+            const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+            const float g_mx = dL_dG * dG_ddelx * ddelx_dx;
+            const float g_my = dL_dG * dG_ddely * ddely_dy;
+            acc[3] += Gm * dL_dalpha;
+            acc[4] += g_mx; acc[5] += g_my;
+            acc[6] += -0.5f * gdx * dx * dL_dG;
+            acc[7] += -0.5f * gdx * dy * dL_dG;
+            acc[8] += -0.5f * gdy * dy * dL_dG;
             acc[9] += fabsf(g_mx); acc[10] += fabsf(g_my);
             if (geo) {
                 acc[11] = bc_fmac<I>(acc[11], K.dA0, w); acc[12] = bc_fmac<I>(acc[12], K.dA1, w); acc[13] = bc_fmac<I>(acc[13], K.dA2, w);
@@ -526,6 +546,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             SpSurf S = {};
             uint32_t okbits = 0u;
             if constexpr (V == GSR_SURFEL) S = sp_surf_setup(q0, q1, q2, q4, K.rowx, K.rowy);
+            else if constexpr (V == GSR_EWA) { S.cdx = q0.x - K.rowx; S.cdy = q0.y - K.rowy; S.oh = -0.5f * q1.y; }
             // `never` is a wave-uniform, never-true condition the compiler cannot fold: the (untaken) scalar branch after every step ends
             // the basic block, so the 16 unrolled steps are scheduled one at a time -- as ONE block the scheduler overlaps them and the
             // kernel needs 280+ VGPRs (one wave per SIMD); split, every step's temporaries die inside the step.
@@ -538,6 +559,11 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             if constexpr (V == GSR_SURFEL) { t0 = r[0]; t1 = r[1]; }
             SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
 #undef SP_STEP
+            if constexpr (V == GSR_EWA) {              // moments -> mean2D terms: 2 (A Sx + B Sy) W/2, 2 (C Sy + B Sx) H/2
+                const float sx = acc[4], sy = acc[5];
+                acc[4] = (2.0f * ddelx_dx) * fmaf(q0.w, sy, q0.z * sx);
+                acc[5] = (2.0f * ddely_dy) * fmaf(q0.w, sx, q1.x * sy);
+            }
             if constexpr (V == GSR_SURFEL) {
                 if (mn_live) {
 #define SP_MN(I) sp_mn_pixel<I>(K, okbits, acc);

@@ -148,16 +148,17 @@ __device__ __forceinline__ uint32_t pre_tile_count(const PreParams& p, const int
     uint32_t tiles = tc.tiles;
     if (p.tile_cull) {                                // kernel-uniform
         __shared__ float4 s_cull[2 * 256];
+        __shared__ float2 s_slope[256];
         __shared__ ushort4 s_rect[256];
         const uint32_t lane = tds_lane(), wbase = threadIdx.x & ~63u;
-        s_cull[2 * threadIdx.x] = tc.c0; s_cull[2 * threadIdx.x + 1] = tc.c1; s_rect[threadIdx.x] = tc.rect;
+        s_cull[2 * threadIdx.x] = tc.c0; s_cull[2 * threadIdx.x + 1] = tc.c1; s_slope[threadIdx.x] = tc_slopes(tc.c0, tc.c1); s_rect[threadIdx.x] = tc.rect;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t incl = tds_wave_incl_scan(tc.tiles);
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64), excl = incl - tc.tiles;
         uint32_t kept = 0u;
         for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
-            const TcCand c = tc_candidate<V>(k0 + lane, total, excl, s_cull + 2 * wbase, s_rect + wbase);
+            const TcCand c = tc_candidate<V>(k0 + lane, total, excl, s_cull + 2 * wbase, s_slope + wbase, s_rect + wbase);
             const uint64_t hits = __ballot(c.hit);
             // this gaussian's candidates occupy [excl, incl) of the walk: bits [lo, hi) of this batch
             const uint32_t lo = max(excl, k0) - k0, hi = min(incl, k0 + 64u) > k0 ? min(incl, k0 + 64u) - k0 : 0u;
