@@ -641,6 +641,73 @@ extern "C" int gsr_plane_allmap_backward(int32_t P, const float* means3D, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Activations of the explicit-Gaussian models, the step right in front of the rasterizer call of vanilla-3dgs / 2dgs / pgsr
+// (gssr/gaussian/vanilla_gaussian.py:86-90,250-269: get_scaling = exp(_scaling), get_rotation = F.normalize(_rotation), get_opacity =
+// sigmoid(_opacity)): three torch forward ops and ~8 autograd kernels per iteration there, one streaming kernel each way here.
+// normalize: x / max(|x|_2, 1e-12) (torch.nn.functional.normalize, dim 1); its backward (g - r <r, g>) / max(|x|, eps), zero coupling when clamped.
+__global__ void __launch_bounds__(256) k_gauss_act_fwd(int P, int S, const float* __restrict__ scl_log, const float4* __restrict__ rot_raw,
+                                                       const float* __restrict__ op_raw, float* __restrict__ scl, float4* __restrict__ rot, float* __restrict__ op)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    for (int k = 0; k < S; k++) scl[(size_t)p * S + k] = expf(scl_log[(size_t)p * S + k]);
+    const float4 q = rot_raw[p];
+    const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    rot[p] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+    op[p] = 1.0f / (1.0f + expf(-op_raw[p]));
+}
+__global__ void __launch_bounds__(256) k_gauss_act_bwd(int P, int S, const float* __restrict__ scl, const float4* __restrict__ rot_raw, const float4* __restrict__ rot,
+                                                       const float* __restrict__ op, const float* __restrict__ d_scl, const float4* __restrict__ d_rot,
+                                                       const float* __restrict__ d_op, float* __restrict__ d_scl_log, float4* __restrict__ d_rot_raw,
+                                                       float* __restrict__ d_op_raw)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    for (int k = 0; k < S; k++) d_scl_log[(size_t)p * S + k] = d_scl ? d_scl[(size_t)p * S + k] * scl[(size_t)p * S + k] : 0.0f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d_rot) {
+        const float4 q = rot_raw[p], r = rot[p], g = d_rot[p];
+        const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        if (nn > 1e-12f) {
+            const float dot = r.x * g.x + r.y * g.y + r.z * g.z + r.w * g.w;
+            o = make_float4((g.x - r.x * dot) / nn, (g.y - r.y * dot) / nn, (g.z - r.z * dot) / nn, (g.w - r.w * dot) / nn);
+        } else o = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);      // clamped denominator: y = x / eps
+    }
+    d_rot_raw[p] = o;
+    const float a = op[p];
+    d_op_raw[p] = d_op ? d_op[p] * a * (1.0f - a) : 0.0f;
+}
+extern "C" int gsr_gauss_activations(int32_t P, int32_t scale_dim, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                     float* scaling, float* rotation, float* opacity, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!scaling_raw || !rotation_raw || !opacity_raw || !scaling || !rotation || !opacity || scale_dim < 1 || scale_dim > 3) {
+        gsr_set_error("gauss_activations: null pointer or scale_dim outside 1..3"); return 1;
+    }
+    if ((((uintptr_t)rotation_raw | (uintptr_t)rotation) & 15) != 0) { gsr_set_error("gauss_activations: rotations must be 16-byte aligned"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gauss_act_fwd, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, scale_dim, scaling_raw, (const float4*)rotation_raw, opacity_raw,
+                       scaling, (float4*)rotation, opacity);
+    return gsr_check_launch("gauss_activations", s, false);
+}
+extern "C" int gsr_gauss_activations_backward(int32_t P, int32_t scale_dim, const float* scaling, const float* rotation_raw, const float* rotation,
+                                              const float* opacity, const float* dL_dscaling, const float* dL_drotation, const float* dL_dopacity,
+                                              float* dL_dscaling_raw, float* dL_drotation_raw, float* dL_dopacity_raw, void* stream)
+{
+    if (P <= 0) return 0;
+    if (!scaling || !rotation_raw || !rotation || !opacity || !dL_dscaling_raw || !dL_drotation_raw || !dL_dopacity_raw || scale_dim < 1 || scale_dim > 3) {
+        gsr_set_error("gauss_activations_backward: null pointer or scale_dim outside 1..3"); return 1;
+    }
+    if ((((uintptr_t)rotation_raw | (uintptr_t)rotation | (uintptr_t)dL_drotation | (uintptr_t)dL_drotation_raw) & 15) != 0) {
+        gsr_set_error("gauss_activations_backward: rotations must be 16-byte aligned"); return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gauss_act_bwd, dim3(gsr_div_up((uint32_t)P, 256)), dim3(256), 0, s, P, scale_dim, scaling, (const float4*)rotation_raw, (const float4*)rotation,
+                       opacity, dL_dscaling, (const float4*)dL_drotation, dL_dopacity, dL_dscaling_raw, (float4*)dL_drotation_raw, dL_dopacity_raw);
+    return gsr_check_launch("gauss_activations_backward", s, false);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Per-iteration densification statistics of the explicit-Gaussian methods (vanilla_gaussian.py:467-472,428-430; pgsr_gaussian.py:164-172,
 // 157-161).  The reference writes them as boolean-mask index assignments (a nonzero() host synchronisation each: 3 for 3DGS/2DGS, 5 for
 // PGSR per iteration); one elementwise kernel here.

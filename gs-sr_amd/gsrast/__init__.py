@@ -69,7 +69,7 @@ EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward
            "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward",
            "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_loss_scaling_prod", "gsr_octree_visible",
            "gsr_loss_plane_mv_scratch_bytes", "gsr_loss_plane_mv_geo", "gsr_loss_plane_mv_ncc",
-           "gsr_plane_allmap", "gsr_plane_allmap_backward", "gsr_sample_mask_scratch_bytes", "gsr_sample_mask", "gsr_densify_stats", "gsr_adam_step", "gsr_adam_step_multi", "gsr_adam_step_multi_dev"]
+           "gsr_plane_allmap", "gsr_plane_allmap_backward", "gsr_gauss_activations", "gsr_gauss_activations_backward", "gsr_sample_mask_scratch_bytes", "gsr_sample_mask", "gsr_densify_stats", "gsr_adam_step", "gsr_adam_step_multi", "gsr_adam_step_multi_dev"]
 PROF_LABELS = ["preprocess", "depth_order", "binning", "blend_fwd", "bwd_memset", "blend_bwd", "preprocess_bwd", "_"]
 
 _lib = None
@@ -152,6 +152,10 @@ def lib():
     L.gsr_plane_allmap.argtypes = [C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]
     L.gsr_plane_allmap_backward.restype = C.c_int
     L.gsr_plane_allmap_backward.argtypes = [C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_gauss_activations.restype = C.c_int
+    L.gsr_gauss_activations.argtypes = [C.c_int32, C.c_int32] + [_vp] * 7
+    L.gsr_gauss_activations_backward.restype = C.c_int
+    L.gsr_gauss_activations_backward.argtypes = [C.c_int32, C.c_int32] + [_vp] * 11
     L.gsr_octree_visible.restype = C.c_int
     L.gsr_octree_visible.argtypes = [C.POINTER(Cfg), C.POINTER(LodCfg), _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]
     L.gsr_dist2_scratch_bytes.restype = sz; L.gsr_dist2_scratch_bytes.argtypes = [C.c_int32]

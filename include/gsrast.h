@@ -316,6 +316,16 @@ int gsr_densify_stats(int32_t P, const uint8_t* visibility_filter, const int32_t
                       int32_t grad_stride, const float* viewspace_grad_abs, float* max_radii2D, float* xyz_gradient_accum, float* denom,
                       float* xyz_gradient_accum_abs, float* denom_abs, void* stream);
 
+/* ---- activations of the explicit-Gaussian models (round 4): replaces the three torch ops + ~8 autograd kernels of
+ * /root/reference/gssr/gaussian/vanilla_gaussian.py:86-90,250-269 (get_scaling = exp, get_rotation = F.normalize(dim=1, eps=1e-12),
+ * get_opacity = sigmoid) in front of every rasterizer call of vanilla-3dgs / 2dgs / pgsr.  scaling (P, scale_dim <= 3), rotation (P, 4), opacity (P, 1);
+ * backward: upstream gradients may be NULL (that output was unused). */
+int gsr_gauss_activations(int32_t P, int32_t scale_dim, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                          float* scaling, float* rotation, float* opacity, void* stream);
+int gsr_gauss_activations_backward(int32_t P, int32_t scale_dim, const float* scaling, const float* rotation_raw, const float* rotation,
+                                   const float* opacity, const float* dL_dscaling, const float* dL_drotation, const float* dL_dopacity,
+                                   float* dL_dscaling_raw, float* dL_drotation_raw, float* dL_dopacity_raw, void* stream);
+
 /* Per-Gaussian `all_map` input of the plane rasterizer, as PGSRScene.render() builds it (gssr/scene/pgsr_scene.py:241-257
  * get_rotation_matrix / get_smallest_axis / get_normal and :297-304):  all_map[i] = {local_normal (3), 1, local_distance} with
  *   n = quaternion_to_matrix(rotations[i])[:, argmin(scales[i])] (pytorch3d convention: real part first, normalised by 2/(q.q); first

@@ -25,6 +25,7 @@ import scenes                          # noqa: E402
 import diff_plane_rasterization as dpr   # noqa: E402
 from gsrast.losses import l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss  # noqa: E402
 from gsrast.plane_prep import plane_input_all_map  # noqa: E402
+from gsrast.activations import gaussian_activations  # noqa: E402
 from gsrast.optim import Adam          # noqa: E402
 
 
@@ -86,7 +87,10 @@ def build(a, dev):
                                           all_map=am)
 
     def step():
-        scl = torch.exp(scl_log); rot = torch.nn.functional.normalize(rot_raw); op = torch.sigmoid(op_raw)
+        if a.glue == "hip":              # get_scaling / get_rotation / get_opacity (vanilla_gaussian.py:250-269) as one kernel each way
+            scl, rot, op = gaussian_activations(scl_log, rot_raw, op_raw)
+        else:
+            scl = torch.exp(scl_log); rot = torch.nn.functional.normalize(rot_raw); op = torch.sigmoid(op_raw)
         img, radii, obs, oam, pd = render(rs1, t, xyz, scl, rot, op)
         _, _, _, _, pd2 = render(rs2, t2, xyz, scl, rot, op)
         if a.glue == "hip":
