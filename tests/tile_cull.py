@@ -7,7 +7,7 @@ n_contrib) are positions in the filtered list.  This module holds the filtered l
 
   reference_view(st, f)   asserts  (1) the HIP list is the oracle's list restricted to a subset `keep`, order preserved, tile by tile;
                                    (2) no dropped instance passes the reference's alpha gate on any pixel of its tile (oracle
-                                       ref_instance_max_alpha, float32 build -- and the float64 build when `truth` is given);
+                                       ref_instance_max_alpha: the float64 build when `truth` is given, else the float32 build);
                                    (3) tiles_touched == per-gaussian count of kept instances, ranges == prefix of the per-tile counts;
                           returns  the mask and n_contrib mapped back to positions in the oracle's list, so that the index parity
                                    checks compare like with like.
@@ -50,13 +50,14 @@ def reference_view(st, f, truth=None, P=None, variant=None):
     # ---- (2) nothing that contributes was dropped
     dropped = ~keep
     if dropped.any():
-        amax = f.instance_max_alpha()
-        bad = dropped & (amax >= 1.0 / 255.0)
-        assert not bad.any(), f"{int(bad.sum())} dropped instances pass the reference's alpha gate (float32 oracle), max alpha {amax[bad].max():.4g}"
-        if truth is not None:
+        if truth is not None:          # float64 evaluation of every (pixel, instance) pair of the dropped set's tiles
             a64 = truth.instance_max_alpha()
             bad = dropped & (a64 >= 1.0 / 255.0)
             assert not bad.any(), f"{int(bad.sum())} dropped instances pass the alpha gate in the float64 truth, max alpha {a64[bad].max():.4g}"
+        else:                          # the float32 oracle's own evaluation
+            amax = f.instance_max_alpha()
+            bad = dropped & (amax >= 1.0 / 255.0)
+            assert not bad.any(), f"{int(bad.sum())} dropped instances pass the reference's alpha gate (float32 oracle), max alpha {amax[bad].max():.4g}"
     stats = dict(R_reference=int(f.R), R_emitted=R, dropped_frac=float(dropped.mean()) if f.R else 0.0)
     if variant is not None and f.R:
         F = region_filter64(f, variant)
