@@ -264,6 +264,57 @@ __global__ void __launch_bounds__(1024) k_mv_finish(const float2* __restrict__ p
     }
 }
 
+// The loss values and the gradient scaling of the two multi-view losses without a chain of scalar framework kernels (round 4: the wrapper spent
+// ~14 tiny launches per iteration on lambda * mean, clamp(count), lambda / count and three image-sized multiplies):
+//   k_mv_values: out[0] = lambda_geo * stats[2], out[1] = lambda_ncc * stats[5]
+//   k_mv_scale : o_depth = g_depth * sg, o_near = g_near * sg, o_am = g_am * sn  with  sg = up_geo * lambda_geo / max(stats[1], 1),
+//                sn = up_ncc * lambda_ncc / max(stats[4], 1) (d mean / d x = (d sum / d x) / count; an empty mask leaves zero maps); up_* are the
+//                upstream gradients of the two loss values (device scalars; NULL = 1).  One launch, out of place (the saved maps survive a
+//                second backward).  Optional addends (the single-view normal loss's maps of the same pixels, times their own upstream scalar)
+//                let one autograd node hand back the SUM of all three PGSR geometry losses' gradients: no image-sized framework adds.
+__global__ void k_mv_values(const float* __restrict__ stats, float lg, float ln, float* __restrict__ out)
+{
+    out[0] = lg * stats[2]; out[1] = ln * stats[5];
+}
+__global__ void __launch_bounds__(256) k_mv_scale(size_t n_d, size_t n_n, size_t n_a, const float* __restrict__ g_d, const float* __restrict__ g_n,
+                                                  const float* __restrict__ g_a, const float* __restrict__ stats, float lg, float ln,
+                                                  const float* __restrict__ up_geo, const float* __restrict__ up_ncc,
+                                                  const float* __restrict__ add_d, const float* __restrict__ add_a, const float* __restrict__ up_add, int have_add,
+                                                  float* __restrict__ o_d, float* __restrict__ o_n, float* __restrict__ o_a)
+{
+    // a NULL up_* with its maps present means "upstream gradient 1"; the caller passes n = 0 for maps whose loss sent no gradient
+    const float sg = (up_geo ? up_geo[0] : 1.0f) * lg / fmaxf(stats[1], 1.0f);
+    const float sn = (up_ncc ? up_ncc[0] : 1.0f) * ln / fmaxf(stats[4], 1.0f);
+    const float sa = have_add ? (up_add ? up_add[0] : 1.0f) : 0.0f;
+    const size_t total = n_d + n_n + n_a, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        if (i < n_d) o_d[i] = (g_d ? g_d[i] * sg : 0.0f) + (add_d ? add_d[i] * sa : 0.0f);
+        else if (i < n_d + n_n) o_n[i - n_d] = g_n[i - n_d] * sg;
+        else { const size_t k = i - n_d - n_n; o_a[k] = (g_a ? g_a[k] * sn : 0.0f) + (add_a ? add_a[k] * sa : 0.0f); }
+    }
+}
+extern "C" int gsr_loss_plane_mv_values(const float* stats, float lambda_geo, float lambda_ncc, float* out2, void* stream)
+{
+    if (!stats || !out2) { gsr_set_error("loss_plane_mv_values: null pointer"); return 1; }
+    hipLaunchKernelGGL(k_mv_values, dim3(1), dim3(1), 0, (hipStream_t)stream, stats, lambda_geo, lambda_ncc, out2);
+    return gsr_check_launch("loss_plane_mv_values", (hipStream_t)stream, false);
+}
+extern "C" int gsr_loss_plane_mv_scale(size_t n_depth, size_t n_near, size_t n_am, const float* g_depth, const float* g_near, const float* g_am,
+                                       const float* stats, float lambda_geo, float lambda_ncc, const float* up_geo, const float* up_ncc,
+                                       const float* add_depth, const float* add_am, const float* up_add, int32_t have_add,
+                                       float* o_depth, float* o_near, float* o_am, void* stream)
+{
+    if (!stats || (n_depth && ((!g_depth && !add_depth) || !o_depth)) || (n_near && (!g_near || !o_near)) || (n_am && ((!g_am && !add_am) || !o_am))) {
+        gsr_set_error("loss_plane_mv_scale: null pointer"); return 1;
+    }
+    const size_t total = n_depth + n_near + n_am;
+    if (total == 0) return 0;
+    const unsigned blocks = (unsigned)((total + 1023) / 1024 < 8192 ? (total + 1023) / 1024 : 8192);
+    hipLaunchKernelGGL(k_mv_scale, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, n_depth, n_near, n_am, g_depth, g_near, g_am, stats, lambda_geo,
+                       lambda_ncc, up_geo, up_ncc, add_depth, add_am, up_add, have_add ? 1 : 0, o_depth, o_near, o_am);
+    return gsr_check_launch("loss_plane_mv_scale", (hipStream_t)stream, false);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Uniform sample WITHOUT replacement of at most `num` set entries of a byte mask, on the device and without a sort
 // (pgsr_scene.py:147-151 draws it with np.random.choice on the host).  Every entry gets a 24-bit hashed key from (seed, index); the `num`

@@ -68,7 +68,7 @@ EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward
            "gsr_tsdf_integrate", "gsr_tsdf_integrate_dense", "gsr_tsdf_sparse_integrate", "gsr_tsdf_sparse_merge", "gsr_loss_l1_linear", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
            "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward",
            "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_loss_scaling_prod", "gsr_octree_visible",
-           "gsr_loss_plane_mv_scratch_bytes", "gsr_loss_plane_mv_geo", "gsr_loss_plane_mv_ncc",
+           "gsr_loss_plane_mv_scratch_bytes", "gsr_loss_plane_mv_geo", "gsr_loss_plane_mv_ncc", "gsr_loss_plane_mv_values", "gsr_loss_plane_mv_scale",
            "gsr_plane_allmap", "gsr_plane_allmap_backward", "gsr_gauss_activations", "gsr_gauss_activations_backward", "gsr_sample_mask_scratch_bytes", "gsr_sample_mask", "gsr_densify_stats", "gsr_adam_step", "gsr_adam_step_multi", "gsr_adam_step_multi_dev"]
 PROF_LABELS = ["preprocess", "depth_order", "binning", "blend_fwd", "bwd_memset", "blend_bwd", "preprocess_bwd", "_"]
 
@@ -143,6 +143,10 @@ def lib():
     L.gsr_loss_plane_mv_geo.argtypes = [C.POINTER(MvCfg)] + [_vp] * 9 + [sz, _vp]
     L.gsr_loss_plane_mv_ncc.restype = C.c_int
     L.gsr_loss_plane_mv_ncc.argtypes = [C.POINTER(MvCfg), C.c_int32] + [_vp] * 12 + [sz, _vp]
+    L.gsr_loss_plane_mv_values.restype = C.c_int
+    L.gsr_loss_plane_mv_values.argtypes = [_vp, C.c_float, C.c_float, _vp, _vp]
+    L.gsr_loss_plane_mv_scale.restype = C.c_int
+    L.gsr_loss_plane_mv_scale.argtypes = [sz, sz, sz, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]
     L.gsr_sample_mask_scratch_bytes.restype = sz; L.gsr_sample_mask_scratch_bytes.argtypes = [C.c_int64]
     L.gsr_sample_mask.restype = C.c_int
     L.gsr_sample_mask.argtypes = [C.c_int64, _vp, C.c_int32, C.c_uint64, _vp, _vp, sz, _vp]

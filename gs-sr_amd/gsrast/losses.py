@@ -182,28 +182,34 @@ def surfel_geo_loss(allmap, ray_mat, normal_rot, depth_ratio=0.0, lambda_normal=
     return _SurfelGeo.apply(allmap, ray_mat, normal_rot, depth_ratio, lambda_normal, lambda_dist, bool(return_maps), bool(unit_upstream))
 
 
+def _plane_geo_fwd(plane_depth, out_all_map, weight, ray_mat, lambda_normal, want_map):
+    """gsr_loss_plane_geo: -> (out[3] = {mean weighted L1, -, lambda * mean}, dD, dA (5,H,W; channels 3, 4 zero), depth_normal map or None)."""
+    d = dev_f32(plane_depth, "plane_depth", allow_empty=False)
+    am = dev_f32(out_all_map, "out_all_map", allow_empty=False)
+    if am.dim() != 3 or am.shape[0] != 5 or d.numel() != am.shape[1] * am.shape[2]:
+        raise RuntimeError("out_all_map must be (5, H, W) and plane_depth (1, H, W) / (H, W)")
+    w = dev_f32(weight, "weight") if weight is not None else None
+    rm = dev_f32(ray_mat, "ray_mat", allow_empty=False)
+    _, H, W = am.shape
+    L = lib()
+    dev = am.device
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    dD = torch.empty_like(d)
+    dA = torch.empty_like(am)                       # the kernel writes every pixel of the three normal channels;
+    dA[3:].zero_()                                  # channels 3 (alpha, detached) and 4 (distance) get no gradient here
+    dn = torch.empty(3, H, W, dtype=torch.float32, device=dev) if want_map else None
+    scratch = torch.empty(max(L.gsr_loss_surfel_geo_scratch_bytes(H, W), 8), dtype=torch.uint8, device=dev)
+    alpha = am[3]
+    check(L.gsr_loss_plane_geo(H, W, ptr(d), ptr(alpha), ptr(am), ptr(w), ptr(rm), float(lambda_normal), ptr(out), ptr(dD), ptr(dA), ptr(dn),
+                               ptr(scratch), scratch.numel(), stream_ptr(dev)), "loss_plane_geo")
+    return out, dD, dA, dn
+
+
 class _PlaneGeo(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plane_depth, out_all_map, weight, ray_mat, lambda_normal, want_map, unit_upstream=False):
         ctx.unit = bool(unit_upstream)
-        d = dev_f32(plane_depth, "plane_depth", allow_empty=False)
-        am = dev_f32(out_all_map, "out_all_map", allow_empty=False)
-        if am.dim() != 3 or am.shape[0] != 5 or d.numel() != am.shape[1] * am.shape[2]:
-            raise RuntimeError("out_all_map must be (5, H, W) and plane_depth (1, H, W) / (H, W)")
-        w = dev_f32(weight, "weight") if weight is not None else None
-        rm = dev_f32(ray_mat, "ray_mat", allow_empty=False)
-        _, H, W = am.shape
-        L = lib()
-        dev = am.device
-        out = torch.empty(3, dtype=torch.float32, device=dev)
-        dD = torch.empty_like(d)
-        dA = torch.empty_like(am)                       # the kernel writes every pixel of the three normal channels;
-        dA[3:].zero_()                                  # channels 3 (alpha, detached) and 4 (distance) get no gradient here
-        dn = torch.empty(3, H, W, dtype=torch.float32, device=dev) if want_map else None
-        scratch = torch.empty(max(L.gsr_loss_surfel_geo_scratch_bytes(H, W), 8), dtype=torch.uint8, device=dev)
-        alpha = am[3]
-        check(L.gsr_loss_plane_geo(H, W, ptr(d), ptr(alpha), ptr(am), ptr(w), ptr(rm), float(lambda_normal), ptr(out), ptr(dD), ptr(dA), ptr(dn),
-                                   ptr(scratch), scratch.numel(), stream_ptr(dev)), "loss_plane_geo")
+        out, dD, dA, dn = _plane_geo_fwd(plane_depth, out_all_map, weight, ray_mat, lambda_normal, want_map)
         ctx.save_for_backward(dD, dA)
         extras = [out[:1].detach()] + ([dn] if want_map else [])
         ctx.mark_non_differentiable(*extras)
@@ -285,7 +291,7 @@ def sample_valid_pixels(d_mask, num_sample, generator=None, seed=None):
 class _PlaneMultiview(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plane_depth, near_plane_depth, normal, distance, gray, near_gray, cfg, lambda_geo, lambda_ncc, num_sample, indices, generator,
-                all_map=None):
+                all_map=None, single_view=None):
         import ctypes as C
         d = dev_f32(plane_depth, "plane_depth", allow_empty=False)
         nd = dev_f32(near_plane_depth, "near_plane_depth", allow_empty=False)
@@ -321,37 +327,63 @@ class _PlaneMultiview(torch.autograd.Function):
             gAM = f(5, H, W); gAM[3].zero_()
             gNm, gDs = gAM[0:3], gAM[4]
         else:
-            gAM = None
-            gNm, gDs = f(3, H, W), f(H, W)
+            gAM = f(4, H, W)                     # normal (3) and distance (1) gradient maps in one buffer: one scaling launch in backward
+            gNm, gDs = gAM[0:3], gAM[3]
         ncc = f(max(idx.numel(), 1))
         cmask = torch.empty(max(idx.numel(), 1), dtype=torch.uint8, device=dev)
         check(L.gsr_loss_plane_mv_ncc(C.byref(cfg), int(idx.numel()), ptr(idx), ptr(weight), ptr(nm), ptr(ds), ptr(g), ptr(ng), ptr(ncc), ptr(cmask),
                                       ptr(stats[3:]), ptr(gNm), ptr(gDs), ptr(scratch), scratch.numel(), stream_ptr(dev)), "loss_plane_mv_ncc")
-        geo = stats[2] * float(lambda_geo)
-        nccl = stats[5] * float(lambda_ncc)
-        # d mean / d x = (d sum / d x) / count; an empty mask leaves zero maps, so the clamp only avoids 0/0
-        sg = float(lambda_geo) / torch.clamp(stats[1], min=1.0)
-        sn = float(lambda_ncc) / torch.clamp(stats[4], min=1.0)
-        ctx.save_for_backward(gD, gN, gNm if gAM is None else gAM, gDs, sg, sn)
-        ctx.whole = gAM is not None
+        # loss values lambda * mean on the device, one launch (the means' 1 / count and the lambdas reach the gradient maps in backward, one launch too)
+        vals = f(2)
+        check(L.gsr_loss_plane_mv_values(ptr(stats), float(lambda_geo), float(lambda_ncc), ptr(vals), stream_ptr(dev)), "loss_plane_mv_values")
+        geo, nccl = vals[0], vals[1]
+        # single_view = (ray_mat, weight, lambda_normal): the single-view normal loss of the same render (plane_geo_loss) evaluated by THIS node, so that
+        # its gradients to plane_depth / out_all_map leave backward already summed with the multi-view ones (plane_losses below)
+        sv_val, svD, svA = None, None, None
+        if single_view is not None:
+            if am is None:
+                raise RuntimeError("plane_losses needs out_all_map")
+            out3, svD, svA, _ = _plane_geo_fwd(plane_depth, am, single_view[1], single_view[0], single_view[2], False)
+            sv_val = out3[2]
+        ctx.has_sv = svD is not None
+        ctx.save_for_backward(gD, gN, gAM, stats, *([svD, svA] if svD is not None else []))
+        ctx.lams = (float(lambda_geo), float(lambda_ncc))
+        ctx.whole = am is not None
         ctx.shapes = (plane_depth.shape, near_plane_depth.shape, normal.shape, distance.shape)
         aux = {"pixel_noise": noise.view(H, W), "d_mask": dmask.view(H, W).bool(), "weights": weight.view(H, W), "indices": idx,
                "ncc": ncc[: idx.numel()], "ncc_mask": cmask[: idx.numel()].bool(), "stats": stats}
         ctx.mark_non_differentiable(*[v for v in aux.values()])
         ctx.set_materialize_grads(False)     # seven auxiliary outputs (H*W masks, sample lists): no zero-filled gradients for them
+        if sv_val is not None:
+            return (geo, nccl, sv_val, *aux.values())
         return (geo, nccl, *aux.values())
 
     @staticmethod
-    def backward(ctx, g_geo, g_ncc, *_):
-        gD, gN, gNm, gDs, sg, sn = ctx.saved_tensors
+    def backward(ctx, g_geo, g_ncc, *rest):
+        sv = ctx.saved_tensors
+        gD, gN, gAM, stats = sv[:4]
+        svD, svA = (sv[4], sv[5]) if ctx.has_sv else (None, None)
+        g_sv = rest[0] if ctx.has_sv else None
         s0, s1, s2, s3 = ctx.shapes
-        a = None if g_geo is None else g_geo * sg          # a loss the caller did not use sends no gradient
-        b = None if g_ncc is None else g_ncc * sn
-        gd, gn = (None, None) if a is None else ((gD * a).view(s0), (gN * a).view(s1))
-        if ctx.whole:                              # gNm is the whole (5,H,W) gradient of out_all_map
-            return (gd, gn, None, None, None, None, None, None, None, None, None, None, None if b is None else gNm * b)
-        return (gd, gn, None if b is None else (gNm * b).view(s2), None if b is None else (gDs * b).view(s3), None, None, None, None, None, None, None,
-                None, None)
+        lg, ln = ctx.lams
+        L = lib()
+        dev = gD.device
+        up = lambda g: None if g is None else g.reshape(1).to(torch.float32)      # a view for the float32 scalars autograd sends
+        ug, un, us = up(g_geo), up(g_ncc), up(g_sv)   # a loss the caller did not use sends no gradient: its maps are not produced
+        add = us is not None
+        oD = torch.empty_like(gD) if (ug is not None or add) else None
+        oN = torch.empty_like(gN) if ug is not None else None
+        oA = torch.empty_like(gAM) if (un is not None or add) else None
+        check(L.gsr_loss_plane_mv_scale(gD.numel() if oD is not None else 0, gN.numel() if oN is not None else 0, gAM.numel() if oA is not None else 0,
+                                        ptr(gD) if ug is not None else None, ptr(gN), ptr(gAM) if un is not None else None, ptr(stats), lg, ln, ptr(ug), ptr(un),
+                                        ptr(svD) if add else None, ptr(svA) if add else None, ptr(us), 1 if add else 0,
+                                        ptr(oD), ptr(oN), ptr(oA), stream_ptr(dev)), "loss_plane_mv_scale")
+        gd = None if oD is None else oD.view(s0)
+        gn = None if oN is None else oN.view(s1)
+        if ctx.whole:                              # the whole (5,H,W) gradient of out_all_map
+            return (gd, gn, None, None, None, None, None, None, None, None, None, None, oA, None)
+        return (gd, gn, None if oA is None else oA[0:3].view(s2), None if oA is None else oA[3].view(s3), None, None, None, None, None, None, None,
+                None, None, None)
 
 
 _MV_AUX = ("pixel_noise", "d_mask", "weights", "indices", "ncc", "ncc_mask", "stats")
@@ -374,3 +406,14 @@ def plane_multiview_loss(plane_depth, near_plane_depth, rendered_normal, rendere
     if return_aux:
         return out[0], out[1], dict(zip(_MV_AUX, out[2:]))
     return out[0], out[1]
+
+
+def plane_losses(plane_depth, near_plane_depth, out_all_map, gray, near_gray, cfg, ray_mat, weight=None, lambda_normal=0.015, lambda_geo=0.03,
+                 lambda_ncc=0.15, num_sample=102400, indices=None, generator=None):
+    """The three PGSR geometry losses of one view after step 7000 -- plane_geo_loss (single-view normal, pgsr_scene.py:105-112) and the two of
+    plane_multiview_loss (:113-204) -- as ONE autograd node: -> (normal_loss, geo_loss, ncc_loss), the same values and the same total gradient as the
+    two separate calls.  plane_depth and out_all_map feed all three; evaluated separately, autograd sums their gradient maps with two image-sized add
+    launches per iteration (5 x H x W and H x W), here they leave backward already summed (gsr_loss_plane_mv_scale with addends)."""
+    out = _PlaneMultiview.apply(plane_depth, near_plane_depth, None, None, gray, near_gray, cfg, lambda_geo, lambda_ncc, int(num_sample), indices, generator,
+                                out_all_map, (ray_mat, weight, float(lambda_normal)))
+    return out[2], out[0], out[1]

@@ -378,6 +378,17 @@ int gsr_loss_plane_mv_geo(const gsr_mv_cfg* cfg, const float* plane_depth, const
 int gsr_loss_plane_mv_ncc(const gsr_mv_cfg* cfg, int32_t n_samples, const int32_t* idx, const float* weight, const float* normal,
                           const float* distance, const float* gray, const float* near_gray, float* ncc, uint8_t* mask, float* stats,
                           float* g_normal, float* g_distance, void* scratch, size_t scratch_bytes, void* stream);
+/* The two loss values and the scaled gradient maps from the six stats words of the two calls above (stats[0..2] geo, stats[3..5] ncc), on the device:
+ * out2 = {lambda_geo * stats[2], lambda_ncc * stats[5]};  o_depth / o_near = g_depth / g_near * up_geo * lambda_geo / max(stats[1], 1),
+ * o_am = g_am * up_ncc * lambda_ncc / max(stats[4], 1) (g_am: the n_am floats of the normal / distance gradient maps, contiguous); up_geo / up_ncc:
+ * DEVICE scalars (upstream gradients of the two loss values), NULL = 1.  have_add != 0: o_depth += add_depth * up_add, o_am += add_am * up_add (maps
+ * of another loss over the same pixels -- gsr_loss_plane_geo's -- and its upstream scalar, NULL = 1; either map may be NULL; g_depth / g_am may then
+ * be NULL as well = that loss sent no gradient).  Replaces the framework's scalar-op chain of pgsr_scene.py:141-143,197-199. */
+int gsr_loss_plane_mv_values(const float* stats, float lambda_geo, float lambda_ncc, float* out2, void* stream);
+int gsr_loss_plane_mv_scale(size_t n_depth, size_t n_near, size_t n_am, const float* g_depth, const float* g_near, const float* g_am,
+                            const float* stats, float lambda_geo, float lambda_ncc, const float* up_geo, const float* up_ncc,
+                            const float* add_depth, const float* add_am, const float* up_add, int32_t have_add,
+                            float* o_depth, float* o_near, float* o_am, void* stream);
 size_t gsr_dist2_scratch_bytes(int32_t P);
 int gsr_dist2(int32_t P, const float* points /*[P,3]*/, float* out /*[P]*/, void* scratch, size_t scratch_bytes,
               void* stream);

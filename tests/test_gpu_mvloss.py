@@ -186,3 +186,39 @@ def test_out_all_map_argument_gives_the_same_loss_and_gradients():
     for a, b in zip(res[0][2:], res[1][2:]):       # overlapping patches add their gradients with float atomics: the order differs from run to run
         assert (a - b).norm() <= 1e-5 * b.norm()
     assert res[1][4][3].abs().max() == 0 and res[1][4][0:3].abs().max() > 0
+
+
+@pytest.mark.parametrize("weights", [(1.0, 1.0, 1.0), (0.5, 2.0, 3.0), (1.0, None, 1.0), (None, 1.0, None), (None, None, 2.0)])
+def test_plane_losses_one_node_equals_the_separate_calls(weights):
+    """gsrast.losses.plane_losses (single-view normal loss + the two multi-view losses as ONE autograd node, their gradients to plane_depth and
+    out_all_map summed by gsr_loss_plane_mv_scale's addends) == plane_geo_loss + plane_multiview_loss evaluated separately: the three values and
+    the total gradients, for every combination of used / unused losses (an unused one sends no upstream gradient)."""
+    import mv_cases
+    from gsrast.losses import multiview_cfg, plane_multiview_loss, plane_geo_loss, plane_losses
+    c = mv_cases.plane_pair(W=96, H=64, seed=5, tex=2.0)
+    dev = "cuda:0"
+    t = lambda a: torch.tensor(a, device=dev)
+    cfg = multiview_cfg(mv_cases.cam_ns(c["view"]), mv_cases.cam_ns(c["near"]), c["W"], c["H"], near_size=(c["W"], c["H"]))
+    idx = torch.arange(0, c["W"] * c["H"], 3, dtype=torch.int32, device=dev)
+    g = torch.Generator().manual_seed(1)
+    wmap = torch.rand(c["H"], c["W"], generator=g).to(dev)
+    K = torch.tensor([[80.0, 0, c["W"] / 2], [0, 80.0, c["H"] / 2], [0, 0, 1]], device=dev)
+    rm = torch.inverse(K.double().t()).float()
+    res = []
+    for fused in (False, True):
+        pd = t(c["plane_depth"]).requires_grad_(True); pd2 = t(c["near_plane_depth"]).requires_grad_(True)
+        oam = torch.cat([t(c["rendered_normal"]), torch.full((1, c["H"], c["W"]), 0.9, device=dev), t(c["rendered_distance"])], dim=0).requires_grad_(True)
+        if fused:
+            nrm, geo, ncc = plane_losses(pd, pd2, oam, t(c["gray"]), t(c["near_gray"]), cfg, rm, wmap, 0.015, 0.03, 0.15, indices=idx)
+        else:
+            nrm = plane_geo_loss(pd, oam, rm, wmap, 0.015)[0]
+            geo, ncc = plane_multiview_loss(pd, pd2, None, None, t(c["gray"]), t(c["near_gray"]), cfg, 0.03, 0.15, indices=idx, out_all_map=oam)
+        total = sum(w * v for w, v in zip(weights, (nrm, geo, ncc)) if w is not None)
+        total.backward()
+        z = lambda x, like: torch.zeros_like(like) if x is None else x.clone()
+        res.append((nrm.item(), geo.item(), ncc.item(), z(pd.grad, pd), z(pd2.grad, pd2), z(oam.grad, oam)))
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert abs(a - b) <= 1e-6 * max(abs(a), 1e-12)
+    for a, b in zip(res[0][3:], res[1][3:]):       # float atomics in the multi-view kernels: the summation order differs from run to run
+        assert (a - b).norm() <= 1e-5 * a.norm() + 1e-12, ((a - b).norm().item(), a.norm().item())
+    assert (weights[0] is None and weights[2] is None) or res[1][5].abs().max() > 0

@@ -22,7 +22,7 @@ import diff_plane_rasterization as dpr   # noqa: E402
 import scaffold_filter as sf           # noqa: E402
 from bench_pipeline_pgsr import cam_of   # noqa: E402
 from gsrast import decode, octree      # noqa: E402
-from gsrast.losses import scaling_prod_mean, l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss  # noqa: E402
+from gsrast.losses import scaling_prod_mean, l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss, plane_losses  # noqa: E402
 from gsrast.plane_prep import plane_input_all_map  # noqa: E402
 from gsrast.optim import Adam, shadow_parameters          # noqa: E402
 
@@ -47,7 +47,7 @@ def build(a, dev, seed=0):
     feat = torch.randn(a.Na, 32, generator=g).to(dev).requires_grad_(True)
     offset = (0.5 * torch.randn(a.Na, k, 3, generator=g)).to(dev).requires_grad_(True)
     rot_anchor = torch.nn.functional.normalize(torch.randn(a.Na, 4, generator=g), dim=1).to(dev)
-    level = torch.randint(0, LEVELS, (a.Na, 1), generator=g).to(dev)
+    level = torch.randint(0, LEVELS, (a.Na, 1), generator=g).to(dev).to(torch.int32)      # int32 as the kernels read it (an int64 buffer costs a conversion launch per render)
     extra_level = torch.zeros(a.Na, device=dev)
     dist = (t["means3D"] - t["campos"]).norm(dim=1)
     standard_dist = float(dist.median()) * FORK ** 3.5         # median anchor predicts level 3.5: levels 0..3 or 0..4 of 0..5 pass the mask
@@ -91,6 +91,9 @@ def build(a, dev, seed=0):
         am = plane_input_all_map(xyz, rot, scl, tt["viewmatrix"], tt["campos"])
         # screen-space gradient carriers: the rasterizer only uses their .grad slot.  Static shapes: two persistent zero leaves per camera (no fill per
         # iteration); dynamic shapes: fresh ones, as the reference makes them (pgsr_scene.py: torch.zeros_like(means3D, requires_grad=True) + 0).
+        # Screen-space gradient carriers: the rasterizer only uses their .grad slot and never reads or writes their values, so two persistent zero
+        # buffers per camera serve every iteration -- static shapes: the leaves themselves; reference shapes (P changes every iteration): fresh leaves
+        # that VIEW the first P rows of a zero buffer grown on demand (the reference fills two (P,3) tensors per render, pgsr_scene.py:287-288).
         if static:
             key = (cam_id, xyz.shape[0])
             if key not in carriers:
@@ -98,7 +101,11 @@ def build(a, dev, seed=0):
             m2, m2a = carriers[key]
             m2.grad = None; m2a.grad = None
         else:
-            m2 = torch.zeros_like(xyz, requires_grad=True); m2a = torch.zeros_like(xyz, requires_grad=True)
+            buf = carriers.get(cam_id)
+            if buf is None or buf[0].shape[0] < xyz.shape[0]:
+                n = int(xyz.shape[0] * 1.25) + 1024
+                buf = carriers[cam_id] = (torch.zeros(n, 3, device=xyz.device), torch.zeros(n, 3, device=xyz.device))
+            m2 = buf[0][: xyz.shape[0]].detach().requires_grad_(True); m2a = buf[1][: xyz.shape[0]].detach().requires_grad_(True)
         img, radii, obs, oam, pd = dpr.GaussianRasterizer(rs)(means3D=xyz, means2D=m2, means2D_abs=m2a, opacities=opacity, colors_precomp=color,
                                                              scales=scl, rotations=rot, all_map=am)
         return img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vis["visible_mask"], count
@@ -112,9 +119,13 @@ def build(a, dev, seed=0):
             reg = 0.01 * (vol.sum() / count.to(torch.float32)[0] if static else vol.mean())
         else:                                             # scaling_loss (octree_pgsr_scene.py:23), value and gradient in one kernel
             reg = scaling_prod_mean(scl, 0.01, count=count if static else None, unit_upstream=True)
-        loss = l1_ssim(img, gt, 0.2, unit_upstream=True) + plane_geo_loss(pd, oam, rm1, weight, 0.015, unit_upstream=True)[0] + reg
-        geo, ncc = plane_multiview_loss(pd, pd2, None, None, gray1, gray2, mcfg, 0.03, 0.15, out_all_map=oam)
-        (loss + geo + ncc).backward()
+        nrm, geo, ncc = plane_losses(pd, pd2, oam, gray1, gray2, mcfg, rm1, weight, 0.015, 0.03, 0.15)      # one node: gradients to pd / oam leave it summed
+        # the total loss is the SUM of five terms; its backward sends 1 to each: five roots with unit gradients are the same backward pass without the
+        # four scalar add launches (and their autograd nodes) of `(a + b + c + d + e).backward()`
+        roots = [l1_ssim(img, gt, 0.2, unit_upstream=True), nrm, reg, geo, ncc]
+        if "ones" not in st:
+            st["ones"] = [torch.ones_like(r) for r in roots]
+        torch.autograd.backward(roots, st["ones"])
         decode.training_stats_(acc["opacity_accum"], acc["anchor_demon"], acc["offset_gradient_accum"], acc["offset_denom"], m2.grad, nop, radii > 0,
                                mask, vis_idx=vis_idx)
         opt.step(); opt.zero_grad(set_to_none=True)

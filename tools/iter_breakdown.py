@@ -39,7 +39,10 @@ def measure(step, dev, steps=20, warmup=8, top=14):
     kernels = sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]
     return {"wall_ms": round(wall * 1e3, 4), "kernel_ms": round(tot, 4), "wall_over_kernel": round(wall * 1e3 / max(tot, 1e-9), 3),
             "launches_per_iter": round(n, 1),
-            "top_kernels_ms": {k[:70]: round(v[0] / steps / 1e3, 4) for k, v in kernels}}
+            "top_kernels_ms": {k[:70]: round(v[0] / steps / 1e3, 4) for k, v in kernels},
+            # every framework (at::native / rocclr) kernel by its full functor name: [launches per iteration, ms per iteration]
+            "framework_kernels": {k[:260]: [round(v[1] / steps, 2), round(v[0] / steps / 1e3, 4)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])
+                                  if ("at::native" in k or "rocclr" in k or k.startswith("Memset") or k.startswith("Memcpy"))}}
 
 
 def main():
