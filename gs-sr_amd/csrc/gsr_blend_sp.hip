@@ -552,12 +552,16 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             // kernel needs 280+ VGPRs (one wave per SIMD); split, every step's temporaries die inside the step.
             const bool never = p.gx == 0x7fffffff;
 #define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, S, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc, okbits); sp_pin<TR::NPIN>(acc); if (never) asm volatile("s_nop 0");
+#ifndef SP_DIAG_NO_STEPS      // diagnostic build only (make BLEND_EXTRA=-DSP_DIAG_NO_STEPS): what the kernel costs without its pixel steps (results are then wrong)
             SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6) SP_STEP(7)
             SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11)
+#endif
             // SURFEL: Tu, Tv (dead since sp_surf_setup) come back for sp_surf_finish; requested here, four steps ahead of their use
             float4 t0 = z4, t1 = z4;
             if constexpr (V == GSR_SURFEL) { t0 = r[0]; t1 = r[1]; }
+#ifndef SP_DIAG_NO_STEPS
             SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
+#endif
 #undef SP_STEP
             if constexpr (V == GSR_EWA) {              // moments -> mean2D terms: 2 (A Sx + B Sy) W/2, 2 (C Sy + B Sx) H/2
                 const float sx = acc[4], sy = acc[5];

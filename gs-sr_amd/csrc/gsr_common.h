@@ -13,10 +13,21 @@
 #define GSR_REC_EWA 3
 #define GSR_REC_PLANE 4
 #define GSR_REC_SURFEL 5
-// backward accumulator stride (floats) per variant
+// backward accumulator: floats per gaussian row (STRIDE) and the part the kernels write (USED: EWA 9, PLANE 16, SURFEL 18 components, rounded up to
+// float4s).  The rows are packed.  Round 4 measured power-of-two strides (EWA 16, SURFEL 32 floats), with which the 16-lane float atomic of the blend
+// backward's flush stays inside one 64-byte line instead of straddling two for 50-84 % of the instructions (TCC_ATOMIC 1.85 M / 1.64 M line operations
+// for 1.25 M / 0.89 M instructions): blend_bwd 0.4007 vs 0.4014 ms (SURFEL), 0.2793 vs 0.2791 (EWA), iterations 1.5 % / 0.4 % SLOWER (the preprocess
+// backward reads and clears wider rows) -- the atomics are not what the kernel waits for.  -DGSR_ACC_SURFEL=32 -DGSR_ACC_EWA=16 rebuilds that variant.
+#ifndef GSR_ACC_EWA
 #define GSR_ACC_EWA 12
+#endif
 #define GSR_ACC_PLANE 16
+#ifndef GSR_ACC_SURFEL
 #define GSR_ACC_SURFEL 20
+#endif
+#define GSR_ACC_USED_EWA 12
+#define GSR_ACC_USED_PLANE 16
+#define GSR_ACC_USED_SURFEL 20
 
 // radix sort geometry
 #define GSR_SORT_THREADS 256

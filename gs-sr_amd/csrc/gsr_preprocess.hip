@@ -520,11 +520,11 @@ struct PreBwdParams {
     gsr_in_grads ig;
 };
 // zero one accumulator row (AS floats, 16-byte aligned: AS is a multiple of 4) after the thread has read it
-template <int AS4> __device__ __forceinline__ void clear_acc_row(float* acc_clear, int idx)
+template <int STRIDE, int USED> __device__ __forceinline__ void clear_acc_row(float* acc_clear, int idx)
 {
-    float4* r = reinterpret_cast<float4*>(acc_clear + (size_t)idx * (AS4 * 4));
+    float4* r = reinterpret_cast<float4*>(acc_clear + (size_t)idx * STRIDE);
 #pragma unroll
-    for (int k = 0; k < AS4; k++) r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < USED / 4; k++) r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // SH backward, 3DGS backward.cu:20-139.  Writes dL_dsh[idx] and returns the view-direction term of dL/dmean.
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_ewa(PreBwdParams p)
     for (int i = 0; i < 6; i++) ig.dL_dcov3D[6 * idx + i] = dcov[i];
     for (int i = 0; i < 3; i++) ig.dL_dscales[3 * idx + i] = dsc[i];
     for (int i = 0; i < 4; i++) ig.dL_drotations[4 * idx + i] = drot[i];
-    if (p.acc_clear) { if (p.variant == GSR_PLANE) clear_acc_row<GSR_ACC_PLANE / 4>(p.acc_clear, idx); else clear_acc_row<GSR_ACC_EWA / 4>(p.acc_clear, idx); }
+    if (p.acc_clear) { if (p.variant == GSR_PLANE) clear_acc_row<GSR_ACC_PLANE, GSR_ACC_USED_PLANE>(p.acc_clear, idx); else clear_acc_row<GSR_ACC_EWA, GSR_ACC_USED_EWA>(p.acc_clear, idx); }
     };
     if (idx < p.P) body();
     if constexpr (SH16) sh_rows_store(sh_row - lane * GSR_SH_ROW, p.ig.dL_dsh, g0, lane, (size_t)p.P * 48);      // the wave's 64 rows of dL_dsh
@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd_surfel(PreBwdParams p)
     for (int i = 0; i < 9; i++) ig.dL_dcov3D[9 * idx + i] = dTout[i];
     ig.dL_dscales[2 * idx] = dsc[0]; ig.dL_dscales[2 * idx + 1] = dsc[1];
     for (int i = 0; i < 4; i++) ig.dL_drotations[4 * idx + i] = drot[i];
-    if (p.acc_clear) clear_acc_row<GSR_ACC_SURFEL / 4>(p.acc_clear, idx);
+    if (p.acc_clear) clear_acc_row<GSR_ACC_SURFEL, GSR_ACC_USED_SURFEL>(p.acc_clear, idx);
     };
     if (idx < p.P) body();
     if constexpr (SH16) sh_rows_store(sh_row - lane * GSR_SH_ROW, p.ig.dL_dsh, g0, lane, (size_t)p.P * 48);
