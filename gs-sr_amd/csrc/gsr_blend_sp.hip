@@ -528,7 +528,11 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
         const int loads = (int)((max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])) + 15u) >> 4);
 
         // ------------------------------------------------------------ 16 splats per row x 16 pixel steps
+#ifdef SP_DIAG_NO_LOADS
+        for (int ld = 0; ld < 0; ld++) {
+#else
         for (int ld = 0; ld < loads; ld++) {
+#endif
             const int pos = Qmine - 1 - (16 * ld + j);      // lane 0 = deepest entry of this load
             const bool valid = pos >= 0;
             const uint32_t e = valid ? (uint32_t)myqueue[pos] : 0u;
@@ -609,8 +613,12 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
                 }
             }
             float* dst = p.acc + (size_t)s_ids[e] * AS;
+#ifndef SP_DIAG_NO_FLUSH
             if (v0 != 0.f) atomic_addf(dst + c, v0);
             if (NACC > 16 && v1 != 0.f) atomic_addf(dst + 16 + c, v1);
+#else
+            if (v0 == 123.456f && v1 == 1.f) dst[c] = v0;
+#endif
         }
         hi = cbase;
         want = SP_CH;
