@@ -81,7 +81,11 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         // LDS address (broadcast ds_read_b128), so the blend maths runs on VGPR operands only -- on gfx950 a VALU instruction with an SGPR
         // operand issues in ~4.2 cycles against ~2.7 for VGPR-only fma / mul / add (tools/microbench/valu_rate.hip), and the 6 v_mov the
         // two-SGPR fmas of the surfel intersection needed are gone.  Measured: surfel 0.234 -> 0.201 ms, EWA 0.233 -> 0.189, PLANE 0.199 -> 0.176.
+#ifndef FWD_DIAG_NO_STAGE
         if (hit) {
+#else
+        if (hit && p.W < 0) {
+#endif
             const float4* __restrict__ rr = p.rec + (size_t)id * ST;
             if constexpr (V == GSR_SURFEL) {
                 // SURFEL: the staging lane also does the per-(splat, sub-tile) part of the ray-splat intersection.  p = k x l (k = px Tw - Tu, l = py Tw - Tv,
@@ -105,6 +109,12 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 for (int k = 0; k < ST; k++) s_rec[(wave * ST + k) * 64 + lane] = rr[k];      // [wave][k][slot]: lane-contiguous 16-byte stores
             }
         }
+#ifdef FWD_DIAG_NO_PAIRS      // diagnostic build only: the kernel without its pair loop (results are then wrong)
+        m = 0;
+#endif
+#ifdef FWD_DIAG_NO_STAGE
+        m = 0; if (lane == 99) s_rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         while (m) {
             const int j = __ffsll((unsigned long long)m) - 1;
             m &= m - 1;

@@ -31,11 +31,8 @@
 #include "gsr_blend_common.h"
 #include <hip/hip_ext.h>
 
-// Waves per SIMD the register budget of each variant is sized for.  SURFEL (128 VGPRs, 12 spills outside the step loop): 3 waves 0.693 ms,
-// 4 waves 0.633, 5 waves (96 VGPRs, 37 spills) 0.759 -- measured on the first table version; EWA needs 94 VGPRs and runs 5 waves per SIMD:
-// 0.387 -> 0.355 ms; PLANE needs 113-115 and stays at 4.  Round 3, same-box rebuilds (tools/ab_wpe.sh): EWA at 6 waves (85 VGPRs; its 25 KB of LDS allow
-// exactly six workgroups per CU) 0.3244 vs 0.3337 ms at 5, 0.367 at 4; PLANE at 5 waves with a 96-row table (31.5 KB of LDS, 102 VGPRs): 0.296 vs 0.320 ms at 4 waves / 112 rows (tools/ab_wpe2.sh; EWA at 7 or 8 waves with
-// shorter tables spills and loses: 0.386 / 0.396 ms; SURFEL at 5 waves with an 80- or 64-row table: 0.615 / 0.714 ms against 0.472).
+// Waves per SIMD the register budget of each variant is sized for, and the rows of a wave's accumulation table (SP_CAP_*): the measurements behind
+// these values are in DESIGN.md Appendix A (21), (53).
 #ifndef SP_WPE_EWA
 #define SP_WPE_EWA 6
 #endif

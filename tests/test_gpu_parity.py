@@ -658,3 +658,34 @@ def test_prefiltered_set_and_a_point_behind_the_camera(variant):
         with pytest.raises(RuntimeError, match="prefiltered is set"):
             rz.forward(vid, bad, *args[1:], rs)
     rz.forward(vid, bad, *args[1:], rs._replace(prefiltered=False))   # without the promise the point is simply culled
+
+
+def test_stage2_refuses_a_geom_arena_without_its_depth_order_record():
+    """The depth order of a forward (global sort / per-tile sort: it fixes the layout of offsets / scan_tmp / sorted_idx) is recorded IN the geom arena by
+    the preprocess kernel; gsr_forward_stage2 reads it back and fails loudly on an arena that carries none (a side table keyed by the arena's
+    address could miss -- after 256 other arenas, or when the caller moved the bytes -- and stage 2 then silently binned on the static rule).  A MOVED copy
+    of the arena is accepted: the record travels with the bytes."""
+    import ctypes as C
+    from gsrast import rasterize as rz, Outputs, lib, ptr, stream_ptr, check
+    hr = _hiprun()
+    W, H, P = 160, 112, 2000
+    sc = scenes.make_scene("surfel", P, W, H, seed=9)
+    t = hr.to_dev(sc, "cuda")
+    rs = hr.settings("surfel", t)
+    vid = hr.VID["surfel"]
+    rz._R_HINT.pop((torch.cuda.current_device(), vid, W, H), None)
+    R, outs, radii, geom, binning, img = rz.forward(vid, t["means3D"], None, t["colors_precomp"], t["opacities"], t["scales"], t["rotations"], None, None, rs)
+    L = lib()
+    cfg, inp, keep, _, _ = rz._prepare(vid, t["means3D"], None, t["colors_precomp"], t["opacities"], t["scales"], t["rotations"], None, None, rs)
+    color2, others2 = torch.empty_like(outs["color"]), torch.empty_like(outs["others"])
+    o = Outputs(ptr(color2), ptr(others2), None, None, None)
+    bin2 = torch.empty_like(binning)
+    moved = geom.clone()                                   # the arena's bytes at another address: stage 2 must find the record in them
+    check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(moved), moved.numel(), ptr(bin2), bin2.numel(), ptr(img), img.numel(), R, C.byref(o),
+                               stream_ptr(geom.device)), "forward")
+    torch.cuda.synchronize()
+    assert torch.equal(color2, outs["color"]) and torch.equal(others2, outs["others"])
+    blank = torch.zeros_like(geom)                         # never seen by a preprocess kernel
+    with pytest.raises(RuntimeError, match="depth-order record"):
+        check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(blank), blank.numel(), ptr(bin2), bin2.numel(), ptr(img), img.numel(), R, C.byref(o),
+                                   stream_ptr(geom.device)), "forward")
