@@ -194,3 +194,41 @@ def test_scaffold_iteration_replayed_from_a_graph_tracks_the_eager_one():
         assert float(e_st["optimizers"][0].state[a]["step"]) == float(g_st["optimizers"][0].state[b]["step"]) == n_warm + n_run
         d = (a.detach() - b.detach()).norm().item(); n = a.detach().norm().item()
         assert d <= 2e-3 * n + 1e-6, (tuple(a.shape), d, n)
+
+
+def test_forward_async_reports_a_prefiltered_violation_and_profile_enable_values():
+    """(1) the sync-free forward used to ignore `prefiltered=True` violations that the synchronous forwards fail on (the reference traps the
+    device, auxiliary.h:156-160); it now sets a third sticky status word that async_status() raises on.  (2) gsr_profile_enable: any non-zero value
+    without stage bits (2, -1 & 0xFF) keeps its old meaning "every stage" instead of silently switching the profiler off."""
+    import hiprun as hr
+    import gsrast
+    from gsrast import rasterize as rz
+    W, H, P = 160, 112, 1500
+    sc = scenes.make_scene("surfel", P, W, H, seed=5)
+    t = hr.to_dev(sc, "cuda")
+    vid = hr.VID["surfel"]
+    rs = hr.settings("surfel", t)._replace(prefiltered=True)
+    args = lambda m: (m, None, t["colors_precomp"], t["opacities"], t["scales"], t["rotations"], None, None)
+    rz.async_status_reset()
+    with rz.static_capacity(200000):
+        rz.forward(vid, *args(t["means3D"]), rs)
+    assert rz.async_status(reset=True)[0][1] is False                 # the scene keeps the promise: nothing raised
+    bad = t["means3D"].clone()
+    V = t["viewmatrix"]
+    bad[7] = (torch.tensor([0.0, 0.0, -1.0], device=bad.device) - V[3, :3]) @ torch.linalg.inv(V[:3, :3])      # one gaussian behind the camera
+    with rz.static_capacity(200000):
+        rz.forward(vid, *args(bad), rs)
+    with pytest.raises(RuntimeError, match="prefiltered is set"):
+        rz.async_status(reset=True)
+    with rz.static_capacity(200000):
+        rz.forward(vid, *args(bad), rs._replace(prefiltered=False))   # without the promise the point is simply culled
+    rz.async_status(reset=True)
+    # profiler enable values
+    L = gsrast.lib()
+    for val in (2, 255, 1):
+        L.gsr_profile_enable(val)
+        rz.forward(vid, *args(t["means3D"]), rs._replace(prefiltered=False))
+        torch.cuda.synchronize()
+        rec = gsrast.profile_read()
+        assert rec["preprocess"][1] >= 1 and rec["blend_fwd"][1] >= 1, (val, rec)
+    L.gsr_profile_enable(0)
