@@ -17,7 +17,7 @@ struct BlendParams {
     // the kernel's prologue sorts it by (depth_key, id) in place (gsr_tile_sort.h); nullptr: the list is already in its final order
     const uint32_t* depth_key;
     uint32_t* list_rw;               // == point_list
-    int sort_buckets;                // 1 (default): rank inside depth buckets (gsr_tile_sort.h tds_bucket_rank_wg); 0 (GSR_TILE_RANK=plain): all-pairs count / bitonic
+    int sort_buckets;                // 1: rank inside depth buckets (gsr_tile_sort.h tds_bucket_rank_wg); 0: all-pairs count / bitonic
     uint32_t* tile_keys; uint32_t* scratch_keys; uint32_t* scratch_ids;      // the long-list fallback's scratch (free ping-pong half of the binning arena)
     const float4* cull;
     const float4* rec;

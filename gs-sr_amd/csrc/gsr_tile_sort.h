@@ -234,7 +234,7 @@ __device__ __forceinline__ void tds_sort_tile_wg(void* lds, uint32_t* list, uint
     {
         // rank by counting inside depth buckets, up to 1024 entries (2 words per entry + 264 of the lent LDS; four entries per thread -- eight, for
         // 2048 entries, cost k_blend_fwd 71 VGPRs and its eighth wave per SIMD);
-        // buckets == false (GSR_TILE_RANK=plain): the all-pairs count up to 512 entries and the bitonic network above, as before
+        // buckets == false: the all-pairs count up to 512 entries and the bitonic network above
         constexpr uint32_t BCAP = ((LDS_BYTES / 4 - 264) / 2 >= 1024) ? 1024u : 512u;
         // Lists up to 256 entries keep the all-pairs count: it has three barriers against seven, and at that length the prologue is its chain of
         // dependent loads and barriers, not its compares (measured: blend forward 0.2307 vs 0.2314 ms at mean 169, 0.1018 vs 0.0979 at mean 56 with
