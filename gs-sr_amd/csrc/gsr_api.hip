@@ -165,7 +165,9 @@ BinView gsr_carve_bin(int variant, uint32_t R, int W, int H, void* base)
     {
         const size_t T = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * ((H + GSR_TILE - 1) / GSR_TILE);
         b.qmask = take<unsigned long long>(p, ((n >> 6) + T + 2) * 4);
+        b.tile_tab = take<uint32_t>(p, gsr_tile_bucket_words((uint32_t)n, T) + (T <= (size_t)GSR_TB_TILES_MAX ? (size_t)GSR_TB_ROWS_MAX * GSR_TB_GROUPS_MAX : (size_t)2));
     }
+    b.cap = R;
     b.bytes = (size_t)(p - reinterpret_cast<char*>(base));
     return b;
 }
@@ -574,7 +576,15 @@ extern "C" int gsr_backward(const gsr_cfg* cfg, const gsr_inputs* in, const int3
 __global__ void k_debug_ranges_view(uint2* r, int T)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T && r[i].x > r[i].y) r[i] = make_uint2(0u, 0u);
+    if (i < T && r[i].x >= r[i].y) r[i] = make_uint2(0u, 0u);
+}
+// the tile id of every instance, rebuilt from the ranges: BinView::tile_keys itself is only written by the two-pass radix path (gsr_binning.hip)
+__global__ void __launch_bounds__(256) k_debug_tile_keys(const uint2* __restrict__ ranges, int T, uint32_t R, uint32_t* __restrict__ dst)
+{
+    const int t = blockIdx.x;
+    if (t >= T) return;
+    const uint2 r = ranges[t];
+    for (uint32_t e = r.x + threadIdx.x; e < r.y && e < R; e += 256u) dst[e] = (uint32_t)t;
 }
 
 extern "C" int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geom, const void* binning, size_t binning_bytes,
@@ -588,15 +598,19 @@ extern "C" int gsr_debug_read(const gsr_cfg* cfg, int32_t field, const void* geo
     switch (field) {
     case GSR_DBG_TILES_TOUCHED: { GeomView g = gsr_carve_geom(cfg->variant, cfg->P, const_cast<void*>(geom)); src = g.tiles_touched; bytes = (size_t)cfg->P * 4; break; }
     case GSR_DBG_POINT_LIST: { BinView b = gsr_carve_bin(cfg->variant, bcap, cfg->W, cfg->H, const_cast<void*>(binning)); src = b.point_list; bytes = (size_t)num_rendered * 4; break; }
-    case GSR_DBG_TILE_KEYS: { BinView b = gsr_carve_bin(cfg->variant, bcap, cfg->W, cfg->H, const_cast<void*>(binning)); src = b.tile_keys; bytes = (size_t)num_rendered * 4; break; }
+    case GSR_DBG_TILE_KEYS: {
+        ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img));
+        if (num_rendered) hipLaunchKernelGGL(k_debug_tile_keys, dim3(gx * gy), dim3(256), 0, s, im.ranges, gx * gy, num_rendered, (uint32_t*)dst);
+        return gsr_check_launch("debug tile keys", s, cfg->debug);
+    }
     case GSR_DBG_RANGES: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.ranges; bytes = (size_t)gx * gy * 8; break; }
     case GSR_DBG_FINAL_T: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.final_T; bytes = N * 4 * (cfg->variant == GSR_SURFEL ? 3 : 1); break; }
     case GSR_DBG_N_CONTRIB: { ImgView im = gsr_carve_img(cfg->variant, cfg->W, cfg->H, const_cast<void*>(img)); src = im.n_contrib; bytes = N * 4 * (cfg->variant == GSR_SURFEL ? 2 : 1); break; }
     default: gsr_set_error("unknown debug field %d", field); return 1;
     }
     if (bytes) GSR_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s), "debug copy");
-    // a tile without instances is held as (0xFFFFFFFF, 0) (gsr_binning.hip: range candidates are merged with atomicMin / atomicMax); the reference's
-    // view of it is (0, 0) (cudaMemset, rasterizer_impl.cu:310)
+    // a tile without instances is held as (0xFFFFFFFF, 0) (two-pass radix path of gsr_binning.hip) or as (start, start) (one-pass bucket sort); the
+    // reference's view of it is (0, 0) (cudaMemset, rasterizer_impl.cu:310)
     if (field == GSR_DBG_RANGES && bytes) hipLaunchKernelGGL(k_debug_ranges_view, dim3((gx * gy + 255) / 256), dim3(256), 0, s, (uint2*)dst, gx * gy);
     return 0;
 }

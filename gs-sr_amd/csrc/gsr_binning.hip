@@ -523,6 +523,131 @@ __global__ void __launch_bounds__(256) k_tile_ranges(uint32_t R, const uint32_t*
     if (i == R - 1) ranges[cur].y = R;
 }
 
+// ------------------------------------------------------------------------------------------------ one-pass bucket sort on the tile id
+// With the per-tile depth order the instances only have to be GROUPED by tile -- the sort by (depth, id) that follows (gsr_tile_sort.h) takes a
+// tile's list in any order -- so the two stable 8-bit radix passes and k_tile_ranges (45 us at the headline size, each kernel near its launch
+// floor) are replaced by one counting sort over all tile ids, three kernels:
+//   k_tb_hist     per chunk of 4096..16384 instances a histogram over the T tiles in LDS (16-bit counters, two tiles per word: a chunk holds
+//                 < 65536 instances) -> one row of the table of per-(chunk, tile) counts; and, per GROUP of 64 tiles, the chunk's instances in the
+//                 groups in front of it (a second, small table; atomics on a total per group were tried first: 109 workgroups adding to the same
+//                 128 words took 20 us, ~0.2 us per same-address atomic);
+//   k_tb_columns  workgroup = one group of 64 tiles: first slot of the group = that column of the small table summed over the chunks, first slot
+//                 of a tile = +
+//                 the wave scan of the group's column totals (written out as the tiles' ranges: no k_tile_ranges); every cell of the table becomes
+//                 the ABSOLUTE first slot of its (chunk, tile) cell;
+//   k_tb_scatter  every instance goes to its cell's first slot + its rank inside the cell, taken from the same LDS counters as in k_tb_hist.
+// No global atomic per instance (two of them per instance cost more than the radix sort they would replace: DESIGN Appendix A (69)).
+// TH threads take a chunk of 16 TH instances, 16 per thread.  Dynamic LDS: Tp / 2 words rounded up to a multiple of 32.
+template <int TH>
+__global__ void __launch_bounds__(TH) k_tb_hist(const uint32_t* __restrict__ keys, uint32_t R, const uint32_t* __restrict__ n_dev, uint32_t Tp,
+                                                uint32_t* __restrict__ tab, uint32_t* __restrict__ group_prefix)
+{
+    extern __shared__ uint32_t tb_lds[];
+    __shared__ uint32_t gs[GSR_TB_GROUPS_MAX];
+    uint32_t* h = tb_lds;
+    if (n_dev) R = min(R, *n_dev);
+    const uint32_t TB = Tp >> 1, TBp = (TB + 31u) & ~31u;
+    const uint32_t base = blockIdx.x * (16u * TH) + threadIdx.x;
+    uint32_t k[16];
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; j++) k[j] = (base + j * TH < R) ? keys[base + j * TH] : 0xFFFFFFFFu;      // all loads in flight
+    for (uint32_t w = threadIdx.x; w < TBp; w += TH) h[w] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; j++)
+        if (k[j] != 0xFFFFFFFFu) atomicAdd(&h[k[j] >> 1], (k[j] & 1u) ? 65536u : 1u);
+    __syncthreads();
+    uint2* row = reinterpret_cast<uint2*>(tab + (size_t)blockIdx.x * Tp);
+    for (uint32_t w = threadIdx.x; w < TB; w += TH) { const uint32_t v = h[w]; row[w] = make_uint2(v & 0xFFFFu, v >> 16); }
+    // group sums: a group of 64 tiles = 32 LDS words; a wave takes two groups per pass (lanes 0-31 / 32-63: consecutive words, no bank conflict)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ngroups = TBp >> 5;
+    for (uint32_t g0 = 2u * wave; g0 < ngroups; g0 += 2u * (TH / 64)) {
+        const uint32_t g = g0 + (lane >> 5);
+        uint32_t v = 0u;
+        if (g < ngroups) { const uint32_t x = h[32u * g + (lane & 31u)]; v = (x & 0xFFFFu) + (x >> 16); }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        if ((lane & 31u) == 0u && g < ngroups) gs[g] = v;
+    }
+    __syncthreads();
+    if (wave == 0u) {                                    // exclusive prefix over the (at most 256) groups: four per lane
+        uint32_t c[4], sum = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { c[q] = (4u * lane + q < ngroups) ? gs[4u * lane + q] : 0u; sum += c[q]; }
+        uint32_t run = wave_incl_scan(sum) - sum;
+        uint32_t* out = group_prefix + (size_t)blockIdx.x * GSR_TB_GROUPS_MAX;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { if (4u * lane + q < ngroups) out[4u * lane + q] = run; run += c[q]; }
+    }
+}
+// Workgroup = one group of 64 tiles x 4 row segments (wave = segment, lane = tile: every load is a coalesced 256-byte piece of a row); the segments'
+// sums meet in LDS.  In: the per-(chunk, tile) counts and the chunks' prefixes over the groups.  Out: every cell = the absolute first slot of its (chunk, tile) cell;
+// ranges[t] = the tile's slots.
+__global__ void __launch_bounds__(256) k_tb_columns(uint32_t* __restrict__ tab, uint32_t rows, uint32_t Tp, uint32_t T, const uint32_t* __restrict__ group_prefix,
+                                                    uint2* __restrict__ ranges)
+{
+    __shared__ uint32_t seg[4][64];
+    __shared__ uint32_t s_part[4];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * 64u + lane;
+    const uint32_t per = (rows + 3u) >> 2, b0 = min(rows, w * per), b1 = min(rows, b0 + per);
+    constexpr int MAXSEG = (GSR_TB_ROWS_MAX + 3) / 4;          // 64 rows per segment at most
+    uint32_t c[MAXSEG];
+    uint32_t sum = 0u;
+    if (t < T) {
+#pragma unroll
+        for (int q = 0; q < MAXSEG; q++) { c[q] = (b0 + q < b1) ? tab[(size_t)(b0 + q) * Tp + t] : 0u; }
+#pragma unroll
+        for (int q = 0; q < MAXSEG; q++) sum += c[q];
+    }
+    // first slot of the group: over the chunks (at most GSR_TB_ROWS_MAX = 256, one per thread), the chunk's instances in the groups in front of this one
+    uint32_t part = (threadIdx.x < rows) ? group_prefix[(size_t)threadIdx.x * GSR_TB_GROUPS_MAX + blockIdx.x] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+    seg[w][lane] = sum;
+    if (lane == 0u) s_part[w] = part;
+    __syncthreads();
+    const uint32_t group_base = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    const uint32_t total = (seg[0][lane] + seg[1][lane]) + (seg[2][lane] + seg[3][lane]);      // the tile's instances (0 for lanes past T)
+    const uint32_t first = group_base + wave_incl_scan(total) - total;
+    if (t >= T) return;
+    if (w == 0u) ranges[t] = make_uint2(first, first + total);
+    uint32_t run = first;
+    for (uint32_t q = 0; q < w; q++) run += seg[q][lane];
+#pragma unroll
+    for (int q = 0; q < MAXSEG; q++)
+        if (b0 + q < b1) { tab[(size_t)(b0 + q) * Tp + t] = run; run += c[q]; }
+}
+// Dynamic LDS: Tp / 2 words.
+template <int TH>
+__global__ void __launch_bounds__(TH) k_tb_scatter(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t R,
+                                                   const uint32_t* __restrict__ n_dev, uint32_t Tp, const uint32_t* __restrict__ tab,
+                                                   uint32_t* __restrict__ point_list)
+{
+    extern __shared__ uint32_t tb_lds[];
+    uint32_t* h = tb_lds;
+    if (n_dev) R = min(R, *n_dev);
+    const uint32_t TB = Tp >> 1;
+    const uint32_t base = blockIdx.x * (16u * TH) + threadIdx.x;
+    const uint32_t* row = tab + (size_t)blockIdx.x * Tp;
+    uint32_t k[16], v[16], cell[16];
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; j++) {
+        const bool in = base + j * TH < R;
+        k[j] = in ? keys[base + j * TH] : 0xFFFFFFFFu; v[j] = in ? vals[base + j * TH] : 0u;
+    }
+    for (uint32_t w = threadIdx.x; w < TB; w += TH) h[w] = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; j++) cell[j] = (k[j] != 0xFFFFFFFFu) ? row[k[j]] : 0u;          // gathers in flight
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; j++)
+        if (k[j] != 0xFFFFFFFFu) {
+            const uint32_t old = atomicAdd(&h[k[j] >> 1], (k[j] & 1u) ? 65536u : 1u);
+            point_list[cell[j] + ((k[j] & 1u) ? (old >> 16) : (old & 0xFFFFu))] = v[j];
+        }
+}
+
 // Launch order of the blend kernels: tiles by DESCENDING list length (eight power-of-two classes, raster order inside a class so that
 // neighbouring tiles -- which share most of their splats -- still run close together).  The blend kernels run one workgroup per tile and a
 // tile's time is proportional to its list; in raster order the launch ends on whichever long tiles happen to come late, with this order the
@@ -638,7 +763,7 @@ __device__ __forceinline__ void tds_rank_sort(unsigned long long* sl64, uint32_t
 }
 __global__ void __launch_bounds__(256) k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t T, uint32_t cap, const uint32_t* __restrict__ depth_key,
                                                          uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
-                                                         uint32_t* __restrict__ scratch_keys, uint32_t* __restrict__ scratch_ids)
+                                                         uint32_t* __restrict__ scratch_keys, uint32_t* __restrict__ scratch_ids, int any_order)
 {
     __shared__ unsigned long long s_all[TDS_WG_CAP];        // four wave slices of TDS_WAVE_CAP words, or one block-level buffer
     __shared__ uint32_t s_hist[256], s_cnt[4 * 256], s_lds[17];
@@ -709,7 +834,7 @@ __global__ void __launch_bounds__(256) k_tile_depth_sort(const uint2* __restrict
             for (uint32_t e = threadIdx.x; e < nn; e += 256u) scratch_keys[rr.x + e] = depth_key[point_list[rr.x + e]];
             __threadfence_block();
             __syncthreads();
-            tds_global_radix(point_list + rr.x, scratch_keys + rr.x, scratch_ids + rr.x, tile_keys + rr.x, nn, s_hist, s_cnt, s_lds);
+            tds_global_radix(point_list + rr.x, scratch_keys + rr.x, scratch_ids + rr.x, tile_keys + rr.x, nn, s_hist, s_cnt, s_lds, any_order != 0);
             for (uint32_t e = threadIdx.x; e < nn; e += 256u) tile_keys[rr.x + e] = t4;
             __syncthreads();
         }
@@ -722,6 +847,18 @@ bool gsr_tile_cull_enabled()
     static int on = -1;
     if (on < 0) { const char* e = getenv("GSR_TILE_CULL"); on = e ? (atoi(e) != 0) : 1; }
     return on != 0;
+}
+
+// GSR_TILE_BUCKET=0: the two-pass radix sort on the tile id even where the one-pass bucket sort applies (A/B, and the test that both leave the same
+// bytes behind the per-tile depth sort).
+uint32_t gsr_tile_bucket_chunk(bool global_order, int T, uint32_t cap)
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("GSR_TILE_BUCKET"); on = e ? (atoi(e) != 0) : 1; }
+    if (!on || global_order || T > GSR_TB_TILES_MAX) return 0u;
+    for (uint32_t chunk = 4096u; chunk <= 16384u; chunk <<= 1)
+        if (gsr_div_up(cap > 0u ? cap : 1u, chunk) <= GSR_TB_ROWS_MAX) return chunk;
+    return 0u;
 }
 
 // GSR_TILE_SORT=fused (default): k_blend_fwd orders its tile's list in its prologue (gsr_tile_sort.h); =kernel: the separate k_tile_depth_sort launch.
@@ -764,20 +901,40 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     if (!big_from0) { const char* e = getenv("GSR_SORT_BIG_FROM"); big_from0 = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : 1700000u; }
     // R is the CAPACITY of the arena when the count is read on the device (speculative / sync-free forwards: 1.25 x the last count + 16384)
     const uint32_t big_from = n_dev ? big_from0 + big_from0 / 4 : big_from0;
+    const uint32_t chunk = gsr_tile_bucket_chunk(global_order, T, b.cap);         // decided on the arena's capacity: the blend forward decides the same way
+    const bool bucket = chunk != 0u;
+    if (bucket) { k0 = b.keys_b; v0 = b.vals_b; }                               // emission order -> (keys_b, vals_b); BinView::tile_keys is not written
     {
         const dim3 dg(gsr_div_up((uint32_t)max(cfg->P, T), 256)), db(256);
         const uint32_t* sidx = global_order ? (const uint32_t*)g.sorted_idx : (const uint32_t*)nullptr;
-        const uint32_t zn = gsr_sort_group_words(R, R >= big_from, 256);
+        const uint32_t zn = bucket ? 0u : gsr_sort_group_words(R, R >= big_from, 256);
+        uint32_t* zp = b.hist;                           // first group histogram of the radix sort
         // per-tile order: 256-gaussian blocks, RAW block sums (every workgroup adds up the ones in front of its own, the last one publishes the
         // total); global order: GSR_SCAN_BLOCK-gaussian blocks, block sums already scanned by k_scan_small
         const uint32_t sblk = global_order ? (uint32_t)GSR_SCAN_BLOCK : 256u;
         const uint32_t snb = global_order ? 0u : gsr_div_up((uint32_t)cfg->P, 256u);
 #define GSR_DUP(CV) hipLaunchKernelGGL(k_duplicate<CV>, dg, db, 0, s, (uint32_t)cfg->P, sidx, g.offsets, g.scan_tmp, g.tiles_touched, g.rect, g.cull, gx, k0, v0, R, \
-                                       im.ranges, (uint32_t)T, b.hist, zn, im.tile_order + T, sblk, snb, g.counters, host_word_dev)
+                                       im.ranges, (uint32_t)T, zp, zn, im.tile_order + T, sblk, snb, g.counters, host_word_dev)
         if (!gsr_tile_cull_enabled()) GSR_DUP(-1);
         else if (cfg->variant == GSR_SURFEL) GSR_DUP(GSR_SURFEL);
         else GSR_DUP(GSR_EWA);
 #undef GSR_DUP
+    }
+    if (bucket) {
+        const uint32_t rows = gsr_div_up(R, chunk), Tp = ((uint32_t)T + 1u) & ~1u;
+        const size_t lds_h = (size_t)(((Tp >> 1) + 31u) & ~31u) * 4u;
+        uint32_t* group_prefix = b.tile_tab + gsr_tile_bucket_words(b.cap, (size_t)T);     // [rows][GSR_TB_GROUPS_MAX]
+#define GSR_TB(TH) do { \
+        hipLaunchKernelGGL((k_tb_hist<TH>), dim3(rows), dim3(TH), lds_h, s, k0, R, n_dev, Tp, b.tile_tab, group_prefix); \
+        hipLaunchKernelGGL(k_tb_columns, dim3(gsr_div_up((uint32_t)T, 64u)), dim3(256), 0, s, b.tile_tab, rows, Tp, (uint32_t)T, group_prefix, im.ranges); \
+        hipLaunchKernelGGL((k_tb_scatter<TH>), dim3(rows), dim3(TH), lds_h, s, k0, v0, R, n_dev, Tp, b.tile_tab, b.point_list); } while (0)
+        if (chunk == 4096u) GSR_TB(256); else if (chunk == 8192u) GSR_TB(512); else GSR_TB(1024);
+#undef GSR_TB
+        if (!gsr_tile_sort_is_fused())
+            hipLaunchKernelGGL(k_tile_depth_sort, dim3(gsr_div_up((uint32_t)T, 4u)), dim3(256), 0, s, im.ranges, (uint32_t)T, R, g.depth_key, b.point_list, b.tile_keys,
+                               b.keys_b, b.vals_b, 1);
+        if (gsr_tile_order_wanted()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
+        return gsr_check_launch("binning", s, cfg->debug);
     }
     bool in_b = false;
     // (tile ranges written by the last scatter pass instead of k_tile_ranges were measured in round 3 and lost: binning 0.0847 vs 0.0748 ms, DESIGN Appendix A (42))
@@ -785,7 +942,7 @@ int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, ui
     hipLaunchKernelGGL(k_tile_ranges, dim3(gsr_div_up(R, 256)), dim3(256), 0, s, R, n_dev, b.tile_keys, im.ranges);
     if (!global_order && !gsr_tile_sort_is_fused())
         hipLaunchKernelGGL(k_tile_depth_sort, dim3(gsr_div_up((uint32_t)T, 4u)), dim3(256), 0, s, im.ranges, (uint32_t)T, R, g.depth_key, b.point_list, b.tile_keys,
-                           b.keys_b, b.vals_b);
+                           b.keys_b, b.vals_b, 0);
     if (gsr_tile_order_wanted()) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.ranges, (uint32_t)T, im.tile_order);
     return gsr_check_launch("binning", s, cfg->debug);
 }

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         // per-tile depth order, fused: the four waves put the tile's list in (depth, id) order before any of them blends (the only barriers of
         // the kernel; s_rec is free until the first batch is staged).  The backward reads the same list afterwards.
         TdsScratch sc; sc.tile_keys = p.tile_keys; sc.keys = p.scratch_keys; sc.ids = p.scratch_ids;
-        tds_sort_tile_wg<(int)sizeof(s_rec)>(s_rec, p.list_rw + range.x, range.y > range.x ? range.y - range.x : 0u, range.x, (uint32_t)tile, p.depth_key, sc, p.sort_buckets != 0);
+        tds_sort_tile_wg<(int)sizeof(s_rec)>(s_rec, p.list_rw + range.x, range.y > range.x ? range.y - range.x : 0u, range.x, (uint32_t)tile, p.depth_key, sc, p.sort_buckets != 0, p.list_any_order != 0);
     }
     if (p.long_word && threadIdx.x == 0 && range.y > range.x && range.y - range.x > p.long_len) *p.long_word = range.y - range.x;      // feedback for the launch order
     if (ox >= p.W || oy >= p.H) return;                 // wave-uniform: this sub-tile is outside the image
@@ -465,7 +465,7 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
     p.qmask = b.qmask;                    // the forward's per-(batch, quadrant) cull ballots, read by the splat-parallel backward
     p.ranges = im.ranges; p.point_list = b.point_list; p.cull = g.cull; p.rec = g.rec; p.bg = cfg->bg;
     p.depth_key = nullptr; p.list_rw = nullptr; p.tile_keys = nullptr; p.scratch_keys = nullptr; p.scratch_ids = nullptr;
-    p.sort_buckets = 1;
+    p.sort_buckets = 1; p.list_any_order = 0;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib;
     return p;
 }
@@ -477,6 +477,7 @@ int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, B
     BlendParams p = make_bp(cfg, g, b, im, s);
     if (!global_order && gsr_tile_sort_is_fused()) {
         p.depth_key = g.depth_key; p.list_rw = b.point_list; p.tile_keys = b.tile_keys; p.scratch_keys = b.keys_b; p.scratch_ids = b.vals_b;
+        p.list_any_order = gsr_tile_bucket_chunk(global_order, p.gx * p.gy, b.cap) ? 1 : 0;
     }
     {   // long-list feedback for the launch order of the forwards that follow (gsr_tile_order_wanted): "long" = beyond max(1024, ~4 x the mean list,
         // the mean taken as 5 instances per gaussian over T tiles)

@@ -18,6 +18,7 @@ struct BlendParams {
     const uint32_t* depth_key;
     uint32_t* list_rw;               // == point_list
     int sort_buckets;                // 1: rank inside depth buckets (gsr_tile_sort.h tds_bucket_rank_wg); 0: all-pairs count / bitonic
+    int list_any_order;              // 1: a tile's list arrives in no particular order (one-pass bucket sort, gsr_binning.hip) -- only the long-list fallback cares
     uint32_t* tile_keys; uint32_t* scratch_keys; uint32_t* scratch_ids;      // the long-list fallback's scratch (free ping-pong half of the binning arena)
     const float4* cull;
     const float4* rec;

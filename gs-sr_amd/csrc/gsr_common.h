@@ -72,6 +72,8 @@ struct BinView {
     uint32_t* vals_b;         // [R]
     uint32_t* hist;           // [128 * nblk(R)]
     uint32_t* scan_tmp;
+    uint32_t* tile_tab;       // [(rows + 1) * Tp] one-pass bucket sort on the tile id (gsr_binning.hip): instances per (16384-key chunk, tile), then the tiles' totals
+    uint32_t cap;             // the R this view was carved for
     // per (tile, 64-entry batch of its list, 8x8 quadrant): the forward's sub-tile cull ballot, reused by the splat-parallel backward instead of
     // re-testing every entry against the four quadrants.  Word index ((range.x >> 6) + tile + batch) * 4 + quadrant (unique per tile and batch).
     unsigned long long* qmask;
@@ -125,6 +127,22 @@ void gsr_blend_bwd_attach_events(hipEvent_t start, hipEvent_t stop);     // spla
 // the runtime's memset.  nbytes must be a multiple of 4.
 bool gsr_depth_order_static_rule(int P, int T, bool* forced, int variant = GSR_SURFEL);   // GSR_DEPTH_ORDER=tile|global|auto and the P <= 192 T rule (gsr_binning.hip)
 bool gsr_tile_cull_enabled();         // GSR_TILE_CULL=0|1 (default 1): tile instances culled at emission (gsr_tile_cull.h, gsr_binning.hip)
+// One-pass bucket sort on the tile id (per-tile depth order only: it leaves a tile's list in no particular order, which the sort by (depth, id) that
+// follows does not mind).  Chunks of 4096 / 8192 / 16384 instances (the smallest that keeps the arena's capacity within GSR_TB_ROWS_MAX chunks: more
+// workgroups for the scattered stores), a table of per-(chunk, tile) counts; applies up to GSR_TB_TILES_MAX tiles (the 16-bit counters of two tiles
+// share an LDS word) and GSR_TB_ROWS_MAX chunks of 16384, else the two-pass radix sort.  GSR_TILE_BUCKET=0: never.
+#define GSR_TB_ROWS_MAX 256u
+#define GSR_TB_TILES_MAX 16384
+// -> instances per chunk (0: the bucket sort does not apply).  Decided on the ARENA's capacity, so that binning and blend forward agree.
+uint32_t gsr_tile_bucket_chunk(bool global_order, int T, uint32_t cap);
+static inline size_t gsr_tile_bucket_words(uint32_t cap, size_t T)
+{
+    if (T > (size_t)GSR_TB_TILES_MAX) return 0;
+    const size_t Tp = (T + 1) & ~(size_t)1, rows = ((size_t)cap + 4095) / 4096;      // upper envelope over the three chunk sizes, monotone in cap:
+    return ((rows < GSR_TB_ROWS_MAX ? rows : (size_t)GSR_TB_ROWS_MAX) + 1) * Tp;      // gsr_binning_capacity inverts gsr_binning_bytes by bisection
+}
+#define GSR_TB_GROUPS_MAX (GSR_TB_TILES_MAX / 64)       // behind the table (BinView::tile_tab + gsr_tile_bucket_words(cap, T)): per chunk, the exclusive prefix of its
+                                                        // instances over the groups of 64 tiles, [GSR_TB_ROWS_MAX][GSR_TB_GROUPS_MAX]
 bool gsr_tile_sort_is_fused();        // GSR_TILE_SORT=fused|kernel: who orders a tile's list by depth when the depth order is per tile (gsr_binning.hip)
 bool gsr_tile_order_wanted();         // GSR_TILE_ORDER=0|1, default auto: on while recent forwards reported long tile lists (gsr_api.hip); once per forward
 const uint32_t* gsr_static_tile_map(int gx, int gy, hipStream_t s);     // device [gx*gy] blockIdx -> tile, block-cyclic over the XCDs; cached per device and grid; nullptr if unavailable (gsr_api.hip)

@@ -45,18 +45,23 @@ __device__ __forceinline__ void tds_cmpx(unsigned long long* s, uint32_t t, uint
 
 // stable LSD radix sort of (keys_a, ids_a)[0, n) by key in GLOBAL memory, 8 bits per pass, ping-ponging with (keys_b, ids_b); the four passes
 // end in the a arrays.  Slow and correct: only lists too long for the LDS network come here.  hist: LDS [256], cnt: LDS [4][256], lds17: LDS [17].
+// any_order: the list does not arrive in ascending id order (one-pass bucket sort on the tile id, gsr_binning.hip): four passes on the id digits
+// first, so that the four stable passes on the key leave equal keys in id order, as the reference's single stable sort of an id-ordered emission does.
 __device__ inline void tds_global_radix(uint32_t* __restrict__ ids_a, uint32_t* __restrict__ keys_a, uint32_t* __restrict__ ids_b, uint32_t* __restrict__ keys_b,
-                                        uint32_t n, uint32_t* hist, uint32_t* cnt, uint32_t* lds17)
+                                        uint32_t n, uint32_t* hist, uint32_t* cnt, uint32_t* lds17, bool any_order = false)
 {
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const uint64_t lt = (1ull << tds_lane()) - 1ull;
-    for (int pass = 0; pass < 4; pass++) {
+    const int id_passes = any_order ? 4 : 0;             // workgroup-uniform; the total stays even: the result ends in the a arrays
+    for (int pass = 0; pass < 4 + id_passes; pass++) {
         const uint32_t* ki = (pass & 1) ? keys_b : keys_a; const uint32_t* vi = (pass & 1) ? ids_b : ids_a;
         uint32_t* ko = (pass & 1) ? keys_a : keys_b; uint32_t* vo = (pass & 1) ? ids_a : ids_b;
-        const int shift = 8 * pass;
+        const bool on_id = pass < id_passes;
+        const uint32_t* di = on_id ? vi : ki;            // the array this pass takes its digit from
+        const int shift = 8 * (on_id ? pass : pass - id_passes);
         hist[tid] = 0;
         __syncthreads();
-        for (uint32_t e = tid; e < n; e += 256u) atomicAdd(&hist[(ki[e] >> shift) & 255u], 1u);
+        for (uint32_t e = tid; e < n; e += 256u) atomicAdd(&hist[(di[e] >> shift) & 255u], 1u);
         __syncthreads();
         {
             const uint32_t v = hist[tid];
@@ -71,7 +76,7 @@ __device__ inline void tds_global_radix(uint32_t* __restrict__ ids_a, uint32_t* 
             const uint32_t e = c0 + tid;
             const bool valid = e < n;
             const uint32_t key = valid ? ki[e] : 0u, val = valid ? vi[e] : 0u;
-            const uint32_t d = (key >> shift) & 255u;
+            const uint32_t d = ((on_id ? val : key) >> shift) & 255u;
             uint64_t peers = __ballot(valid);
             if (!valid) peers = ~peers;
             for (int b = 0; b < 8; b++) { const bool bit = (d >> b) & 1u; const uint64_t m = __ballot(bit); peers &= bit ? m : ~m; }
@@ -225,7 +230,7 @@ struct TdsScratch {
 //   longer: four-pass radix sort in global memory.
 template <int LDS_BYTES>
 __device__ __forceinline__ void tds_sort_tile_wg(void* lds, uint32_t* list, uint32_t n, uint32_t first, uint32_t tile,
-                                                 const uint32_t* __restrict__ depth_key, TdsScratch sc, bool buckets = true)
+                                                 const uint32_t* __restrict__ depth_key, TdsScratch sc, bool buckets = true, bool any_order = false)
 {
     static_assert(LDS_BYTES >= 6148, "tds_sort_tile_wg: at least 3 * 512 + 1 words of LDS");
     constexpr uint32_t CAPW = (LDS_BYTES / 8 >= 4096) ? 4096u : (LDS_BYTES / 8 >= 2048) ? 2048u : (LDS_BYTES / 8 >= 1024) ? 1024u : 512u;
@@ -287,7 +292,7 @@ __device__ __forceinline__ void tds_sort_tile_wg(void* lds, uint32_t* list, uint
         for (uint32_t e = t; e < n; e += 256u) sc.keys[first + e] = depth_key[list[e]];
         __threadfence_block();
         __syncthreads();
-        tds_global_radix(list, sc.keys + first, sc.ids + first, sc.tile_keys + first, n, hist, cnt, lds17);
+        tds_global_radix(list, sc.keys + first, sc.ids + first, sc.tile_keys + first, n, hist, cnt, lds17, any_order);
         for (uint32_t e = t; e < n; e += 256u) sc.tile_keys[first + e] = tile;
         __threadfence_block();
         __syncthreads();

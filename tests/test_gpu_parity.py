@@ -591,10 +591,10 @@ def test_long_tile_lists_sort_paths(variant, P, monkeypatch):
         _ncontrib_close(view["n_contrib"][0], nc[0], st["final_T"][0], ft[0])
 
 
-@pytest.mark.parametrize("env", [{"GSR_XCD_REMAP": "0"}, {"GSR_XCD_REMAP": "1"}, {"GSR_TILE_CULL": "0"}])
+@pytest.mark.parametrize("env", [{"GSR_XCD_REMAP": "0"}, {"GSR_XCD_REMAP": "1"}, {"GSR_TILE_CULL": "0"}, {"GSR_TILE_BUCKET": "0"}])
 def test_kept_switches_keep_the_results(env):
     """The switches that stay (raster / banded launch order of the blend workgroups; GSR_TILE_CULL=0 = the reference-shaped instance list, every tile
-    of every rect emitted): the parity cases incl. SH colours, the speculative forward with its overflow redo and the edge cases re-run in a child
+    of every rect emitted; GSR_TILE_BUCKET=0 = the two-pass radix sort on the tile id instead of the one-pass bucket sort): the parity cases incl. SH colours, the speculative forward with its overflow redo and the edge cases re-run in a child
     process with each switch set.  With GSR_TILE_CULL=0 test_forward_backward_parity also holds R, tiles_touched, point_list, tile keys and ranges
     bit-exactly against the oracle's."""
     import subprocess
