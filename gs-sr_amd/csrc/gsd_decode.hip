@@ -59,100 +59,52 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
     return v;
 }
 
-__global__ void __launch_bounds__(1024) k_scan_block(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ sums)
+// Exclusive scan of data[0, n) in place, one launch, no ticket: every workgroup scans its 1024 words, PUBLISHES its total (flag word = ready bit |
+// total) and then adds up the published totals of all workgroups in front of it -- one load per predecessor, spinning on the ready bits.  Workgroups
+// are dispatched in index order and only ever wait for lower indices, so the wait ends; nobody waits in a chain (each total is published before its
+// workgroup looks back).  flags[0, gridDim.x) must be ZERO at launch (the kernel in front of this one clears them: k_pack_img / k_flags).
+// The last workgroup writes the grand total.  (Rounds 2-3 had a ticket counter instead -- the workgroup that drew the last ticket scanned the block
+// sums, a third kernel added them: 59 atomics on one word cost 8.9 us, 0.15 us each, plus the 3.9 us of k_scan_add; DESIGN Appendix A (70).)
+#define GSD_SCAN_READY 0x80000000u
+__global__ void __launch_bounds__(1024) k_scan_lookback(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ flags, uint32_t* __restrict__ total)
 {
     __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wback[16];
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     const uint32_t v = i < n ? data[i] : 0u;
     const uint32_t incl = wave_scan_incl(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; w++) base += wsum[w];
-    if (i < n) data[i] = base + incl - v;
-    if (threadIdx.x == 1023) sums[blockIdx.x] = base + incl;
-}
-
-__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t* __restrict__ sums, uint32_t nblk, uint32_t* __restrict__ total)
-{
-    __shared__ uint32_t wsum[16];
-    uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < nblk; c0 += 1024u) {
-        const uint32_t i = c0 + threadIdx.x;
-        const uint32_t v = i < nblk ? sums[i] : 0u;
-        const uint32_t incl = wave_scan_incl(v);
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t base = 0, all = 0;
-        for (int w = 0; w < 16; w++) { if (w < wave) base += wsum[w]; all += wsum[w]; }
-        if (i < nblk) sums[i] = carry + base + incl - v;
-        carry += all;
-        __syncthreads();
+    uint32_t base = 0, all = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) base += wsum[w]; all += wsum[w]; }
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], GSD_SCAN_READY | all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t back = 0;
+    for (uint32_t q = threadIdx.x; q < blockIdx.x; q += 1024u) {
+        uint32_t f;
+        while (!((f = __hip_atomic_load(&flags[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & GSD_SCAN_READY)) __builtin_amdgcn_s_sleep(1);
+        back += f & ~GSD_SCAN_READY;
     }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-__global__ void __launch_bounds__(1024) k_scan_add(uint32_t* __restrict__ data, uint32_t n, const uint32_t* __restrict__ sums)
-{
-    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-    if (i < n) data[i] += sums[blockIdx.x];
-}
-
-// k_scan_block + k_scan_sums in one launch: the block that finishes last (ticket counter, zeroed by k_pack_img) scans the block sums
-__global__ void __launch_bounds__(1024) k_scan_block_last(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ sums,
-                                                          uint32_t* __restrict__ total /*[0] total, [1] ticket*/)
-{
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t is_last;
-    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-    const uint32_t v = i < n ? data[i] : 0u;
-    const uint32_t incl = wave_scan_incl(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 63) wsum[wave] = incl;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) back += (uint32_t)__shfl_xor((int)back, d, 64);
+    if (lane == 0) wback[wave] = back;
     __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; w++) base += wsum[w];
-    if (i < n) data[i] = base + incl - v;
-    if (threadIdx.x == 1023) {
-        sums[blockIdx.x] = base + incl;
-        __threadfence();
-        is_last = atomicAdd(&total[1], 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    const uint32_t nblk = gridDim.x;
-    uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < nblk; c0 += 1024u) {
-        const uint32_t q = c0 + threadIdx.x;
-        const uint32_t sv = q < nblk ? __hip_atomic_load(&sums[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        const uint32_t sincl = wave_scan_incl(sv);
-        __syncthreads();
-        if (lane == 63) wsum[wave] = sincl;
-        __syncthreads();
-        uint32_t b2 = 0, all = 0;
-        for (int w = 0; w < 16; w++) { if (w < wave) b2 += wsum[w]; all += wsum[w]; }
-        if (q < nblk) sums[q] = carry + b2 + sincl - sv;
-        carry += all;
-    }
-    if (threadIdx.x == 0) { total[0] = carry; total[1] = 0u; }
+    uint32_t prev = 0;
+    for (int w = 0; w < 16; w++) prev += wback[w];
+    if (i < n) data[i] = prev + base + incl - v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = prev + all;
 }
-
-// data[0..n) -> exclusive prefix in place, *total_dev = sum.  sums: >= div_up(n,1024) words.
-static void launch_scan(uint32_t* data, uint32_t n, uint32_t* sums, uint32_t* total_dev, hipStream_t s)
+// data[0..n) -> exclusive prefix in place, *total_dev = sum.  flags: >= div_up(n,1024) words, zeroed by the kernel in front (k_flags).
+static void launch_scan(uint32_t* data, uint32_t n, uint32_t* flags, uint32_t* total_dev, hipStream_t s)
 {
-    const uint32_t nblk = gsr_div_up(n, 1024u);
-    hipLaunchKernelGGL(k_scan_block, dim3(nblk), dim3(1024), 0, s, data, n, sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, sums, nblk, total_dev);
-    hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(1024), 0, s, data, n, sums);
+    hipLaunchKernelGGL(k_scan_lookback, dim3(gsr_div_up(n, 1024u)), dim3(1024), 0, s, data, n, flags, total_dev);
 }
 
-// ------------------------------------------------------------------------------------------------ visible-anchor compaction
-__global__ void __launch_bounds__(256) k_flags(const uint8_t* __restrict__ mask, uint32_t n, uint32_t* __restrict__ flags)
+__global__ void __launch_bounds__(256) k_flags(const uint8_t* __restrict__ mask, uint32_t n, uint32_t* __restrict__ flags, uint32_t* __restrict__ scan_flags,
+                                               uint32_t n_scan_flags)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n_scan_flags) scan_flags[i] = 0u;           // k_scan_lookback's ready words (n_scan_flags = ceil(n / 1024) <= the threads of this grid)
     if (i < n) flags[i] = mask[i] ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256) k_scatter_idx(const uint8_t* __restrict__ mask, uint32_t n, const uint32_t* __restrict__ pos,
@@ -192,7 +144,7 @@ struct PackArgs {
     gsd_cfg cfg;
     const float *W1o, *b1o, *W2o, *b2o, *W1c, *b1c, *W2c, *b2c, *W1k, *b1k, *W2k, *b2k, *app;
     float* img;
-    uint32_t* ticket;       // scan ticket counter to clear, or NULL
+    uint32_t* scan_flags; uint32_t n_scan_flags;       // k_scan_lookback's ready words to clear (or NULL, 0)
 };
 
 // packed layer-1 weight: columns feat 0..31, view 32..34, dist 35, level 36, 37 = bias + appearance contribution, 38.. = 0
@@ -233,7 +185,7 @@ __device__ float w2row(const PackArgs& p, int head, int rho, int hid, bool bias)
 __global__ void __launch_bounds__(256) k_pack_img(PackArgs p)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e == 0 && p.ticket) *p.ticket = 0u;
+    for (uint32_t z = (uint32_t)e; z < p.n_scan_flags; z += gridDim.x * 256u) p.scan_flags[z] = 0u;
     if (e >= IMG_FLOATS) return;
     const int slot = e >> 6, l = e & 63, m = l & 15, kk = l >> 4;
     float v;
@@ -823,10 +775,10 @@ static DecArgs make_args(const gsd_cfg* c, const gsd_inputs* in)
     return a;
 }
 
-static void launch_pack(const gsd_cfg* c, const gsd_params* p, float* img, uint32_t* ticket, hipStream_t s)
+static void launch_pack(const gsd_cfg* c, const gsd_params* p, float* img, uint32_t* scan_flags, uint32_t n_scan_flags, hipStream_t s)
 {
     PackArgs pa;
-    pa.ticket = ticket;
+    pa.scan_flags = scan_flags; pa.n_scan_flags = n_scan_flags;
     pa.cfg = *c;
     pa.W1o = p->W1o; pa.b1o = p->b1o; pa.W2o = p->W2o; pa.b2o = p->b2o;
     pa.W1c = p->W1c; pa.b1c = p->b1c; pa.W2c = p->W2c; pa.b2c = p->b2c;
@@ -865,7 +817,7 @@ extern "C" int gsd_compact_visible(const uint8_t* mask, int32_t Na, int32_t* vis
     uint32_t* total = (uint32_t*)scratch;
     uint32_t* pos = (uint32_t*)((char*)scratch + 256);
     uint32_t* sums = (uint32_t*)((char*)pos + gsr_align((size_t)Na * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_flags, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos);
+    hipLaunchKernelGGL(k_flags, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos, sums, gsr_div_up((uint32_t)Na, 1024u));
     launch_scan(pos, (uint32_t)Na, sums, total, s);
     hipLaunchKernelGGL(k_scatter_idx, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos, vis_idx);
     GSR_CHECK(hipMemcpyAsync(count_host, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "gsd_compact_visible: copy");
@@ -888,7 +840,7 @@ extern "C" int gsd_compact_visible_padded(const uint8_t* mask, int32_t Na, int32
     uint32_t* pos = (uint32_t*)((char*)scratch + 256);
     uint32_t* sums = (uint32_t*)((char*)pos + gsr_align((size_t)Na * sizeof(uint32_t)));
     if (gsr_memset_async(vis_idx, 0xFF, (size_t)Na * sizeof(int32_t), s)) { gsr_set_error("gsd_compact_visible_padded: fill"); return 1; };
-    hipLaunchKernelGGL(k_flags, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos);
+    hipLaunchKernelGGL(k_flags, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos, sums, gsr_div_up((uint32_t)Na, 1024u));
     launch_scan(pos, (uint32_t)Na, sums, total, s);
     hipLaunchKernelGGL(k_scatter_idx, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos, vis_idx);
     if (count_dev) GSR_CHECK(hipMemcpyAsync(count_dev, total, sizeof(uint32_t), hipMemcpyDeviceToDevice, s), "gsd_compact_visible_padded: count");
@@ -910,15 +862,14 @@ static void enqueue_stage1(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_p
     float* img = (float*)scratch;
     uint32_t* total = fwd_total(scratch);
     uint32_t* sums = (uint32_t*)((char*)scratch + fwd_sums_off());
-    launch_pack(cfg, p, img, total + 1, s);
+    const uint32_t nblk = gsr_div_up((uint32_t)(cfg->Nv > 0 ? cfg->Nv : 1), 1024u);
+    launch_pack(cfg, p, img, sums, nblk, s);
     if (cfg->Nv == 0) return;
     DecArgs a = make_args(cfg, in);
     const int n_tiles = (cfg->Nv + 15) / 16;
     hipLaunchKernelGGL(k_dec_opacity, dim3(tile_grid(n_tiles, GSD_BLOCK / 64, 2048)), dim3(GSD_BLOCK), 0, s, a, (const float*)img,
                        neural_opacity, mask, row_offset, n_tiles);
-    const uint32_t nblk = gsr_div_up((uint32_t)cfg->Nv, 1024u);
-    hipLaunchKernelGGL(k_scan_block_last, dim3(nblk), dim3(1024), 0, s, row_offset, (uint32_t)cfg->Nv, sums, total);
-    if (nblk > 1) hipLaunchKernelGGL(k_scan_add, dim3(nblk), dim3(1024), 0, s, row_offset, (uint32_t)cfg->Nv, sums);
+    hipLaunchKernelGGL(k_scan_lookback, dim3(nblk), dim3(1024), 0, s, row_offset, (uint32_t)cfg->Nv, sums, total);
 }
 static void enqueue_stage2(const gsd_cfg* cfg, const gsd_inputs* in, const float* neural_opacity, const uint32_t* row_offset,
                            const gsd_outputs* out, const void* scratch, hipStream_t s)
@@ -1057,7 +1008,7 @@ extern "C" int gsd_backward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_
     float* sc = (float*)((char*)scratch + gsr_align(IMG_FLOATS * sizeof(float)));
     float* part = (float*)((char*)sc + gsr_align((size_t)SC_COLS * ld * sizeof(float)));
     float* bias_part = (float*)((char*)part + gsr_align((size_t)WG_MAXPROB * WG_WAVES * 3 * 256 * sizeof(float)));
-    if (!fwd_scratch) launch_pack(cfg, p, (float*)scratch, nullptr, s);
+    if (!fwd_scratch) launch_pack(cfg, p, (float*)scratch, nullptr, 0u, s);
     DecArgs a = make_args(cfg, in);
     {
         const int n_tiles = (int)(ld / 16);
