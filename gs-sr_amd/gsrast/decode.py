@@ -104,42 +104,79 @@ def _structs(flags, Na, Nv, tensors, params):
     return cfg, inp, prm
 
 
+def _decode_inputs(vis_idx, campos, level, opacity_scale, anchor, feat, offset, scaling, params):
+    t = {"anchor": dev_f32(anchor, "anchor", False), "feat": dev_f32(feat, "feat", False), "offset": dev_f32(offset, "offset", False),
+         "scaling": dev_f32(scaling, "scaling", False), "level": dev_f32(level, "level"), "opacity_scale": dev_f32(opacity_scale, "opacity_scale"),
+         "vis_idx": vis_idx.contiguous(), "campos": dev_f32(campos, "campos", False)}
+    if t["vis_idx"].dtype != torch.int32:
+        raise RuntimeError("vis_idx must be int32")
+    prm = {n: dev_f32(p, n) for n, p in zip(PARAM_NAMES, params)}
+    return t, prm
+
+
+def _decode_launch(flags, t, prm, mode):
+    """Enqueue the decode forward.  mode "sync": gsd_forward (one host synchronisation, n = P on return); "static": gsd_forward_static (no
+    synchronisation, all Nv*k rows, device count); "deferred": as static, plus an asynchronous copy of the count to pinned memory and an event
+    behind it -- the caller learns P later (PendingDecode.finish).  -> dict of the buffers the autograd node keeps."""
+    L = _lib()
+    dev = t["anchor"].device
+    k = flags[0]
+    Na, Nv = t["anchor"].shape[0], t["vis_idx"].numel()
+    cfg, inp, cp = _structs(flags, Na, Nv, t, prm)
+    b = {"nop": torch.empty(Nv * k, 1, dtype=torch.float32, device=dev), "mask": torch.empty(Nv * k, dtype=torch.uint8, device=dev),
+         "row_offset": torch.empty(max(Nv, 1), dtype=torch.int32, device=dev),
+         "scratch": torch.empty(L.gsd_forward_scratch_bytes(Nv), dtype=torch.uint8, device=dev), "count": None}
+    cap = Nv * k              # worst case: every offset emitted -> stage 2 is enqueued without waiting for the host to learn P
+    b["out"] = [torch.empty(cap, c, dtype=torch.float32, device=dev) for c in (3, 3, 1, 3, 4)]       # xyz, color, opacity, scaling, rot
+    out = Outputs(*[ptr(x) for x in b["out"]])
+    if mode == "sync":
+        P = C.c_uint32(0)
+        check(L.gsd_forward(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(b["nop"]), ptr(b["mask"]), ptr(b["row_offset"]), C.byref(out), C.byref(P),
+                            ptr(b["scratch"]), b["scratch"].numel(), stream_ptr(dev)), "decode forward")
+        b["n"] = P.value
+        return b
+    b["count"] = torch.empty(1, dtype=torch.int32, device=dev)
+    check(L.gsd_forward_static(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(b["nop"]), ptr(b["mask"]), ptr(b["row_offset"]), C.byref(out), ptr(b["count"]),
+                               ptr(b["scratch"]), b["scratch"].numel(), stream_ptr(dev)), "decode forward (static rows)")
+    b["n"] = cap
+    if mode == "deferred":
+        b["count_host"] = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        b["count_host"].copy_(b["count"], non_blocking=True)
+        b["event"] = torch.cuda.Event()
+        b["event"].record(torch.cuda.current_stream(dev))
+    return b
+
+
+class PendingDecode:
+    """A decode whose kernels are enqueued but whose Gaussian count the host has not read yet (neural_gaussians(..., deferred=True)).  Enqueue other
+    device work -- e.g. the next camera's LOD mask and decode -- then call finish(): it waits for THIS decode's count only (an event behind its
+    kernels, not the stream) and returns the reference-shaped tuple (xyz, color, opacity, scaling, rot, neural_opacity, mask) with its autograd node.
+    The inputs must not be modified in between (they are read by the kernels already enqueued and saved for the backward at finish())."""
+
+    def __init__(self, flags, args, launched):
+        self._flags, self._args, self._launched = flags, args, launched
+
+    def finish(self):
+        b = self._launched
+        if b is None:
+            raise RuntimeError("PendingDecode.finish() called twice")
+        self._launched = None
+        b["event"].synchronize()
+        b["n"] = int(b["count_host"][0])
+        return _NeuralDecode.apply(tuple(self._flags[:6]) + (False, b), *self._args)
+
+
 class _NeuralDecode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flags, vis_idx, campos, level, opacity_scale, anchor, feat, offset, scaling, *params):
-        L = _lib()
-        dev = anchor.device
         static_rows = len(flags) > 6 and bool(flags[6])
+        launched = flags[7] if len(flags) > 7 else None           # PendingDecode.finish(): the kernels ran already
         flags = tuple(flags[:6])
-        k = flags[0]
-        t = {"anchor": dev_f32(anchor, "anchor", False), "feat": dev_f32(feat, "feat", False), "offset": dev_f32(offset, "offset", False),
-             "scaling": dev_f32(scaling, "scaling", False), "level": dev_f32(level, "level"), "opacity_scale": dev_f32(opacity_scale, "opacity_scale"),
-             "vis_idx": vis_idx.contiguous(), "campos": dev_f32(campos, "campos", False)}
-        if t["vis_idx"].dtype != torch.int32:
-            raise RuntimeError("vis_idx must be int32")
-        prm = {n: dev_f32(p, n) for n, p in zip(PARAM_NAMES, params)}
-        Na, Nv = t["anchor"].shape[0], t["vis_idx"].numel()
-        cfg, inp, cp = _structs(flags, Na, Nv, t, prm)
-        nop = torch.empty(Nv * k, 1, dtype=torch.float32, device=dev)
-        mask = torch.empty(Nv * k, dtype=torch.uint8, device=dev)
-        row_offset = torch.empty(max(Nv, 1), dtype=torch.int32, device=dev)
-        scratch = torch.empty(L.gsd_forward_scratch_bytes(Nv), dtype=torch.uint8, device=dev)
-        P = C.c_uint32(0)
-        cap = Nv * k          # worst case: every offset emitted -> stage 2 is enqueued without waiting for the host to learn P
-        xyz = torch.empty(cap, 3, dtype=torch.float32, device=dev); color = torch.empty(cap, 3, dtype=torch.float32, device=dev)
-        opacity = torch.empty(cap, 1, dtype=torch.float32, device=dev); scl = torch.empty(cap, 3, dtype=torch.float32, device=dev)
-        rot = torch.empty(cap, 4, dtype=torch.float32, device=dev)
-        out = Outputs(ptr(xyz), ptr(color), ptr(opacity), ptr(scl), ptr(rot))
-        count = None
-        if static_rows:         # no host synchronisation: all Nv*k rows are returned, the rows behind the emitted ones parked at the camera centre
-            count = torch.empty(1, dtype=torch.int32, device=dev)
-            check(L.gsd_forward_static(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(mask), ptr(row_offset), C.byref(out), ptr(count),
-                                       ptr(scratch), scratch.numel(), stream_ptr(dev)), "decode forward (static rows)")
-            n = cap
-        else:
-            check(L.gsd_forward(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(nop), ptr(mask), ptr(row_offset), C.byref(out), C.byref(P),
-                                ptr(scratch), scratch.numel(), stream_ptr(dev)), "decode forward")
-            n = P.value
+        t, prm = _decode_inputs(vis_idx, campos, level, opacity_scale, anchor, feat, offset, scaling, params)
+        b = launched if launched is not None else _decode_launch(flags, t, prm, "static" if static_rows else "sync")
+        nop, mask, row_offset, scratch, count, n = b["nop"], b["mask"], b["row_offset"], b["scratch"], b["count"], b["n"]
+        xyz, color, opacity, scl, rot = b["out"]
+        if not static_rows:
             xyz, color, opacity, scl, rot = xyz[:n], color[:n], opacity[:n], scl[:n], rot[:n]
         ctx.flags, ctx.n = flags, n
         ctx.save_for_backward(t["anchor"], t["feat"], t["offset"], t["scaling"], t["level"], t["opacity_scale"], t["vis_idx"], t["campos"],
@@ -208,7 +245,7 @@ def feature_bank_blend(anchor, feat, vis_idx, campos, mlp_feature_bank):
 
 def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_color, campos, visible_mask=None, vis_idx=None,
                      appearance=None, level=None, opacity_scale=None, add_opacity_dist=False, add_cov_dist=False, add_color_dist=False,
-                     use_feat_bank=False, mlp_feature_bank=None, padded=False, static_rows=False):
+                     use_feat_bank=False, mlp_feature_bank=None, padded=False, static_rows=False, deferred=False):
     """-> (xyz, color, opacity, scaling, rot, neural_opacity, mask), the `is_training=True` tuple of the reference.
 
     anchor (Na,3), feat (Na,32), offset (Na,k,3), scaling (Na,6) = get_scaling; `appearance` = embedding_appearance row of this camera
@@ -222,7 +259,10 @@ def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_co
     (every rasterizer of this library culls them: radii 0, no tile instance, zero gradients), and an eighth value `count` (int32 device tensor,
     shape (1,)) = P is returned for consumers that average over the Gaussians (the reference's scaling loss: use sum() / count).  The parked rows
     sit at view depth 0, i.e. they FAIL the frustum test by construction: rasterize them with `prefiltered=False` (what every scene of the reference
-    passes, e.g. scaffold_scene.py:101) -- with `prefiltered=True` the rasterizer reports them as the reference does ("Point is filtered ...")."""
+    passes, e.g. scaffold_scene.py:101) -- with `prefiltered=True` the rasterizer reports them as the reference does ("Point is filtered ...").
+    `deferred=True` (round 4): the kernels are enqueued and a PendingDecode is returned instead of the tuple; its finish() waits for the count and
+    returns the reference-shaped tuple.  A caller that renders two cameras per iteration (PGSR after step 7000) starts the second camera's decode
+    before finishing the first: the host's wait for the first count is covered by the second decode's kernels."""
     if use_feat_bank and mlp_feature_bank is None:
         raise RuntimeError("gsrast.decode: use_feat_bank=True needs mlp_feature_bank (get_featurebank_mlp of the gaussian model)")
     if feat.shape[1] != 32:
@@ -240,6 +280,14 @@ def neural_gaussians(anchor, feat, offset, scaling, mlp_opacity, mlp_cov, mlp_co
     osc = None if opacity_scale is None else opacity_scale.reshape(-1)
     flags = (int(k), int(A), bool(add_opacity_dist), bool(add_cov_dist), bool(add_color_dist), lvl is not None, bool(static_rows))
     app = None if appearance is None else appearance.reshape(-1)
+    if deferred:
+        if static_rows:
+            raise RuntimeError("gsrast.decode: deferred=True returns the reference-shaped tuple; static_rows=True has no count to wait for")
+        args = (vis_idx, campos, lvl, osc, anchor, feat, offset, scaling, *heads, app)
+        with torch.no_grad():
+            t, prm = _decode_inputs(vis_idx, campos, lvl, osc, anchor, feat, offset, scaling, (*heads, app))
+            launched = _decode_launch(flags[:6], t, prm, "deferred")
+        return PendingDecode(flags, args, launched)
     return _NeuralDecode.apply(flags, vis_idx, campos, lvl, osc, anchor, feat, offset, scaling, *heads, app)
 
 

@@ -172,3 +172,44 @@ def test_padded_visible_list_gives_identical_gaussians_without_the_count_sync():
         assert torch.allclose(gp0[n], gp1[n], rtol=1e-4, atol=1e-5), n
     for a, b in zip(a0, a1):
         assert torch.equal(a, b)
+
+
+def test_deferred_decode_two_in_flight_equal_the_synchronous_calls():
+    """neural_gaussians(..., deferred=True): the kernels are enqueued, the count is read at finish().  Two decodes of different cameras / visible sets
+    in flight at once, finished in order, give bit-identical outputs and the same gradients as two synchronous calls; finish() twice is an error."""
+    from gsrast import decode
+    t = lambda a: None if a is None else torch.tensor(a, device=DEV)
+    cases = [decode_cases.make_case(Na=6000, seed=21, vis_frac=0.55), decode_cases.make_case(Na=6000, seed=22, vis_frac=0.8)]
+
+    def run(deferred):
+        leaves, pars, pend = [], [], []
+        for case in cases:
+            lv = {n: t(case[n]).requires_grad_(True) for n in GRAD_LEAVES}
+            par = {n: (None if v is None else t(v).requires_grad_(True)) for n, v in case["params"].items()}
+            vis = torch.tensor(case["vis_idx"], dtype=torch.int32, device=DEV)
+            out = decode.neural_gaussians(lv["anchor"], lv["feat"], lv["offset"], lv["scaling"],
+                                          (par["W1o"], par["b1o"], par["W2o"], par["b2o"]), (par["W1c"], par["b1c"], par["W2c"], par["b2c"]),
+                                          (par["W1k"], par["b1k"], par["W2k"], par["b2k"]), t(case["campos"]), vis_idx=vis, appearance=par["app"],
+                                          deferred=deferred)
+            leaves.append(lv); pars.append(par); pend.append(out)
+        if deferred:
+            assert all(isinstance(p, decode.PendingDecode) for p in pend)
+            outs = [p.finish() for p in pend]
+            with pytest.raises(RuntimeError, match="twice"):
+                pend[0].finish()
+        else:
+            outs = pend
+        loss = sum((o * (i + 1.0)).sum() for out in outs for i, o in enumerate(out[:5]))
+        loss.backward()
+        return outs, leaves, pars
+
+    o0, l0, p0 = run(False)
+    o1, l1, p1 = run(True)
+    for a, b in zip(o0, o1):
+        assert len(a) == len(b) == 7 and a[0].shape[0] > 1000
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x, y)
+    for a, b in zip(l0 + p0, l1 + p1):
+        for n in a:
+            if a[n] is not None:
+                assert torch.allclose(a[n].grad, b[n].grad, rtol=1e-5, atol=1e-6), n

@@ -31,6 +31,7 @@ def build(a, dev, seed=0):
     """-> (step, st): one octree-pgsr training iteration (step > 7000); a has .Na and optionally .static (the sync-free static-shape form:
     decode with static_rows, recordable into a HIP graph -- gsrast.graphs.GraphedStep)."""
     static = bool(getattr(a, "static", False))
+    defer = os.environ.get("GSR_PIPE_DEFER", "1") != "0"       # A/B: "0" = each render reads its decode's count before anything else is enqueued
     W, H, k, A, LEVELS, FORK = 1920, 1080, 10, 32, 6, 2.0
     sc = scenes.make_scene("plane", a.Na, W, H, seed=seed, color_mode="precomp")
     t = hiprun.to_dev(sc, dev)
@@ -77,7 +78,9 @@ def build(a, dev, seed=0):
     st = {}
     carriers = {}
 
-    def render(view, cam_id, L):
+    def render_begin(view, cam_id, L):
+        """LOD mask + prefilter + decode, enqueued; in the reference-shaped (eager) mode the decode is DEFERRED: its count is read in render_finish,
+        after the other camera's decode has been enqueued behind it (gsrast.decode.PendingDecode)."""
         tt, rs, fs = view
         anchor, feat, offset, emb, mlp_o, mlp_c, mlp_k = L["anchor"], L["feat"], L["offset"], L["emb"], L["mlp_o"], L["mlp_c"], L["mlp_k"]
         scaling = torch.exp(L["scaling_log"])
@@ -85,7 +88,17 @@ def build(a, dev, seed=0):
                                     extra_level=extra_level)   # set_anchor_mask + prefilter_voxel, no host sync
         vis_idx = decode.compact_visible(vis["visible_mask"], padded=True)
         out = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, tt["campos"], vis_idx=vis_idx, appearance=emb.weight[cam_id],
-                                      static_rows=static)
+                                      static_rows=static, deferred=not static and defer)
+        return view, cam_id, vis, vis_idx, out
+
+    def render(view, cam_id, L):
+        return render_finish(render_begin(view, cam_id, L))
+
+    def render_finish(begun):
+        view, cam_id, vis, vis_idx, out = begun
+        tt, rs, fs = view
+        if isinstance(out, decode.PendingDecode):
+            out = out.finish()
         xyz, color, opacity, scl, rot, nop, mask = out[:7]
         count = out[7] if static else None
         am = plane_input_all_map(xyz, rot, scl, tt["viewmatrix"], tt["campos"])
@@ -111,8 +124,9 @@ def build(a, dev, seed=0):
         return img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vis["visible_mask"], count
 
     def step():
-        img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask, count = render(views[0], 1, first)
-        pd2 = render(views[1], 2, second)[3]
+        b1, b2 = render_begin(views[0], 1, first), render_begin(views[1], 2, second)       # both decodes in flight before the first count is read
+        img, radii, oam, pd, scl, m2, nop, mask, vis_idx, vmask, count = render_finish(b1)
+        pd2 = render_finish(b2)[3]
         if os.environ.get("GSR_PIPE_TORCH_REG", "0") == "1":
             sx, sy, sz = scl.unbind(dim=1)                # x*y*z on unbound columns (backward = ONE stack), not prod(dim=1): prod's backward
             vol = sx * sy * sz                            # synchronises (nonzero) when an entry is 0, and not scl[:, i]: one zero-filled (P,3) per slice
