@@ -966,6 +966,27 @@ extern "C" int gsd_forward_static(const gsd_cfg* cfg, const gsd_inputs* in, cons
     return gsr_check_launch("gsd_forward_static", s, false);
 }
 
+extern "C" int gsd_forward_deferred(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask,
+                                    uint32_t* row_offset, const gsd_outputs* out, uint32_t* count_host, void* event, void* scratch, size_t scratch_bytes,
+                                    void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (fwd_checks(cfg, in, p, scratch, scratch_bytes, "gsd_forward_deferred")) return 1;
+    if (!count_host || !event) { gsr_set_error("gsd_forward_deferred: count_host / event is NULL"); return 1; }
+    if (cfg->Nv && (!neural_opacity || !mask || !row_offset)) { gsr_set_error("gsd_forward_deferred: null output"); return 1; }
+    if (cfg->Nv && check_outputs(out, "gsd_forward_deferred")) return 1;
+    enqueue_stage1(cfg, in, p, neural_opacity, mask, row_offset, scratch, s);
+    if (cfg->Nv == 0) {
+        *count_host = 0u;
+        GSR_CHECK(hipEventRecord((hipEvent_t)event, s), "gsd_forward_deferred: event");
+        return gsr_check_launch("gsd_forward_deferred", s, false);
+    }
+    GSR_CHECK(hipMemcpyAsync(count_host, fwd_total(scratch), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "gsd_forward_deferred: count copy");
+    GSR_CHECK(hipEventRecord((hipEvent_t)event, s), "gsd_forward_deferred: event");
+    enqueue_stage2(cfg, in, neural_opacity, row_offset, out, scratch, s);
+    return gsr_check_launch("gsd_forward_deferred", s, false);
+}
+
 // backward scratch: [weight image][feature-major columns SC_COLS x ld][tile partials][bias partials]
 static size_t bwd_ld(const gsd_cfg* c) { return (size_t)gsr_div_up((uint32_t)(c->Nv > 0 ? c->Nv : 1), GSD_BLOCK) * GSD_BLOCK; }
 extern "C" size_t gsd_backward_scratch_bytes(const gsd_cfg* cfg)

@@ -14,7 +14,7 @@ from . import check, dev_f32, lib, ptr, stream_ptr
 _vp = C.c_void_p
 PARAM_NAMES = ("W1o", "b1o", "W2o", "b2o", "W1c", "b1c", "W2c", "b2c", "W1k", "b1k", "W2k", "b2k", "app")
 EXPORTS = ["gsd_compact_scratch_bytes", "gsd_compact_visible", "gsd_compact_visible_padded", "gsd_forward_scratch_bytes", "gsd_forward_stage1", "gsd_forward_stage2",
-           "gsd_forward", "gsd_forward_static", "gsd_backward_scratch_bytes", "gsd_backward", "gsd_training_stats_scratch_bytes", "gsd_training_stats"]
+           "gsd_forward", "gsd_forward_static", "gsd_forward_deferred", "gsd_backward_scratch_bytes", "gsd_backward", "gsd_training_stats_scratch_bytes", "gsd_training_stats"]
 
 
 class Cfg(C.Structure):
@@ -64,6 +64,8 @@ def _lib():
                                   C.POINTER(C.c_uint32), _vp, sz, _vp]
         L.gsd_forward_static.restype = C.c_int
         L.gsd_forward_static.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, _vp, C.POINTER(Outputs), _vp, _vp, sz, _vp]
+        L.gsd_forward_deferred.restype = C.c_int
+        L.gsd_forward_deferred.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, _vp, C.POINTER(Outputs), _vp, _vp, _vp, sz, _vp]
         L.gsd_backward_scratch_bytes.restype = sz; L.gsd_backward_scratch_bytes.argtypes = [C.POINTER(Cfg)]
         L.gsd_backward.restype = C.c_int
         L.gsd_backward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), C.POINTER(Params), _vp, _vp, C.c_uint32, C.POINTER(OutGrads),
@@ -116,8 +118,8 @@ def _decode_inputs(vis_idx, campos, level, opacity_scale, anchor, feat, offset, 
 
 def _decode_launch(flags, t, prm, mode):
     """Enqueue the decode forward.  mode "sync": gsd_forward (one host synchronisation, n = P on return); "static": gsd_forward_static (no
-    synchronisation, all Nv*k rows, device count); "deferred": as static, plus an asynchronous copy of the count to pinned memory and an event
-    behind it -- the caller learns P later (PendingDecode.finish).  -> dict of the buffers the autograd node keeps."""
+    synchronisation, all Nv*k rows, device count); "deferred": gsd_forward_deferred -- the count is copied to pinned memory behind stage 1 with an
+    event behind the copy, stage 2 follows; the caller learns P later (PendingDecode.finish).  -> dict of the buffers the autograd node keeps."""
     L = _lib()
     dev = t["anchor"].device
     k = flags[0]
@@ -135,16 +137,31 @@ def _decode_launch(flags, t, prm, mode):
                             ptr(b["scratch"]), b["scratch"].numel(), stream_ptr(dev)), "decode forward")
         b["n"] = P.value
         return b
+    if mode == "deferred":    # the count leaves for pinned memory right behind stage 1; the event is recorded there, stage 2 follows (gsd_forward_deferred)
+        b["slot"] = _count_slot(dev)
+        b["count_host"], b["event"] = b["slot"]
+        check(L.gsd_forward_deferred(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(b["nop"]), ptr(b["mask"]), ptr(b["row_offset"]), C.byref(out),
+                                     b["count_host"].data_ptr(), b["event"].cuda_event, ptr(b["scratch"]), b["scratch"].numel(), stream_ptr(dev)),
+              "decode forward (deferred count)")
+        b["n"] = cap
+        return b
     b["count"] = torch.empty(1, dtype=torch.int32, device=dev)
     check(L.gsd_forward_static(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(b["nop"]), ptr(b["mask"]), ptr(b["row_offset"]), C.byref(out), ptr(b["count"]),
                                ptr(b["scratch"]), b["scratch"].numel(), stream_ptr(dev)), "decode forward (static rows)")
     b["n"] = cap
-    if mode == "deferred":
-        b["count_host"] = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        b["count_host"].copy_(b["count"], non_blocking=True)
-        b["event"] = torch.cuda.Event()
-        b["event"].record(torch.cuda.current_stream(dev))
     return b
+
+
+_count_slots = {}       # device index -> free (pinned int32[1], event) pairs: a pair is taken per deferred decode and returned by finish()
+
+
+def _count_slot(dev):
+    free = _count_slots.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
+    if free:
+        return free.pop()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))          # creates the hipEvent_t (torch makes it lazily); the library re-records it behind the count copy
+    return torch.zeros(1, dtype=torch.int32, pin_memory=True), ev
 
 
 class PendingDecode:
@@ -163,6 +180,8 @@ class PendingDecode:
         self._launched = None
         b["event"].synchronize()
         b["n"] = int(b["count_host"][0])
+        dev = b["nop"].device
+        _count_slots[dev.index if dev.index is not None else torch.cuda.current_device()].append(b.pop("slot"))
         return _NeuralDecode.apply(tuple(self._flags[:6]) + (False, b), *self._args)
 
 

@@ -115,6 +115,13 @@ int gsd_forward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, f
 int gsd_forward_static(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask, uint32_t* row_offset,
                        const gsd_outputs* out, uint32_t* count_dev, void* scratch, size_t scratch_bytes, void* stream);
 
+/* deferred-count forward (round 4): stage 1, then an asynchronous copy of P to *count_host (PINNED host memory) with `event` (a hipEvent_t the
+   caller created) recorded behind it, then stage 2 against the worst-case-sized `out` -- no host synchronisation in the call.  The caller waits on
+   the event when it needs P (the first *count_host rows of `out` are valid once the stream has passed stage 2): P is known as soon as the opacity
+   head and its scan are done, while the device is still emitting the Gaussians or decoding another camera.  Rows behind P are left unwritten. */
+int gsd_forward_deferred(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask, uint32_t* row_offset,
+                         const gsd_outputs* out, uint32_t* count_host, void* event, void* scratch, size_t scratch_bytes, void* stream);
+
 /* backward: recomputes the heads, writes the per-anchor gradients, and contracts the weight gradients over the anchors with MFMA.
    scratch >= gsd_backward_scratch_bytes(cfg).  fwd_scratch: the forward's scratch buffer if the caller kept it and the parameters are
    unchanged since (its repacked weights are reused), else NULL. */

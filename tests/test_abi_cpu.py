@@ -33,7 +33,7 @@ def test_decode_exports_match_header():
     from gsrast import decode
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gsdecode.h")).read(), flags=re.S)
     decl = sorted(set(re.findall(r"\b(gsd_[a-z0-9_]+)\s*\(", src)))
-    assert sorted(decode.EXPORTS) == decl and len(decl) == 12
+    assert sorted(decode.EXPORTS) == decl and len(decl) == 13
     L = gsrast.lib()
     for s in decl:
         assert hasattr(L, s), f"libgsrast_hip.so does not export {s}"

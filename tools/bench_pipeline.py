@@ -95,8 +95,11 @@ def build(a, dev, seed=0):
                 xyz, color, opacity, scl, rot, nop, mask, count = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos,
                                                                                          vis_idx=vis_idx, appearance=app, static_rows=True)
             else:
-                xyz, color, opacity, scl, rot, nop, mask = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos,
-                                                                                  vis_idx=vis_idx, appearance=app)
+                # reference-shaped rows; the count is read as soon as the opacity head and its scan are done (deferred decode: the emit kernel is still
+                # running while the host goes on to enqueue the rasterizer).  GSR_PIPE_DEFER=0: the synchronous call, for A/B
+                out = decode.neural_gaussians(anchor, feat, offset, scaling, mlp_o, mlp_c, mlp_k, campos, vis_idx=vis_idx, appearance=app,
+                                              deferred=os.environ.get("GSR_PIPE_DEFER", "1") != "0")
+                xyz, color, opacity, scl, rot, nop, mask = out.finish() if isinstance(out, decode.PendingDecode) else out
         else:
             vis = torch.nonzero(vmask).view(-1)
             leaves = {"anchor": anchor, "feat": feat, "offset": offset, "scaling": scaling}
