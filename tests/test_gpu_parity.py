@@ -591,6 +591,24 @@ def test_long_tile_lists_sort_paths(variant, P, monkeypatch):
         _ncontrib_close(view["n_contrib"][0], nc[0], st["final_T"][0], ft[0])
 
 
+@pytest.mark.parametrize("W,H,what", [(80, 48, "15 tiles: an odd count, the last 16-bit counter pair half used"),
+                                      (2048, 2048, "16384 tiles: the largest image the bucket sort takes"),
+                                      (2064, 2048, "16512 tiles: one tile column more, the two radix passes")])
+def test_tile_count_edges_of_the_bucket_sort(W, H, what):
+    """The one-pass bucket sort on the tile id packs two tiles' 16-bit counters into an LDS word and applies up to GSR_TB_TILES_MAX = 16384 tiles
+    (gs-sr_amd/csrc/gsr_binning.hip): an odd tile count, the limit itself and the first size beyond it (which falls back to the radix passes) give the
+    oracle's lists, ranges and images."""
+    hr = _hiprun()
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    sc = scenes.make_scene("ewa", min(6000, 120 * T), W, H, seed=33)          # <= 155 gaussians per tile: the per-tile depth order (gsr_depth_order_static_rule)
+    with oracle.Forward(sc, "ewa") as f:
+        st = hr.run_raw("ewa", sc)
+        assert st["ranges"].shape[0] == T
+        _lists(st, f)
+        _img_close(st["color"], f.color)
+        assert np.array_equal(st["radii"], f.radii)
+
+
 @pytest.mark.parametrize("env", [{"GSR_XCD_REMAP": "0"}, {"GSR_XCD_REMAP": "1"}, {"GSR_TILE_CULL": "0"}, {"GSR_TILE_BUCKET": "0"}])
 def test_kept_switches_keep_the_results(env):
     """The switches that stay (raster / banded launch order of the blend workgroups; GSR_TILE_CULL=0 = the reference-shaped instance list, every tile
