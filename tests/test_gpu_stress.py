@@ -53,6 +53,32 @@ def test_many_small_splats_3M_properties():
     assert np.isfinite(st["color"]).all() and np.isfinite(st["others"]).all()
 
 
+@pytest.mark.parametrize("P,chunk", [(120000, 4096), (520000, 8192), (1000000, 16384)])
+def test_bucket_sort_chunk_sizes_properties(P, chunk):
+    """Per-tile depth order at 1080p with 0.12 / 0.52 / 1.0 million surfels: the one-pass bucket sort on the tile id runs with 4096- / 8192- /
+    16384-instance chunks (gsr_tile_bucket_chunk: the smallest that keeps the arena within 256 chunks).  Size-independent checks: every instance
+    once, grouped by tile, ranges = histogram of the tile ids, each tile's list in (depth bits, id) order."""
+    hr = _hr()
+    W, H = 1920, 1080
+    sc = scenes.make_scene("surfel", P, W, H, seed=7)
+    st = hr.run_raw("surfel", sc)
+    R = st["R"]
+    assert R == int(st["tiles_touched"].sum()) and R > P
+    want = 4096 if R <= 256 * 4096 else (8192 if R <= 256 * 8192 else 16384)
+    assert want == chunk, (R, want)                                  # the scene does land in the chunk size this case is named for
+    tk, pl = st["tile_keys"].astype(np.int64)[:R], st["point_list"].astype(np.int64)[:R]
+    assert np.all(np.diff(tk) >= 0)
+    assert np.array_equal(np.bincount(pl, minlength=P), st["tiles_touched"])
+    counts = np.bincount(tk, minlength=st["ranges"].shape[0])
+    assert np.array_equal(st["ranges"][:, 1] - st["ranges"][:, 0], counts)
+    pv = sc["means3D"] @ sc["viewmatrix"][:3, :3] + sc["viewmatrix"][3, :3]
+    db = pv[:, 2].astype(np.float32).view(np.uint32).astype(np.int64)
+    same = np.nonzero(np.diff(tk) == 0)[0]
+    a, b = pl[same], pl[same + 1]
+    assert np.all((db[a] < db[b]) | ((db[a] == db[b]) & (a < b)))
+    assert np.isfinite(st["color"]).all() and np.isfinite(st["others"]).all()
+
+
 def test_tall_image_many_tile_rows_and_16bit_tile_ids():
     """More than 65 536 tiles would need 17 bits; 4096x4096 = 65 536 tiles exercises the 16-bit (2-pass) boundary."""
     hr = _hr()
