@@ -487,12 +487,6 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
 
 // No host synchronisation, no host-visible state: every call is a fixed sequence of launches on `stream` whose shapes depend only on cfg and the
 // arena capacities -- the form a HIP graph can record and replay.
-__global__ void k_forward_status(const uint32_t* __restrict__ counters, uint32_t cap, uint32_t* __restrict__ status)
-{
-    const uint32_t R = counters[0];
-    status[0] = R;
-    if (R > cap) status[1] = 1u;
-}
 extern "C" int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
                                  void* binning, size_t binning_bytes, void* img, size_t img_bytes, int32_t* radii,
                                  const gsr_outputs* out, uint32_t* status_dev, void* stream)
@@ -514,8 +508,9 @@ extern "C" int gsr_forward_async(const gsr_cfg* cfg, const gsr_inputs* in, void*
     if (gsr_launch_preprocess(cfg, in, g, radii, s, global_order, status_dev + 2)) return 1;
     if (gsr_launch_depth_order(cfg, g, nullptr, s, global_order, false)) return 1;
     if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s, global_order, nullptr)) return 1;
-    hipLaunchKernelGGL(k_forward_status, dim3(1), dim3(1), 0, s, g.counters, cap, status_dev);      // after the binning: k_duplicate may be the one that publishes the total
-    if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s, global_order)) return 1;
+    // status_dev[0] <- num_rendered, status_dev[1] <- 1 when it exceeds the capacity (sticky: never cleared here): written by the blend forward's
+    // first workgroup -- after the binning, whose k_duplicate publishes the total
+    if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s, global_order, status_dev, cap)) return 1;
     return 0;
 }
 

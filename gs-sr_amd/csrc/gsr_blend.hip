@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
         TdsScratch sc; sc.tile_keys = p.tile_keys; sc.keys = p.scratch_keys; sc.ids = p.scratch_ids;
         tds_sort_tile_wg<(int)sizeof(s_rec)>(s_rec, p.list_rw + range.x, range.y > range.x ? range.y - range.x : 0u, range.x, (uint32_t)tile, p.depth_key, sc, p.sort_buckets != 0, p.list_any_order != 0);
     }
+    if (p.status && blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t R = *p.status_total; p.status[0] = R; if (R > p.status_cap) p.status[1] = 1u; }
     if (p.long_word && threadIdx.x == 0 && range.y > range.x && range.y - range.x > p.long_len) *p.long_word = range.y - range.x;      // feedback for the launch order
     if (ox >= p.W || oy >= p.H) return;                 // wave-uniform: this sub-tile is outside the image
     const int px = ox + (lane & 7), py = oy + (lane >> 3);
@@ -461,7 +462,7 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
     p.fy = cfg->H / (2.0f * cfg->tanfovy);
     p.fx = cfg->W / (2.0f * cfg->tanfovx);
     p.tile_order = im.tile_order;         // used when its word T is set: decided per forward (gsr_tile_order_wanted, gsr_api.hip)
-    p.long_word = nullptr; p.long_len = 0xFFFFFFFFu;
+    p.long_word = nullptr; p.long_len = 0xFFFFFFFFu; p.status = nullptr; p.status_total = nullptr; p.status_cap = 0u;
     p.qmask = b.qmask;                    // the forward's per-(batch, quadrant) cull ballots, read by the splat-parallel backward
     p.ranges = im.ranges; p.point_list = b.point_list; p.cull = g.cull; p.rec = g.rec; p.bg = cfg->bg;
     p.depth_key = nullptr; p.list_rw = nullptr; p.tile_keys = nullptr; p.scratch_keys = nullptr; p.scratch_ids = nullptr;
@@ -471,10 +472,11 @@ static BlendParams make_bp(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im
 }
 
 int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
-                         const gsr_outputs* out, hipStream_t s, bool global_order)
+                         const gsr_outputs* out, hipStream_t s, bool global_order, uint32_t* status_dev, uint32_t status_cap)
 {
     (void)in;
     BlendParams p = make_bp(cfg, g, b, im, s);
+    if (status_dev) { p.status = status_dev; p.status_total = g.counters; p.status_cap = status_cap; }
     if (!global_order && gsr_tile_sort_is_fused()) {
         p.depth_key = g.depth_key; p.list_rw = b.point_list; p.tile_keys = b.tile_keys; p.scratch_keys = b.keys_b; p.scratch_ids = b.vals_b;
         p.list_any_order = gsr_tile_bucket_chunk(global_order, p.gx * p.gy, b.cap) ? 1 : 0;

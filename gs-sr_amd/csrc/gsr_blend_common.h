@@ -10,6 +10,7 @@ struct BlendParams {
     const uint2* ranges;
     const uint32_t* tile_order;      // ImgView::tile_order [T + 1]: used when word T is set (k_tile_order ran for this forward)
     const uint32_t* static_map;      // [T] blockIdx -> tile, block-cyclic over the XCDs (gsr_static_tile_map, GSR_XCD_REMAP=2), or nullptr
+    uint32_t* status; const uint32_t* status_total; uint32_t status_cap;      // gsr_forward_async: workgroup 0 writes status[0] = *status_total and sets status[1] when it exceeds the capacity (sticky); else nullptr
     uint32_t* long_word; uint32_t long_len;     // forward: a tile whose list is longer than long_len stores its length into *long_word (feedback, or nullptr)
     const uint32_t* point_list;
     unsigned long long* qmask;       // BinView::qmask, or nullptr (GSR_CULL_REUSE=0)

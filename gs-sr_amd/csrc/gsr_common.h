@@ -117,7 +117,7 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
 int gsr_launch_binning(const gsr_cfg* cfg, GeomView g, BinView b, ImgView im, uint32_t R, const uint32_t* n_dev, hipStream_t s,
                        bool global_order, uint32_t* host_word_dev = nullptr);
 int gsr_launch_blend_fwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
-                         const gsr_outputs* out, hipStream_t s, bool global_order);
+                         const gsr_outputs* out, hipStream_t s, bool global_order, uint32_t* status_dev = nullptr, uint32_t status_cap = 0u);
 int gsr_launch_blend_bwd(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, BinView b, ImgView im,
                          const gsr_out_grads* og, float* acc, hipStream_t s);
 bool gsr_blend_bwd_is_sp();            // GSR_BWD=sp (default) | px (gsr_blend.hip)

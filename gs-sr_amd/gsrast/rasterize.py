@@ -42,7 +42,6 @@ def _bytes(n, device):
 # overflowed the capacity (outputs of that run were incomplete -> raise the capacity and re-run / re-capture; gsrast.graphs does that).
 _ASYNC = threading.local()
 PREFILTERED_MSG = "Point is filtered although prefiltered is set. This shouldn't happen!"      # auxiliary.h:157; status word 2 of a sync-free forward
-PREFILTERED_MSG = "Point is filtered although prefiltered is set. This shouldn't happen!"      # auxiliary.h:157; status word 2 of a sync-free forward
 _ASYNC_STATUS = []            # [(status int32[3] tensor, capacity)] of the async forwards issued since async_status_reset()
 
 
@@ -59,6 +58,29 @@ class static_capacity:
 
     def __exit__(self, *a):
         _ASYNC.cap = self.prev
+
+
+# Status words of forwards recorded INTO A HIP GRAPH live outside the graph: rows of a per-device pool that was zeroed eagerly (the eager run that
+# seeds the capacity hint creates it).  The library only ever sets words 1 and 2, so an overflow in ANY replay stays visible until the owner of the
+# graph looks (gsrast.graphs.GraphedStep.check) -- a torch.zeros() inside the capture would be a fill node that clears it again on every replay.
+_STATUS_POOL = {}             # device index -> [int32 (rows, 3) tensor, rows handed out]
+_STATUS_ROWS = 256
+
+
+def _status_pool(dev):
+    """Called on every forward outside a capture: makes sure the device has a pool with free rows."""
+    st = _STATUS_POOL.get(dev.index)
+    if st is None or st[1] >= _STATUS_ROWS:
+        _STATUS_POOL[dev.index] = [torch.zeros((_STATUS_ROWS, 3), dtype=torch.int32, device=dev), 0]
+
+
+def _status_row(dev):
+    st = _STATUS_POOL.get(dev.index)
+    if st is None or st[1] >= _STATUS_ROWS:
+        raise RuntimeError("gsrast: no zeroed status row for a rasterizer forward under graph capture: run the call once eagerly first "
+                           f"(more than {_STATUS_ROWS} forwards recorded since the last eager one)")
+    st[1] += 1
+    return st[0][st[1] - 1]
 
 
 def async_status(reset=False):
@@ -165,7 +187,10 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
                 hint = capacity_hint if capacity_hint is not None else _R_HINT.get(key)
     overflowed = False
     acap = getattr(_ASYNC, "cap", False)
-    if (acap is False) and torch.cuda.is_current_stream_capturing():
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing:
+        _status_pool(dev)
+    elif acap is False:
         acap = True
     if acap is not False and not cfg.debug:
         if acap is True:
@@ -175,7 +200,7 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
                 raise RuntimeError("gsrast: a sync-free forward needs a capacity: pass static_capacity(cap) or run the call once eagerly first")
             acap = int(h * 1.25) + 16384
         binning = _bytes(L.gsr_binning_bytes(variant, int(acap), W, H), dev)
-        status = torch.zeros((3,), dtype=torch.int32, device=dev)
+        status = _status_row(dev) if capturing else torch.zeros((3,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             check(L.gsr_forward_async(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(), ptr(img),
                                       img.numel(), ptr(radii), C.byref(o), ptr(status), s), "forward_async")

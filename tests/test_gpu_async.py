@@ -232,3 +232,51 @@ def test_forward_async_reports_a_prefiltered_violation_and_profile_enable_values
         rec = gsrast.profile_read()
         assert rec["preprocess"][1] >= 1 and rec["blend_fwd"][1] >= 1, (val, rec)
     L.gsr_profile_enable(0)
+
+
+def test_overflow_of_any_replay_stays_flagged_until_checked():
+    """A rasterizer forward recorded into a HIP graph keeps its status words OUTSIDE the graph (a zeroed row of a per-device pool, never cleared by
+    the library): a replay that overflows the recorded binning capacity is still flagged after later replays that fit, until the owner looks."""
+    import hiprun as hr
+    import diff_gaussian_rasterization as dgr
+    from gsrast import rasterize as rz
+    W, H, P = 320, 200, 6000
+    sc = scenes.make_scene("ewa", P, W, H, seed=12)
+    t = hr.to_dev(sc, "cuda")
+    rs = hr.settings("ewa", t)
+    leaves = {k: t[k].clone() for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations")}
+    m2 = torch.zeros(P, 3, device="cuda")
+
+    def fwd():
+        with torch.no_grad():
+            return dgr.GaussianRasterizer(rs)(means2D=m2, **leaves)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            ref_color = fwd()[0].clone()         # eager: seeds the capacity hint and the status pool
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    rz.async_status_reset()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fwd()
+    rows = list(rz._ASYNC_STATUS)
+    rz.async_status_reset()
+    assert len(rows) == 1
+    graph.replay(); torch.cuda.synchronize()
+    h = rows[0][0].cpu()
+    R = int(h[0])
+    assert R > 0 and int(h[1]) == 0 and torch.equal(out[0], ref_color)
+    keep = leaves["scales"].clone()
+    leaves["scales"].mul_(5.0)                    # ~25 x the footprint: far beyond the recorded capacity
+    graph.replay()
+    leaves["scales"].copy_(keep)
+    graph.replay(); torch.cuda.synchronize()
+    h = rows[0][0].cpu()
+    assert int(h[0]) == R and int(h[1]) == 1      # the last replay fitted; the overflow of the one before is still on record
+    assert torch.equal(out[0], ref_color)
+    rows[0][0].zero_()
+    graph.replay(); torch.cuda.synchronize()
+    assert int(rows[0][0].cpu()[1]) == 0
