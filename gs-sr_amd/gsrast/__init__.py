@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libgsrast_hip.so")   # override: experiments only
 
 EWA, SURFEL, PLANE = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp = C.c_void_p
 

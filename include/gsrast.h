@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 
 enum gsr_variant {
     GSR_EWA = 0,     /* diff_gaussian_rasterization : 3DGS EWA splats, RGB only                          */
