@@ -315,10 +315,17 @@ def parity_full_size(variant, sc, og, device, color_mode):
             out[k] = rep[k]
     out["maps_err_vs_f64"] = {k: {"hip_robust_max": rnd(v["robust_max"]), "f32_oracle_robust_max": rnd(v["oracle_robust_max"]),
                                   "hip_robust_px_beyond_tol": v["robust_px_beyond_tol"], "f32_oracle_robust_px_beyond_tol": v["oracle_robust_px_beyond_tol"],
-                                  "hip_fragile_px_beyond_tol": v["fragile_px_beyond_tol"], "f32_oracle_fragile_px_beyond_tol": v["oracle_fragile_px_beyond_tol"]}
+                                  "hip_fragile_px_beyond_tol": v["fragile_px_beyond_tol"], "f32_oracle_fragile_px_beyond_tol": v["oracle_fragile_px_beyond_tol"],
+                                  "f32_geometry_floor_robust_px_beyond_tol": v.get("floor_robust_px_beyond_tol"), "f32_geometry_floor_robust_max": rnd(v.get("floor_robust_max", 0.0)),
+                                  "hip_robust_px_beyond_tol_vs_floor_run": v.get("robust_px_beyond_tol_vs_floor"), "hip_robust_max_vs_floor_run": rnd(v.get("robust_max_vs_floor", 0.0))}
                               for k, v in rep.items() if isinstance(v, dict) and "robust_max" in v and k in ("color", "final_T", "others[0]", "others[2]", "others[6]", "all_map", "plane_depth")}
     out["grad_rel_l2_vs_f64"] = {k: {"hip": rnd(v["rel_l2"]), "f32_oracle": rnd(v["oracle_rel_l2"]), "hip_all_rows": rnd(v["rel_l2_all_rows"]),
-                                     "f32_oracle_all_rows": rnd(v["oracle_rel_l2_all_rows"])} for k, v in rep.items() if isinstance(v, dict) and "rel_l2" in v}
+                                     "f32_oracle_all_rows": rnd(v["oracle_rel_l2_all_rows"]),
+                                     # the float64 blend of the FLOAT32 per-gaussian state (tests/parity_truth.py "THE FLOOR"): what the reference's own float32
+                                     # preprocess costs any blend implementation, and how far the HIP blend is from exact arithmetic on that state
+                                     "f32_geometry_floor": rnd(v.get("floor_rel_l2", 0.0)), "hip_vs_floor_run": rnd(v.get("rel_l2_vs_floor", 0.0)),
+                                     "f32_oracle_vs_floor_run": rnd(v.get("oracle_rel_l2_vs_floor", 0.0))}
+                                 for k, v in rep.items() if isinstance(v, dict) and "rel_l2" in v}
     return out
 
 

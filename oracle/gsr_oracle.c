@@ -709,6 +709,12 @@ ref_state* ref_forward(int variant, const ref_inputs* in, real* out_color, int32
 #endif
     for (int i = 0; i < P; i++) preprocess_one(st, in, i, focal_x, focal_y);
     if (radii) memcpy(radii, st->radii, (size_t)P * 4);
+    /* float32-geometry runs (gsr_oracle.h ov_cov ...): blend what a float32 preprocess produced */
+    if (in->ov_cov) memcpy(st->cov3D, in->ov_cov, (size_t)P * tm * RS);
+    if (in->ov_conic_opacity) memcpy(st->conic_opacity, in->ov_conic_opacity, (size_t)P * 4 * RS);
+    if (in->ov_means2D) memcpy(st->means2D, in->ov_means2D, (size_t)P * 2 * RS);
+    if (in->ov_depths) memcpy(st->depths, in->ov_depths, (size_t)P * RS);
+    if (in->ov_rgb && !in->colors_precomp) memcpy(st->rgb, in->ov_rgb, (size_t)P * 3 * RS);
 
     if (in->ov_radii) {
         /* truth run: sorted instance list and tile ranges of the float32 run */

@@ -68,6 +68,14 @@ typedef struct ref_inputs {
     int32_t* gate_id;                /* [H*W] REF_GATE_* */
     int32_t* gate_splat;             /* [H*W] */
     real* splat_noise;               /* [P] or NULL: max over the splat's evaluated pairs of the relative float32 error bound of alpha */
+    /* "float32 geometry, exact blend" runs (the floor diagnostic of tests/parity_truth.py): the per-gaussian state the preprocess hands the blend
+       kernels -- what the reference keeps in its float32 geomBuffer -- is REPLACED by these arrays (values of a float32 run, widened) after the
+       preprocess, so that blend forward / backward are evaluated in `real` on exactly the numbers a float32 implementation blends.  NULL = keep own. */
+    const real* ov_cov;              /* [P,9] transMat (SURFEL) / [P,6] cov3D */
+    const real* ov_conic_opacity;    /* [P,4] conic + opacity (SURFEL: normal + opacity) */
+    const real* ov_means2D;          /* [P,2] */
+    const real* ov_depths;           /* [P] */
+    const real* ov_rgb;              /* [P,3] (used when colours come from SH) */
 } ref_inputs;
 
 enum { REF_GATE_NONE = 0, REF_GATE_POWER = 1,   /* power > 0 */

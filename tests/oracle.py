@@ -33,7 +33,8 @@ def _structs(ct):
                     ("shs", rp), ("colors_precomp", rp), ("opacities", rp), ("scales", rp), ("rotations", rp),
                     ("cov3D_precomp", rp), ("all_map", rp),
                     ("ov_radii", _i32p), ("ov_point_list", _u32p), ("ov_ranges", _u32p), ("ov_R", C.c_int32),
-                    ("gate_margin", rp), ("gate_id", _i32p), ("gate_splat", _i32p), ("splat_noise", rp)]
+                    ("gate_margin", rp), ("gate_id", _i32p), ("gate_splat", _i32p), ("splat_noise", rp),
+                    ("ov_cov", rp), ("ov_conic_opacity", rp), ("ov_means2D", rp), ("ov_depths", rp), ("ov_rgb", rp)]
 
     class RefOutGrads(C.Structure):
         _fields_ = [("dL_dcolor", rp), ("dL_dothers", rp), ("dL_dout_all_map", rp), ("dL_dplane_depth", rp)]
@@ -296,7 +297,10 @@ class Truth:
         gate    [H,W]  which decision is the closest one (GATE_NAMES), splat [H,W] the Gaussian it concerns
         splat_noise [P] max over a Gaussian's evaluated pairs of the relative float32 error bound of its alpha (conditioning of the splat)"""
 
-    def __init__(self, scene, variant, f32):
+    def __init__(self, scene, variant, f32, f32_geometry=False):
+        """f32_geometry: blend (forward and backward, in float64) the per-gaussian state of the FLOAT32 run `f32` -- transMat / conic, normal, opacity,
+        projected centre, depth, SH colour as a float32 preprocess leaves them in the geomBuffer -- instead of this run's own float64 values: the
+        distance of such a run from the plain truth is the error floor the reference's float32 preprocess imposes on ANY blend implementation."""
         if isinstance(variant, str):
             variant = VARIANT_ID[variant]
         L = lib64()
@@ -307,6 +311,11 @@ class Truth:
         self._ov = (np.ascontiguousarray(f32.radii, np.int32), np.ascontiguousarray(f32.point_list(), np.uint32), np.ascontiguousarray(f32.ranges(), np.uint32))
         ri.ov_radii = self._ov[0].ctypes.data_as(_i32p); ri.ov_point_list = self._ov[1].ctypes.data_as(_u32p)
         ri.ov_ranges = self._ov[2].ctypes.data_as(_u32p); ri.ov_R = int(self._ov[1].shape[0])
+        if f32_geometry:
+            gm = f32.geom()
+            self._ovg = {k: np.ascontiguousarray(gm[k], np.float64) for k in ("cov", "conic_opacity", "means2D", "depths", "rgb")}
+            ri.ov_cov = _p(self._ovg["cov"]); ri.ov_conic_opacity = _p(self._ovg["conic_opacity"]); ri.ov_means2D = _p(self._ovg["means2D"])
+            ri.ov_depths = _p(self._ovg["depths"]); ri.ov_rgb = _p(self._ovg["rgb"])
         self.margin = np.zeros((H, W), np.float64); self.gate = np.zeros((H, W), np.int32); self.splat = np.zeros((H, W), np.int32)
         self.splat_noise = np.zeros((P,), np.float64)
         ri.gate_margin = _p(self.margin); ri.gate_id = self.gate.ctypes.data_as(_i32p); ri.gate_splat = self.splat.ctypes.data_as(_i32p)

@@ -60,7 +60,7 @@ def _quat_to_rot(q):
 
 
 def make_scene(variant, P, W, H, fx=None, fy=None, seed=0, color_mode="precomp", sh_degree=3, pose=0,
-               sigma_px=4.0, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, normalize_quat=True):
+               sigma_px=4.0, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, normalize_quat=True, sh_M=16):
     """variant in {'ewa','surfel','plane'}.  Returns the kwargs dict the oracle/HIP wrappers consume.
 
     Distribution follows SURVEY.md §8d: z~U[1,20], x,y inside 1.1x the frustum, pixel sigma ~ LogNormal(ln sigma_px, 0.6),
@@ -94,7 +94,8 @@ def make_scene(variant, P, W, H, fx=None, fy=None, seed=0, color_mode="precomp",
               rotations=q.astype(np.float32), opacities=opac.astype(np.float32)[:, None],
               bg=np.asarray(bg, np.float32), scale_modifier=scale_modifier, sh_degree=0, render_geo=True)
     if color_mode == "sh":
-        M = 16
+        M = int(sh_M)                # 16 = what every reference model allocates ((max_sh_degree + 1)^2, base_gaussian.py); 1 / 4 / 9 = models
+        assert (sh_degree + 1) ** 2 <= M     # built with max_sh_degree 0 / 1 / 2 (the kernels take M = shs.size(1), rasterize_points.cu:66-70)
         shs = rng.normal(0, 0.1, (P, M, 3))
         shs[:, 0, :] = rng.uniform(-1, 1, (P, 3)) / 0.28209479177387814
         sc["shs"] = shs.astype(np.float32)

@@ -164,6 +164,99 @@ def test_forward_backward_parity(variant, cm, P, W, H, pose):
         _grad_close(gg[a], g[b])
 
 
+# (active degree, coefficients per gaussian).  M = 16 with degree 0 / 1 / 2 is the vanilla model at iterations 1 ... 3000 (base_gaussian.py:45,
+# vanilla_gaussian.py:440-442: every model allocates (max_sh_degree + 1)^2 = 16 coefficients and raises active_sh_degree every 1000 steps) and goes
+# through the LDS-staged SH16 kernels; M = 1 / 4 / 9 (a model built with max_sh_degree 0 / 1 / 2; M = shs.size(1), 3DGS/rasterize_points.cu:66-70)
+# takes the generic kernels (k_preprocess_* <false>, k_preprocess_bwd_* <false>), also with the degree below what M allows.
+SH_CASES = [(0, 16), (1, 16), (2, 16), (0, 1), (1, 4), (2, 9), (0, 4), (1, 9)]
+
+
+@pytest.mark.parametrize("deg,M", SH_CASES)
+@pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
+def test_sh_degrees_and_coefficient_counts(variant, deg, M):
+    """3DGS/forward.cu:20-71 (computeColorFromSH: bands up to the ACTIVE degree, +0.5, clamp at 0 with a per-channel mask), backward.cu:20-139 (dL_dsh
+    for the active bands only -- the rows above stay at the zeros the glue allocated --, the clamp mask zeroing a channel's gradient, and the
+    view-direction term added to dL_dmeans3D from degree 1 on).  SURFEL / PLANE carry copies of both functions."""
+    hr = _hiprun()
+    P, W, H = 3000, 208, 128
+    sc = scenes.make_scene(variant, P, W, H, seed=20 + deg, color_mode="sh", sh_degree=deg, sh_M=M, bg=(0.1, 0.0, 0.3), pose=deg % 2)
+    assert sc["shs"].shape == (P, M, 3) and sc["sh_degree"] == deg
+    sc["shs"][:, 1:] *= 8.0                                           # strong view dependence: the direction term of dL_dmeans3D is 1e-2-class, not 1e-4
+    og = scenes.random_out_grads(variant, W, H, seed=20 + deg, scale=1.0)
+    # every output and gradient (dL_dsh included) against the float64 truth; the integer stages and the instance list against the float32 oracle
+    rep = _check_against_truth(hr, variant, "sh", sc, og)
+    with oracle.Forward(sc, variant) as f:
+        g = f.backward(**og)
+        vis = f.radii > 0
+    gg = rep["hip_grads"]
+    used = (deg + 1) ** 2
+    dsh = gg["dL_dshs"]
+    assert dsh.shape == (P, M, 3)
+    assert not dsh[:, used:].any()                                    # exact zeros above the active degree (and nothing written past them)
+    assert not dsh[~vis].any()                                        # culled gaussians: the rows the reference never touches
+    assert np.abs(dsh[vis][:, :used]).max() > 0
+    # clamp mask: a channel whose colour was clamped at 0 receives no gradient in ANY band -- same (gaussian, channel) set as the oracle's
+    dead_hip = ~dsh[vis][:, :used].any(axis=1)
+    dead_ref = ~g["dL_dsh"][vis][:, :used].any(axis=1)
+    assert dead_ref.any() and not dead_ref.all()                      # the scene exercises both sides of the clamp
+    assert (dead_hip != dead_ref).mean() < 2e-3                       # (a channel can also be dead because no pixel sent it a gradient: same on both sides up to gate flips)
+    if deg > 0:
+        # the view-direction term exists from degree 1 on: the same gaussians with their (clamped) colours handed over as colors_precomp get
+        # the same image and a DIFFERENT dL_dmeans3D; the difference is the term, and it must match the oracle's difference
+        with oracle.Forward(sc, variant) as f:
+            rgb = f.geom()["rgb"].copy()
+        sc2 = {k: v for k, v in sc.items() if k != "shs"}
+        sc2["colors_precomp"] = rgb; sc2["sh_degree"] = 0
+        with oracle.Forward(sc2, variant) as f2:
+            g2 = f2.backward(**og)
+        res2 = hr.run(variant, sc2, og)
+        _img_close(res2["color"], rep["hip_color"], tol=2e-6)
+        term_hip = gg["dL_dmeans3D"].astype(np.float64) - res2["grads"]["dL_dmeans3D"]
+        term_ref = g["dL_dmeans3D"].astype(np.float64) - g2["dL_dmeans3D"]
+        gn = np.linalg.norm(g["dL_dmeans3D"])
+        assert np.linalg.norm(term_ref) > 1e-3 * gn
+        # both runs of a side share the blend, so the difference IS the term (+ the summation-order noise of two float32 gradients, 1e-5-class of |g|)
+        err = np.linalg.norm(term_hip - term_ref)
+        assert err <= 2 * GRAD_TOL * np.linalg.norm(term_ref) + 2e-5 * gn, (err, np.linalg.norm(term_ref), gn)
+
+
+@pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
+def test_sh16_coefficients_at_an_unaligned_address_take_the_generic_kernels(variant):
+    """The SH16 kernels need 16-byte aligned rows (gsr_preprocess.hip: sh16 = M == 16 && aligned); a (P,16,3) VIEW that starts 4 bytes into its
+    storage must give bit-identical colours and the same dL_dsh through the generic kernels."""
+    hr = _hiprun()
+    P, W, H = 2000, 160, 112
+    sc = scenes.make_scene(variant, P, W, H, seed=31, color_mode="sh", sh_degree=3)
+    og = scenes.random_out_grads(variant, W, H, seed=31, scale=1.0)
+    t = hr.to_dev(sc)
+    rs = hr.settings(variant, t)
+    gcol = torch.from_numpy(og["dL_dcolor"]).cuda()
+    mod = {"ewa": hr.dgr, "surfel": hr.dsr, "plane": hr.dpr}[variant]
+
+    def render(shs):
+        kw = dict(means3D=t["means3D"], means2D=torch.zeros((P, 3), device="cuda"), opacities=t["opacities"], shs=shs, colors_precomp=None,
+                  scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+        if variant == "plane":
+            kw.update(means2D_abs=torch.zeros((P, 3), device="cuda"), all_map=t["all_map"])
+        out = mod.GaussianRasterizer(rs)(**kw)
+        (out[0] * gcol).sum().backward()
+        return out[0].detach().clone(), out[1].clone()
+
+    leaf = t["shs"].clone().requires_grad_(True)
+    c0, r0 = render(leaf)
+    store = torch.zeros(P * 48 + 1, dtype=torch.float32, device="cuda")
+    store[1:] = t["shs"].reshape(-1)
+    store.requires_grad_(True)
+    un = store[1:].view(P, 16, 3)
+    assert un.data_ptr() % 16 == 4 and un.is_contiguous()
+    c1, r1 = render(un)
+    assert torch.equal(c0, c1) and torch.equal(r0, r1)
+    # dL_dsh is a function of dL_dcolors, which the blend backward sums with float atomics: equal up to the summation order of two launches
+    ga, gb = store.grad[1:].view(P, 16, 3), leaf.grad
+    assert store.grad[0] == 0 and torch.equal(ga == 0, gb == 0)
+    assert torch.linalg.norm(ga - gb) <= 1e-5 * torch.linalg.norm(gb)
+
+
 @pytest.mark.parametrize("variant", ["ewa", "surfel", "plane"])
 @pytest.mark.parametrize("seed,W,H,fx,fy,sigma,bg", [
     (101, 400, 225, 333.0, 333.0, 4.0, (0.0, 0.0, 0.0)),      # the loader's 1600x900 cap, scaled
@@ -426,6 +519,8 @@ FULL_CASES = [
     ("surfel", "precomp", 0, 0), ("surfel", "precomp", 1, 0), ("surfel", "precomp", 2, 1), ("surfel", "sh", 1, 1),
     ("ewa", "precomp", 0, 0), ("ewa", "sh", 1, 0), ("ewa", "precomp", 2, 1), ("ewa", "sh", 0, 1),
     ("plane", "precomp", 0, 0), ("plane", "precomp", 1, 1), ("plane", "sh", 2, 0),
+    # "sh:d" = (P,16,3) coefficients with active degree d < 3: the vanilla model before iteration 3000 (vanilla_gaussian.py:440-442)
+    ("ewa", "sh:0", 3, 0), ("surfel", "sh:1", 3, 1), ("plane", "sh:2", 3, 1),
 ]
 
 
@@ -452,6 +547,7 @@ def _check_against_truth(hr, variant, cm, sc, og):
     cand["n_contrib"] = ints["view"]["n_contrib"]                             # positions in the oracle's list
     rep = pt.check_case(variant, cm, cand, f32, fma, truth)
     rep["tile_instances"] = {k: v for k, v in ints["view"].items() if k not in ("keep", "n_contrib")}
+    rep["hip_grads"] = cand["grads"]; rep["hip_color"] = cand["color"]
     return rep
 
 
@@ -461,10 +557,14 @@ def test_full_size_oracle_parity(variant, cm, seed, pose):
     compared with a float64 evaluation of the same computation, see _check_against_truth."""
     hr = _hiprun()
     P, W, H = 300000, 1920, 1080
-    sc = scenes.make_scene(variant, P, W, H, seed=seed, color_mode=cm, pose=pose, bg=(0.1, 0.3, 0.2) if seed else (0.0, 0.0, 0.0))
+    cm, _, deg = cm.partition(":")
+    sc = scenes.make_scene(variant, P, W, H, seed=seed, color_mode=cm, pose=pose, bg=(0.1, 0.3, 0.2) if seed else (0.0, 0.0, 0.0),
+                           sh_degree=int(deg or 3))
     og = scenes.random_out_grads(variant, W, H, seed=seed)           # SURVEY 8d: N(0,1)/N
     rep = _check_against_truth(hr, variant, cm, sc, og)
     assert rep["robust_pixel_fraction"] > 0.95
+    if deg:
+        assert not rep["hip_grads"]["dL_dshs"][:, (int(deg) + 1) ** 2:].any()
 
 
 @pytest.mark.parametrize("variant,cm,P,W,H,pose", CASES)

@@ -68,3 +68,35 @@ def test_criterion_rejects_defects(case, what):
         c["grads"]["dL_dopacity"] = c["grads"]["dL_dopacity"] * 0.97
     with pytest.raises(AssertionError):
         pt.check_case(variant, "precomp", c, f32, fma, truth)
+
+
+def test_floor_run_is_the_exact_blend_of_the_float32_geometry(case):
+    """truth["floor"] (oracle.Truth(f32_geometry=True)): float64 blend of the float32 run's per-gaussian state.  It is a different computation from the
+    truth (its inputs were rounded), it is what a perfect float32-state blend would return -- so the criterion accepts it with zero distance from itself --
+    and for EWA / PLANE, whose blend inputs are well conditioned, it lies within float32 accuracy of the truth."""
+    variant, f32, fma, truth, ints = case
+    flo = truth["floor"]
+    d = pt._rel(flo["grads"]["dL_dmeans3D"], truth["grads"]["dL_dmeans3D"])
+    assert 0.0 < d < (2e-2 if variant == "surfel" else 1e-3)
+    robust = truth["margin"] > 1.0
+    rows = pt.robust_rows(truth["splat"], ~robust, d and truth["grads"]["dL_dmeans3D"].shape[0])
+    for k in ("dL_dmeans3D", "dL_drotations", "dL_dopacity"):
+        rep = {}
+        try:
+            pt.check_grad(k, flo["grads"][k], [f32["grads"][k], fma["grads"][k]], truth["grads"][k], rows, report=rep, floor=flo["grads"][k])
+        except AssertionError as e:      # (its gate decisions on the FRAGILE rows may legitimately differ from the float32 oracle's: only that bar may trip)
+            assert "flipping splats" in str(e)
+        assert rep[k]["rel_l2_vs_floor"] == 0.0 and rep[k]["floor_rel_l2"] == rep[k]["rel_l2"]
+    rep = pt.check_map("color", flo["color"], [f32["color"], fma["color"]], truth["color"], robust, floor=flo["color"])
+    assert rep["robust_px_beyond_tol_vs_floor"] == 0 and rep["floor_robust_px_beyond_tol"] == rep["robust_px_beyond_tol"]
+
+
+def test_criterion_rejects_a_blend_error_above_the_nominal_tolerance_even_below_the_floor(case):
+    """The bar against the floor run has no relative term: a 0.3 % error in a surfel's geometric gradient is rejected although the float32 floor of that
+    tensor (and the unfused float32 oracle's own error) may be larger."""
+    variant, f32, fma, truth, ints = case
+    flo = truth["floor"]
+    rows = pt.robust_rows(truth["splat"], truth["margin"] <= 1.0, flo["grads"]["dL_drotations"].shape[0])
+    with pytest.raises(AssertionError, match="float32.geometry"):
+        pt.check_grad("dL_drotations", flo["grads"]["dL_drotations"] * 1.003, [f32["grads"]["dL_drotations"], fma["grads"]["dL_drotations"]],
+                      truth["grads"]["dL_drotations"], rows, floor=flo["grads"]["dL_drotations"])

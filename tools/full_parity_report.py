@@ -18,8 +18,12 @@ from test_gpu_parity import FULL_CASES, _hip_outputs      # noqa: E402
 def compact(v):
     if isinstance(v, dict):
         return {k: compact(x) for k, x in v.items()}
-    if isinstance(v, float):
-        return float(f"{v:.4g}")
+    if isinstance(v, (float, np.floating)):
+        return float(f"{float(v):.4g}")
+    if isinstance(v, np.integer):
+        return int(v)
+    if isinstance(v, np.bool_):
+        return bool(v)
     return v
 
 
@@ -27,18 +31,21 @@ def main():
     P, W, H = 300000, 1920, 1080
     cases = FULL_CASES if len(sys.argv) < 2 else [c for c in FULL_CASES if c[0] in sys.argv[1:]]
     for variant, cm, seed, pose in cases:
-        sc = scenes.make_scene(variant, P, W, H, seed=seed, color_mode=cm, pose=pose, bg=(0.1, 0.3, 0.2) if seed else (0.0, 0.0, 0.0))
+        cm, _, deg = cm.partition(":")          # "sh:d" = (P,16,3) coefficients at active degree d
+        sc = scenes.make_scene(variant, P, W, H, seed=seed, color_mode=cm, pose=pose, bg=(0.1, 0.3, 0.2) if seed else (0.0, 0.0, 0.0),
+                               sh_degree=int(deg or 3))
         og = scenes.random_out_grads(variant, W, H, seed=seed)
-        f32, fma, truth, ints = pt.run_oracles(sc, variant, og)
         st, cand = _hip_outputs(hiprun, variant, sc, og)
+        f32, fma, truth, ints = pt.run_oracles(sc, variant, og, hip_state=st)      # incl. the filtered instance list against the oracle's (tests/tile_cull.py)
+        cand["n_contrib"] = ints["view"]["n_contrib"]                              # positions in the oracle's list
         rep, verdict = {}, "pass"
         try:
             pt.check_case(variant, cm, cand, f32, fma, truth, rep)
         except AssertionError as e:
             verdict = "FAIL: " + str(e)
-        out = dict(case=dict(variant=variant, color_mode=cm, seed=seed, pose=pose, P=P, W=W, H=H, R=int(st["R"])), verdict=verdict,
-                   integer_stages_bit_exact=bool(st["R"] == ints["R"] and np.array_equal(st["radii"], ints["radii"]) and
-                                                 np.array_equal(st["tiles_touched"], ints["tiles_touched"]) and np.array_equal(st["point_list"], ints["point_list"])),
+        out = dict(case=dict(variant=variant, color_mode=cm, sh_degree=int(deg or 3) if cm == "sh" else None, seed=seed, pose=pose, P=P, W=W, H=H, R=int(st["R"])), verdict=verdict,
+                   radii_bit_exact=bool(np.array_equal(st["radii"], ints["radii"])),
+                   tile_instances=compact({k: v for k, v in ints["view"].items() if k not in ("keep", "n_contrib")}),
                    report=compact(rep))
         print(json.dumps(out), flush=True)
 
