@@ -59,8 +59,15 @@ template <int V> struct SpOcc { static constexpr int WPE = (V == GSR_EWA) ? SP_W
 template <int V> struct SpTraits;
 // NACC: gradient components per splat, TS: floats per table row, NREG: per-lane register accumulators of a load (SURFEL: the nine transMat components
 // are accumulated as three moments of dL/dp over the load's 16 pixels plus three depth terms and turned into dL/dTu, dL/dTv, dL/dTw once per load)
+// PLANE's table row is exactly its 16 components = 64 bytes, so the 16 lanes of a DPP row (16 different table rows, same column) meet in two 8-byte bank
+// pairs: 36 % of the kernel's LDS cycles are bank conflicts (profiles/r04_pmc_summary.json).  Both fixes were built and measured in round 5 and BOTH ARE
+// SLOWER (EXPERIMENTS.md (71)): 72-byte rows (-DSP_TS_PLANE=18, with the 84 rows that still fit five workgroups per CU) 0.291 ms against 0.278, an XOR
+// swizzle of the float2 slots (16 address instructions per load) 0.2845 against 0.278 -- the kernel waits for its VALU, not for the LDS.
+#ifndef SP_TS_PLANE
+#define SP_TS_PLANE 16
+#endif
 template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10, NREG = 10, NPIN = 9; };
-template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = 16, NREG = 16, NPIN = 16; };
+template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = SP_TS_PLANE, NREG = 16, NPIN = 16; };
 template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 18, NREG = 21, NPIN = 21; };
 
 // inclusive scans along the 16 lanes of each DPP row, lane 0 first, in place.  A lane whose source would lie outside the row is
@@ -128,6 +135,24 @@ template <int I> __device__ __forceinline__ float bc_fmac(float acc, float c, fl
 template <int I> __device__ __forceinline__ float bc_fresh(float x)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + I, 0xf, 0xf, true));
+}
+
+// New carry of pixel I: lane I of every row <- lane 15's value, every other lane keeps its own.  One v_cndmask_b32_dpp per carry (D = vcc ? src1 :
+// dpp(src0), vcc = the constant mask "lane != I of its row", written by two scalar moves) instead of a DPP move and a v_cndmask each -- two VALU
+// instructions less per pixel step in every variant.  The scalar moves and the s_nop are the wait states between the VALU write of a / b and their DPP read.
+template <int I> __device__ __forceinline__ void carry_put(float& Tc, float& Sc, float a, float b)
+{
+#ifndef SP_CARRY_TWO_STEP
+    constexpr int M = (int)~(0x00010001u << I);
+    asm volatile("s_mov_b32 vcc_lo, %4\n\ts_mov_b32 vcc_hi, %4\n\ts_nop 1\n\t"
+                 "v_cndmask_b32_dpp %0, %2, %0, vcc row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_dpp %1, %3, %1, vcc row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "+v"(Tc), "+v"(Sc) : "v"(a), "v"(b), "n"(M) : "vcc");
+#else
+    const float nT = bc_fresh<15>(a), nS = bc_fresh<15>(b);
+    const bool mine = ((int)(lane_id() & 15u) == I);
+    Tc = mine ? nT : Tc; Sc = mine ? nS : Sc;
+#endif
 }
 
 // Opaque in-place use of the accumulators at the end of every pixel step.  The accumulations are pure arithmetic whose only reader is
@@ -218,7 +243,7 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
             dx = q0.x - (K.rowx + (float)DX); dy = q0.y - (K.rowy + (float)DY);
             power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
         }
-        const float G = __expf(power);
+        const float G = __expf(power);      // (folding log2(e) into the conic once per load: 0.2687 vs 0.2690 ms and two more spills, EXPERIMENTS.md (72))
         const float alpha = fminf(0.99f, q1.y * G);
         const bool ok = valid & (idx0 < last) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
         const float al = ok ? alpha : 0.0f, Gm = ok ? G : 0.0f;
@@ -242,11 +267,7 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float Scb = bc_fresh<I>(K.Sc);
         const float Sfx = Scb + (si - wu);
         const float dL_dalpha = ok ? (u * Tj - Sfx * r1a) : 0.0f;
-        {   // new carry of pixel I = the state in front of lane 15's splat
-            const float nT = bc_fresh<15>(Tj), nS = bc_fresh<15>(Scb + si);
-            const bool mine = (j == I);
-            K.Tc = mine ? nT : K.Tc; K.Sc = mine ? nS : K.Sc;
-        }
+        carry_put<I>(K.Tc, K.Sc, Tj, Scb + si);      // new carry of pixel I = the state in front of lane 15's splat
         // Gradients of this pair (3DGS backward.cu:520-545) with gG = G dL_dalpha and h = -opacity gG / 2 = -G dL_dG / 2:
         //   opacity += gG;  conic (xx, xy, yy) += h (dx^2, dx dy, dy^2);  mean2D.x += 2 h (A dx + B dy) W/2,  mean2D.y += 2 h (C dy + B dx) H/2.
         // EWA accumulates the two moments sum h dx, sum h dy and applies A, B, C and the NDC factors once per load (end of the load loop); PLANE needs
@@ -290,8 +311,7 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float rho = fminf(rho3d, rho2d);
         const bool b3 = rho3d <= rho2d;
         const float c_d = b3 ? S.D * rpz : S.Tw2;
-        const float power = -0.5f * rho;
-        const float G = __expf(power);
+        const float G = __builtin_amdgcn_exp2f(rho * (-0.5f * 1.4426950408889634f));      // exp(-rho / 2): one multiply in front of v_exp_f32 instead of two
         const float alpha = fminf(0.99f, opa * G);
         // the reference's `power > 0` gate (forward.cu:389) cannot fire here: rho = min of two sums of squares, power = -rho / 2 <= 0 (NaN passes it as well)
         const bool ok = valid & (idx0 < last) & !(ppz == 0.0f) & !(c_d < NEAR_N) & !(alpha < 1.0f / 255.0f);      // '&': no short-circuit control flow, EXEC stays full for the DPP reads
@@ -317,11 +337,7 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float Scb = bc_fresh<I>(K.Sc);
         const float Sfx = Scb + (si - wu);
         const float dL_dalpha = ok ? (u * Tj - Sfx * r1a) : 0.0f;
-        {
-            const float nT = bc_fresh<15>(Tj), nS = bc_fresh<15>(Scb + si);
-            const bool mine = (j == I);
-            K.Tc = mine ? nT : K.Tc; K.Sc = mine ? nS : K.Sc;
-        }
+        carry_put<I>(K.Tc, K.Sc, Tj, Scb + si);      // new carry of pixel I = the state in front of lane 15's splat
         // (skipping the three instructions below when no pixel of the wave has a median-depth gradient was tried: a wave-uniform branch here splits
         // the step's basic block and costs the taken side 13 us, 0.485 vs 0.472 ms; two copies of the 16 steps spill 29 VGPRs, 0.540 ms)
         const uint32_t med = bc_movu<I>(K.med);
@@ -501,10 +517,17 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             const uint32_t id = s_ids[e];
             float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = make_float4(0.f, -1.f, 0.f, 0.f);
             if (v) { ca = p.cull[2 * (size_t)id]; cb = p.cull[2 * (size_t)id + 1]; }
+#ifndef SP_CULL_PER_BLOCK
+            const uint32_t hit4 = cull_hit_quad4<V>(ca, cb, (float)qx, (float)qy);      // the four blocks share their bounding lines (gsr_blend_common.h)
+#endif
 #pragma unroll
             for (int k = 0; k < 4; k++) {
+#ifndef SP_CULL_PER_BLOCK
+                const bool hit = v && (cbase + e < mlast_b[k]) && ((hit4 >> k) & 1u);
+#else
                 const bool hit = v && (cbase + e < mlast_b[k]) &&
                                  cull_hit_rec<V>(ca, cb, (float)(qx + (k & 1) * 4), (float)(qy + (k >> 1) * 4), 3.f);
+#endif
                 const uint64_t bm = __ballot(hit);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
                 if (hit) s_queue[(wave * 4 + k) * SP_CH + cnt[k] + rank] = (uint8_t)e;
@@ -590,7 +613,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
                 if (b == rr && valid) {
                     float2* t = mytab + cid * (TS / 2);
 #pragma unroll
-                    for (int c = 0; c < TS / 2; c++) { float2 v = t[c]; v.x += acc[2 * c]; v.y += acc[2 * c + 1]; t[c] = v; }
+                    for (int c = 0; c < (NACC + 1) / 2; c++) { float2 v = t[c]; v.x += acc[2 * c]; v.y += acc[2 * c + 1]; t[c] = v; }      // (a row may be padded: TS >= NACC)
                 }
             }
         }
