@@ -13,11 +13,21 @@
 // The voxel rule is the one k_tsdf_dense (gsr_extra.hip) uses, instruction for instruction, so a sparse volume equals the dense
 // volume on every allocated unit bit for bit (tested); the CPU checker used by the tests restates the same algorithm in plain C.
 //
-// MI355X shape: three launches per frame -- (1) one thread per sampled pixel inserts <= 8 unit keys into an open-addressing table
-// (64-bit atomicCAS; the winner takes the next pool slot), (2) the same pixels stamp their units for this frame and append the newly
-// stamped ones to a work list, (3) one 256-thread workgroup per listed unit streams its 16^3 voxels (z fastest: 4-/4-/12-byte
-// coalesced read-modify-write, 80 KB per unit).  HBM-bound: 40 B per touched voxel, the pool is sized for 288 GB parts.
+// MI355X shape: four launches per frame -- (0) depth + colour planes -> one (r, g, b, depth) texel per pixel, colours put on the 0..255 scale on the way
+// (k_ts_texels: the voxel pass then needs ONE 16-byte gather per voxel, and the wrapper's four torch launches for the uint8 conversion are gone),
+// (1) one thread per sampled pixel inserts <= 8 unit keys into an open-addressing table (64-bit atomicCAS; the winner takes the next pool slot),
+// (2) the same pixels stamp their units for this frame and append the newly stamped ones to a work list (a unit whose stamp was still 0 has never
+// been written: it is listed as FRESH, so the pools need no zero-fill -- 80 KB per unit of capacity -- and a fresh unit is written without being read),
+// (3) a persistent grid walks the list (its length is read on the device: the launch does not wait for the host): a workgroup takes a unit, thread =
+// four groups of four consecutive z (a wave = 64 consecutive 16-byte groups = 1 KB per load / store instruction in each of the five planes tsdf, weight,
+// r, g, b -- the colour of a unit is stored as three planes since ABI 7), two groups per pass: 8 projections and texel gathers first, then -- only for a
+// group with an update -- its five 16-byte loads, the running averages and five 16-byte stores.  (First round-5 form: thread = a z-column, 64 bytes per
+// lane: contiguous per thread but 64 lines per wave instruction -- 2.11 ms on the config-5 tail against round 4's 1.73.)
+// Round 4's form (thread = every 256th voxel, 16 dependent load -> test -> read-modify-write rounds per thread, four 4-byte gathers per voxel, one
+// workgroup per unit behind a host read of the list length) is kept as k_ts_integrate for A/B (GSR_TSDF_V1=1).
+// HBM-bound: 40 B per updated voxel; the pool is sized for 288 GB parts.
 #include "gsr_common.h"
+#include <algorithm>
 
 #define TS_RES 16
 #define TS_VOX (TS_RES * TS_RES * TS_RES)
@@ -30,7 +40,7 @@ struct SparseTsdf {
     uint32_t* stamp;               // [cap_blocks] last frame that touched the unit
     int32_t* list;                 // [cap_blocks] units touched by the current frame
     int32_t* counters;             // [0] = units allocated, [1] = units in `list`, [2] = pool/hash overflow flag
-    float* tsdf; float* weight; float* color;      // pools: [cap_blocks][4096], [..][4096], [..][4096][3]
+    float* tsdf; float* weight; float* color;      // pools: [cap_blocks][4096], [..][4096], [..][3][4096] (colour PLANES per unit since ABI 7)
     uint32_t cap_hash_log2, cap_blocks;
 };
 
@@ -112,6 +122,9 @@ __global__ void __launch_bounds__(256) k_ts_touch_insert(SparseTsdf v, TouchPara
         for (int y = lo[1]; y <= hi[1]; y++)
             for (int z = lo[2]; z <= hi[2]; z++) (void)ts_insert(v, x, y, z);
 }
+// (Round 5 also tried the <= 8 units of a sample as one batch -- eight independent first-probe loads, then the slots, then the stamps, then the exchanges --
+// instead of this chain of ~4 dependent random loads per unit: 93 us against 45 for the smooth frame.  The chain is what spreads the ~150 samples of a unit
+// in time so that the plain load below sees the first one's stamp; batched, they all read the old stamp and all exchange.)
 __global__ void __launch_bounds__(256) k_ts_touch_stamp(SparseTsdf v, TouchParams t, const float* __restrict__ depth, int n, uint32_t frame)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,7 +137,11 @@ __global__ void __launch_bounds__(256) k_ts_touch_stamp(SparseTsdf v, TouchParam
             for (int z = lo[2]; z <= hi[2]; z++) {
                 const int idx = ts_find(v, x, y, z);
                 if (idx < 0) continue;
-                if (atomicExch(&v.stamp[idx], frame) != frame) v.list[atomicAdd(&v.counters[1], 1)] = idx;
+                // ~150 sampled pixels stamp the same unit: the plain load lets all but the first few skip the same-address atomic (0.15 us each, serialised:
+                // round 4's kernel took 83 us for 3569 units); the exchange still decides who lists the unit.  Old stamp 0 = never written: listed as fresh (~idx).
+                if (__hip_atomic_load(&v.stamp[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == frame) continue;
+                const uint32_t old = atomicExch(&v.stamp[idx], frame);
+                if (old != frame) v.list[atomicAdd(&v.counters[1], 1)] = old ? idx : ~idx;
             }
 }
 
@@ -136,7 +153,14 @@ struct IntParams {
 // the voxel rule of k_tsdf_dense (gsr_extra.hip), same operations in the same order
 __global__ void __launch_bounds__(256) k_ts_integrate(SparseTsdf v, IntParams p, const float* __restrict__ depth, const float* __restrict__ rgb)
 {
-    const int b = v.list[blockIdx.x];
+    const int e = v.list[blockIdx.x];
+    const bool fresh = e < 0;
+    const int b = fresh ? ~e : e;
+    if (fresh) {      // never written: the pools are not zero-filled any more
+        for (int i = threadIdx.x; i < TS_VOX; i += 256) { v.tsdf[(size_t)b * TS_VOX + i] = 0.f; v.weight[(size_t)b * TS_VOX + i] = 0.f; }
+        for (int i = threadIdx.x; i < 3 * TS_VOX; i += 256) v.color[(size_t)b * TS_VOX * 3 + i] = 0.f;
+        __syncthreads();
+    }
     const float ox = (float)v.coord[3 * b] * p.unit_len, oy = (float)v.coord[3 * b + 1] * p.unit_len, oz = (float)v.coord[3 * b + 2] * p.unit_len;
     float* tsdf = v.tsdf + (size_t)b * TS_VOX; float* weight = v.weight + (size_t)b * TS_VOX; float* color = v.color + (size_t)b * TS_VOX * 3;
     const size_t HW = (size_t)p.W * p.H;
@@ -160,9 +184,140 @@ __global__ void __launch_bounds__(256) k_ts_integrate(SparseTsdf v, IntParams p,
         const float w = weight[i], wp = w + 1.0f, rwp = __builtin_amdgcn_rcpf(wp);
         tsdf[i] = (tsdf[i] * w + t) * rwp;
 #pragma unroll
-        for (int c = 0; c < 3; c++) color[3 * i + c] = (color[3 * i + c] * w + rgb[c * HW + (size_t)vv * p.W + u]) * rwp;
+        for (int c = 0; c < 3; c++) color[c * TS_VOX + i] = (color[c * TS_VOX + i] * w + rgb[c * HW + (size_t)vv * p.W + u]) * rwp;
         weight[i] = wp;
     }
+}
+
+
+// ---- (r, g, b, depth) texels.  quant 0: colours as given; 1: clamp to [0,1], x 255 (the scale the volume stores); 2: additionally truncated to an integer, the
+// uint8 round trip of mesh_utils.py:170 (`(rgb * 255).astype(np.uint8)`, here on the clamped value like the wrapper's torch chain of rounds 2-4)
+__global__ void __launch_bounds__(256) k_ts_texels(const float* __restrict__ depth, const float* __restrict__ rgb, float4* __restrict__ tex, int N, int quant)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float c[3] = { rgb[i], rgb[(size_t)N + i], rgb[2 * (size_t)N + i] };
+    if (quant) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            c[k] = fminf(fmaxf(c[k], 0.0f), 1.0f) * 255.0f;
+            if (quant == 2) c[k] = floorf(c[k]);
+        }
+    }
+    tex[i] = make_float4(c[0], c[1], c[2], depth[i]);
+}
+
+// the voxel rule of k_tsdf_dense (gsr_extra.hip), the same operations in the same order per voxel; see the file header for the shape.
+// A unit's 4096 voxels are 1024 groups of four consecutive z; thread t takes groups t, t + 256, t + 512, t + 768 (x = (t >> 6) + 4 r): the 64 lanes of a
+// wave read and write 64 consecutive 16-byte groups = 1 KB per instruction in each of the five planes (tsdf, weight, three colour planes).
+#define TS_GPT 2      // groups per pass: 8 voxels' projections and texel gathers are in flight before anything of the volume is read
+#ifndef TS_WPE
+#define TS_WPE 3
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TS_WPE, TS_WPE))) k_ts_integrate_col(SparseTsdf v, IntParams p, const float4* __restrict__ tex, int n_fixed)
+{
+    const int n = n_fixed >= 0 ? n_fixed : v.counters[1];
+    if (v.counters[2] | v.counters[3]) {
+        // the touch pass ran out of pool slots / key range: nothing of this frame is integrated (the host grows the pool and runs the frame again, or raises).
+        // Units stamped as fresh by this frame go back to "never written".
+        for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) { const int e = v.list[k]; if (e < 0) v.stamp[~e] = 0u; }
+        return;
+    }
+    const int iy = (threadIdx.x >> 2) & 15, iz0 = (threadIdx.x & 3) << 2, ixb = threadIdx.x >> 6;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int e = v.list[k];
+        const bool fresh = e < 0;
+        const int b = fresh ? ~e : e;
+        const float ox = (float)v.coord[3 * b] * p.unit_len, oy = (float)v.coord[3 * b + 1] * p.unit_len, oz = (float)v.coord[3 * b + 2] * p.unit_len;
+        const float y = oy + p.vl * ((float)iy + 0.5f);
+        float4* W4 = reinterpret_cast<float4*>(v.weight + (size_t)b * TS_VOX);
+        float4* S4 = reinterpret_cast<float4*>(v.tsdf + (size_t)b * TS_VOX);
+        float4* C4 = reinterpret_cast<float4*>(v.color + (size_t)b * TS_VOX * 3);      // three planes of 4096 floats: [channel][voxel]
+#pragma unroll
+        for (int pass = 0; pass < 4 / TS_GPT; pass++) {
+            float4 t[4 * TS_GPT];
+            float zcs[4 * TS_GPT];
+            uint32_t uv[4 * TS_GPT];
+            uint32_t cand = 0;
+#pragma unroll
+            for (int q = 0; q < TS_GPT; q++) {
+                const int ix = ixb + 4 * (pass * TS_GPT + q);
+                const float x = ox + p.vl * ((float)ix + 0.5f);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int s_ = 4 * q + j;
+                    const float z = oz + p.vl * ((float)(iz0 + j) + 0.5f);
+                    const float xc = p.E[0] * x + p.E[1] * y + p.E[2] * z + p.E[3];
+                    const float yc = p.E[4] * x + p.E[5] * y + p.E[6] * z + p.E[7];
+                    const float zc = p.E[8] * x + p.E[9] * y + p.E[10] * z + p.E[11];
+                    zcs[s_] = zc; uv[s_] = 0u; t[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!(zc > 0.f)) continue;
+                    const float rz = __builtin_amdgcn_rcpf(zc);
+                    const float uf = xc * p.fx * rz + p.cx + 0.5f, vf = yc * p.fy * rz + p.cy + 0.5f;
+                    if (!(uf >= 0.f && uf < (float)p.W && vf >= 0.f && vf < (float)p.H)) continue;
+                    const int u = (int)uf, vv = (int)vf;
+                    uv[s_] = (uint32_t)u | ((uint32_t)vv << 16);
+                    cand |= 1u << s_;
+                    t[s_] = tex[(size_t)vv * p.W + u];
+                }
+            }
+            uint32_t m = 0;
+            float tv[4 * TS_GPT];
+#pragma unroll
+            for (int s_ = 0; s_ < 4 * TS_GPT; s_++) {
+                tv[s_] = 0.f;
+                if (!((cand >> s_) & 1u)) continue;
+                const float d = t[s_].w;
+                if (!(d > 0.f) || d > p.dtrunc) continue;
+                const float rx = ((float)(uv[s_] & 0xFFFFu) - p.cx) * p.rfx, ry = ((float)(uv[s_] >> 16) - p.cy) * p.rfy;
+                const float sdf = (d - zcs[s_]) * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + 1.0f);
+                if (!(sdf > -p.trunc)) continue;
+                tv[s_] = fminf(1.0f, sdf * p.rtrunc);
+                m |= 1u << s_;
+            }
+#pragma unroll
+            for (int q = 0; q < TS_GPT; q++) {
+                const uint32_t mq = (m >> (4 * q)) & 0xFu;
+                if (mq == 0 && !fresh) continue;
+                const int g = (int)threadIdx.x + 256 * (pass * TS_GPT + q);      // group index inside the unit
+                float w[4] = { 0.f, 0.f, 0.f, 0.f }, sd[4] = { 0.f, 0.f, 0.f, 0.f }, c[3][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+                if (!fresh) {
+                    const float4 a = W4[g], bq = S4[g], c0 = C4[g], c1 = C4[1024 + g], c2 = C4[2048 + g];
+                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; sd[0] = bq.x; sd[1] = bq.y; sd[2] = bq.z; sd[3] = bq.w;
+                    c[0][0] = c0.x; c[0][1] = c0.y; c[0][2] = c0.z; c[0][3] = c0.w; c[1][0] = c1.x; c[1][1] = c1.y; c[1][2] = c1.z; c[1][3] = c1.w;
+                    c[2][0] = c2.x; c[2][1] = c2.y; c[2][2] = c2.z; c[2][3] = c2.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (!((mq >> j) & 1u)) continue;
+                    const int s_ = 4 * q + j;
+                    const float wo = w[j], wp = wo + 1.0f, rwp = __builtin_amdgcn_rcpf(wp);
+                    sd[j] = (sd[j] * wo + tv[s_]) * rwp;
+                    c[0][j] = (c[0][j] * wo + t[s_].x) * rwp; c[1][j] = (c[1][j] * wo + t[s_].y) * rwp; c[2][j] = (c[2][j] * wo + t[s_].z) * rwp;
+                    w[j] = wp;
+                }
+                // (a fresh unit is written in full: zeros where nothing was observed)
+                W4[g] = make_float4(w[0], w[1], w[2], w[3]); S4[g] = make_float4(sd[0], sd[1], sd[2], sd[3]);
+                C4[g] = make_float4(c[0][0], c[0][1], c[0][2], c[0][3]); C4[1024 + g] = make_float4(c[1][0], c[1][1], c[1][2], c[1][3]);
+                C4[2048 + g] = make_float4(c[2][0], c[2][1], c[2][2], c[2][3]);
+            }
+        }
+    }
+}
+
+// re-keys a table after its pools were re-allocated (growth): unit i keeps slot i.  keys must be all-ones, coord[0..n) valid.
+__global__ void __launch_bounds__(256) k_ts_rehash(SparseTsdf v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = ts_pack(v.coord[3 * i], v.coord[3 * i + 1], v.coord[3 * i + 2]);
+    const uint32_t mask = (1u << v.cap_hash_log2) - 1u;
+    uint32_t h = ts_hash(key, v.cap_hash_log2);
+    for (uint32_t probe = 0; probe <= mask; probe++, h = (h + 1) & mask) {
+        unsigned long long expect = TS_EMPTY;
+        if (__hip_atomic_compare_exchange_strong(&v.keys[h], &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v.slot[h] = i; return; }
+    }
+    v.counters[2] = 1;
 }
 
 // ---- bulk insertion of a list of unit coordinates (merging volumes / loading a fused volume): keys first, data in a second launch
@@ -181,13 +336,26 @@ __global__ void __launch_bounds__(256) k_ts_merge_list(SparseTsdf v, const int32
     if (b < 0) return;
     float* tsdf = v.tsdf + (size_t)b * TS_VOX; float* weight = v.weight + (size_t)b * TS_VOX; float* color = v.color + (size_t)b * TS_VOX * 3;
     const float* ot = o_tsdf + (size_t)k * TS_VOX; const float* ow = o_weight + (size_t)k * TS_VOX; const float* oc = o_color + (size_t)k * TS_VOX * 3;
+    // a unit this call (or an aborted frame) allocated has never been written -- the pools are not zero-filled: it becomes a copy of the incoming unit
+    const bool fresh = v.stamp[b] == 0u;
+    __syncthreads();
+    if (fresh) {
+        if (threadIdx.x == 0) v.stamp[b] = 0xFFFFFFFFu;      // written, by no frame
+        for (int i = threadIdx.x; i < TS_VOX; i += 256) {
+            const bool has = ow[i] > 0.f;
+            tsdf[i] = has ? ot[i] : 0.f; weight[i] = has ? ow[i] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) color[c * TS_VOX + i] = has ? oc[3 * i + c] : 0.f;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < TS_VOX; i += 256) {
         const float w0 = weight[i], w1 = ow[i], ws = w0 + w1;
         if (!(w1 > 0.f)) continue;
         const float r = 1.0f / ws;
         tsdf[i] = (tsdf[i] * w0 + ot[i] * w1) * r;
 #pragma unroll
-        for (int c = 0; c < 3; c++) color[3 * i + c] = (color[3 * i + c] * w0 + oc[3 * i + c] * w1) * r;
+        for (int c = 0; c < 3; c++) color[c * TS_VOX + i] = (color[c * TS_VOX + i] * w0 + oc[3 * i + c] * w1) * r;      // pool: colour planes; incoming list: [voxel][3]
         weight[i] = ws;
     }
 }
@@ -217,18 +385,39 @@ static int check_vol(const gsr_tsdf_sparse* s)
     return 0;
 }
 
+static void fill_params(const gsr_tsdf_sparse* s, int32_t W, int32_t H, float fx, float fy, float cx, float cy, const float* extrinsic, const float* pose,
+                        float depth_trunc, int32_t stride, TouchParams& t, IntParams& p)
+{
+    t.W = W; t.H = H; t.stride = stride; t.fx = fx; t.fy = fy; t.cx = cx; t.cy = cy; t.rfx = 1.0f / fx; t.rfy = 1.0f / fy;
+    t.trunc = s->sdf_trunc; t.dtrunc = depth_trunc; t.unit_len = s->voxel_length * TS_RES; t.inv_unit = 1.0f / t.unit_len;
+    for (int k = 0; k < 12; k++) t.P[k] = pose[k];
+    p.W = W; p.H = H; p.vl = s->voxel_length; p.trunc = s->sdf_trunc; p.dtrunc = depth_trunc; p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy;
+    p.rfx = 1.0f / fx; p.rfy = 1.0f / fy; p.rtrunc = 1.0f / s->sdf_trunc; p.unit_len = t.unit_len;
+    for (int k = 0; k < 12; k++) p.E[k] = extrinsic[k];
+}
+// what the counters of a finished frame mean for the caller (shared by the synchronous entry points and gsr_tsdf_sparse_status)
+static int frame_errors(const gsr_tsdf_sparse* s, const int32_t* c, hipStream_t st)
+{
+    if (c[2]) { gsr_set_error("tsdf_sparse: capacity exhausted (%u units); allocate a larger volume", s->cap_blocks); return 1; }
+    if (c[3]) {
+        (void)gsr_memset_async((int32_t*)s->counters + 3, 0, sizeof(int32_t), st);
+        gsr_set_error("tsdf_sparse: a depth sample lies outside the addressable volume (|unit coordinate| >= 2^20, i.e. %g scene units from the origin)",
+                      (double)(1 << 20) * s->voxel_length * TS_RES); return 1;
+    }
+    return 0;
+}
+
 extern "C" int gsr_tsdf_sparse_integrate(const gsr_tsdf_sparse* s, int32_t W, int32_t H, const float* depth, const float* rgb, float fx, float fy,
                                          float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc, int32_t stride,
                                          uint32_t frame, uint32_t* n_touched_host, void* stream)
 {
+    // round-2 entry point, kept: planes in, colours already on the volume's scale, one host read of the list length in front of the voxel pass
     if (check_vol(s)) return 1;
     if (W <= 0 || H <= 0 || stride <= 0 || !depth || !rgb || !extrinsic || !pose) { gsr_set_error("tsdf_sparse_integrate: bad arguments"); return 1; }
     hipStream_t st = (hipStream_t)stream;
     SparseTsdf v = make_view(s);
-    TouchParams t;
-    t.W = W; t.H = H; t.stride = stride; t.fx = fx; t.fy = fy; t.cx = cx; t.cy = cy; t.rfx = 1.0f / fx; t.rfy = 1.0f / fy;
-    t.trunc = s->sdf_trunc; t.dtrunc = depth_trunc; t.unit_len = s->voxel_length * TS_RES; t.inv_unit = 1.0f / t.unit_len;
-    for (int k = 0; k < 12; k++) t.P[k] = pose[k];
+    TouchParams t; IntParams p;
+    fill_params(s, W, H, fx, fy, cx, cy, extrinsic, pose, depth_trunc, stride, t, p);
     const int n = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
     if (gsr_memset_async(v.counters + 1, 0, sizeof(int32_t), st)) { gsr_set_error("tsdf_sparse: reset list"); return 1; };
     hipLaunchKernelGGL(k_ts_touch_insert, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n);
@@ -236,21 +425,61 @@ extern "C" int gsr_tsdf_sparse_integrate(const gsr_tsdf_sparse* s, int32_t W, in
     int32_t c[4] = { 0, 0, 0, 0 };
     GSR_CHECK(hipMemcpyAsync(c, v.counters, sizeof(c), hipMemcpyDeviceToHost, st), "tsdf_sparse: read counters");
     GSR_CHECK(hipStreamSynchronize(st), "tsdf_sparse: sync");
-    if (c[2]) { gsr_set_error("tsdf_sparse: capacity exhausted (%u units); allocate a larger volume", s->cap_blocks); return 1; }
-    if (c[3]) {
-        (void)gsr_memset_async(v.counters + 3, 0, sizeof(int32_t), st);
-        gsr_set_error("tsdf_sparse: a depth sample lies outside the addressable volume (|unit coordinate| >= 2^20, i.e. %g scene units from the origin)",
-                      (double)(1 << 20) * s->voxel_length * TS_RES); return 1;
+    if (c[2] || c[3]) {      // nothing of the frame is integrated: its fresh units go back to "never written" (the pools are not zero-filled)
+        if (c[1] > 0) hipLaunchKernelGGL(k_ts_integrate_col, dim3(std::min((c[1] + 255) / 256, 1024)), dim3(256), 0, st, v, p, (const float4*)nullptr, c[1]);
+        return frame_errors(s, c, st);
     }
     if (n_touched_host) *n_touched_host = (uint32_t)c[1];
-    if (c[1] > 0) {
-        IntParams p;
-        p.W = W; p.H = H; p.vl = s->voxel_length; p.trunc = s->sdf_trunc; p.dtrunc = depth_trunc; p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy;
-        p.rfx = 1.0f / fx; p.rfy = 1.0f / fy; p.rtrunc = 1.0f / s->sdf_trunc; p.unit_len = t.unit_len;
-        for (int k = 0; k < 12; k++) p.E[k] = extrinsic[k];
-        hipLaunchKernelGGL(k_ts_integrate, dim3((uint32_t)c[1]), dim3(256), 0, st, v, p, depth, rgb);
-    }
+    if (c[1] > 0) hipLaunchKernelGGL(k_ts_integrate, dim3((uint32_t)c[1]), dim3(256), 0, st, v, p, depth, rgb);
     return gsr_check_launch("tsdf_sparse_integrate", st, false);
+}
+
+extern "C" int gsr_tsdf_sparse_integrate2(const gsr_tsdf_sparse* s, int32_t W, int32_t H, const float* depth, const float* rgb, int32_t quant, float fx,
+                                          float fy, float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc, int32_t stride,
+                                          uint32_t frame, float* texels, int32_t* status_host, uint32_t flags, void* stream)
+{
+    if (check_vol(s)) return 1;
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || stride <= 0 || !depth || !rgb || !extrinsic || !pose || !texels || quant < 0 || quant > 2) {
+        gsr_set_error("tsdf_sparse_integrate2: bad arguments"); return 1;
+    }
+    if ((flags & GSR_TSDF_NO_SYNC) && !status_host) { gsr_set_error("tsdf_sparse_integrate2: GSR_TSDF_NO_SYNC needs a status buffer"); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    SparseTsdf v = make_view(s);
+    TouchParams t; IntParams p;
+    fill_params(s, W, H, fx, fy, cx, cy, extrinsic, pose, depth_trunc, stride, t, p);
+    const int n = ((W + stride - 1) / stride) * ((H + stride - 1) / stride), N = W * H;
+    if (gsr_memset_async(v.counters + 1, 0, sizeof(int32_t), st)) { gsr_set_error("tsdf_sparse: reset list"); return 1; };
+    hipLaunchKernelGGL(k_ts_texels, dim3((N + 255) / 256), dim3(256), 0, st, depth, rgb, (float4*)texels, N, (int)quant);
+    hipLaunchKernelGGL(k_ts_touch_insert, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n);
+    hipLaunchKernelGGL(k_ts_touch_stamp, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n, frame);
+    // the voxel pass reads the list length on the device: it is enqueued without waiting for the host (a persistent grid: 8 workgroups per CU)
+    hipLaunchKernelGGL(k_ts_integrate_col, dim3(2048), dim3(256), 0, st, v, p, (const float4*)texels, -1);
+    int32_t local[4] = { 0, 0, 0, 0 };
+    int32_t* c = status_host ? status_host : local;
+    GSR_CHECK(hipMemcpyAsync(c, v.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st), "tsdf_sparse: read counters");
+    if (flags & GSR_TSDF_NO_SYNC) return gsr_check_launch("tsdf_sparse_integrate2", st, false);      // the caller waits for its own event and calls gsr_tsdf_sparse_status
+    GSR_CHECK(hipStreamSynchronize(st), "tsdf_sparse: sync");
+    if (frame_errors(s, c, st)) return 1;
+    return gsr_check_launch("tsdf_sparse_integrate2", st, false);
+}
+
+// the status words a GSR_TSDF_NO_SYNC frame copied to the host, once the caller knows the copy has landed: 0, or 1 + gsr_last_error() exactly like the synchronous call
+extern "C" int gsr_tsdf_sparse_status(const gsr_tsdf_sparse* s, const int32_t* status_host, void* stream)
+{
+    if (check_vol(s) || !status_host) return 1;
+    return frame_errors(s, status_host, (hipStream_t)stream);
+}
+
+// after the caller re-allocated the arrays of a volume (growth: larger pools, coord / stamp / pool contents of units [0, n) copied, keys all-ones,
+// counters[0] = n): every unit gets its key back with the slot it had.  No voxel is touched.
+extern "C" int gsr_tsdf_sparse_rehash(const gsr_tsdf_sparse* s, int32_t n_units, void* stream)
+{
+    if (check_vol(s)) return 1;
+    if (n_units < 0 || (uint32_t)n_units > s->cap_blocks) { gsr_set_error("tsdf_sparse_rehash: %d units do not fit the volume", n_units); return 1; }
+    if (n_units == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ts_rehash, dim3((n_units + 255) / 256), dim3(256), 0, st, make_view(s), n_units);
+    return gsr_check_launch("tsdf_sparse_rehash", st, false);
 }
 
 extern "C" int gsr_tsdf_sparse_merge(const gsr_tsdf_sparse* s, int32_t n_units, const int32_t* coords, const float* tsdf, const float* weight,

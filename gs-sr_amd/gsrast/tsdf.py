@@ -1,5 +1,7 @@
 """HIP TSDF voxel integration: the per-frame update of GaussianExtractor.extract_mesh_unbounded's
 compute_unbounded_tsdf (gssr/utils/mesh_utils.py:195-246) as one streaming kernel."""
+import os
+
 import torch
 
 from . import last_error, lib, check, ptr, stream_ptr, dev_f32, TsdfSparse
@@ -103,6 +105,7 @@ class ScalableTSDFVolume:
     (weighted running averages are associative), `merge_from(other)` fuses two volumes on one device."""
 
     RES = 16
+    TSDF_NO_SYNC = 1
 
     def __init__(self, voxel_length, sdf_trunc, capacity_units=16384, device="cuda", depth_sampling_stride=4, auto_grow=True):
         self.voxel_length = float(voxel_length)
@@ -114,9 +117,19 @@ class ScalableTSDFVolume:
         if self.device.type != "cuda":
             raise RuntimeError("ScalableTSDFVolume lives on a HIP device; there is no CPU path")
         self.stride = int(depth_sampling_stride)
-        self.cap = int(capacity_units)
-        self.log2 = max(4, (2 * self.cap - 1).bit_length())
+        self._alloc(int(capacity_units))
+        self.frame = 0
+        self.last_touched = 0
+        self._tex = None              # (r, g, b, depth) texel scratch of the last frame size
+        self._pending = None          # a frame enqueued with defer=True whose status words have not been looked at yet
+        self._status = None           # pinned int32[4]
+
+    def _alloc(self, cap):
+        """The volume's arrays for `cap` units.  The pools (80 KB per unit) are NOT zero-filled: a unit is written in full by the first frame / merge that
+        touches it (its stamp, 0 until then, says so) -- a 16 384-unit volume used to start with a 1.3 GB memset, a 131 072-unit one with 10.7 GB."""
         d = self.device
+        self.cap = int(cap)
+        self.log2 = max(4, (2 * self.cap - 1).bit_length())
         self.keys = torch.full((1 << self.log2,), -1, dtype=torch.int64, device=d)
         self.slot = torch.zeros((1 << self.log2,), dtype=torch.int32, device=d)
         self.coord = torch.zeros((self.cap, 3), dtype=torch.int32, device=d)
@@ -124,72 +137,153 @@ class ScalableTSDFVolume:
         self.list = torch.zeros((self.cap,), dtype=torch.int32, device=d)
         self.counters = torch.zeros((4,), dtype=torch.int32, device=d)
         V = self.RES ** 3
-        self.tsdf = torch.zeros((self.cap, V), dtype=torch.float32, device=d)
-        self.weight = torch.zeros((self.cap, V), dtype=torch.float32, device=d)
-        self.color = torch.zeros((self.cap, V, 3), dtype=torch.float32, device=d)
-        self.frame = 0
-        self.last_touched = 0
+        self.tsdf = torch.empty((self.cap, V), dtype=torch.float32, device=d)
+        self.weight = torch.empty((self.cap, V), dtype=torch.float32, device=d)
+        self.color = torch.empty((self.cap, 3, V), dtype=torch.float32, device=d)      # three colour planes per unit (ABI 7)
 
     def _struct(self):
         return TsdfSparse(ptr(self.keys), ptr(self.slot), ptr(self.coord), ptr(self.stamp), ptr(self.list), ptr(self.counters), ptr(self.tsdf),
                           ptr(self.weight), ptr(self.color), self.log2, self.cap, self.voxel_length, self.sdf_trunc)
 
-    def integrate(self, rgb, depth, fx, fy, cx, cy, extrinsic, depth_trunc=float("inf"), quantize_rgb8=True):
+    def integrate(self, rgb, depth, fx, fy, cx, cy, extrinsic, depth_trunc=float("inf"), quantize_rgb8=True, defer=False):
         """rgb [3,H,W] in [0,1], depth [1,H,W] or [H,W] (0 = invalid, as mesh_utils.py:165-166 writes for masked pixels),
-        extrinsic 4x4 world->camera (Open3D convention)."""
+        extrinsic 4x4 world->camera (Open3D convention).  Colours are put on the 0..255 scale on the device (quantize_rgb8: through the uint8
+        truncation of mesh_utils.py:170).
+        defer=True: the frame is only ENQUEUED (no host synchronisation at all: texels, touch, stamp and the voxel pass run back to back behind whatever
+        produced rgb / depth); its outcome -- pool exhausted, sample out of range -- is looked at by the next integrate() / finish() / any read of the
+        volume, which then grows the pool and runs the frame again exactly as the synchronous call would have."""
         import ctypes as C
+        self.finish()
         d = dev_f32(depth, "depth", allow_empty=False)
         c = dev_f32(rgb, "rgb", allow_empty=False)
-        if quantize_rgb8:        # mesh_utils.py:170 converts colours to uint8 before fusion
-            c = (torch.clamp(c, 0.0, 1.0) * 255).to(torch.uint8).to(torch.float32).contiguous()
-        else:                    # same 0..255 scale without the rounding, so that volumes built either way can be merged
-            c = (torch.clamp(c, 0.0, 1.0) * 255).contiguous()
         H, W = int(d.shape[-2]), int(d.shape[-1])
+        if tuple(c.shape[-2:]) != (H, W) or c.numel() != 3 * H * W:
+            raise RuntimeError("ScalableTSDFVolume.integrate: rgb must be [3,H,W] with the depth map's H, W")
         E = torch.as_tensor(extrinsic, dtype=torch.float64).reshape(4, 4).cpu()
         Pm = torch.linalg.inv(E)
         Ea = (C.c_float * 12)(*[float(v) for v in E[:3].reshape(-1).tolist()])
         Pa = (C.c_float * 12)(*[float(v) for v in Pm[:3].reshape(-1).tolist()])
+        if os.environ.get("GSR_TSDF_V1") == "1":        # A/B: round 4's path (torch colour conversion, host read in front of the voxel pass, one workgroup per unit)
+            return self._integrate_v1(c, d, W, H, fx, fy, cx, cy, Ea, Pa, depth_trunc, quantize_rgb8)
+        if self._tex is None or self._tex.numel() != 4 * H * W:
+            self._tex = torch.empty((H * W, 4), dtype=torch.float32, device=self.device)
+        if self._status is None:
+            self._status = torch.zeros((4,), dtype=torch.int32).pin_memory()
+        frame = dict(d=d, c=c, W=W, H=H, intr=(float(fx), float(fy), float(cx), float(cy)), Ea=Ea, Pa=Pa, dt=float(min(depth_trunc, 3.0e38)),
+                     quant=2 if quantize_rgb8 else 1)
+        self._enqueue(frame, sync=not defer)
+        if defer:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            frame["event"] = ev
+            self._pending = frame
+        else:
+            self._resolve(frame)
+        return self
+
+    def _enqueue(self, f, sync):
+        import ctypes as C
         self.frame += 1
+        st = self._struct()
+        with torch.cuda.device(self.device):
+            rc = lib().gsr_tsdf_sparse_integrate2(C.byref(st), f["W"], f["H"], ptr(f["d"]), ptr(f["c"]), f["quant"], *f["intr"], f["Ea"], f["Pa"], f["dt"],
+                                                  self.stride, self.frame, ptr(self._tex), C.c_void_p(self._status.data_ptr()),
+                                                  0 if sync else self.TSDF_NO_SYNC, stream_ptr(self.device))
+        f["rc"] = rc
+
+    def _resolve(self, f):
+        """Looks at the outcome of an enqueued frame whose status words are on the host: grows the pool and runs the frame again while it says "capacity
+        exhausted" (nothing of such a frame has been integrated), raises what the library reports otherwise."""
+        import ctypes as C
+        while True:
+            rc = f["rc"]
+            if rc == 0 and "event" in f:
+                st = self._struct()
+                with torch.cuda.device(self.device):
+                    rc = lib().gsr_tsdf_sparse_status(C.byref(st), C.c_void_p(self._status.data_ptr()), stream_ptr(self.device))
+            if rc != 0 and self.auto_grow and "capacity exhausted" in last_error() and self.cap < (1 << 27):
+                self._grow()
+                f.pop("event", None)
+                self._enqueue(f, sync=True)
+                continue
+            if rc != 0:
+                self._scrub_unwritten()
+            check(rc, "tsdf_sparse_integrate")
+            break
+        self.last_touched = int(self._status[1])
+
+    def finish(self):
+        """Waits for a frame enqueued with defer=True (if any) and handles its outcome.  Every method that reads the volume calls it."""
+        f, self._pending = self._pending, None
+        if f is not None:
+            f["event"].synchronize()
+            self._resolve(f)
+        return self
+
+    def _integrate_v1(self, c, d, W, H, fx, fy, cx, cy, Ea, Pa, depth_trunc, quantize_rgb8):
+        import ctypes as C
+        if quantize_rgb8:
+            c = (torch.clamp(c, 0.0, 1.0) * 255).to(torch.uint8).to(torch.float32).contiguous()
+        else:
+            c = (torch.clamp(c, 0.0, 1.0) * 255).contiguous()
         n = C.c_uint32(0)
         while True:
+            self.frame += 1
             st = self._struct()
             with torch.cuda.device(self.device):
                 rc = lib().gsr_tsdf_sparse_integrate(C.byref(st), W, H, ptr(d), ptr(c), float(fx), float(fy), float(cx), float(cy), Ea, Pa,
                                                      float(min(depth_trunc, 3.0e38)), self.stride, self.frame, C.byref(n), stream_ptr(self.device))
             if rc != 0 and self.auto_grow and "capacity exhausted" in last_error() and self.cap < (1 << 27):
-                self._grow()              # the touch pass ran out of pool slots before any voxel was updated: double the pool, integrate again
+                self._grow()
                 continue
+            if rc != 0:
+                self._scrub_unwritten()
             check(rc, "tsdf_sparse_integrate")
             break
         self.last_touched = int(n.value)
         return self
 
-    def _grow(self):
-        """Doubles the unit pool: a fresh volume of twice the capacity receives the units allocated so far (one device-side merge)."""
+    def _scrub_unwritten(self):
+        """After a frame that failed for good: units it allocated but never wrote (stamp 0) become explicit empty units, so that units() never
+        shows uninitialised pool memory."""
         n = min(int(self.counters[0].item()), self.cap)
-        fresh = ScalableTSDFVolume(self.voxel_length, self.sdf_trunc, 2 * self.cap, self.device, self.stride, self.auto_grow)
-        if n:
-            R = self.RES
-            fresh.merge_units_(self.coord[:n], self.tsdf[:n].view(n, R, R, R), self.weight[:n].view(n, R, R, R), self.color[:n].view(n, R, R, R, 3),
-                               assume_unique=True)
-        fresh.frame = self.frame
-        self.__dict__.update(fresh.__dict__)
+        idx = (self.stamp[:n] == 0).nonzero().flatten()
+        if idx.numel():
+            self.tsdf[idx] = 0; self.weight[idx] = 0; self.color[idx] = 0
+            self.stamp[idx] = -1
+
+    def _grow(self):
+        """Doubles the unit pool: new arrays of twice the capacity, the allocated units' coordinates, stamps and voxels copied (device-to-device, no
+        arithmetic, and no fill of the part that is not in use), the hash table re-keyed with every unit in its old slot.  Rounds 3-4 built a fresh
+        zero-filled volume and merged the old one in voxel by voxel."""
+        import ctypes as C
+        n = min(int(self.counters[0].item()), self.cap)
+        old = (self.coord, self.stamp, self.tsdf, self.weight, self.color)
+        self._alloc(2 * self.cap)
+        for dst, src in zip((self.coord, self.stamp, self.tsdf, self.weight, self.color), old):
+            dst[:n].copy_(src[:n])
+        self.counters[0] = n
+        st = self._struct()
+        with torch.cuda.device(self.device):
+            check(lib().gsr_tsdf_sparse_rehash(C.byref(st), n, stream_ptr(self.device)), "tsdf_sparse_rehash")
 
     @property
     def num_units(self):
+        self.finish()
         return int(self.counters[0].item())
 
     def units(self):
         """-> (coords [n,3] int32, tsdf [n,16,16,16], weight [n,16,16,16], color [n,16,16,16,3]) views of the allocated units
         (voxel index x-major, z fastest, like Open3D's UniformTSDFVolume::IndexOf)."""
-        n, R = self.num_units, self.RES
-        return self.coord[:n], self.tsdf[:n].view(n, R, R, R), self.weight[:n].view(n, R, R, R), self.color[:n].view(n, R, R, R, 3)
+        n, R = min(self.num_units, self.cap), self.RES
+        return self.coord[:n], self.tsdf[:n].view(n, R, R, R), self.weight[:n].view(n, R, R, R), self.color[:n].view(n, 3, R, R, R).permute(0, 2, 3, 4, 1)
 
     def merge_units_(self, coords, tsdf, weight, color, assume_unique=False):
         """self <- weighted merge with the given units (tensors shaped like `units()`, on this device).  The merge kernel runs one workgroup per
         listed unit, so a coordinate must not appear twice in one list: unless `assume_unique` the list is first fused with itself
         (merge_unit_lists: sort-unique + index_add)."""
         import ctypes as C
+        self.finish()
         n = int(coords.shape[0])
         if n == 0:
             return self
@@ -219,7 +313,7 @@ class ScalableTSDFVolume:
             return self
         co, t, w, c = self.units()
         merged = merge_unit_lists(*gather_unit_lists(co, t.reshape(len(co), -1), w.reshape(len(co), -1), c.reshape(len(co), -1, 3), group))
-        fresh = ScalableTSDFVolume(self.voxel_length, self.sdf_trunc, max(self.cap, int(merged[0].shape[0])), self.device, self.stride)
+        fresh = ScalableTSDFVolume(self.voxel_length, self.sdf_trunc, max(self.cap, int(merged[0].shape[0])), self.device, self.stride, self.auto_grow)
         fresh.merge_units_(*merged, assume_unique=True)
         fresh.frame = self.frame
         self.__dict__.update(fresh.__dict__)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6
+#define GSR_ABI_VERSION 7
 
 enum gsr_variant {
     GSR_EWA = 0,     /* diff_gaussian_rasterization : 3DGS EWA splats, RGB only                          */
@@ -203,7 +203,9 @@ int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* or
  * `stride`-th valid depth pixel's world point p and applies the gsr_tsdf_integrate_dense voxel rule to each opened unit once.
  * All buffers are caller-owned device memory: keys [2^cap_hash_log2] int64 filled with -1, slot [2^cap_hash_log2] int32,
  * coord [cap_blocks,3] int32, stamp/list [cap_blocks], counters [4] int32 zero-filled, pools tsdf/weight [cap_blocks,4096] and
- * color [cap_blocks,4096,3] float32 ZERO-FILLED.  counters[0] = units allocated so far. */
+ * color [cap_blocks,3,4096] float32 (ABI 7: three colour PLANES per unit, so that every plane is read and written in coalesced 16-byte groups; ABI <= 6:
+ * [cap_blocks,4096,3]) -- since ABI 7 the pools need NOT be initialised (80 KB per unit of capacity): a unit whose stamp is 0 has never been
+ * written and is written in full, without being read, by the first frame / merge that touches it.  counters[0] = units allocated so far. */
 typedef struct gsr_tsdf_sparse {
     void* keys; int32_t* slot; int32_t* coord; uint32_t* stamp; int32_t* list; int32_t* counters;
     float* tsdf; float* weight; float* color;
@@ -215,6 +217,21 @@ typedef struct gsr_tsdf_sparse {
 int gsr_tsdf_sparse_integrate(const gsr_tsdf_sparse* vol, int32_t W, int32_t H, const float* depth /*[H,W]*/, const float* rgb /*[3,H,W]*/,
                               float fx, float fy, float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc,
                               int32_t stride, uint32_t frame, uint32_t* n_touched_host, void* stream);
+/* ABI 7.  The same frame, MI355X-shaped (csrc/gsr_tsdf_sparse.hip): rgb [3,H,W] as rendered; quant 0 = store as given, 1 = clamp to [0,1] and scale to
+ * 0..255, 2 = additionally truncate to an integer (the uint8 conversion of mesh_utils.py:170) -- done on the device while the planes are interleaved into
+ * `texels` [H*W*4] (caller-owned scratch); the voxel pass reads the length of its work list on the device, so nothing waits for the host in front of it.
+ * status_host [4] (may be NULL without GSR_TSDF_NO_SYNC) receives {units allocated, units integrated by this frame, capacity exhausted, sample out of range}.
+ * Default: synchronises once at the end and reports the two error conditions like gsr_tsdf_sparse_integrate (in either case NOTHING of the frame has been
+ * integrated: grow the volume and run it again with a new frame number).  GSR_TSDF_NO_SYNC: returns after enqueuing; status_host must be pinned and stay
+ * alive; the caller waits for an event of its own and passes the words to gsr_tsdf_sparse_status. */
+#define GSR_TSDF_NO_SYNC 1u
+int gsr_tsdf_sparse_integrate2(const gsr_tsdf_sparse* vol, int32_t W, int32_t H, const float* depth /*[H,W]*/, const float* rgb /*[3,H,W]*/, int32_t quant,
+                               float fx, float fy, float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc, int32_t stride,
+                               uint32_t frame, float* texels, int32_t* status_host, uint32_t flags, void* stream);
+int gsr_tsdf_sparse_status(const gsr_tsdf_sparse* vol, const int32_t* status_host, void* stream);
+/* After the caller re-allocated a volume's arrays (growth): keys all -1, coord / stamp / pool contents of units [0, n_units) copied, counters[0] = n_units --
+ * gives every unit its key back with the slot it had.  No voxel is touched. */
+int gsr_tsdf_sparse_rehash(const gsr_tsdf_sparse* vol, int32_t n_units, void* stream);
 /* vol <- weighted merge with n_units units given as (coords [n,3] int32, tsdf/weight [n,4096], color [n,4096,3]): the fusion step of
  * extract_mesh_split.py when every GPU integrated its own tile's frames (running averages are associative in (sum w*tsdf, sum w)). */
 int gsr_tsdf_sparse_merge(const gsr_tsdf_sparse* vol, int32_t n_units, const int32_t* coords, const float* tsdf, const float* weight,

@@ -13,11 +13,18 @@ pytestmark = pytest.mark.gpu
 VL, TR, DT = 0.02, 0.1, 6.0
 
 
-def _hip_volume(frs, cap=4096):
+def _poison(vol):
+    """The pools are not zero-filled by the library any more (ABI 7): whatever a unit's 80 KB held before must never show."""
+    vol.tsdf.fill_(float("nan")); vol.weight.fill_(float("nan")); vol.color.fill_(float("nan"))
+    return vol
+
+
+def _hip_volume(frs, cap=4096, defer=False):
     from gsrast.tsdf import ScalableTSDFVolume
-    vol = ScalableTSDFVolume(VL, TR, capacity_units=cap)
+    vol = _poison(ScalableTSDFVolume(VL, TR, capacity_units=cap))
     for f in frs:
-        vol.integrate(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda(), f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT)
+        vol.integrate(torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda(), f["fx"], f["fy"], f["cx"], f["cy"], f["E"], depth_trunc=DT,
+                      defer=defer)
     return vol
 
 
@@ -109,16 +116,34 @@ def test_two_tile_volumes_merge_to_the_joint_volume():
             dist.destroy_process_group()
 
 
+def test_deferred_frames_equal_the_synchronous_ones_also_through_a_pool_growth():
+    """integrate(defer=True) only enqueues (no host synchronisation); the outcome of a frame is handled by the next call that needs the volume.  Same units,
+    bit-identical voxels -- also when a deferred frame runs out of pool slots (nothing of it is integrated; the next call grows the pool and runs it again)."""
+    frs = tsdf_cases.frames(4)
+    ref = _hip_volume(frs, cap=8192)
+    for cap in (8192, 64):
+        vol = _hip_volume(frs, cap=cap, defer=True)
+        assert vol._pending is not None                       # the last frame is still in flight
+        n = vol.num_units                                     # ... until somebody reads the volume
+        assert vol._pending is None and n == ref.num_units and (cap == 8192 or vol.cap > 64)
+        kr = {tuple(k): i for i, k in enumerate(ref.units()[0].tolist())}
+        order = torch.tensor([kr[tuple(k)] for k in vol.units()[0].tolist()], device="cuda")
+        for a, b in zip(vol.units()[1:], ref.units()[1:]):
+            assert torch.equal(a, b[order])
+        assert not torch.isnan(vol.units()[1]).any()
+
+
 def test_capacity_overflow_raises_or_grows():
     """auto_grow=False: a frame that needs more units than the pool holds raises; the default doubles the pool until the frame fits and then
     holds exactly the volume a large-enough pool would have built."""
     from gsrast.tsdf import ScalableTSDFVolume
     f = tsdf_cases.frames(1)[0]
     args = (torch.from_numpy(f["rgb"]).cuda(), torch.from_numpy(f["depth"]).cuda(), f["fx"], f["fy"], f["cx"], f["cy"], f["E"])
-    vol = ScalableTSDFVolume(VL, TR, capacity_units=16, auto_grow=False)
+    vol = _poison(ScalableTSDFVolume(VL, TR, capacity_units=16, auto_grow=False))
     with pytest.raises(RuntimeError, match="capacity exhausted"):
         vol.integrate(*args, depth_trunc=DT)
-    small = ScalableTSDFVolume(VL, TR, capacity_units=16)
+    assert not torch.isnan(vol.units()[2]).any() and not vol.units()[2].any()      # the units the failed frame allocated: explicit empty units, not pool garbage
+    small = _poison(ScalableTSDFVolume(VL, TR, capacity_units=16))
     small.integrate(*args, depth_trunc=DT)
     big = ScalableTSDFVolume(VL, TR, capacity_units=8192)
     big.integrate(*args, depth_trunc=DT)
@@ -151,7 +176,7 @@ def test_merge_units_fuses_duplicate_coordinates_and_colour_scales_agree():
     co = torch.tensor([[1, 2, 3], [0, 0, 0], [1, 2, 3]], dtype=torch.int32).cuda()
     t = torch.rand(3, 16, 16, 16, generator=g).cuda(); w = torch.randint(1, 4, (3, 16, 16, 16), generator=g).float().cuda()
     c = torch.rand(3, 16, 16, 16, 3, generator=g).cuda()
-    vol = ScalableTSDFVolume(VL, TR, capacity_units=64)
+    vol = _poison(ScalableTSDFVolume(VL, TR, capacity_units=64))
     vol.merge_units_(co, t, w, c)
     uc, ut, uw, _ = vol.units()
     assert vol.num_units == 2

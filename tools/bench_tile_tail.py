@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--P", type=int, default=300000); ap.add_argument("--W", type=int, default=1920); ap.add_argument("--H", type=int, default=1080)
     ap.add_argument("--mesh-res", type=int, default=1024); ap.add_argument("--depth-trunc", type=float, default=8.0)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--count-updates", action="store_true", help="one extra (untimed) pass that counts the voxels every frame updates (from the weights)")
+    ap.add_argument("--sync-frames", action="store_true", help="integrate(defer=False): one host synchronisation per frame, as in rounds 2-4")
     a = ap.parse_args()
     import diff_surfel_rasterization as dsr
     from gsrast.tsdf import ScalableTSDFVolume
@@ -41,9 +43,14 @@ def main():
             fr.append((hiprun.settings("surfel", t), t, tile_tail.o3d_camera(cam)))
         frames.append(fr)
 
-    def run():
-        vols, n_units = [], []
+    touched = []
+
+    updated = []
+
+    def run(count=False):
+        vols, n_units, evs = [], [], []
         t_r = t_i = 0.0
+        touched.clear(); updated.clear()
         for fr in frames:
             vol = ScalableTSDFVolume(vl, tr, capacity_units=65536)
             for rs, t, (fx, fy, cx, cy, E) in fr:
@@ -54,12 +61,18 @@ def main():
                                                                      colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"])
                     depth = tile_tail.surf_depth_torch(allmap, 0.0)
                 e1.record()
-                vol.integrate(color, depth, fx, fy, cx, cy, E, depth_trunc=a.depth_trunc)
+                if count:
+                    n0 = vol.num_units; w0 = float(vol.weight[:n0].double().sum()) if n0 else 0.0
+                vol.integrate(color, depth, fx, fy, cx, cy, E, depth_trunc=a.depth_trunc, defer=not a.sync_frames and not count)
                 e2.record()
-                torch.cuda.synchronize()
-                t_r += e0.elapsed_time(e1); t_i += e1.elapsed_time(e2)
+                evs.append((e0, e1, e2, vol))
+                if count:
+                    updated.append(float(vol.weight[:vol.num_units].double().sum()) - w0); touched.append(vol.last_touched)
+            vol.finish()
             vols.append(vol); n_units.append(vol.num_units)
         torch.cuda.synchronize()
+        for e0, e1, e2, _ in evs:
+            t_r += e0.elapsed_time(e1); t_i += e1.elapsed_time(e2)
         t0 = time.perf_counter()
         joint = ScalableTSDFVolume(vl, tr, capacity_units=max(65536, 2 * sum(n_units)))
         for v in vols:
@@ -78,10 +91,20 @@ def main():
             best = (wall,) + r
     wall, t_r, t_i, t_m, n_units, n_joint = best
     nf = a.tiles * a.cams
+    upd = units = None
+    if a.count_updates:
+        run(count=True)
+        upd = sum(updated) / max(len(updated), 1); units = sum(touched) / max(len(touched), 1)
     print(json.dumps({"what": "config 5 tail: surfel render -> surface depth -> sparse TSDF integrate per frame, then merge of the tiles' volumes; device-resident images",
                       "device": torch.cuda.get_device_name(0), "tiles": a.tiles, "cameras_per_tile": a.cams, "gaussians_per_tile": a.P, "image": [a.W, a.H],
                       "voxel_length": vl, "sdf_trunc": tr, "depth_trunc": a.depth_trunc, "frames": nf,
                       "render_ms_per_frame": round(t_r / nf, 4), "integrate_ms_per_frame": round(t_i / nf, 4),
+                      "units_integrated_per_frame": None if units is None else round(units), "voxels_updated_per_frame": None if upd is None else round(upd),
+                      "updated_fraction_of_the_listed_units": None if upd is None else round(upd / (units * 4096), 3),
+                      "algorithmic_GB_per_frame": None if upd is None else round((upd * 40 + a.W * a.H * 16) / 1e9, 3),
+                      "frames_deferred": not a.sync_frames,
+                      "integrate_note": "HIP events around ScalableTSDFVolume.integrate: texels, touch, stamp, voxel pass and any pool growth (capacity 65536 units per tile, ~88k needed); "
+                                        "deferred frames are only enqueued (their status is read when the next frame starts), --sync-frames restores the per-frame host wait",
                       "frames_per_s_gpu": round(nf / ((t_r + t_i) * 1e-3), 1), "merge_ms": round(t_m, 3), "units_per_tile": n_units, "units_merged": n_joint,
                       "wall_ms_total": round(wall, 2), "frames_per_s_wall_incl_merge": round(nf / (wall * 1e-3), 1)}))
 
