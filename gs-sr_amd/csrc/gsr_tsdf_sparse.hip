@@ -112,37 +112,119 @@ __device__ __forceinline__ bool ts_pixel_range(const TouchParams& t, const float
     }
     return true;
 }
+// ---- the two touch kernels.  A unit of 16 voxels is ~12 sampled pixels wide, so the 64 consecutive samples of a wave name the same few units over and over:
+// a lane looks a unit up only if its left neighbour's sample did not name the same one at the same corner of its box (corner c = lo or hi per axis; the
+// boxes of neighbouring samples are translates of each other).  That cuts the hash lookups ~10 x and, more important, leaves ~12 stampers per unit
+// instead of ~150: the same-address exchanges of round 4's stamp kernel (83 us for 3569 units) are gone without relying on the timing of a plain load,
+// so a lane can issue the independent loads of its (<= 8) units together.  Boxes wider than two units per axis (sdf_trunc > one unit) take the plain loops.
+__device__ __forceinline__ bool ts_corner(const int* lo, const int* hi, int c, int* x)
+{
+    x[0] = (c & 1) ? hi[0] : lo[0]; x[1] = (c & 2) ? hi[1] : lo[1]; x[2] = (c & 4) ? hi[2] : lo[2];
+    return !(((c & 1) && hi[0] == lo[0]) || ((c & 2) && hi[1] == lo[1]) || ((c & 4) && hi[2] == lo[2]));
+}
+__device__ __forceinline__ unsigned long long shfl_up1_u64(unsigned long long v)
+{
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, 1, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), 1, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// -> small: every lane of the wave with a sample has a box of <= 2 units per axis (wave-uniform); lead[c]: this lane looks corner c up
+__device__ __forceinline__ bool ts_leaders(bool valid, const int* lo, const int* hi, unsigned long long* key, bool* lead)
+{
+    const bool small = !valid || (hi[0] - lo[0] <= 1 && hi[1] - lo[1] <= 1 && hi[2] - lo[2] <= 1);
+    if (__ballot(!small) != 0ull) return false;
+    const bool first = (threadIdx.x & 63) == 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        int x[3] = { 0, 0, 0 };
+        const bool use = valid && ts_corner(lo, hi, c, x);
+        key[c] = use ? ts_pack(x[0], x[1], x[2]) : TS_EMPTY;
+        const unsigned long long prev = shfl_up1_u64(key[c]);
+        lead[c] = use && (first || prev != key[c]);
+    }
+    return true;
+}
 __global__ void __launch_bounds__(256) k_ts_touch_insert(SparseTsdf v, TouchParams t, const float* __restrict__ depth, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int lo[3], hi[3];
-    if (!ts_pixel_range(t, depth, i, lo, hi, &v.counters[3])) return;
+    int lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+    const bool valid = i < n && ts_pixel_range(t, depth, i, lo, hi, &v.counters[3]);
+    unsigned long long key[8];
+    bool lead[8];
+    if (ts_leaders(valid, lo, hi, key, lead)) {
+        unsigned long long cur[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            cur[c] = lead[c] ? __hip_atomic_load(&v.keys[ts_hash(key[c], v.cap_hash_log2)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : key[c];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if (!lead[c] || cur[c] == key[c]) continue;      // present at its first probe position: the common case after the first frames
+            int x[3];
+            (void)ts_corner(lo, hi, c, x);
+            (void)ts_insert(v, x[0], x[1], x[2]);
+        }
+        return;
+    }
+    if (!valid) return;
     for (int x = lo[0]; x <= hi[0]; x++)
         for (int y = lo[1]; y <= hi[1]; y++)
             for (int z = lo[2]; z <= hi[2]; z++) (void)ts_insert(v, x, y, z);
 }
-// (Round 5 also tried the <= 8 units of a sample as one batch -- eight independent first-probe loads, then the slots, then the stamps, then the exchanges --
-// instead of this chain of ~4 dependent random loads per unit: 93 us against 45 for the smooth frame.  The chain is what spreads the ~150 samples of a unit
-// in time so that the plain load below sees the first one's stamp; batched, they all read the old stamp and all exchange.)
+// One same-address atomic per listed unit (`list[atomicAdd(&counters[1], 1)] = ...`) is what round 4's stamp kernel spent its time on once the exchanges were
+// out of the way: device-scope atomics on one word retire every 2-10 ns (36 us for 3569 units, 122 us for the 53 580 of a config-5 frame).  A workgroup now
+// reserves the list slots of all its winners with ONE global atomic: winners take a rank from an LDS counter, thread 0 adds the total, everybody writes.
 __global__ void __launch_bounds__(256) k_ts_touch_stamp(SparseTsdf v, TouchParams t, const float* __restrict__ depth, int n, uint32_t frame)
 {
+    __shared__ int s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int lo[3], hi[3];
+    int lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
     int scratch_flag = 0;
-    if (!ts_pixel_range(t, depth, i, lo, hi, &scratch_flag)) return;
-    for (int x = lo[0]; x <= hi[0]; x++)
-        for (int y = lo[1]; y <= hi[1]; y++)
-            for (int z = lo[2]; z <= hi[2]; z++) {
-                const int idx = ts_find(v, x, y, z);
-                if (idx < 0) continue;
-                // ~150 sampled pixels stamp the same unit: the plain load lets all but the first few skip the same-address atomic (0.15 us each, serialised:
-                // round 4's kernel took 83 us for 3569 units); the exchange still decides who lists the unit.  Old stamp 0 = never written: listed as fresh (~idx).
-                if (__hip_atomic_load(&v.stamp[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == frame) continue;
-                const uint32_t old = atomicExch(&v.stamp[idx], frame);
-                if (old != frame) v.list[atomicAdd(&v.counters[1], 1)] = old ? idx : ~idx;
-            }
+    const bool valid = i < n && ts_pixel_range(t, depth, i, lo, hi, &scratch_flag);
+    unsigned long long key[8];
+    bool lead[8];
+    int won[8];            // list entries (idx, or ~idx for a unit that has never been written) this thread's exchanges won
+    int nwon = 0, rank0 = 0;
+    const bool small = ts_leaders(valid, lo, hi, key, lead);      // wave-uniform
+    if (small) {
+        uint32_t h[8];
+        unsigned long long cur[8];
+        int idx[8];
+        uint32_t st[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) { h[c] = ts_hash(key[c], v.cap_hash_log2); cur[c] = lead[c] ? v.keys[h[c]] : 0ull; }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            idx[c] = -1;
+            if (!lead[c]) continue;
+            if (cur[c] == key[c]) idx[c] = v.slot[h[c]];
+            else { int x[3]; (void)ts_corner(lo, hi, c, x); idx[c] = ts_find(v, x[0], x[1], x[2]); }      // displaced by a collision: walk the probe sequence
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) st[c] = idx[c] >= 0 ? __hip_atomic_load(&v.stamp[idx[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : frame;
+        uint32_t old[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) old[c] = (st[c] != frame) ? atomicExch(&v.stamp[idx[c]], frame) : frame;      // all of a lane's exchanges in flight together
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            won[c] = 0;
+            if (old[c] != frame) { won[nwon] = old[c] ? idx[c] : ~idx[c]; nwon++; }      // the exchange decides who lists the unit.  Old stamp 0 = never written: fresh (~idx)
+        }
+        if (nwon) rank0 = atomicAdd(&s_cnt, nwon);
+    } else if (valid) {      // boxes wider than two units per axis somewhere in the wave (sdf_trunc > one unit): plain loops, one global atomic per listed unit
+        for (int x = lo[0]; x <= hi[0]; x++)
+            for (int y = lo[1]; y <= hi[1]; y++)
+                for (int z = lo[2]; z <= hi[2]; z++) {
+                    const int idx = ts_find(v, x, y, z);
+                    if (idx < 0 || __hip_atomic_load(&v.stamp[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == frame) continue;
+                    const uint32_t old = atomicExch(&v.stamp[idx], frame);
+                    if (old != frame) v.list[atomicAdd(&v.counters[1], 1)] = old ? idx : ~idx;
+                }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&v.counters[1], s_cnt) : 0;
+    __syncthreads();
+    for (int k = 0; k < nwon; k++) v.list[s_base + rank0 + k] = won[k];
 }
 
 struct IntParams {
