@@ -355,12 +355,24 @@ const uint32_t* gsr_static_tile_map(int gx, int gy, hipStream_t s)
 #define GSR_PREFILTERED_MSG "Point is filtered although prefiltered is set. This shouldn't happen!"
 
 // ------------------------------------------------------------------------------------------------ forward
-extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
-                                  int32_t* radii, uint32_t* num_rendered_host, void* stream)
+// cfg->debug (the stream has just been synchronised by gsr_check_launch): did k_duplicate emit what the preprocess kernel counted?
+static int check_cull_agreement(const gsr_cfg* cfg, const GeomView& g, hipStream_t s)
+{
+    if (!cfg->debug) return 0;
+    uint32_t w = 0u;
+    GSR_CHECK(hipMemcpyAsync(&w, g.counters + GSR_CNT_CULL_MISMATCH, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read cull agreement word");
+    GSR_CHECK(hipStreamSynchronize(s), "debug sync");
+    if (w) { gsr_set_error("tile culling: k_duplicate emitted a different number of instances than the preprocess kernel counted (gsr_tile_cull.h evaluated differently in the two units)"); return 1; }
+    return 0;
+}
+
+extern "C" int gsr_forward_stage1_ex(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                                     int32_t* radii, uint32_t* num_rendered_host, uint32_t* depth_order_host, void* stream)
 {
     if (check_cfg(cfg, in)) return 1;
     hipStream_t s = (hipStream_t)stream;
     *num_rendered_host = 0;
+    if (depth_order_host) *depth_order_host = 0u;
     if (cfg->P == 0) return 0;
     GeomView g = gsr_carve_geom(cfg->variant, cfg->P, geom);
     if (g.bytes > geom_bytes) { gsr_set_error("geom buffer too small: %zu < %zu", geom_bytes, g.bytes); return 1; }
@@ -368,7 +380,8 @@ extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void
     const unsigned slot = mb ? take_slot(mb) : 0u;
     struct SlotGuard { Mailbox* m; unsigned s; ~SlotGuard() { if (m) release_slot(m, s); } } guard{mb, slot};
     if (mb) mb->host[16 * slot + 1] = 0u;                      // "a gaussian failed the frustum test although prefiltered is set"
-    const bool global_order = gsr_decide_depth_order(cfg);      // recorded in the geom arena by the preprocess kernel; stage 2 reads it back
+    const bool global_order = gsr_decide_depth_order(cfg);      // recorded in the geom arena by the preprocess kernel, and handed to the caller for stage 2
+    if (depth_order_host) *depth_order_host = global_order ? GSR_MODE_GLOBAL : GSR_MODE_TILE;
     { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s, global_order, mb ? mb->dev + 16 * slot + 1 : nullptr)) return 1; }
     { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb ? mb->dev + 16 * slot : nullptr, s, global_order, true)) return 1; }
     // the one host<->device sync of the forward (reference: cudaMemcpy of point_offsets[P-1], rasterizer_impl.cu:281)
@@ -382,10 +395,15 @@ extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void
     }
     return 0;
 }
+extern "C" int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                                  int32_t* radii, uint32_t* num_rendered_host, void* stream)
+{
+    return gsr_forward_stage1_ex(cfg, in, geom, geom_bytes, radii, num_rendered_host, nullptr, stream);
+}
 
-extern "C" int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
-                                  void* binning, size_t binning_bytes, void* img, size_t img_bytes,
-                                  uint32_t num_rendered, const gsr_outputs* out, void* stream)
+extern "C" int gsr_forward_stage2_ex(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                                     void* binning, size_t binning_bytes, void* img, size_t img_bytes,
+                                     uint32_t num_rendered, uint32_t depth_order, const gsr_outputs* out, void* stream)
 {
     if (check_cfg(cfg, in)) return 1;
     hipStream_t s = (hipStream_t)stream;
@@ -402,19 +420,29 @@ extern "C" int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void
         return 0;
     }
     // The depth order the geom arena was laid out for (which of sorted_idx / offsets / scan_tmp mean what): recorded there by the preprocess kernel of
-    // the stage-1 call -- or of the gsr_forward whose overflow this call repairs.  Read back (the stream is idle: the caller has synchronised to learn
-    // num_rendered); an arena without the record is refused instead of being binned on a guess.
-    uint32_t mode = 0u;
-    GSR_CHECK(hipMemcpyAsync(&mode, g.counters + GSR_CNT_MODE, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read depth-order record");
-    GSR_CHECK(hipStreamSynchronize(s), "stage2 sync");
+    // the stage-1 call -- or of the gsr_forward whose overflow this call repairs -- and returned to the caller by gsr_forward_stage1_ex / gsr_forward_ex.
+    // Handed back in `depth_order`, stage 2 is a pure enqueue again (the read-back below drained the stream on every two-stage forward); with
+    // depth_order = 0 (the ABI <= 6 entry point) the record is read back from the arena; an arena without one is refused instead of being binned on a guess.
+    uint32_t mode = depth_order;
+    if (mode == 0u) {
+        GSR_CHECK(hipMemcpyAsync(&mode, g.counters + GSR_CNT_MODE, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read depth-order record");
+        GSR_CHECK(hipStreamSynchronize(s), "stage2 sync");
+    }
     if (mode != GSR_MODE_TILE && mode != GSR_MODE_GLOBAL) {
         gsr_set_error("geom buffer carries no depth-order record (0x%08x): it must come from gsr_forward_stage1 / gsr_forward of this library, unmodified", mode);
         return 1;
     }
     const bool global_order = mode == GSR_MODE_GLOBAL;
     { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, num_rendered, nullptr, s, global_order)) return 1; }
+    if (check_cull_agreement(cfg, g, s)) return 1;
     { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s, global_order)) return 1; }
     return 0;
+}
+extern "C" int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                                  void* binning, size_t binning_bytes, void* img, size_t img_bytes,
+                                  uint32_t num_rendered, const gsr_outputs* out, void* stream)
+{
+    return gsr_forward_stage2_ex(cfg, in, geom, geom_bytes, binning, binning_bytes, img, img_bytes, num_rendered, 0u, out, stream);
 }
 
 // Largest instance count whose binning arena fits in `bytes` (inverse of gsr_binning_bytes).
@@ -463,6 +491,7 @@ extern "C" int gsr_forward(const gsr_cfg* cfg, const gsr_inputs* in, void* geom,
     { ProfScope ps(GSR_PROF_PREPROCESS, s); if (gsr_launch_preprocess(cfg, in, g, radii, s, global_order, mb->dev + 16 * slot + 1)) return 1; }
     { ProfScope ps(GSR_PROF_DEPTH_ORDER, s); if (gsr_launch_depth_order(cfg, g, mb->dev + 16 * slot, s, global_order, false)) return 1; }
     { ProfScope ps(GSR_PROF_BINNING, s); if (gsr_launch_binning(cfg, g, b, im, cap, g.counters, s, global_order, mb->dev + 16 * slot)) return 1; }
+    if (check_cull_agreement(cfg, g, s)) return 1;
     { ProfScope ps(GSR_PROF_BLEND_FWD, s); if (gsr_launch_blend_fwd(cfg, in, g, b, im, out, s, global_order)) return 1; }
     uint32_t R;
     {

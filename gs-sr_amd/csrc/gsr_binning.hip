@@ -474,6 +474,9 @@ __global__ void __launch_bounds__(256) k_duplicate(uint32_t P, const uint32_t* _
             }
             run += (uint32_t)__popcll(hits);
         }
+        // count (k_preprocess_*) and emission (here) must agree instance for instance: one wave-level comparison, free
+        const uint32_t counted = (uint32_t)__shfl((int)wave_incl_scan(cnt), 63, 64);
+        if (lane == 0 && run - wave_base != counted) total_out[GSR_CNT_CULL_MISMATCH] = 1u;
         return;
     }
     // lanes past P carry incl = 0: give them the wave's running total so the prefix stays monotone

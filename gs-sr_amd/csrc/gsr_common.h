@@ -107,6 +107,10 @@ int gsr_check_launch(const char* what, hipStream_t s, bool debug);
 // offsets / scan_tmp / sorted_idx in the geom arena, so the preprocess kernel records it IN the arena (GeomView::counters[GSR_CNT_MODE]); a later call
 // on that arena (gsr_forward_stage2, also the redo after an overflowed gsr_forward) reads it back and refuses an arena that carries none.
 #define GSR_CNT_MODE 1
+// counters[GSR_CNT_CULL_MISMATCH]: set by k_duplicate when a wave emitted a different number of instances than its gaussians counted in the preprocess kernel
+// (both run gsr_tile_cull.h's test on the same words; a disagreement would shift every later instance of the list).  Cleared by the preprocess kernel, looked
+// at by the forward when cfg->debug is set (it synchronises after every stage then) and by gsr_debug_read.
+#define GSR_CNT_CULL_MISMATCH 2
 #define GSR_MODE_TILE 0x47530001u
 #define GSR_MODE_GLOBAL 0x47530002u
 bool gsr_decide_depth_order(const gsr_cfg* cfg);          // static rule (GSR_DEPTH_ORDER, P <= ~192 T) + the long-list feedback; polls the feedback word: call once per forward

@@ -185,7 +185,7 @@ __device__ __forceinline__ void pre_block_scan(const PreParams& p, const int idx
 template <bool FILTER_ONLY>
 __global__ void __launch_bounds__(256) k_preprocess_ewa(PreParams p)
 {
-    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) *p.mode_word = p.mode;
+    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) { *p.mode_word = p.mode; p.mode_word[GSR_CNT_CULL_MISMATCH - GSR_CNT_MODE] = 0u; }
     for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     PreTc tc; tc.tiles = 0u; tc.rect = make_ushort4(0, 0, 0, 0); tc.c0 = make_float4(0, 0, 0, 0); tc.c1 = make_float4(0, -1, 0, 0);
@@ -231,7 +231,7 @@ __device__ __forceinline__ void sh_rows_store(const float* my, float* __restrict
 }
 __global__ void __launch_bounds__(256) k_preprocess_ewa_sh16(PreParams p)
 {
-    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) *p.mode_word = p.mode;
+    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) { *p.mode_word = p.mode; p.mode_word[GSR_CNT_CULL_MISMATCH - GSR_CNT_MODE] = 0u; }
     __shared__ float s_sh[4 * 64 * GSR_SH_ROW];
     for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,7 +362,7 @@ __device__ __forceinline__ PreTc pre_surfel_one(const PreParams& p, const int id
 template <bool SH16>
 __global__ void __launch_bounds__(256) k_preprocess_surfel(PreParams p)
 {
-    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) *p.mode_word = p.mode;
+    if (p.mode_word && blockIdx.x == 0 && threadIdx.x == 0) { *p.mode_word = p.mode; p.mode_word[GSR_CNT_CULL_MISMATCH - GSR_CNT_MODE] = 0u; }
     for (uint32_t z = (uint32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < p.zero_n; z += gridDim.x * blockDim.x) p.zero_ptr[z] = 0u;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const float* sh_row = nullptr;

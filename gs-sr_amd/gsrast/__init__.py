@@ -64,7 +64,7 @@ class LodCfg(C.Structure):
 
 
 EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward_scratch_bytes",
-           "gsr_forward_stage1", "gsr_forward_stage2", "gsr_backward", "gsr_backward_ex", "gsr_forward_async", "gsr_mark_visible", "gsr_visible_filter",
+           "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward_stage1_ex", "gsr_forward_stage2_ex", "gsr_backward", "gsr_backward_ex", "gsr_forward_async", "gsr_mark_visible", "gsr_visible_filter",
            "gsr_tsdf_integrate", "gsr_tsdf_integrate_dense", "gsr_tsdf_sparse_integrate", "gsr_tsdf_sparse_integrate2", "gsr_tsdf_sparse_status", "gsr_tsdf_sparse_rehash", "gsr_tsdf_sparse_merge", "gsr_loss_l1_linear", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
            "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward",
            "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_loss_scaling_prod", "gsr_octree_visible",
@@ -91,9 +91,14 @@ def lib():
     L.gsr_backward_scratch_bytes.restype = sz; L.gsr_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
     L.gsr_forward_stage1.restype = C.c_int
     L.gsr_forward_stage1.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, C.POINTER(C.c_uint32), _vp]
+    L.gsr_forward_stage1_ex.restype = C.c_int
+    L.gsr_forward_stage1_ex.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _vp]
     L.gsr_forward_stage2.restype = C.c_int
     L.gsr_forward_stage2.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, sz, _vp, sz, C.c_uint32,
                                      C.POINTER(Outputs), _vp]
+    L.gsr_forward_stage2_ex.restype = C.c_int
+    L.gsr_forward_stage2_ex.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, sz, _vp, sz, C.c_uint32, C.c_uint32,
+                                        C.POINTER(Outputs), _vp]
     L.gsr_binning_capacity.restype = C.c_uint32; L.gsr_binning_capacity.argtypes = [C.c_int32, sz, C.c_int32, C.c_int32]
     L.gsr_forward.restype = C.c_int
     L.gsr_forward.argtypes = [C.POINTER(Cfg), C.POINTER(Inputs), _vp, sz, _vp, sz, _vp, sz, _vp, C.POINTER(Outputs),

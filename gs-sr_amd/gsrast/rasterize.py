@@ -222,10 +222,13 @@ def forward(variant, means3D, sh, colors_precomp, opacities, scales, rotations, 
                 check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
                                            ptr(img), img.numel(), R.value, C.byref(o), s), "forward")
         else:
-            check(L.gsr_forward_stage1(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(radii), C.byref(R), s), "forward")
+            # the depth order stage 1 decided travels back with num_rendered and into stage 2, which is then a pure enqueue (ABI 7; the ABI <= 6 stage 2
+            # read the record back from the geom arena: a stream drain per two-stage forward)
+            order = C.c_uint32(0)
+            check(L.gsr_forward_stage1_ex(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(radii), C.byref(R), C.byref(order), s), "forward")
             binning = _bytes(L.gsr_binning_bytes(variant, R.value, W, H), dev)
-            check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
-                                       ptr(img), img.numel(), R.value, C.byref(o), s), "forward")
+            check(L.gsr_forward_stage2_ex(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
+                                          ptr(img), img.numel(), R.value, order.value, C.byref(o), s), "forward")
     with _HINT_LOCK:
         prev = _R_HINT.get(key)
         _R_HINT[key] = int(R.value) if (prev is None or overflowed) else max(int(R.value), int(0.9 * prev))

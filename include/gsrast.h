@@ -126,6 +126,14 @@ int gsr_forward_stage1(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, siz
 int gsr_forward_stage2(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
                        void* binning, size_t binning_bytes, void* img, size_t img_bytes,
                        uint32_t num_rendered, const gsr_outputs* out, void* stream);
+/* ABI 7.  The same pair with the forward's depth order made explicit: stage 1 decides it (and records it in the geom arena), *depth_order_host receives an
+ * opaque non-zero word that the caller hands back to stage 2 -- which is then a pure enqueue.  gsr_forward_stage2 (= depth_order 0) reads the record back from
+ * the arena instead: one more host<->device round trip per forward (it also serves the redo after an overflowed gsr_forward). */
+int gsr_forward_stage1_ex(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                          int32_t* radii /*[P]*/, uint32_t* num_rendered_host, uint32_t* depth_order_host, void* stream);
+int gsr_forward_stage2_ex(const gsr_cfg* cfg, const gsr_inputs* in, void* geom, size_t geom_bytes,
+                          void* binning, size_t binning_bytes, void* img, size_t img_bytes,
+                          uint32_t num_rendered, uint32_t depth_order, const gsr_outputs* out, void* stream);
 
 /* ---- single-call forward without the GPU idle gap at the sync.  `binning` is an arena of ANY capacity
  * (gsr_binning_capacity(bytes) instances, e.g. sized from the previous iteration's num_rendered with head-room):

@@ -516,12 +516,15 @@ def test_full_size_properties(variant):
 # ---- BASELINE full size against the oracle: 300k gaussians, 1920x1080, seeds {0,1,2}, both poses, both colour modes.
 # The oracle runs the whole workload in ~2 s on the GPU host's cores, so there is no reason to stop at properties.
 FULL_CASES = [
-    ("surfel", "precomp", 0, 0), ("surfel", "precomp", 1, 0), ("surfel", "precomp", 2, 1), ("surfel", "sh", 1, 1),
-    ("ewa", "precomp", 0, 0), ("ewa", "sh", 1, 0), ("ewa", "precomp", 2, 1), ("ewa", "sh", 0, 1),
-    ("plane", "precomp", 0, 0), ("plane", "precomp", 1, 1), ("plane", "sh", 2, 0),
+    ("surfel", "precomp", 0, 0), ("surfel", "sh", 1, 1),
+    ("ewa", "precomp", 0, 0), ("ewa", "sh", 0, 1),
+    ("plane", "precomp", 0, 0), ("plane", "sh", 2, 0),
     # "sh:d" = (P,16,3) coefficients with active degree d < 3: the vanilla model before iteration 3000 (vanilla_gaussian.py:440-442)
     ("ewa", "sh:0", 3, 0), ("surfel", "sh:1", 3, 1), ("plane", "sh:2", 3, 1),
 ]
+# the other seeds / poses of rounds 2-4 run in tools/full_parity_report.py (profiles/r05_full_size_parity.jsonl holds all 14): every case costs ~25 s of
+# oracle time (float32, FMA twin, float64 truth, float64 floor) on the GPU box's host
+FULL_CASES_REPORT = FULL_CASES + [("surfel", "precomp", 1, 0), ("surfel", "precomp", 2, 1), ("ewa", "sh", 1, 0), ("ewa", "precomp", 2, 1), ("plane", "precomp", 1, 1)]
 
 
 def _hip_outputs(hr, variant, sc, og):
@@ -542,7 +545,7 @@ def _check_against_truth(hr, variant, cm, sc, og):
     gradients within max(1e-3, 2 x the float32 oracle's own error vs the truth)."""
     import parity_truth as pt
     st, cand = _hip_outputs(hr, variant, sc, og)
-    f32, fma, truth, ints = pt.run_oracles(sc, variant, og, hip_state=st)     # incl. the filtered instance list against the oracle's (tests/tile_cull.py)
+    f32, fma, truth, ints = pt.run_oracles(sc, variant, og, hip_state=st, fma=sc["means3D"].shape[0] <= 50000)     # incl. the filtered instance list against the oracle's (tests/tile_cull.py)
     assert np.array_equal(st["radii"], ints["radii"])
     cand["n_contrib"] = ints["view"]["n_contrib"]                             # positions in the oracle's list
     rep = pt.check_case(variant, cm, cand, f32, fma, truth)
@@ -573,18 +576,6 @@ def test_small_cases_against_the_float64_truth(variant, cm, P, W, H, pose):
     sc = scenes.make_scene(variant, P, W, H, seed=11, color_mode=cm, bg=(0.2, 0.4, 0.6), pose=pose)
     og = scenes.random_out_grads(variant, W, H, seed=11, scale=1.0)
     _check_against_truth(hr, variant, cm, sc, og)
-
-
-def test_pixel_parallel_backward_kept_switchable():
-    """GSR_BWD=px selects round 1's pixel-parallel backward (kept for A/B, gsr_blend.hip).  The library reads the switch once per process,
-    so the parity cases above are re-run in a child process with it set: the kernel nobody runs by default has to stay parity-green."""
-    import subprocess
-    import sys
-    env = dict(os.environ, GSR_BWD="px")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity or test_edge_cases",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 @pytest.mark.parametrize("variant", ["surfel", "plane"])
@@ -648,31 +639,6 @@ def test_equal_depths_tie_by_id(variant):
         assert (np.diff(k.astype(np.uint64)) == 0).sum() > 100          # the sorted list really holds runs of equal (tile, depth) keys
 
 
-@pytest.mark.parametrize("who", ["fused", "kernel"])
-def test_per_tile_depth_sort_forced(who):
-    """The long-list cases below with GSR_DEPTH_ORDER=tile, in a child process (the switches are read once per process): once with the sort in
-    k_blend_fwd's prologue (GSR_TILE_SORT=fused, the default) and once as the separate k_tile_depth_sort launch (=kernel)."""
-    import subprocess
-    import sys
-    env = dict(os.environ, GSR_DEPTH_ORDER="tile", GSR_TILE_SORT=who)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_long_tile_lists or test_forward_backward_parity or test_equal_depths",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout and "skipped" not in r.stdout.splitlines()[-1]
-
-
-def test_global_depth_sort_kept_switchable():
-    """GSR_DEPTH_ORDER=global selects rounds 1-2's ordering (stable LSD sort of the P gaussians by depth bits, instances emitted in that order) instead
-    of the per-tile depth sort; the bit-exact list checks of the parity cases are re-run in a child process with it set."""
-    import subprocess
-    import sys
-    env = dict(os.environ, GSR_DEPTH_ORDER="global")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_forward_backward_parity or test_long_tile_lists",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
-
-
 @pytest.mark.parametrize("variant,P", [("ewa", 700), ("surfel", 1500), ("plane", 2200), ("surfel", 5000), ("plane", 9000), ("ewa", 40000), ("surfel", 24000)])
 def test_long_tile_lists_sort_paths(variant, P, monkeypatch):
     """(GSR_DEPTH_ORDER=tile unless the environment already chose: "auto" would send these gaussian counts to the global sort.)  A 48x32 image (6 tiles) with thousands of gaussians per tile: the per-tile depth sort's paths -- rank by counting (<= 256 entries), the LDS
@@ -709,19 +675,32 @@ def test_tile_count_edges_of_the_bucket_sort(W, H, what):
         assert np.array_equal(st["radii"], f.radii)
 
 
-@pytest.mark.parametrize("env", [{"GSR_XCD_REMAP": "0"}, {"GSR_XCD_REMAP": "1"}, {"GSR_TILE_CULL": "0"}, {"GSR_TILE_BUCKET": "0"}])
-def test_kept_switches_keep_the_results(env):
-    """The switches that stay (raster / banded launch order of the blend workgroups; GSR_TILE_CULL=0 = the reference-shaped instance list, every tile
-    of every rect emitted; GSR_TILE_BUCKET=0 = the two-pass radix sort on the tile id instead of the one-pass bucket sort): the parity cases incl. SH colours, the speculative forward with its overflow redo and the edge cases re-run in a child
-    process with each switch set.  With GSR_TILE_CULL=0 test_forward_backward_parity also holds R, tiles_touched, point_list, tile keys and ranges
-    bit-exactly against the oracle's."""
+# The switches that stay in the product, each read once per process, so every set runs in a child process; orthogonal switches share a child (round 4 spent
+# eight child processes on them):
+#   A  the reference-shaped paths: GSR_BWD=px (round 1's pixel-parallel backward), GSR_DEPTH_ORDER=global (rounds 1-2's global LSD sort of the gaussians),
+#      GSR_TILE_CULL=0 (every tile of every rect emitted: R, tiles_touched, point_list, tile keys and ranges bit-exact against the oracle's, see
+#      test_forward_backward_parity), GSR_XCD_REMAP=0 (raster launch order);
+#   B  GSR_DEPTH_ORDER=tile forced + GSR_TILE_SORT=kernel (the per-tile sort as its own launch), GSR_TILE_BUCKET=0 (two radix passes on the tile id: real tile
+#      keys, so `ranges` is held against keys the bucket sort's debug view would have rebuilt from it), GSR_XCD_REMAP=1 (banded launch order);
+#   C  GSR_DEPTH_ORDER=tile forced + GSR_TILE_SORT=fused: the long-list paths of the blend forward's prologue.
+SWITCH_SETS = {
+    "A": (dict(GSR_BWD="px", GSR_DEPTH_ORDER="global", GSR_TILE_CULL="0", GSR_XCD_REMAP="0"),
+          "test_forward_backward_parity or test_edge_cases or test_long_tile_lists or test_speculative_forward or test_full_size_properties"),
+    "B": (dict(GSR_DEPTH_ORDER="tile", GSR_TILE_SORT="kernel", GSR_TILE_BUCKET="0", GSR_XCD_REMAP="1"),
+          "test_forward_backward_parity or test_edge_cases or test_long_tile_lists or test_equal_depths or test_speculative_forward or test_full_size_properties"),
+    "C": (dict(GSR_DEPTH_ORDER="tile", GSR_TILE_SORT="fused"), "test_long_tile_lists or test_equal_depths or test_forward_backward_parity"),
+}
+
+
+@pytest.mark.parametrize("which", sorted(SWITCH_SETS))
+def test_kept_switches_keep_the_results(which):
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
-                        "test_forward_backward_parity or test_speculative_forward or test_edge_cases", "-p", "no:cacheprovider"],
+    env, select = SWITCH_SETS[which]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", select, "-p", "no:cacheprovider"],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    assert " passed" in r.stdout and "failed" not in r.stdout and "skipped" not in r.stdout.splitlines()[-1]
 
 
 @pytest.mark.parametrize("P,frac,scale,longest", [(24000, 0.6, 0.12, 1562), (40000, 0.7, 0.05, 6000)])
@@ -801,6 +780,16 @@ def test_stage2_refuses_a_geom_arena_without_its_depth_order_record():
     moved = geom.clone()                                   # the arena's bytes at another address: stage 2 must find the record in them
     check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(moved), moved.numel(), ptr(bin2), bin2.numel(), ptr(img), img.numel(), R, C.byref(o),
                                stream_ptr(geom.device)), "forward")
+    torch.cuda.synchronize()
+    assert torch.equal(color2, outs["color"]) and torch.equal(others2, outs["others"])
+    # ABI 7: the word stage 1 returned, handed back -> stage 2 does not touch the host at all; same results
+    order = C.c_uint32(0); R1 = C.c_uint32(0)
+    radii2 = torch.empty_like(radii)
+    check(L.gsr_forward_stage1_ex(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(radii2), C.byref(R1), C.byref(order), stream_ptr(geom.device)), "forward")
+    assert R1.value == R and order.value != 0 and torch.equal(radii2, radii)
+    color2.zero_(); others2.zero_()
+    check(L.gsr_forward_stage2_ex(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(bin2), bin2.numel(), ptr(img), img.numel(), R, order.value, C.byref(o),
+                                  stream_ptr(geom.device)), "forward")
     torch.cuda.synchronize()
     assert torch.equal(color2, outs["color"]) and torch.equal(others2, outs["others"])
     blank = torch.zeros_like(geom)                         # never seen by a preprocess kernel

@@ -34,8 +34,13 @@ def reference_view(st, f, truth=None, P=None, variant=None):
     hip_list = st["point_list"].astype(np.int64); hip_tile = st["tile_keys"].astype(np.int64)
     R = int(st["R"])
     assert hip_list.shape[0] == R and R <= f.R, (R, f.R)
-    # ---- (1) subsequence, order preserved: (tile, id) is unique in either list
-    keep = np.isin(ref_tile * P + ref_list, hip_tile * P + hip_list)
+    # ---- (1) subsequence, order preserved: (tile, id) is unique in either list.  On the bucket-sort path hip_tile is rebuilt from the library's `ranges`
+    # (k_debug_tile_keys): the check is not circular -- a boundary of `ranges` that is off by one entry hands that entry's id to the neighbouring tile, and
+    # the pair (neighbour, id) is then either not in the reference's list, or a second copy of a pair the list already holds, or sits at the wrong
+    # position of the neighbour's depth order: the three assertions below.
+    pairs = hip_tile * P + hip_list
+    assert np.unique(pairs).shape[0] == R, "a (tile, gaussian) pair appears twice in the HIP list"
+    keep = np.isin(ref_tile * P + ref_list, pairs)
     assert int(keep.sum()) == R, f"{R} instances emitted, {int(keep.sum())} of them found in the reference's list"
     assert np.array_equal(ref_list[keep], hip_list), "HIP instance list is not the reference's list restricted to a subset (order or members differ)"
     assert np.array_equal(ref_tile[keep], hip_tile)

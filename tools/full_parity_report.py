@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "gs-sr_amd")); sys.path.insert(0, os.path.
 import hiprun      # noqa: E402
 import parity_truth as pt      # noqa: E402
 import scenes      # noqa: E402
-from test_gpu_parity import FULL_CASES, _hip_outputs      # noqa: E402
+from test_gpu_parity import FULL_CASES_REPORT as FULL_CASES, _hip_outputs      # noqa: E402
 
 
 def compact(v):
