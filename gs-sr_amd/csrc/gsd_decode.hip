@@ -62,14 +62,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 // Exclusive scan of data[0, n) in place, one launch, no ticket: every workgroup scans its 1024 words, PUBLISHES its total (flag word = ready bit |
 // total) and then adds up the published totals of all workgroups in front of it -- one load per predecessor, spinning on the ready bits.  Workgroups
 // are dispatched in index order and only ever wait for lower indices, so the wait ends; nobody waits in a chain (each total is published before its
-// workgroup looks back).  flags[0, gridDim.x) must be ZERO at launch (the kernel in front of this one clears them: k_pack_img / k_flags).
+// workgroup looks back).  CONTRACT: flags[0, gridDim.x) must be ZERO at launch -- the kernel in front of this one clears them (k_pack_img / k_flags: every
+// caller of launch_scan below launches one of the two right in front of it); stale ready bits of an earlier run would be read as this run's totals.
 // The last workgroup writes the grand total.  (Rounds 2-3 had a ticket counter instead -- the workgroup that drew the last ticket scanned the block
 // sums, a third kernel added them: 59 atomics on one word cost 8.9 us, 0.15 us each, plus the 3.9 us of k_scan_add; DESIGN Appendix A (70).)
 #define GSD_SCAN_READY 0x80000000u
+#define GSD_SCAN_POISON 0xFFFFFFFFu      // *total when the look-back gave up: no real total reaches 2^31 (the ready bit); the host entry points check for it
+#define GSD_SCAN_TIMEOUT_MSG "the scan's look-back timed out (a workgroup in front never published its total: workgroups not dispatched in index order?)"
+#define GSD_SCAN_SPINS (1u << 21)       // x s_sleep 8 (~0.5 us): ~1 s.  A predecessor publishes its total ~2 us after it starts
 __global__ void __launch_bounds__(1024) k_scan_lookback(uint32_t* __restrict__ data, uint32_t n, uint32_t* __restrict__ flags, uint32_t* __restrict__ total)
 {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t wback[16];
+    __shared__ uint32_t s_prev;
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     const uint32_t v = i < n ? data[i] : 0u;
     const uint32_t incl = wave_scan_incl(v);
@@ -79,20 +83,31 @@ __global__ void __launch_bounds__(1024) k_scan_lookback(uint32_t* __restrict__ d
     uint32_t base = 0, all = 0;
     for (int w = 0; w < 16; w++) { if (w < wave) base += wsum[w]; all += wsum[w]; }
     if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], GSD_SCAN_READY | all, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t back = 0;
-    for (uint32_t q = threadIdx.x; q < blockIdx.x; q += 1024u) {
-        uint32_t f;
-        while (!((f = __hip_atomic_load(&flags[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & GSD_SCAN_READY)) __builtin_amdgcn_s_sleep(1);
-        back += f & ~GSD_SCAN_READY;
-    }
+    // The look-back is ONE wave's job (all 1024 threads used to spin): lane l adds the totals of predecessors l, l + 64, ...  The wait relies on
+    // workgroups being DISPATCHED in index order (a workgroup only waits for lower indices, and every workgroup publishes before it looks back, so a
+    // resident predecessor always gets there) -- what the hardware's dispatcher does for a 1-D grid, but not an API guarantee: the spin is bounded, and a
+    // wave that gives up poisons the total instead of hanging the device (the callers turn GSD_SCAN_POISON into an error).
+    if (wave == 0) {
+        uint32_t back = 0;
+        bool gave_up = false;
+        for (uint32_t q = (uint32_t)lane; q < blockIdx.x && !gave_up; q += 64u) {
+            uint32_t f, spins = 0;
+            while (!((f = __hip_atomic_load(&flags[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & GSD_SCAN_READY)) {
+                if (++spins > GSD_SCAN_SPINS) { gave_up = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            back += f & ~GSD_SCAN_READY;
+        }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) back += (uint32_t)__shfl_xor((int)back, d, 64);
-    if (lane == 0) wback[wave] = back;
+        for (int d = 32; d >= 1; d >>= 1) back += (uint32_t)__shfl_xor((int)back, d, 64);
+        // a predecessor that never publishes stops EVERY workgroup behind it, the last one included: the last workgroup's verdict is the launch's
+        if (__ballot(gave_up) != 0ull) back = GSD_SCAN_POISON;
+        if (lane == 0) s_prev = back;
+    }
     __syncthreads();
-    uint32_t prev = 0;
-    for (int w = 0; w < 16; w++) prev += wback[w];
+    const uint32_t prev = s_prev;
     if (i < n) data[i] = prev + base + incl - v;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = prev + all;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = (prev == GSD_SCAN_POISON) ? GSD_SCAN_POISON : prev + all;
 }
 // data[0..n) -> exclusive prefix in place, *total_dev = sum.  flags: >= div_up(n,1024) words, zeroed by the kernel in front (k_flags).
 static void launch_scan(uint32_t* data, uint32_t n, uint32_t* flags, uint32_t* total_dev, hipStream_t s)
@@ -822,6 +837,7 @@ extern "C" int gsd_compact_visible(const uint8_t* mask, int32_t Na, int32_t* vis
     hipLaunchKernelGGL(k_scatter_idx, dim3(gsr_div_up(Na, 256)), dim3(256), 0, s, mask, (uint32_t)Na, pos, vis_idx);
     GSR_CHECK(hipMemcpyAsync(count_host, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "gsd_compact_visible: copy");
     GSR_CHECK(hipStreamSynchronize(s), "gsd_compact_visible: sync");
+    if (*count_host == GSD_SCAN_POISON) { *count_host = 0; gsr_set_error("gsd_compact_visible: %s", GSD_SCAN_TIMEOUT_MSG); return 1; }
     return gsr_check_launch("gsd_compact_visible", s, false);
 }
 
@@ -898,6 +914,7 @@ extern "C" int gsd_forward_stage1(const gsd_cfg* cfg, const gsd_inputs* in, cons
     if (cfg->Nv == 0) return gsr_check_launch("gsd_forward_stage1", s, false);
     GSR_CHECK(hipMemcpyAsync(P_host, fwd_total(scratch), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "gsd_forward_stage1: copy");
     GSR_CHECK(hipStreamSynchronize(s), "gsd_forward_stage1: sync");
+    if (*P_host == GSD_SCAN_POISON) { *P_host = 0; gsr_set_error("gsd_forward_stage1: %s", GSD_SCAN_TIMEOUT_MSG); return 1; }
     return gsr_check_launch("gsd_forward_stage1", s, false);
 }
 
@@ -928,6 +945,7 @@ extern "C" int gsd_forward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_p
     enqueue_stage2(cfg, in, neural_opacity, row_offset, out, scratch, s);       // outputs sized for the worst case: no host round trip
     GSR_CHECK(hipMemcpyAsync(P_host, fwd_total(scratch), sizeof(uint32_t), hipMemcpyDeviceToHost, s), "gsd_forward: copy");
     GSR_CHECK(hipStreamSynchronize(s), "gsd_forward: sync");
+    if (*P_host == GSD_SCAN_POISON) { *P_host = 0; gsr_set_error("gsd_forward: %s", GSD_SCAN_TIMEOUT_MSG); return 1; }
     return gsr_check_launch("gsd_forward", s, false);
 }
 

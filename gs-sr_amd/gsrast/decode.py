@@ -144,6 +144,7 @@ def _decode_launch(flags, t, prm, mode):
                                      b["count_host"].data_ptr(), b["event"].cuda_event, ptr(b["scratch"]), b["scratch"].numel(), stream_ptr(dev)),
               "decode forward (deferred count)")
         b["n"] = cap
+        b["t"], b["prm"] = t, prm
         return b
     b["count"] = torch.empty(1, dtype=torch.int32, device=dev)
     check(L.gsd_forward_static(C.byref(cfg), C.byref(inp), C.byref(cp), ptr(b["nop"]), ptr(b["mask"]), ptr(b["row_offset"]), C.byref(out), ptr(b["count"]),
@@ -164,11 +165,24 @@ def _count_slot(dev):
     return torch.zeros(1, dtype=torch.int32, pin_memory=True), ev
 
 
+SCAN_POISON = 0xFFFFFFFF      # csrc/gsd_decode.hip GSD_SCAN_POISON: the scan's look-back gave up
+
+
+def _return_slot(b):
+    slot = b.pop("slot", None)
+    if slot is not None:
+        dev = b["nop"].device
+        _count_slots[dev.index if dev.index is not None else torch.cuda.current_device()].append(slot)
+
+
 class PendingDecode:
     """A decode whose kernels are enqueued but whose Gaussian count the host has not read yet (neural_gaussians(..., deferred=True)).  Enqueue other
     device work -- e.g. the next camera's LOD mask and decode -- then call finish(): it waits for THIS decode's count only (an event behind its
     kernels, not the stream) and returns the reference-shaped tuple (xyz, color, opacity, scaling, rot, neural_opacity, mask) with its autograd node.
-    The inputs must not be modified in between (they are read by the kernels already enqueued and saved for the backward at finish())."""
+    The node saves for its backward exactly the buffers the enqueued kernels read (`launched["t"]`, `launched["prm"]`: the float32 / contiguous copies
+    _decode_inputs made at launch time, or the caller's own tensors where no copy was needed) -- not a second conversion of the arguments at finish().
+    The caller's tensors must still not be modified in place in between when they were used without a copy.  A PendingDecode that is dropped unfinished
+    gives its pinned count slot and event back when it is collected."""
 
     def __init__(self, flags, args, launched):
         self._flags, self._args, self._launched = flags, args, launched
@@ -179,10 +193,21 @@ class PendingDecode:
             raise RuntimeError("PendingDecode.finish() called twice")
         self._launched = None
         b["event"].synchronize()
-        b["n"] = int(b["count_host"][0])
-        dev = b["nop"].device
-        _count_slots[dev.index if dev.index is not None else torch.cuda.current_device()].append(b.pop("slot"))
+        n = int(b["count_host"][0]) & 0xFFFFFFFF
+        _return_slot(b)
+        if n == SCAN_POISON:
+            raise RuntimeError("decode forward (deferred count): the scan's look-back timed out (a workgroup in front never published its total)")
+        b["n"] = n
         return _NeuralDecode.apply(tuple(self._flags[:6]) + (False, b), *self._args)
+
+    def __del__(self):
+        b = getattr(self, "_launched", None)
+        if b is not None:
+            try:
+                b["event"].synchronize()      # the copy into the pinned word must have landed before the slot is handed to the next decode
+                _return_slot(b)
+            except Exception:                 # interpreter shutdown
+                pass
 
 
 class _NeuralDecode(torch.autograd.Function):
@@ -191,8 +216,11 @@ class _NeuralDecode(torch.autograd.Function):
         static_rows = len(flags) > 6 and bool(flags[6])
         launched = flags[7] if len(flags) > 7 else None           # PendingDecode.finish(): the kernels ran already
         flags = tuple(flags[:6])
-        t, prm = _decode_inputs(vis_idx, campos, level, opacity_scale, anchor, feat, offset, scaling, params)
-        b = launched if launched is not None else _decode_launch(flags, t, prm, "static" if static_rows else "sync")
+        if launched is not None:      # the buffers the enqueued kernels read ARE the ones saved for the backward (a second _decode_inputs here made
+            t, prm, b = launched["t"], launched["prm"], launched      # a second set of copies for non-contiguous / non-float32 arguments)
+        else:
+            t, prm = _decode_inputs(vis_idx, campos, level, opacity_scale, anchor, feat, offset, scaling, params)
+            b = _decode_launch(flags, t, prm, "static" if static_rows else "sync")
         nop, mask, row_offset, scratch, count, n = b["nop"], b["mask"], b["row_offset"], b["scratch"], b["count"], b["n"]
         xyz, color, opacity, scl, rot = b["out"]
         if not static_rows:

@@ -213,3 +213,48 @@ def test_deferred_decode_two_in_flight_equal_the_synchronous_calls():
         for n in a:
             if a[n] is not None:
                 assert torch.allclose(a[n].grad, b[n].grad, rtol=1e-5, atol=1e-6), n
+
+
+def test_deferred_decode_saves_the_buffers_its_kernels_read_and_returns_its_slot():
+    """ADVICE r4.  (1) With arguments that need a conversion (float64 anchors, a non-contiguous feat view) the deferred decode's autograd node keeps the very
+    copies its enqueued kernels read -- modifying the ORIGINALS between the launch and finish() changes neither the outputs nor the gradients (the node no
+    longer converts the arguments a second time at finish()).  (2) A PendingDecode that is dropped unfinished gives its pinned count slot back."""
+    import gc
+    from gsrast import decode
+    t = lambda a: None if a is None else torch.tensor(a, device=DEV)
+    case = decode_cases.make_case(Na=5000, seed=31, vis_frac=0.6)
+    par = {n: (None if v is None else t(v)) for n, v in case["params"].items()}
+    vis = torch.tensor(case["vis_idx"], dtype=torch.int32, device=DEV)
+    heads = ((par["W1o"], par["b1o"], par["W2o"], par["b2o"]), (par["W1c"], par["b1c"], par["W2c"], par["b2c"]), (par["W1k"], par["b1k"], par["W2k"], par["b2k"]))
+
+    def leaves():
+        anchor64 = t(case["anchor"]).double().requires_grad_(True)                         # converted to float32 by the wrapper
+        wide = torch.zeros(case["feat"].shape[0], 2 * case["feat"].shape[1], device=DEV)
+        wide[:, ::2] = t(case["feat"]); wide.requires_grad_(True)
+        return anchor64, wide, t(case["offset"]).requires_grad_(True), t(case["scaling"]).requires_grad_(True)
+
+    def run(deferred, clobber):
+        anchor64, wide, offset, scaling = leaves()
+        feat_view = wide[:, ::2]                                                           # non-contiguous
+        out = decode.neural_gaussians(anchor64, feat_view, offset, scaling, *heads, t(case["campos"]), vis_idx=vis, appearance=par["app"], deferred=deferred)
+        if deferred:
+            if clobber:
+                with torch.no_grad():
+                    anchor64.add_(100.0); wide.mul_(0.0)                                   # the originals change; the launched copies must not care
+            out = out.finish()
+        sum((o * (i + 1.0)).sum() for i, o in enumerate(out[:5])).backward()
+        return out, (anchor64.grad.clone(), wide.grad.clone(), offset.grad.clone(), scaling.grad.clone())
+
+    o0, g0 = run(False, False)
+    o1, g1 = run(True, True)
+    for x, y in zip(o0, o1):
+        assert torch.equal(x, y)
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6)
+    dev = torch.cuda.current_device()
+    free0 = len(decode._count_slots.get(dev, []))
+    anchor64, wide, offset, scaling = leaves()
+    pend = decode.neural_gaussians(anchor64.float(), wide[:, ::2].contiguous(), offset, scaling, *heads, t(case["campos"]), vis_idx=vis, appearance=par["app"], deferred=True)
+    assert len(decode._count_slots.get(dev, [])) == max(free0 - 1, 0)
+    del pend; gc.collect()
+    assert len(decode._count_slots.get(dev, [])) == max(free0, 1)

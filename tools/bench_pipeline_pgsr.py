@@ -26,6 +26,7 @@ import diff_plane_rasterization as dpr   # noqa: E402
 from gsrast.losses import l1_ssim, multiview_cfg, plane_geo_loss, plane_multiview_loss, plane_losses  # noqa: E402
 from gsrast.plane_prep import plane_input_all_map  # noqa: E402
 from gsrast.activations import gaussian_activations  # noqa: E402
+from gsrast.optim import shadow_parameters  # noqa: E402
 from gsrast.optim import Adam          # noqa: E402
 
 
@@ -70,6 +71,14 @@ def build(a, dev):
     op_raw = torch.logit(t["opacities"].clamp(1e-4, 1 - 1e-4)).requires_grad_(True)
     col = t["colors_precomp"].clone().requires_grad_(True)
     opt = (Adam([xyz, scl_log, rot_raw, op_raw, col], lr=1e-4, eps=1e-15) if os.environ.get("GSR_PIPE_TORCH_ADAM", "0") != "1" else torch.optim.Adam([xyz, scl_log, rot_raw, op_raw, col], lr=1e-4, eps=1e-15, fused=True))
+    # The neighbour camera's pass reads a second set of leaves over the same storage (and runs its own activation kernel); the optimizer adds the two passes'
+    # gradients inside its update kernel.  With ONE set autograd sums the two renders' contributions with one `add` launch per tensor the passes share
+    # (xyz, scaling, rotation, opacity, colour: five of the nine adds of round 4's iteration).  GSR_PIPE_SHADOWS=0: one set.
+    first = [xyz, scl_log, rot_raw, op_raw, col]
+    second = first
+    if a.glue == "hip" and os.environ.get("GSR_PIPE_SHADOWS", "1") != "0" and isinstance(opt, Adam):
+        second = shadow_parameters(first)
+        opt.add_shadows(first, second)
     gt = torch.rand((3, H, W), generator=g).to(dev)
     gray1 = gt.mean(0, keepdim=True).contiguous(); gray2 = torch.rand((1, H, W), generator=g).to(dev)
     c1, c2 = cam_of(t, W, H), cam_of(t2, W, H)
@@ -80,7 +89,7 @@ def build(a, dev):
     st = {"P": a.P}
     carriers = {}
 
-    def render(rs, tt, means, scl, rot, op):
+    def render(rs, tt, means, scl, rot, op, col):
         V, cpos = tt["viewmatrix"], tt["campos"]
         am = plane_input_all_map(means, rot, scl, V, cpos) if a.glue == "hip" else torch_all_map(means, rot, scl, V, cpos)
         if a.glue == "hip":      # the rasterizer only uses the carriers' .grad slot: two persistent zero leaves per camera instead of two fills per render
@@ -98,8 +107,12 @@ def build(a, dev):
             scl, rot, op = gaussian_activations(scl_log, rot_raw, op_raw)
         else:
             scl = torch.exp(scl_log); rot = torch.nn.functional.normalize(rot_raw); op = torch.sigmoid(op_raw)
-        img, radii, obs, oam, pd = render(rs1, t, xyz, scl, rot, op)
-        _, _, _, _, pd2 = render(rs2, t2, xyz, scl, rot, op)
+        img, radii, obs, oam, pd = render(rs1, t, xyz, scl, rot, op, col)
+        if second is first:
+            _, _, _, _, pd2 = render(rs2, t2, xyz, scl, rot, op, col)
+        else:
+            scl2, rot2, op2 = gaussian_activations(second[1], second[2], second[3])
+            _, _, _, _, pd2 = render(rs2, t2, second[0], scl2, rot2, op2, second[4])
         if a.glue == "hip":
             nrm, geo, ncc = plane_losses(pd, pd2, oam, gray1, gray2, mcfg, rm1, weight, 0.015, 0.03, 0.15)      # one node: gradients to pd / oam leave it summed
             # sum of four terms -> four roots with unit gradients: the same backward pass without the scalar add launches
