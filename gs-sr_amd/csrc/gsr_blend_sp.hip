@@ -166,6 +166,10 @@ template <int N> __device__ __forceinline__ void sp_pin(float* a)
     if constexpr (N > 18) asm volatile("" : "+v"(a[18]), "+v"(a[19]), "+v"(a[20]));
 }
 
+// (Round 5 tried non-temporal loads for the per-pixel inputs -- read once, 41-158 MB per launch -- so that they would not evict the splat records from the 4 MB
+// L2: FETCH_SIZE rose instead, EWA 77.7 -> 79.8 MiB, surfel 129.2 -> 142.3, and the surfel kernel slowed from 0.385 to 0.389 ms; EXPERIMENTS.md (73).)
+template <typename T> __device__ __forceinline__ T ld_once(const T* p) { return *p; }
+
 // per-pixel constants, lane j of a row holds those of pixel j of the row's 4x4 block
 template <int V> struct SpPix;
 template <> struct SpPix<GSR_EWA> { float dLp0, dLp1, dLp2, Tc, Sc, rowx, rowy; uint32_t last; };
@@ -406,10 +410,10 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
 
     // ---------------------------------------------------------------- per-pixel constants (lane = pixel), kept in registers
     SpPix<V> K;
-    const float T_final = inside ? p.final_T[pix_id] : 0.f;
-    K.last = inside ? p.n_contrib[pix_id] : 0u;
+    const float T_final = inside ? ld_once(p.final_T + pix_id) : 0.f;
+    K.last = inside ? ld_once(p.n_contrib + pix_id) : 0u;
     K.dLp0 = K.dLp1 = K.dLp2 = 0.f;
-    if (inside && p.dL_dcolor) { K.dLp0 = p.dL_dcolor[pix_id]; K.dLp1 = p.dL_dcolor[HW + pix_id]; K.dLp2 = p.dL_dcolor[2 * HW + pix_id]; }
+    if (inside && p.dL_dcolor) { K.dLp0 = ld_once(p.dL_dcolor + pix_id); K.dLp1 = ld_once(p.dL_dcolor + HW + pix_id); K.dLp2 = ld_once(p.dL_dcolor + 2 * HW + pix_id); }
     K.rowx = (float)(qx + (b & 1) * 4); K.rowy = (float)(qy + (b >> 1) * 4);
     K.Tc = T_final;                                          // the chain starts behind the last contributor ...
     K.Sc = T_final * (p.bg[0] * K.dLp0 + p.bg[1] * K.dLp1 + p.bg[2] * K.dLp2);      // ... with the background term of dL_dalpha folded in
@@ -419,11 +423,11 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
         if (geo && inside) {                                 // PLANE backward.cu:433,460-490: plane-depth chain folded into the all_map gradients
             const float rayx = (float)(((float)px - p.W * 0.5) / p.fx), rayy = (float)(((float)py - p.H * 0.5) / p.fy);
             if (p.dL_dout_all_map)
-                for (int c = 0; c < 5; c++) dA[c] = p.dL_dout_all_map[c * HW + pix_id];
-            const float nx = p.all_map_pixels[pix_id], ny = p.all_map_pixels[HW + pix_id], nz = p.all_map_pixels[2 * HW + pix_id];
-            const float distance = p.all_map_pixels[4 * HW + pix_id];
+                for (int c = 0; c < 5; c++) dA[c] = ld_once(p.dL_dout_all_map + c * HW + pix_id);
+            const float nx = ld_once(p.all_map_pixels + pix_id), ny = ld_once(p.all_map_pixels + HW + pix_id), nz = ld_once(p.all_map_pixels + 2 * HW + pix_id);
+            const float distance = ld_once(p.all_map_pixels + 4 * HW + pix_id);
             const float tmp = (float)(nx * rayx + ny * rayy + nz + 1.0e-8);
-            const float dpd = p.dL_dplane_depth ? p.dL_dplane_depth[pix_id] : 0.f;
+            const float dpd = p.dL_dplane_depth ? ld_once(p.dL_dplane_depth + pix_id) : 0.f;
             dA[4] += (-dpd / tmp);
             dA[0] += dpd * (distance / (tmp * tmp) * rayx);
             dA[1] += dpd * (distance / (tmp * tmp) * rayy);
@@ -436,13 +440,13 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
         K.med = 0;
         if (inside) {                                        // SURFEL backward.cu:205-243
             float dLa = 0.f, dLr = 0.f;
-            K.med = p.n_contrib[pix_id + HW];
+            K.med = ld_once(p.n_contrib + pix_id + HW);
             if (p.dL_dothers) {
                 const float* g = p.dL_dothers;
-                K.dLd = g[0 * HW + pix_id]; dLa = g[1 * HW + pix_id]; K.dN0 = g[2 * HW + pix_id]; K.dN1 = g[3 * HW + pix_id]; K.dN2 = g[4 * HW + pix_id];
-                K.dLmd = g[5 * HW + pix_id]; dLr = g[6 * HW + pix_id]; K.dMN0 = g[8 * HW + pix_id]; K.dMN1 = g[9 * HW + pix_id]; K.dMN2 = g[10 * HW + pix_id];
+                K.dLd = ld_once(g + 0 * HW + pix_id); dLa = ld_once(g + 1 * HW + pix_id); K.dN0 = ld_once(g + 2 * HW + pix_id); K.dN1 = ld_once(g + 3 * HW + pix_id); K.dN2 = ld_once(g + 4 * HW + pix_id);
+                K.dLmd = ld_once(g + 5 * HW + pix_id); dLr = ld_once(g + 6 * HW + pix_id); K.dMN0 = ld_once(g + 8 * HW + pix_id); K.dMN1 = ld_once(g + 9 * HW + pix_id); K.dMN2 = ld_once(g + 10 * HW + pix_id);
             }
-            const float fD = p.final_T[pix_id + HW], fD2 = p.final_T[pix_id + 2 * HW];
+            const float fD = ld_once(p.final_T + pix_id + HW), fD2 = ld_once(p.final_T + pix_id + 2 * HW);
             K.c0 = fmaf(dLr, fD2, dLa); K.c1 = -2.0f * dLr * fD; K.c2 = dLr * (1.f - T_final);
         }
     }
