@@ -106,14 +106,11 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
                 dst[3 * 64] = make_float4(r2.y - fox, r2.z - foy, r3.x, r3.y);
                 dst[4 * 64] = make_float4(r3.z, r3.w, r4.x, r4.y);
             } else {
-                // EWA / PLANE: the conic is staged times log2(e), so that a pair pays exp2(power') = one v_exp_f32 instead of a multiply and a v_exp_f32
-                // (power' = log2(e) power has the sign of power: the reference's `power > 0` gate reads the same)
-                constexpr float LOG2E = 1.4426950408889634f;
-                float4 r0 = rr[0], r1 = rr[1];
-                r0.z *= LOG2E; r0.w *= LOG2E; r1.x *= LOG2E;
-                s_rec[(wave * ST + 0) * 64 + lane] = r0; s_rec[(wave * ST + 1) * 64 + lane] = r1;
+                // (staging the conic times log2(e), so that a pair pays exp2 instead of a multiply and a v_exp_f32: PLANE 0.1705 -> 0.168 ms, EWA 0.1695 -> 0.171, and
+                // the three separately rounded products break the cancellation inside `power` of x20 needle splats -- test_needle_splats_are_not_culled_away;
+                // removed, EXPERIMENTS.md (74))
 #pragma unroll
-                for (int k = 2; k < ST; k++) s_rec[(wave * ST + k) * 64 + lane] = rr[k];      // [wave][k][slot]: lane-contiguous 16-byte stores
+                for (int k = 0; k < ST; k++) s_rec[(wave * ST + k) * 64 + lane] = rr[k];      // [wave][k][slot]: lane-contiguous 16-byte stores
             }
         }
 #ifdef FWD_DIAG_NO_PAIRS      // diagnostic build only: the kernel without its pair loop (results are then wrong)
@@ -132,8 +129,8 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
             if (V != GSR_SURFEL) {
                 const float4 q0 = FWD_LD(0), q1 = FWD_LD(1), q2 = FWD_LD(2);
                 const float dx = q0.x - pxf, dy = q0.y - pyf;
-                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;      // log2(e) x the reference's power (staged conic)
-                const float alpha = fminf(0.99f, q1.y * __builtin_amdgcn_exp2f(power));
+                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
+                const float alpha = fminf(0.99f, q1.y * __expf(power));
                 uint64_t okm = live & __builtin_amdgcn_fcmpf(power, 0.0f, 13) & __builtin_amdgcn_fcmpf(alpha, 1.0f / 255.0f, 11);
                 const float test_T = T * (1 - alpha);
                 const uint64_t stopm = okm & __builtin_amdgcn_fcmpf(test_T, 0.0001f, 4);

@@ -216,7 +216,7 @@ def test_deferred_decode_two_in_flight_equal_the_synchronous_calls():
 
 
 def test_deferred_decode_saves_the_buffers_its_kernels_read_and_returns_its_slot():
-    """ADVICE r4.  (1) With arguments that need a conversion (float64 anchors, a non-contiguous feat view) the deferred decode's autograd node keeps the very
+    """ADVICE r4.  (1) With arguments that need a copy (non-contiguous anchor and feat views) the deferred decode's autograd node keeps the very
     copies its enqueued kernels read -- modifying the ORIGINALS between the launch and finish() changes neither the outputs nor the gradients (the node no
     longer converts the arguments a second time at finish()).  (2) A PendingDecode that is dropped unfinished gives its pinned count slot back."""
     import gc
@@ -228,7 +228,8 @@ def test_deferred_decode_saves_the_buffers_its_kernels_read_and_returns_its_slot
     heads = ((par["W1o"], par["b1o"], par["W2o"], par["b2o"]), (par["W1c"], par["b1c"], par["W2c"], par["b2c"]), (par["W1k"], par["b1k"], par["W2k"], par["b2k"]))
 
     def leaves():
-        anchor64 = t(case["anchor"]).double().requires_grad_(True)                         # converted to float32 by the wrapper
+        anchor64 = torch.zeros(case["anchor"].shape[0], 6, device=DEV)                     # the anchors are every other column of this one: a strided view
+        anchor64[:, ::2] = t(case["anchor"]); anchor64.requires_grad_(True)
         wide = torch.zeros(case["feat"].shape[0], 2 * case["feat"].shape[1], device=DEV)
         wide[:, ::2] = t(case["feat"]); wide.requires_grad_(True)
         return anchor64, wide, t(case["offset"]).requires_grad_(True), t(case["scaling"]).requires_grad_(True)
@@ -236,7 +237,7 @@ def test_deferred_decode_saves_the_buffers_its_kernels_read_and_returns_its_slot
     def run(deferred, clobber):
         anchor64, wide, offset, scaling = leaves()
         feat_view = wide[:, ::2]                                                           # non-contiguous
-        out = decode.neural_gaussians(anchor64, feat_view, offset, scaling, *heads, t(case["campos"]), vis_idx=vis, appearance=par["app"], deferred=deferred)
+        out = decode.neural_gaussians(anchor64[:, ::2], feat_view, offset, scaling, *heads, t(case["campos"]), vis_idx=vis, appearance=par["app"], deferred=deferred)
         if deferred:
             if clobber:
                 with torch.no_grad():
@@ -254,7 +255,7 @@ def test_deferred_decode_saves_the_buffers_its_kernels_read_and_returns_its_slot
     dev = torch.cuda.current_device()
     free0 = len(decode._count_slots.get(dev, []))
     anchor64, wide, offset, scaling = leaves()
-    pend = decode.neural_gaussians(anchor64.float(), wide[:, ::2].contiguous(), offset, scaling, *heads, t(case["campos"]), vis_idx=vis, appearance=par["app"], deferred=True)
+    pend = decode.neural_gaussians(anchor64[:, ::2].contiguous(), wide[:, ::2].contiguous(), offset, scaling, *heads, t(case["campos"]), vis_idx=vis, appearance=par["app"], deferred=True)
     assert len(decode._count_slots.get(dev, [])) == max(free0 - 1, 0)
     del pend; gc.collect()
     assert len(decode._count_slots.get(dev, [])) == max(free0, 1)
