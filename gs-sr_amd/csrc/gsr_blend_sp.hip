@@ -379,6 +379,18 @@ template <int I> __device__ __forceinline__ void sp_mn_pixel(const SpPix<GSR_SUR
     acc[4] = bc_fmac<I>(acc[4], K.dMN0, okf); acc[5] = bc_fmac<I>(acc[5], K.dMN1, okf); acc[6] = bc_fmac<I>(acc[6], K.dMN2, okf);
 }
 
+// which 8x8 quadrants of the tile an entry reaches, when the forward left no ballots (GSR_CULL_REUSE-less callers, debug): out of line, so that the four
+// tile-origin constants of this rarely taken path are not hoisted into -- and spilled from -- the kernel's prologue (EWA / PLANE: 4 / 6 spilled registers in round 4)
+template <int V> __device__ __attribute__((noinline)) uint32_t sp_quadrant_mask_slow(const float4* __restrict__ cull, uint32_t id, int tx, int ty)
+{
+    const float4 ca = cull[2 * (size_t)id], cb = cull[2 * (size_t)id + 1];
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (cull_hit_rec<V>(ca, cb, (float)(tx * GSR_TILE + (q & 1) * GSR_SUB), (float)(ty * GSR_TILE + (q >> 1) * GSR_SUB), 7.f)) m |= 1u << q;
+    return m;
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
 {
@@ -489,12 +501,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
                     const unsigned long long* q = p.qmask + (((size_t)(range.x >> 6) + (size_t)tile + (ei >> 6)) << 2);
 #pragma unroll
                     for (int w4 = 0; w4 < 4; w4++) m |= (uint32_t)((q[w4] >> (ei & 63u)) & 1ull) << w4;
-                } else {
-                    const float4 ca = p.cull[2 * (size_t)id], cb = p.cull[2 * (size_t)id + 1];
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (cull_hit_rec<V>(ca, cb, (float)(tx * GSR_TILE + (q & 1) * GSR_SUB), (float)(ty * GSR_TILE + (q >> 1) * GSR_SUB), 7.f)) m |= 1u << q;
-                }
+                } else m = sp_quadrant_mask_slow<V>(p.cull, id, tx, ty);
                 s_mask[t] = (uint16_t)m;
             }
         }
