@@ -133,6 +133,20 @@ def test_deferred_frames_equal_the_synchronous_ones_also_through_a_pool_growth()
         assert not torch.isnan(vol.units()[1]).any()
 
 
+def test_round4_frame_path_kept_for_ab_builds_the_same_volume(monkeypatch):
+    """GSR_TSDF_V1=1: the round-2..4 frame (colour conversion as torch ops, a host read of the work-list length in front of the voxel pass, one workgroup per unit with
+    4-byte accesses) through the ABI <= 6 entry point gsr_tsdf_sparse_integrate -- on the ABI-7 volume (uninitialised pools, colour planes).  Same units, same voxels."""
+    frs = tsdf_cases.frames(3)
+    ref = _hip_volume(frs, cap=8192)
+    monkeypatch.setenv("GSR_TSDF_V1", "1")
+    old = _hip_volume(frs, cap=8192)
+    assert old.num_units == ref.num_units
+    kr = {tuple(k): i for i, k in enumerate(ref.units()[0].tolist())}
+    order = torch.tensor([kr[tuple(k)] for k in old.units()[0].tolist()], device="cuda")
+    for a, b in zip(old.units()[1:], ref.units()[1:]):
+        assert torch.equal(a, b[order])
+
+
 def test_capacity_overflow_raises_or_grows():
     """auto_grow=False: a frame that needs more units than the pool holds raises; the default doubles the pool until the frame fits and then
     holds exactly the volume a large-enough pool would have built."""
