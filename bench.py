@@ -96,18 +96,6 @@ def clock_prewarm(device, ms):
     return (time.perf_counter() - t0) * 1e3
 
 
-def concentrate(sc, frac, scale):
-    """Pull the first `frac` of the gaussians towards the optical axis (camera-space x, y scaled by `scale`): object-centric density, a few hundred
-    tiles with lists several thousand entries long.  For the long-list paths of the per-tile depth sort; not the BASELINE workload."""
-    V = sc["viewmatrix"].astype(np.float64)
-    n = int(frac * sc["means3D"].shape[0])
-    pc = sc["means3D"][:n].astype(np.float64) @ V[:3, :3] + V[3, :3]
-    pc[:, :2] *= scale
-    sc["means3D"][:n] = ((pc - V[3, :3]) @ np.linalg.inv(V[:3, :3])).astype(np.float32)
-    if sc.get("all_map") is not None:
-        sc["all_map"] = scenes.plane_all_map(sc)
-
-
 def make_step(variant, sc, device):
     """One training iteration.  All gaussian parameters live in ONE flat leaf z (contiguous blocks: means 3P, scales 2P|3P,
     rotations 4P, opacity P, colour 3P|48P), optimised by gsrast.optim.Adam (one fused HIP kernel, include/gsrast.h gsr_adam_step) whose
@@ -115,7 +103,7 @@ def make_step(variant, sc, device):
     (GSR_BENCH_TORCH_ADAM=1 selects the earlier form: params = z * lr_scale under torch's fused Adam with lr = 1.)
     The auxiliary-map loss is linear in the 11 (5) channels so autograd hands the rasterizer a dense dL_dothers without
     materialising one zero-padded [11,H,W] tensor per sliced channel; every gradient path of the backward kernel is live."""
-    import hiprun
+    from gsrast import runner as hiprun
     import diff_gaussian_rasterization as dgr
     import diff_surfel_rasterization as dsr
     import diff_plane_rasterization as dpr
@@ -281,7 +269,7 @@ def parity_full_size(variant, sc, og, device, color_mode):
     """HIP rasterizer on the BASELINE workload itself (same scene, same upstream gradients) against the FLOAT64 truth
     (oracle/libgsr_oracle_f64.so on the integer stages of the float32 oracle), with the float32 oracle's own error against the same truth
     beside every figure -- the criterion of tests/test_gpu_parity.py::test_full_size_oracle_parity (tests/parity_truth.py), reported here."""
-    import hiprun
+    from gsrast import runner as hiprun
     import parity_truth as pt
     st = hiprun.run_raw(variant, sc, device=device)
     res = hiprun.run(variant, sc, og, device=device)
@@ -491,7 +479,7 @@ def main():
         dist.all_gather_object(ranks_seen, me)
 
     import gsrast
-    import scenes
+    from gsrast import workloads as scenes
     gsrast.lib()
     if args.method_iteration_child:
         print(json.dumps(method_iteration(device, args.method_iteration_child, steps=60)), flush=True)
@@ -566,7 +554,7 @@ def main():
         except Exception as e:
             graph_info = {"error": str(e)[:200]}
     if rank == 0:
-        import hiprun
+        from gsrast import runner as hiprun
         st = hiprun.run_raw(args.variant, sc, device=device)
         R = int(st["R"])
         R_after = int(hiprun.run_raw(args.variant, state["current_scene"](), device=device)["R"])

@@ -13,18 +13,19 @@
 // The voxel rule is the one k_tsdf_dense (gsr_extra.hip) uses, instruction for instruction, so a sparse volume equals the dense
 // volume on every allocated unit bit for bit (tested); the CPU checker used by the tests restates the same algorithm in plain C.
 //
-// MI355X shape: four launches per frame -- (0) depth + colour planes -> one (r, g, b, depth) texel per pixel, colours put on the 0..255 scale on the way
-// (k_ts_texels: the voxel pass then needs ONE 16-byte gather per voxel, and the wrapper's four torch launches for the uint8 conversion are gone),
+// MI355X shape: four launches per frame -- (0) depth + colour planes -> one texel per pixel, colours put on the 0..255 scale on the way (k_ts_texels: the
+// voxel pass then needs ONE gather per voxel; 8 bytes -- depth + three colour bytes -- with the reference's uint8 colours, 16 otherwise),
 // (1) one thread per sampled pixel inserts <= 8 unit keys into an open-addressing table (64-bit atomicCAS; the winner takes the next pool slot),
 // (2) the same pixels stamp their units for this frame and append the newly stamped ones to a work list (a unit whose stamp was still 0 has never
-// been written: it is listed as FRESH, so the pools need no zero-fill -- 80 KB per unit of capacity -- and a fresh unit is written without being read),
+// been written: it is listed as FRESH),
 // (3) a persistent grid walks the list (its length is read on the device: the launch does not wait for the host): a workgroup takes a unit, thread =
 // four groups of four consecutive z (a wave = 64 consecutive 16-byte groups = 1 KB per load / store instruction in each of the five planes tsdf, weight,
-// r, g, b -- the colour of a unit is stored as three planes since ABI 7), two groups per pass: 8 projections and texel gathers first, then -- only for a
-// group with an update -- its five 16-byte loads, the running averages and five 16-byte stores.  (First round-5 form: thread = a z-column, 64 bytes per
-// lane: contiguous per thread but 64 lines per wave instruction -- 2.11 ms on the config-5 tail against round 4's 1.73.)
-// Round 4's form (thread = every 256th voxel, 16 dependent load -> test -> read-modify-write rounds per thread, four 4-byte gathers per voxel, one
-// workgroup per unit behind a host read of the list length) is kept as k_ts_integrate for A/B (GSR_TSDF_V1=1).
+// r, g, b), two groups per pass: 8 projections and texel gathers first, then -- only for a group with an update -- its five 16-byte loads (only if the group
+// has ever been written: the unit's 1024-bit `mask`), the running averages and five 16-byte stores.
+// ABI 8 (round 6): a unit plane is stored as 4x4x4 bricks of 2x2x4-voxel sectors instead of x-major columns, and nothing is zero-filled any more, not even a
+// unit's first frame: the mask says which groups exist (rounds 2-4 zero-filled the pools at creation, round 5 wrote a fresh unit's 80 KB in full).
+// Earlier forms, measured and gone: thread = a z-column (64 lines per wave instruction, 2.11 ms on the config-5 frame), thread = every 256th voxel behind a
+// host read of the list length (round 4: 1.73 ms; ABI <= 6 entry point gsr_tsdf_sparse_integrate, removed with ABI 8).
 // HBM-bound: 40 B per updated voxel; the pool is sized for 288 GB parts.
 #include "gsr_common.h"
 #include <algorithm>
@@ -40,7 +41,8 @@ struct SparseTsdf {
     uint32_t* stamp;               // [cap_blocks] last frame that touched the unit
     int32_t* list;                 // [cap_blocks] units touched by the current frame
     int32_t* counters;             // [0] = units allocated, [1] = units in `list`, [2] = pool/hash overflow flag
-    float* tsdf; float* weight; float* color;      // pools: [cap_blocks][4096], [..][4096], [..][3][4096] (colour PLANES per unit since ABI 7)
+    float* tsdf; float* weight; float* color;      // pools: [cap_blocks][4096], [..][4096], [..][3][4096] (colour PLANES per unit since ABI 7; brick order since ABI 8)
+    unsigned long long* mask;      // [cap_blocks][16] written-group bits (ABI 8)
     uint32_t cap_hash_log2, cap_blocks;
 };
 
@@ -199,6 +201,7 @@ __global__ void __launch_bounds__(256) k_ts_touch_stamp(SparseTsdf v, TouchParam
             if (!lead[c]) continue;
             if (cur[c] == key[c]) idx[c] = v.slot[h[c]];
             else { int x[3]; (void)ts_corner(lo, hi, c, x); idx[c] = ts_find(v, x[0], x[1], x[2]); }      // displaced by a collision: walk the probe sequence
+            if (idx[c] < 0) v.counters[2] = 1;      // a key without a pool slot (left by an earlier refused frame): the unit cannot be integrated -> "capacity exhausted", never a silent drop
         }
 #pragma unroll
         for (int c = 0; c < 8; c++) st[c] = idx[c] >= 0 ? __hip_atomic_load(&v.stamp[idx[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : frame;
@@ -216,6 +219,7 @@ __global__ void __launch_bounds__(256) k_ts_touch_stamp(SparseTsdf v, TouchParam
             for (int y = lo[1]; y <= hi[1]; y++)
                 for (int z = lo[2]; z <= hi[2]; z++) {
                     const int idx = ts_find(v, x, y, z);
+                    if (idx < 0) v.counters[2] = 1;
                     if (idx < 0 || __hip_atomic_load(&v.stamp[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == frame) continue;
                     const uint32_t old = atomicExch(&v.stamp[idx], frame);
                     if (old != frame) v.list[atomicAdd(&v.counters[1], 1)] = old ? idx : ~idx;
@@ -232,49 +236,13 @@ struct IntParams {
     float vl, trunc, dtrunc, fx, fy, cx, cy, rfx, rfy, rtrunc, unit_len;
     float E[12];
 };
-// the voxel rule of k_tsdf_dense (gsr_extra.hip), same operations in the same order
-__global__ void __launch_bounds__(256) k_ts_integrate(SparseTsdf v, IntParams p, const float* __restrict__ depth, const float* __restrict__ rgb)
-{
-    const int e = v.list[blockIdx.x];
-    const bool fresh = e < 0;
-    const int b = fresh ? ~e : e;
-    if (fresh) {      // never written: the pools are not zero-filled any more
-        for (int i = threadIdx.x; i < TS_VOX; i += 256) { v.tsdf[(size_t)b * TS_VOX + i] = 0.f; v.weight[(size_t)b * TS_VOX + i] = 0.f; }
-        for (int i = threadIdx.x; i < 3 * TS_VOX; i += 256) v.color[(size_t)b * TS_VOX * 3 + i] = 0.f;
-        __syncthreads();
-    }
-    const float ox = (float)v.coord[3 * b] * p.unit_len, oy = (float)v.coord[3 * b + 1] * p.unit_len, oz = (float)v.coord[3 * b + 2] * p.unit_len;
-    float* tsdf = v.tsdf + (size_t)b * TS_VOX; float* weight = v.weight + (size_t)b * TS_VOX; float* color = v.color + (size_t)b * TS_VOX * 3;
-    const size_t HW = (size_t)p.W * p.H;
-    for (int i = threadIdx.x; i < TS_VOX; i += 256) {
-        const int iz = i % TS_RES, iy = (i / TS_RES) % TS_RES, ix = i / (TS_RES * TS_RES);
-        const float x = ox + p.vl * ((float)ix + 0.5f), y = oy + p.vl * ((float)iy + 0.5f), z = oz + p.vl * ((float)iz + 0.5f);
-        const float xc = p.E[0] * x + p.E[1] * y + p.E[2] * z + p.E[3];
-        const float yc = p.E[4] * x + p.E[5] * y + p.E[6] * z + p.E[7];
-        const float zc = p.E[8] * x + p.E[9] * y + p.E[10] * z + p.E[11];
-        if (!(zc > 0.f)) continue;
-        const float rz = __builtin_amdgcn_rcpf(zc);
-        const float uf = xc * p.fx * rz + p.cx + 0.5f, vf = yc * p.fy * rz + p.cy + 0.5f;
-        if (!(uf >= 0.f && uf < (float)p.W && vf >= 0.f && vf < (float)p.H)) continue;
-        const int u = (int)uf, vv = (int)vf;
-        const float d = depth[(size_t)vv * p.W + u];
-        if (!(d > 0.f) || d > p.dtrunc) continue;
-        const float rx = ((float)u - p.cx) * p.rfx, ry = ((float)vv - p.cy) * p.rfy;
-        const float sdf = (d - zc) * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + 1.0f);
-        if (!(sdf > -p.trunc)) continue;
-        const float t = fminf(1.0f, sdf * p.rtrunc);
-        const float w = weight[i], wp = w + 1.0f, rwp = __builtin_amdgcn_rcpf(wp);
-        tsdf[i] = (tsdf[i] * w + t) * rwp;
-#pragma unroll
-        for (int c = 0; c < 3; c++) color[c * TS_VOX + i] = (color[c * TS_VOX + i] * w + rgb[c * HW + (size_t)vv * p.W + u]) * rwp;
-        weight[i] = wp;
-    }
-}
 
-
-// ---- (r, g, b, depth) texels.  quant 0: colours as given; 1: clamp to [0,1], x 255 (the scale the volume stores); 2: additionally truncated to an integer, the
-// uint8 round trip of mesh_utils.py:170 (`(rgb * 255).astype(np.uint8)`, here on the clamped value like the wrapper's torch chain of rounds 2-4)
-__global__ void __launch_bounds__(256) k_ts_texels(const float* __restrict__ depth, const float* __restrict__ rgb, float4* __restrict__ tex, int N, int quant)
+// ---- texels.  quant 0: colours as given; 1: clamp to [0,1], x 255 (the scale the volume stores); 2: additionally truncated to an integer, the
+// uint8 round trip of mesh_utils.py:170 (`(rgb * 255).astype(np.uint8)`, here on the clamped value like the wrapper's torch chain of rounds 2-4).
+// quant 0 / 1: one (r, g, b, depth) float4 per pixel.  quant 2 (the reference's setting): the truncated colours ARE bytes, so the texel is 8 bytes --
+// (depth, r | g << 8 | b << 16) -- half the gather traffic of the voxel pass and half its texel registers (ABI 8).
+template <bool PK>
+__global__ void __launch_bounds__(256) k_ts_texels(const float* __restrict__ depth, const float* __restrict__ rgb, void* __restrict__ tex, int N, int quant)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -286,18 +254,65 @@ __global__ void __launch_bounds__(256) k_ts_texels(const float* __restrict__ dep
             if (quant == 2) c[k] = floorf(c[k]);
         }
     }
-    tex[i] = make_float4(c[0], c[1], c[2], depth[i]);
+    if (PK) reinterpret_cast<float2*>(tex)[i] = make_float2(depth[i], __uint_as_float((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16)));
+    else reinterpret_cast<float4*>(tex)[i] = make_float4(c[0], c[1], c[2], depth[i]);
 }
 
-// the voxel rule of k_tsdf_dense (gsr_extra.hip), the same operations in the same order per voxel; see the file header for the shape.
-// A unit's 4096 voxels are 1024 groups of four consecutive z; thread t takes groups t, t + 256, t + 512, t + 768 (x = (t >> 6) + 4 r): the 64 lanes of a
-// wave read and write 64 consecutive 16-byte groups = 1 KB per instruction in each of the five planes (tsdf, weight, three colour planes).
+// ---- the voxel pass.  The voxel rule of k_tsdf_dense (gsr_extra.hip), the same operations in the same order per voxel.
+// Storage of a unit plane (ABI 8): 4 x 4 x 4 bricks of 256 B; inside a brick 64-byte sectors of 2 x 2 x 4 voxels, 128-byte lines of 2 x 4 x 4 -- the shell of voxels a
+// frame updates is a surface through the unit, and compact sectors are cut by it far less often than the 1 x 1 x 16 columns of ABI 7 (ts_group below).
+// A unit's 4096 voxels are 1024 groups of four consecutive z; thread t takes groups t, t + 256, t + 512, t + 768 (brick x = round): the 64 lanes of a
+// wave read and write 64 consecutive 16-byte groups = 4 bricks = 1 KB per instruction in each of the five planes (tsdf, weight, three colour planes).
+// mask[unit][16] (64-bit words, bit = group): the groups that have ever been written.  A group whose bit is clear is never read (its first update starts
+// from zeros and sets the bit) and a fresh unit writes only the groups the frame observed: nothing zero-fills a unit's 80 KB any more, at creation or later.
+__host__ __device__ __forceinline__ int ts_group(int x, int y, int z)
+{
+    return ((x >> 2) << 8) | ((y >> 2) << 6) | ((z >> 2) << 4) | (((x >> 1) & 1) << 3) | (((y >> 1) & 1) << 2) | ((x & 1) << 1) | (y & 1);
+}
+// the inverse for thread t of a 256-thread workgroup in round r (group t + 256 r): voxel (x, y, z0 .. z0 + 3)
+struct TsLane { int lx, iy, iz0; };
+__device__ __forceinline__ TsLane ts_lane(int t)
+{
+    TsLane l;
+    l.lx = ((t >> 3) & 1) * 2 + ((t >> 1) & 1);
+    l.iy = ((t >> 6) & 3) * 4 + ((t >> 2) & 1) * 2 + (t & 1);
+    l.iz0 = ((t >> 4) & 3) * 4;
+    return l;
+}
+__device__ __forceinline__ unsigned long long ts_uniform64(unsigned long long x)
+{
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
+__device__ __forceinline__ void ts_unpack4(const float4 a, float* o) { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
+
+#ifndef TS_GRID
+#define TS_GRID 2048
+#endif
+#ifndef TS_WGRAN
+#define TS_WGRAN 8      // groups per completed run: 1 (none), 2 (32 B), 4 (64 B), 8 (a 128-byte line)
+#endif
+__device__ __forceinline__ unsigned long long ts_complete_runs(unsigned long long m)
+{
+    if (TS_WGRAN >= 2) m |= m >> 1;
+    if (TS_WGRAN >= 4) m |= m >> 2;
+    if (TS_WGRAN >= 8) m |= m >> 4;
+    if (TS_WGRAN == 2) return (m & 0x5555555555555555ull) * 3ull;
+    if (TS_WGRAN == 4) return (m & 0x1111111111111111ull) * 15ull;
+    if (TS_WGRAN == 8) return (m & 0x0101010101010101ull) * 255ull;
+    return m;
+}
 #define TS_GPT 2      // groups per pass: 8 voxels' projections and texel gathers are in flight before anything of the volume is read
 #ifndef TS_WPE
-#define TS_WPE 3
+#define TS_WPE 4
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TS_WPE, TS_WPE))) k_ts_integrate_col(SparseTsdf v, IntParams p, const float4* __restrict__ tex, int n_fixed)
+template <bool PK> struct TsTexel;
+template <> struct TsTexel<true> { typedef float2 type; static __device__ __forceinline__ float2 zero() { return make_float2(0.f, 0.f); } };
+template <> struct TsTexel<false> { typedef float4 type; static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); } };
+template <bool PK>
+__device__ __forceinline__ void ts_integrate_col(const SparseTsdf& v, const IntParams& p, const void* __restrict__ tex_, int n_fixed)
 {
+    typedef typename TsTexel<PK>::type texel_t;
+    const texel_t* __restrict__ tex = reinterpret_cast<const texel_t*>(tex_);
     const int n = n_fixed >= 0 ? n_fixed : v.counters[1];
     if (v.counters[2] | v.counters[3]) {
         // the touch pass ran out of pool slots / key range: nothing of this frame is integrated (the host grows the pool and runs the frame again, or raises).
@@ -305,40 +320,46 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TS_WPE
         for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) { const int e = v.list[k]; if (e < 0) v.stamp[~e] = 0u; }
         return;
     }
-    const int iy = (threadIdx.x >> 2) & 15, iz0 = (threadIdx.x & 3) << 2, ixb = threadIdx.x >> 6;
+    const TsLane L = ts_lane((int)threadIdx.x);
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
         const int e = v.list[k];
         const bool fresh = e < 0;
         const int b = fresh ? ~e : e;
         const float ox = (float)v.coord[3 * b] * p.unit_len, oy = (float)v.coord[3 * b + 1] * p.unit_len, oz = (float)v.coord[3 * b + 2] * p.unit_len;
-        const float y = oy + p.vl * ((float)iy + 0.5f);
+        const float y = oy + p.vl * ((float)L.iy + 0.5f);
         float4* W4 = reinterpret_cast<float4*>(v.weight + (size_t)b * TS_VOX);
         float4* S4 = reinterpret_cast<float4*>(v.tsdf + (size_t)b * TS_VOX);
         float4* C4 = reinterpret_cast<float4*>(v.color + (size_t)b * TS_VOX * 3);      // three planes of 4096 floats: [channel][voxel]
+        unsigned long long* M = v.mask + (size_t)b * 16;
+        unsigned long long had[4];      // wave-uniform: the written-group words of this wave's four rounds (a fresh unit's words hold whatever the pool held)
+#pragma unroll
+        for (int r = 0; r < 4; r++) had[r] = fresh ? 0ull : ts_uniform64(M[wv + 4 * r]);
 #pragma unroll
         for (int pass = 0; pass < 4 / TS_GPT; pass++) {
-            float4 t[4 * TS_GPT];
-            float zcs[4 * TS_GPT];
-            uint32_t uv[4 * TS_GPT];
+            texel_t t[4 * TS_GPT];
+            float zcs[4 * TS_GPT], rl[4 * TS_GPT];
             uint32_t cand = 0;
 #pragma unroll
             for (int q = 0; q < TS_GPT; q++) {
-                const int ix = ixb + 4 * (pass * TS_GPT + q);
+                const int ix = L.lx + 4 * (pass * TS_GPT + q);
                 const float x = ox + p.vl * ((float)ix + 0.5f);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int s_ = 4 * q + j;
-                    const float z = oz + p.vl * ((float)(iz0 + j) + 0.5f);
+                    const float z = oz + p.vl * ((float)(L.iz0 + j) + 0.5f);
                     const float xc = p.E[0] * x + p.E[1] * y + p.E[2] * z + p.E[3];
                     const float yc = p.E[4] * x + p.E[5] * y + p.E[6] * z + p.E[7];
                     const float zc = p.E[8] * x + p.E[9] * y + p.E[10] * z + p.E[11];
-                    zcs[s_] = zc; uv[s_] = 0u; t[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    zcs[s_] = zc; rl[s_] = 0.f;
+                    t[s_] = TsTexel<PK>::zero();
                     if (!(zc > 0.f)) continue;
                     const float rz = __builtin_amdgcn_rcpf(zc);
                     const float uf = xc * p.fx * rz + p.cx + 0.5f, vf = yc * p.fy * rz + p.cy + 0.5f;
                     if (!(uf >= 0.f && uf < (float)p.W && vf >= 0.f && vf < (float)p.H)) continue;
                     const int u = (int)uf, vv = (int)vf;
-                    uv[s_] = (uint32_t)u | ((uint32_t)vv << 16);
+                    const float rx = ((float)u - p.cx) * p.rfx, ry = ((float)vv - p.cy) * p.rfy;
+                    rl[s_] = __builtin_amdgcn_sqrtf(rx * rx + ry * ry + 1.0f);
                     cand |= 1u << s_;
                     t[s_] = tex[(size_t)vv * p.W + u];
                 }
@@ -349,41 +370,84 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TS_WPE
             for (int s_ = 0; s_ < 4 * TS_GPT; s_++) {
                 tv[s_] = 0.f;
                 if (!((cand >> s_) & 1u)) continue;
-                const float d = t[s_].w;
+                const float d = PK ? ((const float*)&t[s_])[0] : ((const float*)&t[s_])[3];
                 if (!(d > 0.f) || d > p.dtrunc) continue;
-                const float rx = ((float)(uv[s_] & 0xFFFFu) - p.cx) * p.rfx, ry = ((float)(uv[s_] >> 16) - p.cy) * p.rfy;
-                const float sdf = (d - zcs[s_]) * __builtin_amdgcn_sqrtf(rx * rx + ry * ry + 1.0f);
+                const float sdf = (d - zcs[s_]) * rl[s_];
                 if (!(sdf > -p.trunc)) continue;
                 tv[s_] = fminf(1.0f, sdf * p.rtrunc);
                 m |= 1u << s_;
             }
 #pragma unroll
             for (int q = 0; q < TS_GPT; q++) {
+                const int r = pass * TS_GPT + q;
                 const uint32_t mq = (m >> (4 * q)) & 0xFu;
-                if (mq == 0 && !fresh) continue;
-                const int g = (int)threadIdx.x + 256 * (pass * TS_GPT + q);      // group index inside the unit
+                // the groups of this wave's 64 that the frame updates -- completed to whole TS_WGRAN-group runs (8 = a 128-byte line per plane): the lanes of a
+                // run without an update of their own load their group (or start from zeros) and store it back unchanged, so that the L2 evicts FULL lines.
+                // A partially written line costs the memory side a read-modify-write: 52-54 ps per line against 38 ps for a line read and written in full
+                // (tools/microbench/hbm_granule, profiles/r06_hbm_granule.json), and the line has been fetched for the updated group anyway.
+                const unsigned long long now = ts_complete_runs(__ballot(mq != 0));
+                if (lane == 0 && (fresh || (now & ~had[r]) != 0ull)) M[wv + 4 * r] = had[r] | now;      // (a fresh unit's words are written in full: they held garbage)
+                if (!((now >> lane) & 1ull)) continue;
+                const int g = (int)threadIdx.x + 256 * r;      // group index inside the unit
                 float w[4] = { 0.f, 0.f, 0.f, 0.f }, sd[4] = { 0.f, 0.f, 0.f, 0.f }, c[3][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
-                if (!fresh) {
+                if ((had[r] >> lane) & 1ull) {
                     const float4 a = W4[g], bq = S4[g], c0 = C4[g], c1 = C4[1024 + g], c2 = C4[2048 + g];
-                    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; sd[0] = bq.x; sd[1] = bq.y; sd[2] = bq.z; sd[3] = bq.w;
-                    c[0][0] = c0.x; c[0][1] = c0.y; c[0][2] = c0.z; c[0][3] = c0.w; c[1][0] = c1.x; c[1][1] = c1.y; c[1][2] = c1.z; c[1][3] = c1.w;
-                    c[2][0] = c2.x; c[2][1] = c2.y; c[2][2] = c2.z; c[2][3] = c2.w;
+                    ts_unpack4(a, w); ts_unpack4(bq, sd); ts_unpack4(c0, c[0]); ts_unpack4(c1, c[1]); ts_unpack4(c2, c[2]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (!((mq >> j) & 1u)) continue;
                     const int s_ = 4 * q + j;
+                    float cr, cg, cb;
+                    if (PK) {
+                        const uint32_t pk = __float_as_uint(((const float*)&t[s_])[1]);
+                        cr = (float)(pk & 255u); cg = (float)((pk >> 8) & 255u); cb = (float)((pk >> 16) & 255u);
+                    } else { cr = ((const float*)&t[s_])[0]; cg = ((const float*)&t[s_])[1]; cb = ((const float*)&t[s_])[2]; }
                     const float wo = w[j], wp = wo + 1.0f, rwp = __builtin_amdgcn_rcpf(wp);
                     sd[j] = (sd[j] * wo + tv[s_]) * rwp;
-                    c[0][j] = (c[0][j] * wo + t[s_].x) * rwp; c[1][j] = (c[1][j] * wo + t[s_].y) * rwp; c[2][j] = (c[2][j] * wo + t[s_].z) * rwp;
+                    c[0][j] = (c[0][j] * wo + cr) * rwp; c[1][j] = (c[1][j] * wo + cg) * rwp; c[2][j] = (c[2][j] * wo + cb) * rwp;
                     w[j] = wp;
                 }
-                // (a fresh unit is written in full: zeros where nothing was observed)
                 W4[g] = make_float4(w[0], w[1], w[2], w[3]); S4[g] = make_float4(sd[0], sd[1], sd[2], sd[3]);
                 C4[g] = make_float4(c[0][0], c[0][1], c[0][2], c[0][3]); C4[1024 + g] = make_float4(c[1][0], c[1][1], c[1][2], c[1][3]);
                 C4[2048 + g] = make_float4(c[2][0], c[2][1], c[2][2], c[2][3]);
             }
         }
+    }
+}
+
+// 8-byte texels: 124 VGPRs, 4 waves per SIMD, no spills (forcing 5: 31 spilled registers and 1.6 x the time; 3: the same time as 4).  16-byte texels: 3 waves.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TS_WPE, 8))) k_ts_integrate_col(SparseTsdf v, IntParams p, const void* __restrict__ tex, int n_fixed)
+{
+    ts_integrate_col<true>(v, p, tex, n_fixed);
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) k_ts_integrate_col_f32(SparseTsdf v, IntParams p, const void* __restrict__ tex, int n_fixed)
+{
+    ts_integrate_col<false>(v, p, tex, n_fixed);
+}
+
+// every group of units [0, n) becomes readable: what has never been written is zero-filled and marked written (a unit nobody ever wrote -- stamp 0, e.g.
+// allocated by a frame that then ran out of capacity -- in full).  The pools are plain arrays afterwards: units() / export.
+__global__ void __launch_bounds__(256) k_ts_materialize(SparseTsdf v, int n)
+{
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        const bool fresh = v.stamp[b] == 0u;
+        unsigned long long* M = v.mask + (size_t)b * 16;
+        float4* W4 = reinterpret_cast<float4*>(v.weight + (size_t)b * TS_VOX);
+        float4* S4 = reinterpret_cast<float4*>(v.tsdf + (size_t)b * TS_VOX);
+        float4* C4 = reinterpret_cast<float4*>(v.color + (size_t)b * TS_VOX * 3);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned long long had = fresh ? 0ull : ts_uniform64(M[wv + 4 * r]);
+            if (had == ~0ull) continue;
+            const int g = (int)threadIdx.x + 256 * r;
+            if (!((had >> lane) & 1ull)) { W4[g] = z4; S4[g] = z4; C4[g] = z4; C4[1024 + g] = z4; C4[2048 + g] = z4; }
+            if (lane == 0) M[wv + 4 * r] = ~0ull;
+        }
+        __syncthreads();
+        if (fresh && threadIdx.x == 0) v.stamp[b] = 0xFFFFFFFFu;      // written, by no frame
     }
 }
 
@@ -409,36 +473,80 @@ __global__ void __launch_bounds__(256) k_ts_insert_list(SparseTsdf v, const int3
     if (i < n) (void)ts_insert(v, coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]);
 }
 // self <- weighted merge of self and the given units (tsdf, weight, colour per unit): the running averages are associative in
-// (sum w*tsdf, sum w), so fusing per-tile volumes equals integrating all frames into one volume up to fp32 rounding
-__global__ void __launch_bounds__(256) k_ts_merge_list(SparseTsdf v, const int32_t* __restrict__ coords, const float* __restrict__ o_tsdf,
-                                                       const float* __restrict__ o_weight, const float* __restrict__ o_color)
+// (sum w*tsdf, sum w), so fusing per-tile volumes equals integrating all frames into one volume up to fp32 rounding.
+// One workgroup per incoming unit, thread = four 16-byte groups as in the voxel pass; only groups the incoming unit has data in are touched, a group of the
+// target that has never been written becomes a copy (zeros where the incoming weight is 0) without being read.
+// SRC 0: the incoming units are plain arrays in LOGICAL order (x-major, z fastest; colour [voxel][3]) -- the lists merge_() gathers from other ranks;
+// SRC 1: they are the pools of another volume (storage order, colour planes, written-group words, stamps): merge_from() on one device, nothing is copied or
+// re-ordered in between and what the source never wrote is never read.
+template <int SRC>
+__global__ void __launch_bounds__(256) k_ts_merge(SparseTsdf v, const int32_t* __restrict__ coords, const float* __restrict__ o_tsdf, const float* __restrict__ o_weight,
+                                                  const float* __restrict__ o_color, const unsigned long long* __restrict__ o_mask, const uint32_t* __restrict__ o_stamp, int n)
 {
-    const int k = blockIdx.x;
-    const int b = ts_find(v, coords[3 * k], coords[3 * k + 1], coords[3 * k + 2]);
-    if (b < 0) return;
-    float* tsdf = v.tsdf + (size_t)b * TS_VOX; float* weight = v.weight + (size_t)b * TS_VOX; float* color = v.color + (size_t)b * TS_VOX * 3;
-    const float* ot = o_tsdf + (size_t)k * TS_VOX; const float* ow = o_weight + (size_t)k * TS_VOX; const float* oc = o_color + (size_t)k * TS_VOX * 3;
-    // a unit this call (or an aborted frame) allocated has never been written -- the pools are not zero-filled: it becomes a copy of the incoming unit
-    const bool fresh = v.stamp[b] == 0u;
-    __syncthreads();
-    if (fresh) {
-        if (threadIdx.x == 0) v.stamp[b] = 0xFFFFFFFFu;      // written, by no frame
-        for (int i = threadIdx.x; i < TS_VOX; i += 256) {
-            const bool has = ow[i] > 0.f;
-            tsdf[i] = has ? ot[i] : 0.f; weight[i] = has ? ow[i] : 0.f;
+    const TsLane L = ts_lane((int)threadIdx.x);
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        if (SRC == 1 && o_stamp[k] == 0u) continue;      // allocated by the source, never written
+        const int b = ts_find(v, coords[3 * k], coords[3 * k + 1], coords[3 * k + 2]);
+        if (b < 0) continue;
+        const bool fresh = v.stamp[b] == 0u;      // a unit this call (or an aborted frame) allocated: its pool memory and mask words are uninitialised
+        unsigned long long* M = v.mask + (size_t)b * 16;
+        float4* W4 = reinterpret_cast<float4*>(v.weight + (size_t)b * TS_VOX);
+        float4* S4 = reinterpret_cast<float4*>(v.tsdf + (size_t)b * TS_VOX);
+        float4* C4 = reinterpret_cast<float4*>(v.color + (size_t)b * TS_VOX * 3);
+        const float* ot = o_tsdf + (size_t)k * TS_VOX; const float* ow = o_weight + (size_t)k * TS_VOX; const float* oc = o_color + (size_t)k * TS_VOX * 3;
 #pragma unroll
-            for (int c = 0; c < 3; c++) color[c * TS_VOX + i] = has ? oc[3 * i + c] : 0.f;
+        for (int r = 0; r < 4; r++) {
+            const unsigned long long had = fresh ? 0ull : ts_uniform64(M[wv + 4 * r]);
+            const int g = (int)threadIdx.x + 256 * r;
+            float w1[4] = { 0.f, 0.f, 0.f, 0.f }, t1[4] = { 0.f, 0.f, 0.f, 0.f }, c1[3][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+            if (SRC == 1) {
+                const unsigned long long src_has = ts_uniform64(o_mask[(size_t)k * 16 + wv + 4 * r]);
+                if ((src_has >> lane) & 1ull) {
+                    ts_unpack4(reinterpret_cast<const float4*>(ow)[g], w1); ts_unpack4(reinterpret_cast<const float4*>(ot)[g], t1);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) ts_unpack4(reinterpret_cast<const float4*>(oc)[1024 * c + g], c1[c]);
+                }
+            } else {
+                const int i0 = ((L.lx + 4 * r) * TS_RES + L.iy) * TS_RES + L.iz0;      // logical index of the group's first voxel
+                ts_unpack4(*reinterpret_cast<const float4*>(ow + i0), w1); ts_unpack4(*reinterpret_cast<const float4*>(ot + i0), t1);
+                float a[12];
+#pragma unroll
+                for (int q = 0; q < 3; q++) ts_unpack4(*reinterpret_cast<const float4*>(oc + 3 * i0 + 4 * q), a + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { c1[0][j] = a[3 * j]; c1[1][j] = a[3 * j + 1]; c1[2][j] = a[3 * j + 2]; }
+            }
+            const bool any = w1[0] > 0.f || w1[1] > 0.f || w1[2] > 0.f || w1[3] > 0.f;
+            const unsigned long long now = __ballot(any);
+            if (lane == 0 && (fresh || (now & ~had) != 0ull)) M[wv + 4 * r] = had | now;
+            if (!any) continue;
+            float w0[4] = { 0.f, 0.f, 0.f, 0.f }, t0[4] = { 0.f, 0.f, 0.f, 0.f }, c0[3][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+            if ((had >> lane) & 1ull) {
+                ts_unpack4(W4[g], w0); ts_unpack4(S4[g], t0);
+#pragma unroll
+                for (int c = 0; c < 3; c++) ts_unpack4(C4[1024 * c + g], c0[c]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!(w1[j] > 0.f)) continue;
+                if (!(w0[j] > 0.f)) {      // nothing there yet: the incoming voxel as it is (no (t * w) / w round trip)
+                    t0[j] = t1[j]; w0[j] = w1[j];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) c0[c][j] = c1[c][j];
+                    continue;
+                }
+                const float ws = w0[j] + w1[j], rs = 1.0f / ws;
+                t0[j] = (t0[j] * w0[j] + t1[j] * w1[j]) * rs;
+#pragma unroll
+                for (int c = 0; c < 3; c++) c0[c][j] = (c0[c][j] * w0[j] + c1[c][j] * w1[j]) * rs;
+                w0[j] = ws;
+            }
+            W4[g] = make_float4(w0[0], w0[1], w0[2], w0[3]); S4[g] = make_float4(t0[0], t0[1], t0[2], t0[3]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) C4[1024 * c + g] = make_float4(c0[c][0], c0[c][1], c0[c][2], c0[c][3]);
         }
-        return;
-    }
-    for (int i = threadIdx.x; i < TS_VOX; i += 256) {
-        const float w0 = weight[i], w1 = ow[i], ws = w0 + w1;
-        if (!(w1 > 0.f)) continue;
-        const float r = 1.0f / ws;
-        tsdf[i] = (tsdf[i] * w0 + ot[i] * w1) * r;
-#pragma unroll
-        for (int c = 0; c < 3; c++) color[c * TS_VOX + i] = (color[c * TS_VOX + i] * w0 + oc[3 * i + c] * w1) * r;      // pool: colour planes; incoming list: [voxel][3]
-        weight[i] = ws;
+        __syncthreads();
+        if (fresh && threadIdx.x == 0) v.stamp[b] = 0xFFFFFFFFu;      // written, by no frame
     }
 }
 
@@ -447,12 +555,12 @@ static SparseTsdf make_view(const gsr_tsdf_sparse* s)
 {
     SparseTsdf v;
     v.keys = (unsigned long long*)s->keys; v.slot = s->slot; v.coord = s->coord; v.stamp = s->stamp; v.list = s->list; v.counters = s->counters;
-    v.tsdf = s->tsdf; v.weight = s->weight; v.color = s->color; v.cap_hash_log2 = s->cap_hash_log2; v.cap_blocks = s->cap_blocks;
+    v.tsdf = s->tsdf; v.weight = s->weight; v.color = s->color; v.mask = (unsigned long long*)s->mask; v.cap_hash_log2 = s->cap_hash_log2; v.cap_blocks = s->cap_blocks;
     return v;
 }
 static int check_vol(const gsr_tsdf_sparse* s)
 {
-    if (!s || !s->keys || !s->slot || !s->coord || !s->stamp || !s->list || !s->counters || !s->tsdf || !s->weight || !s->color) {
+    if (!s || !s->keys || !s->slot || !s->coord || !s->stamp || !s->list || !s->counters || !s->tsdf || !s->weight || !s->color || !s->mask) {
         gsr_set_error("tsdf_sparse: null volume buffers"); return 1;
     }
     if (s->cap_hash_log2 < 4 || s->cap_hash_log2 > 30 || s->cap_blocks == 0 || (1ull << s->cap_hash_log2) < 2ull * s->cap_blocks) {
@@ -489,33 +597,6 @@ static int frame_errors(const gsr_tsdf_sparse* s, const int32_t* c, hipStream_t 
     return 0;
 }
 
-extern "C" int gsr_tsdf_sparse_integrate(const gsr_tsdf_sparse* s, int32_t W, int32_t H, const float* depth, const float* rgb, float fx, float fy,
-                                         float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc, int32_t stride,
-                                         uint32_t frame, uint32_t* n_touched_host, void* stream)
-{
-    // round-2 entry point, kept: planes in, colours already on the volume's scale, one host read of the list length in front of the voxel pass
-    if (check_vol(s)) return 1;
-    if (W <= 0 || H <= 0 || stride <= 0 || !depth || !rgb || !extrinsic || !pose) { gsr_set_error("tsdf_sparse_integrate: bad arguments"); return 1; }
-    hipStream_t st = (hipStream_t)stream;
-    SparseTsdf v = make_view(s);
-    TouchParams t; IntParams p;
-    fill_params(s, W, H, fx, fy, cx, cy, extrinsic, pose, depth_trunc, stride, t, p);
-    const int n = ((W + stride - 1) / stride) * ((H + stride - 1) / stride);
-    if (gsr_memset_async(v.counters + 1, 0, sizeof(int32_t), st)) { gsr_set_error("tsdf_sparse: reset list"); return 1; };
-    hipLaunchKernelGGL(k_ts_touch_insert, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n);
-    hipLaunchKernelGGL(k_ts_touch_stamp, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n, frame);
-    int32_t c[4] = { 0, 0, 0, 0 };
-    GSR_CHECK(hipMemcpyAsync(c, v.counters, sizeof(c), hipMemcpyDeviceToHost, st), "tsdf_sparse: read counters");
-    GSR_CHECK(hipStreamSynchronize(st), "tsdf_sparse: sync");
-    if (c[2] || c[3]) {      // nothing of the frame is integrated: its fresh units go back to "never written" (the pools are not zero-filled)
-        if (c[1] > 0) hipLaunchKernelGGL(k_ts_integrate_col, dim3(std::min((c[1] + 255) / 256, 1024)), dim3(256), 0, st, v, p, (const float4*)nullptr, c[1]);
-        return frame_errors(s, c, st);
-    }
-    if (n_touched_host) *n_touched_host = (uint32_t)c[1];
-    if (c[1] > 0) hipLaunchKernelGGL(k_ts_integrate, dim3((uint32_t)c[1]), dim3(256), 0, st, v, p, depth, rgb);
-    return gsr_check_launch("tsdf_sparse_integrate", st, false);
-}
-
 extern "C" int gsr_tsdf_sparse_integrate2(const gsr_tsdf_sparse* s, int32_t W, int32_t H, const float* depth, const float* rgb, int32_t quant, float fx,
                                           float fy, float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc, int32_t stride,
                                           uint32_t frame, float* texels, int32_t* status_host, uint32_t flags, void* stream)
@@ -531,11 +612,14 @@ extern "C" int gsr_tsdf_sparse_integrate2(const gsr_tsdf_sparse* s, int32_t W, i
     fill_params(s, W, H, fx, fy, cx, cy, extrinsic, pose, depth_trunc, stride, t, p);
     const int n = ((W + stride - 1) / stride) * ((H + stride - 1) / stride), N = W * H;
     if (gsr_memset_async(v.counters + 1, 0, sizeof(int32_t), st)) { gsr_set_error("tsdf_sparse: reset list"); return 1; };
-    hipLaunchKernelGGL(k_ts_texels, dim3((N + 255) / 256), dim3(256), 0, st, depth, rgb, (float4*)texels, N, (int)quant);
+    const bool pk = quant == 2;      // byte colours: 8-byte texels
+    if (pk) hipLaunchKernelGGL(k_ts_texels<true>, dim3((N + 255) / 256), dim3(256), 0, st, depth, rgb, (void*)texels, N, (int)quant);
+    else hipLaunchKernelGGL(k_ts_texels<false>, dim3((N + 255) / 256), dim3(256), 0, st, depth, rgb, (void*)texels, N, (int)quant);
     hipLaunchKernelGGL(k_ts_touch_insert, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n);
     hipLaunchKernelGGL(k_ts_touch_stamp, dim3((n + 255) / 256), dim3(256), 0, st, v, t, depth, n, frame);
     // the voxel pass reads the list length on the device: it is enqueued without waiting for the host (a persistent grid: 8 workgroups per CU)
-    hipLaunchKernelGGL(k_ts_integrate_col, dim3(2048), dim3(256), 0, st, v, p, (const float4*)texels, -1);
+    if (pk) hipLaunchKernelGGL(k_ts_integrate_col, dim3(TS_GRID), dim3(256), 0, st, v, p, (const void*)texels, -1);
+    else hipLaunchKernelGGL(k_ts_integrate_col_f32, dim3(TS_GRID), dim3(256), 0, st, v, p, (const void*)texels, -1);
     int32_t local[4] = { 0, 0, 0, 0 };
     int32_t* c = status_host ? status_host : local;
     GSR_CHECK(hipMemcpyAsync(c, v.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st), "tsdf_sparse: read counters");
@@ -564,18 +648,53 @@ extern "C" int gsr_tsdf_sparse_rehash(const gsr_tsdf_sparse* s, int32_t n_units,
     return gsr_check_launch("tsdf_sparse_rehash", st, false);
 }
 
-extern "C" int gsr_tsdf_sparse_merge(const gsr_tsdf_sparse* s, int32_t n_units, const int32_t* coords, const float* tsdf, const float* weight,
-                                     const float* color, void* stream)
+// the capacity check both merges share: keys of the incoming units first, then one read of the counters
+static int merge_insert(const gsr_tsdf_sparse* s, SparseTsdf& v, const int32_t* coords, int32_t n_units, hipStream_t st)
 {
-    if (check_vol(s)) return 1;
-    if (n_units <= 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    SparseTsdf v = make_view(s);
     hipLaunchKernelGGL(k_ts_insert_list, dim3((n_units + 255) / 256), dim3(256), 0, st, v, coords, n_units);
     int32_t c[3] = { 0, 0, 0 };
     GSR_CHECK(hipMemcpyAsync(c, v.counters, sizeof(c), hipMemcpyDeviceToHost, st), "tsdf_sparse: read counters");
     GSR_CHECK(hipStreamSynchronize(st), "tsdf_sparse: sync");
     if (c[2]) { gsr_set_error("tsdf_sparse: capacity exhausted (%u units) while merging", s->cap_blocks); return 1; }
-    hipLaunchKernelGGL(k_ts_merge_list, dim3((uint32_t)n_units), dim3(256), 0, st, v, coords, tsdf, weight, color);
+    return 0;
+}
+extern "C" int gsr_tsdf_sparse_merge(const gsr_tsdf_sparse* s, int32_t n_units, const int32_t* coords, const float* tsdf, const float* weight,
+                                     const float* color, void* stream)
+{
+    if (check_vol(s)) return 1;
+    if (n_units <= 0) return 0;
+    if (!coords || !tsdf || !weight || !color) { gsr_set_error("tsdf_sparse_merge: null unit list"); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    SparseTsdf v = make_view(s);
+    if (merge_insert(s, v, coords, n_units, st)) return 1;
+    hipLaunchKernelGGL(k_ts_merge<0>, dim3((uint32_t)std::min(n_units, 8 * TS_GRID)), dim3(256), 0, st, v, coords, tsdf, weight, color, (const unsigned long long*)nullptr,
+                       (const uint32_t*)nullptr, (int)n_units);
     return gsr_check_launch("tsdf_sparse_merge", st, false);
+}
+// ABI 8.  vol <- weighted merge with the first n_units units of another volume ON THE SAME DEVICE, read where they lie (pools in storage order, written-group
+// words, stamps): nothing is exported, re-ordered or copied in between, and what `other` never wrote is never read.
+extern "C" int gsr_tsdf_sparse_merge_volume(const gsr_tsdf_sparse* s, const gsr_tsdf_sparse* other, int32_t n_units, void* stream)
+{
+    if (check_vol(s) || check_vol(other)) return 1;
+    if (n_units <= 0) return 0;
+    if ((uint32_t)n_units > other->cap_blocks) { gsr_set_error("tsdf_sparse_merge_volume: %d units exceed the source's capacity", n_units); return 1; }
+    if (s->voxel_length != other->voxel_length || s->sdf_trunc != other->sdf_trunc) { gsr_set_error("tsdf_sparse_merge_volume: volumes must share voxel_length and sdf_trunc"); return 1; }
+    if (s->tsdf == other->tsdf) { gsr_set_error("tsdf_sparse_merge_volume: a volume cannot be merged into itself"); return 1; }
+    hipStream_t st = (hipStream_t)stream;
+    SparseTsdf v = make_view(s);
+    if (merge_insert(s, v, other->coord, n_units, st)) return 1;
+    hipLaunchKernelGGL(k_ts_merge<1>, dim3((uint32_t)std::min(n_units, 8 * TS_GRID)), dim3(256), 0, st, v, (const int32_t*)other->coord, (const float*)other->tsdf,
+                       (const float*)other->weight, (const float*)other->color, (const unsigned long long*)other->mask, (const uint32_t*)other->stamp, (int)n_units);
+    return gsr_check_launch("tsdf_sparse_merge_volume", st, false);
+}
+// ABI 8.  Makes units [0, n_units) plain arrays: groups that were never written are zero-filled and marked written (see k_ts_materialize).  What a reader of
+// the pools (export, marching cubes, units()) calls first; the kernels of this file never need it.
+extern "C" int gsr_tsdf_sparse_materialize(const gsr_tsdf_sparse* s, int32_t n_units, void* stream)
+{
+    if (check_vol(s)) return 1;
+    if (n_units < 0 || (uint32_t)n_units > s->cap_blocks) { gsr_set_error("tsdf_sparse_materialize: %d units do not fit the volume", n_units); return 1; }
+    if (n_units == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ts_materialize, dim3((uint32_t)std::min(n_units, 8 * TS_GRID)), dim3(256), 0, st, make_view(s), (int)n_units);
+    return gsr_check_launch("tsdf_sparse_materialize", st, false);
 }

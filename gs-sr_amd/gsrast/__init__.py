@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libgsrast_hip.so")   # override: experiments only
 
 EWA, SURFEL, PLANE = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp = C.c_void_p
 
@@ -55,7 +55,7 @@ class MvCfg(C.Structure):
 class TsdfSparse(C.Structure):
     """gsr_tsdf_sparse (include/gsrast.h)."""
     _fields_ = [("keys", _vp), ("slot", _vp), ("coord", _vp), ("stamp", _vp), ("list", _vp), ("counters", _vp), ("tsdf", _vp), ("weight", _vp),
-                ("color", _vp), ("cap_hash_log2", C.c_uint32), ("cap_blocks", C.c_uint32), ("voxel_length", C.c_float), ("sdf_trunc", C.c_float)]
+                ("color", _vp), ("mask", _vp), ("cap_hash_log2", C.c_uint32), ("cap_blocks", C.c_uint32), ("voxel_length", C.c_float), ("sdf_trunc", C.c_float)]
 
 
 class LodCfg(C.Structure):
@@ -65,7 +65,7 @@ class LodCfg(C.Structure):
 
 EXPORTS = ["gsr_geom_bytes", "gsr_img_bytes", "gsr_binning_bytes", "gsr_backward_scratch_bytes",
            "gsr_forward_stage1", "gsr_forward_stage2", "gsr_forward_stage1_ex", "gsr_forward_stage2_ex", "gsr_backward", "gsr_backward_ex", "gsr_forward_async", "gsr_mark_visible", "gsr_visible_filter",
-           "gsr_tsdf_integrate", "gsr_tsdf_integrate_dense", "gsr_tsdf_sparse_integrate", "gsr_tsdf_sparse_integrate2", "gsr_tsdf_sparse_status", "gsr_tsdf_sparse_rehash", "gsr_tsdf_sparse_merge", "gsr_loss_l1_linear", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
+           "gsr_tsdf_integrate", "gsr_tsdf_integrate_dense", "gsr_tsdf_sparse_integrate2", "gsr_tsdf_sparse_status", "gsr_tsdf_sparse_rehash", "gsr_tsdf_sparse_merge", "gsr_tsdf_sparse_merge_volume", "gsr_tsdf_sparse_materialize", "gsr_loss_l1_linear", "gsr_dist2_scratch_bytes", "gsr_dist2", "gsr_debug_read", "gsr_last_error",
            "gsr_abi_version", "gsr_profile_enable", "gsr_profile_read", "gsr_binning_capacity", "gsr_forward",
            "gsr_loss_l1_ssim_scratch_bytes", "gsr_loss_l1_ssim", "gsr_loss_surfel_geo_scratch_bytes", "gsr_loss_surfel_geo", "gsr_loss_plane_geo", "gsr_loss_scaling_prod", "gsr_octree_visible",
            "gsr_loss_plane_mv_scratch_bytes", "gsr_loss_plane_mv_geo", "gsr_loss_plane_mv_ncc", "gsr_loss_plane_mv_values", "gsr_loss_plane_mv_scale",
@@ -120,9 +120,6 @@ def lib():
     L.gsr_tsdf_integrate_dense.restype = C.c_int
     L.gsr_tsdf_integrate_dense.argtypes = [C.c_int32] * 3 + [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                            _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), _vp, _vp, _vp, _vp]
-    L.gsr_tsdf_sparse_integrate.restype = C.c_int
-    L.gsr_tsdf_sparse_integrate.argtypes = [C.POINTER(TsdfSparse), C.c_int32, C.c_int32, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
-                                            C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_uint32, C.POINTER(C.c_uint32), _vp]
     L.gsr_tsdf_sparse_integrate2.restype = C.c_int
     L.gsr_tsdf_sparse_integrate2.argtypes = [C.POINTER(TsdfSparse), C.c_int32, C.c_int32, _vp, _vp, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                              C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_int32, C.c_uint32, _vp, _vp, C.c_uint32, _vp]
@@ -132,6 +129,10 @@ def lib():
     L.gsr_tsdf_sparse_rehash.argtypes = [C.POINTER(TsdfSparse), C.c_int32, _vp]
     L.gsr_tsdf_sparse_merge.restype = C.c_int
     L.gsr_tsdf_sparse_merge.argtypes = [C.POINTER(TsdfSparse), C.c_int32, _vp, _vp, _vp, _vp, _vp]
+    L.gsr_tsdf_sparse_merge_volume.restype = C.c_int
+    L.gsr_tsdf_sparse_merge_volume.argtypes = [C.POINTER(TsdfSparse), C.POINTER(TsdfSparse), C.c_int32, _vp]
+    L.gsr_tsdf_sparse_materialize.restype = C.c_int
+    L.gsr_tsdf_sparse_materialize.argtypes = [C.POINTER(TsdfSparse), C.c_int32, _vp]
     L.gsr_adam_step_multi.restype = C.c_int
     L.gsr_adam_step_multi.argtypes = [C.c_int32, _vp, _vp]
     L.gsr_adam_step_multi_dev.restype = C.c_int

@@ -1,7 +1,5 @@
 """HIP TSDF voxel integration: the per-frame update of GaussianExtractor.extract_mesh_unbounded's
 compute_unbounded_tsdf (gssr/utils/mesh_utils.py:195-246) as one streaming kernel."""
-import os
-
 import torch
 
 from . import last_error, lib, check, ptr, stream_ptr, dev_f32, TsdfSparse
@@ -99,13 +97,16 @@ class ScalableTSDFVolume:
     DenseTSDFVolume.
 
     capacity_units is the INITIAL number of 16^3 units (80 KB each: tsdf + weight + 3 colour floats per voxel); a frame that needs more doubles
-    the pool (a fresh volume, the existing units merged in on the device) unless auto_grow=False, in which case it raises.
+    the pool unless auto_grow=False, in which case it raises.
     Colours are stored on the 0..255 scale whether or not they are quantised to integers first (quantize_rgb8).
+    The pools hold a unit in brick order and only the 16-byte groups a frame or merge has written (`mask`, ABI 8): read them through `units()` /
+    `to_dense()`, which hand out plain x-major arrays.
     Multi-GPU (extract_mesh_split.py:54-128): every rank integrates its own tile's frames, `merge_()` fuses the volumes of all ranks
     (weighted running averages are associative), `merge_from(other)` fuses two volumes on one device."""
 
     RES = 16
     TSDF_NO_SYNC = 1
+    MAX_IN_FLIGHT = 8             # deferred frames whose status words nobody has looked at yet
 
     def __init__(self, voxel_length, sdf_trunc, capacity_units=16384, device="cuda", depth_sampling_stride=4, auto_grow=True):
         self.voxel_length = float(voxel_length)
@@ -120,13 +121,18 @@ class ScalableTSDFVolume:
         self._alloc(int(capacity_units))
         self.frame = 0
         self.last_touched = 0
-        self._tex = None              # (r, g, b, depth) texel scratch of the last frame size
-        self._pending = None          # a frame enqueued with defer=True whose status words have not been looked at yet
-        self._status = None           # pinned int32[4]
+        self._tex = None              # texel scratch of the last frame size (frames of one stream run in order: one buffer serves every frame in flight)
+        self._queue = []              # frames enqueued with defer=True whose status words have not been looked at yet, oldest first
+        self._status = None           # pinned int32[MAX_IN_FLIGHT, 4]
+
+    @property
+    def _pending(self):
+        """The newest frame still in flight (None when the volume is settled)."""
+        return self._queue[-1] if self._queue else None
 
     def _alloc(self, cap):
-        """The volume's arrays for `cap` units.  The pools (80 KB per unit) are NOT zero-filled: a unit is written in full by the first frame / merge that
-        touches it (its stamp, 0 until then, says so) -- a 16 384-unit volume used to start with a 1.3 GB memset, a 131 072-unit one with 10.7 GB."""
+        """The volume's arrays for `cap` units.  Neither the pools (80 KB per unit) nor the written-group words are initialised: a unit whose stamp is 0 has
+        never been written, and a clear mask bit means "zero" whatever the pool holds -- a 131 072-unit volume used to start with a 10.7 GB memset."""
         d = self.device
         self.cap = int(cap)
         self.log2 = max(4, (2 * self.cap - 1).bit_length())
@@ -139,21 +145,23 @@ class ScalableTSDFVolume:
         V = self.RES ** 3
         self.tsdf = torch.empty((self.cap, V), dtype=torch.float32, device=d)
         self.weight = torch.empty((self.cap, V), dtype=torch.float32, device=d)
-        self.color = torch.empty((self.cap, 3, V), dtype=torch.float32, device=d)      # three colour planes per unit (ABI 7)
+        self.color = torch.empty((self.cap, 3, V), dtype=torch.float32, device=d)      # three colour planes per unit (ABI 7), brick order (ABI 8)
+        self.mask = torch.empty((self.cap, 16), dtype=torch.int64, device=d)           # written-group bits (ABI 8)
 
     def _struct(self):
         return TsdfSparse(ptr(self.keys), ptr(self.slot), ptr(self.coord), ptr(self.stamp), ptr(self.list), ptr(self.counters), ptr(self.tsdf),
-                          ptr(self.weight), ptr(self.color), self.log2, self.cap, self.voxel_length, self.sdf_trunc)
+                          ptr(self.weight), ptr(self.color), ptr(self.mask), self.log2, self.cap, self.voxel_length, self.sdf_trunc)
 
     def integrate(self, rgb, depth, fx, fy, cx, cy, extrinsic, depth_trunc=float("inf"), quantize_rgb8=True, defer=False):
         """rgb [3,H,W] in [0,1], depth [1,H,W] or [H,W] (0 = invalid, as mesh_utils.py:165-166 writes for masked pixels),
         extrinsic 4x4 world->camera (Open3D convention).  Colours are put on the 0..255 scale on the device (quantize_rgb8: through the uint8
         truncation of mesh_utils.py:170).
         defer=True: the frame is only ENQUEUED (no host synchronisation at all: texels, touch, stamp and the voxel pass run back to back behind whatever
-        produced rgb / depth); its outcome -- pool exhausted, sample out of range -- is looked at by the next integrate() / finish() / any read of the
-        volume, which then grows the pool and runs the frame again exactly as the synchronous call would have."""
+        produced rgb / depth); up to MAX_IN_FLIGHT frames wait that way.  Their outcome -- pool exhausted, sample out of range -- is looked at when the
+        queue is full, by finish() or by any read of the volume, which then grows the pool and runs the refused frame AND every frame enqueued after it
+        again, in order (a refused frame has integrated nothing, and neither has any frame behind it).  The volume keeps a reference to a deferred frame's
+        rgb / depth until then: the caller must not overwrite those tensors before finish() (pass clones if its render buffers are reused)."""
         import ctypes as C
-        self.finish()
         d = dev_f32(depth, "depth", allow_empty=False)
         c = dev_f32(rgb, "rgb", allow_empty=False)
         H, W = int(d.shape[-2]), int(d.shape[-1])
@@ -163,12 +171,12 @@ class ScalableTSDFVolume:
         Pm = torch.linalg.inv(E)
         Ea = (C.c_float * 12)(*[float(v) for v in E[:3].reshape(-1).tolist()])
         Pa = (C.c_float * 12)(*[float(v) for v in Pm[:3].reshape(-1).tolist()])
-        if os.environ.get("GSR_TSDF_V1") == "1":        # A/B: round 4's path (torch colour conversion, host read in front of the voxel pass, one workgroup per unit)
-            return self._integrate_v1(c, d, W, H, fx, fy, cx, cy, Ea, Pa, depth_trunc, quantize_rgb8)
-        if self._tex is None or self._tex.numel() != 4 * H * W:
-            self._tex = torch.empty((H * W, 4), dtype=torch.float32, device=self.device)
+        if not defer or len(self._queue) >= self.MAX_IN_FLIGHT:
+            self.finish()
+        elif self._queue and self._queue[0]["event"].query():
+            self._settle_done()
         if self._status is None:
-            self._status = torch.zeros((4,), dtype=torch.int32).pin_memory()
+            self._status = torch.zeros((self.MAX_IN_FLIGHT, 4), dtype=torch.int32).pin_memory()
         frame = dict(d=d, c=c, W=W, H=H, intr=(float(fx), float(fy), float(cx), float(cy)), Ea=Ea, Pa=Pa, dt=float(min(depth_trunc, 3.0e38)),
                      quant=2 if quantize_rgb8 else 1)
         self._enqueue(frame, sync=not defer)
@@ -176,91 +184,91 @@ class ScalableTSDFVolume:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
             frame["event"] = ev
-            self._pending = frame
+            self._queue.append(frame)
         else:
-            self._resolve(frame)
+            self._resolve([frame])
         return self
 
     def _enqueue(self, f, sync):
         import ctypes as C
         self.frame += 1
+        used = {q["slot"] for q in self._queue}
+        f["slot"] = next(i for i in range(self.MAX_IN_FLIGHT + 1) if i not in used) % self.MAX_IN_FLIGHT
+        tex = self._tex
+        if tex is None or tex.numel() != 4 * f["H"] * f["W"]:
+            tex = self._tex = torch.empty((f["H"] * f["W"], 4), dtype=torch.float32, device=self.device)
         st = self._struct()
         with torch.cuda.device(self.device):
             rc = lib().gsr_tsdf_sparse_integrate2(C.byref(st), f["W"], f["H"], ptr(f["d"]), ptr(f["c"]), f["quant"], *f["intr"], f["Ea"], f["Pa"], f["dt"],
-                                                  self.stride, self.frame, ptr(self._tex), C.c_void_p(self._status.data_ptr()),
+                                                  self.stride, self.frame, ptr(tex), C.c_void_p(self._status[f["slot"]].data_ptr()),
                                                   0 if sync else self.TSDF_NO_SYNC, stream_ptr(self.device))
         f["rc"] = rc
 
-    def _resolve(self, f):
-        """Looks at the outcome of an enqueued frame whose status words are on the host: grows the pool and runs the frame again while it says "capacity
-        exhausted" (nothing of such a frame has been integrated), raises what the library reports otherwise."""
+    def _frame_rc(self, f):
         import ctypes as C
-        while True:
-            rc = f["rc"]
-            if rc == 0 and "event" in f:
-                st = self._struct()
-                with torch.cuda.device(self.device):
-                    rc = lib().gsr_tsdf_sparse_status(C.byref(st), C.c_void_p(self._status.data_ptr()), stream_ptr(self.device))
-            if rc != 0 and self.auto_grow and "capacity exhausted" in last_error() and self.cap < (1 << 27):
-                self._grow()
-                f.pop("event", None)
-                self._enqueue(f, sync=True)
-                continue
-            if rc != 0:
-                self._scrub_unwritten()
-            check(rc, "tsdf_sparse_integrate")
-            break
-        self.last_touched = int(self._status[1])
-
-    def finish(self):
-        """Waits for a frame enqueued with defer=True (if any) and handles its outcome.  Every method that reads the volume calls it."""
-        f, self._pending = self._pending, None
-        if f is not None:
-            f["event"].synchronize()
-            self._resolve(f)
-        return self
-
-    def _integrate_v1(self, c, d, W, H, fx, fy, cx, cy, Ea, Pa, depth_trunc, quantize_rgb8):
-        import ctypes as C
-        if quantize_rgb8:
-            c = (torch.clamp(c, 0.0, 1.0) * 255).to(torch.uint8).to(torch.float32).contiguous()
-        else:
-            c = (torch.clamp(c, 0.0, 1.0) * 255).contiguous()
-        n = C.c_uint32(0)
-        while True:
-            self.frame += 1
+        rc = f["rc"]
+        if rc == 0 and "event" in f:
             st = self._struct()
             with torch.cuda.device(self.device):
-                rc = lib().gsr_tsdf_sparse_integrate(C.byref(st), W, H, ptr(d), ptr(c), float(fx), float(fy), float(cx), float(cy), Ea, Pa,
-                                                     float(min(depth_trunc, 3.0e38)), self.stride, self.frame, C.byref(n), stream_ptr(self.device))
+                rc = lib().gsr_tsdf_sparse_status(C.byref(st), C.c_void_p(self._status[f["slot"]].data_ptr()), stream_ptr(self.device))
+        return rc
+
+    def _resolve(self, frames):
+        """Looks at the outcome of enqueued frames (oldest first) whose status words are on the host.  "Capacity exhausted": nothing of that frame nor of the
+        frames behind it has been integrated -- the pool is grown and they run again, in order.  Anything else the library reports is raised (the frames
+        behind the failing one are dropped with it: they integrated nothing either)."""
+        frames = list(frames)
+        rerun = False
+        while frames:
+            f = frames[0]
+            if rerun:
+                f.pop("event", None)
+                self._enqueue(f, sync=True)
+            rc = self._frame_rc(f)
             if rc != 0 and self.auto_grow and "capacity exhausted" in last_error() and self.cap < (1 << 27):
                 self._grow()
+                rerun = True
                 continue
             if rc != 0:
-                self._scrub_unwritten()
-            check(rc, "tsdf_sparse_integrate")
-            break
-        self.last_touched = int(n.value)
+                msg = last_error()
+                self._after_failure()
+                raise RuntimeError(f"tsdf_sparse_integrate: {msg}")
+            self.last_touched = int(self._status[f["slot"], 1])
+            frames.pop(0)
+
+    def _settle_done(self):
+        """Resolves the frames at the head of the queue whose event has already fired (no waiting)."""
+        while self._queue and self._queue[0]["event"].query():
+            f = self._queue[0]
+            if self._frame_rc(f) != 0:
+                return self.finish()
+            self.last_touched = int(self._status[f["slot"], 1])
+            self._queue.pop(0)
+
+    def finish(self):
+        """Waits for the frames enqueued with defer=True (if any) and handles their outcome.  Every method that reads the volume calls it."""
+        q, self._queue = self._queue, []
+        if q:
+            q[-1]["event"].synchronize()
+            self._resolve(q)
         return self
 
-    def _scrub_unwritten(self):
-        """After a frame that failed for good: units it allocated but never wrote (stamp 0) become explicit empty units, so that units() never
-        shows uninitialised pool memory."""
+    def _after_failure(self):
+        """A frame or merge failed for good (auto_grow off, or a sample out of range): the unit counter goes back into the pool (keys the failed call put
+        into the table without a pool slot stay harmless: they resolve to slot -1) and the failure flag is cleared, so that the volume stays usable and
+        `num_units` never exceeds the capacity.  Units the failed call allocated but never wrote keep stamp 0: units() shows them as empty."""
         n = min(int(self.counters[0].item()), self.cap)
-        idx = (self.stamp[:n] == 0).nonzero().flatten()
-        if idx.numel():
-            self.tsdf[idx] = 0; self.weight[idx] = 0; self.color[idx] = 0
-            self.stamp[idx] = -1
+        self.counters[0] = n
+        self.counters[2] = 0
 
     def _grow(self):
-        """Doubles the unit pool: new arrays of twice the capacity, the allocated units' coordinates, stamps and voxels copied (device-to-device, no
-        arithmetic, and no fill of the part that is not in use), the hash table re-keyed with every unit in its old slot.  Rounds 3-4 built a fresh
-        zero-filled volume and merged the old one in voxel by voxel."""
+        """Doubles the unit pool: new arrays of twice the capacity, the allocated units' coordinates, stamps, mask words and voxels copied (device-to-device,
+        no arithmetic, and no fill of the part that is not in use), the hash table re-keyed with every unit in its old slot."""
         import ctypes as C
         n = min(int(self.counters[0].item()), self.cap)
-        old = (self.coord, self.stamp, self.tsdf, self.weight, self.color)
+        old = (self.coord, self.stamp, self.tsdf, self.weight, self.color, self.mask)
         self._alloc(2 * self.cap)
-        for dst, src in zip((self.coord, self.stamp, self.tsdf, self.weight, self.color), old):
+        for dst, src in zip((self.coord, self.stamp, self.tsdf, self.weight, self.color, self.mask), old):
             dst[:n].copy_(src[:n])
         self.counters[0] = n
         st = self._struct()
@@ -270,16 +278,38 @@ class ScalableTSDFVolume:
     @property
     def num_units(self):
         self.finish()
-        return int(self.counters[0].item())
+        return min(int(self.counters[0].item()), self.cap)
+
+    def weight_sum(self):
+        """Sum of the weights of every written voxel (float64) WITHOUT materialising the volume -- every update of a voxel adds exactly 1, so the difference
+        across a frame is the number of voxels the frame updated (the benchmarks' algorithmic byte count)."""
+        n = self.num_units
+        if n == 0:
+            return 0.0
+        tot = 0.0
+        for s in range(0, n, 16384):
+            e = min(n, s + 16384)
+            bits = ((self.mask[s:e].view(e - s, 16, 1) >> torch.arange(64, device=self.device).view(1, 1, 64)) & 1).bool().view(e - s, 1024)
+            bits &= (self.stamp[s:e] != 0).view(-1, 1)
+            tot += float(torch.where(bits.unsqueeze(-1), self.weight[s:e].view(e - s, 1024, 4), torch.zeros((), device=self.device)).double().sum())
+        return tot
 
     def units(self):
-        """-> (coords [n,3] int32, tsdf [n,16,16,16], weight [n,16,16,16], color [n,16,16,16,3]) views of the allocated units
-        (voxel index x-major, z fastest, like Open3D's UniformTSDFVolume::IndexOf)."""
-        n, R = min(self.num_units, self.cap), self.RES
-        return self.coord[:n], self.tsdf[:n].view(n, R, R, R), self.weight[:n].view(n, R, R, R), self.color[:n].view(n, 3, R, R, R).permute(0, 2, 3, 4, 1)
+        """-> (coords [n,3] int32, tsdf [n,16,16,16], weight [n,16,16,16], color [n,16,16,16,3]) of the allocated units as plain arrays
+        (voxel index x-major, z fastest, like Open3D's UniformTSDFVolume::IndexOf).  Groups no frame ever wrote are zero-filled in the pools first
+        (gsr_tsdf_sparse_materialize); the arrays are re-ordered COPIES of the brick-ordered pools."""
+        import ctypes as C
+        n = self.num_units
+        st = self._struct()
+        with torch.cuda.device(self.device):
+            check(lib().gsr_tsdf_sparse_materialize(C.byref(st), n, stream_ptr(self.device)), "tsdf_sparse_materialize")
+        # storage index bits, high to low: bx by bz (2 each) | x1 y1 x0 y0 | z (2)
+        plane = lambda a: a.view(n, 4, 4, 4, 2, 2, 2, 2, 4).permute(0, 1, 4, 6, 2, 5, 7, 3, 8).reshape(n, 16, 16, 16)
+        col = self.color[:n].view(n, 3, 4, 4, 4, 2, 2, 2, 2, 4).permute(0, 2, 5, 7, 3, 6, 8, 4, 9, 1).reshape(n, 16, 16, 16, 3)
+        return self.coord[:n], plane(self.tsdf[:n]), plane(self.weight[:n]), col
 
     def merge_units_(self, coords, tsdf, weight, color, assume_unique=False):
-        """self <- weighted merge with the given units (tensors shaped like `units()`, on this device).  The merge kernel runs one workgroup per
+        """self <- weighted merge with the given units (plain arrays shaped like `units()`, on this device).  The merge kernel runs one workgroup per
         listed unit, so a coordinate must not appear twice in one list: unless `assume_unique` the list is first fused with itself
         (merge_unit_lists: sort-unique + index_add)."""
         import ctypes as C
@@ -293,15 +323,38 @@ class ScalableTSDFVolume:
             n = int(coords.shape[0])
         co = coords.to(torch.int32).contiguous()
         t, w, c = (x.to(torch.float32).contiguous() for x in (tsdf, weight, color))
-        st = self._struct()
-        with torch.cuda.device(self.device):
-            check(lib().gsr_tsdf_sparse_merge(C.byref(st), n, ptr(co), ptr(t), ptr(w), ptr(c), stream_ptr(self.device)), "tsdf_sparse_merge")
+        self._merge_call(lambda st: lib().gsr_tsdf_sparse_merge(C.byref(st), n, ptr(co), ptr(t), ptr(w), ptr(c), stream_ptr(self.device)), "tsdf_sparse_merge")
         return self
 
+    def _merge_call(self, call, what):
+        """One merge through the C ABI; "capacity exhausted" grows the pool and runs it again (the units the refused call allocated keep stamp 0 and are
+        found again), anything else leaves the volume usable and raises."""
+        while True:
+            st = self._struct()
+            with torch.cuda.device(self.device):
+                rc = call(st)
+            if rc != 0 and self.auto_grow and "capacity exhausted" in last_error() and self.cap < (1 << 27):
+                self._grow()
+                continue
+            if rc != 0:
+                msg = last_error()
+                self._after_failure()
+                raise RuntimeError(f"{what}: {msg}")
+            return
+
     def merge_from(self, other):
-        """Fuses another volume (same voxel_length / sdf_trunc) into this one, e.g. the volumes of two tiles on one device."""
+        """Fuses another volume (same voxel_length / sdf_trunc) into this one, e.g. the volumes of two tiles.  On one device the other volume's pools are
+        read where they lie (gsr_tsdf_sparse_merge_volume: no export, no re-ordering, unwritten groups never touched)."""
+        import ctypes as C
         if abs(other.voxel_length - self.voxel_length) > 0 or abs(other.sdf_trunc - self.sdf_trunc) > 0:
             raise RuntimeError("merge_from: volumes must share voxel_length and sdf_trunc")
+        self.finish()
+        n = other.num_units
+        if other.device == self.device:
+            if n:
+                so = other._struct()
+                self._merge_call(lambda st: lib().gsr_tsdf_sparse_merge_volume(C.byref(st), C.byref(so), n, stream_ptr(self.device)), "tsdf_sparse_merge_volume")
+            return self
         co, t, w, c = other.units()
         return self.merge_units_(co.to(self.device), t.to(self.device), w.to(self.device), c.to(self.device), assume_unique=True)
 

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 7
+#define GSR_ABI_VERSION 8
 
 enum gsr_variant {
     GSR_EWA = 0,     /* diff_gaussian_rasterization : 3DGS EWA splats, RGB only                          */
@@ -213,23 +213,28 @@ int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* or
  * coord [cap_blocks,3] int32, stamp/list [cap_blocks], counters [4] int32 zero-filled, pools tsdf/weight [cap_blocks,4096] and
  * color [cap_blocks,3,4096] float32 (ABI 7: three colour PLANES per unit, so that every plane is read and written in coalesced 16-byte groups; ABI <= 6:
  * [cap_blocks,4096,3]) -- since ABI 7 the pools need NOT be initialised (80 KB per unit of capacity): a unit whose stamp is 0 has never been
- * written and is written in full, without being read, by the first frame / merge that touches it.  counters[0] = units allocated so far. */
+ * written and is written, without being read, by the first frame / merge that touches it.  counters[0] = units allocated so far.
+ * ABI 8: (1) mask [cap_blocks,16] uint64, uninitialised like the pools: bit g of a unit's 1024 says that 16-byte group g (four consecutive z) has ever been
+ * written.  A clear bit means (tsdf 0, weight 0, colour 0) whatever the pool holds there: the kernels never read such a group and a unit's first frame writes
+ * only the groups it observed.  A reader of the raw pools calls gsr_tsdf_sparse_materialize first.  (2) A unit plane is stored in bricks, not x-major:
+ * voxel (x,y,z) of a unit lives at float index 4*g + (z & 3) with
+ *   g = (x>>2)<<8 | (y>>2)<<6 | (z>>2)<<4 | ((x>>1)&1)<<3 | ((y>>1)&1)<<2 | (x&1)<<1 | (y&1)
+ * (4x4x4 bricks of 256 B, 64-byte sectors of 2x2x4 voxels: the surface shell a frame updates cuts compact sectors less often than 1x1x16 columns). */
 typedef struct gsr_tsdf_sparse {
     void* keys; int32_t* slot; int32_t* coord; uint32_t* stamp; int32_t* list; int32_t* counters;
     float* tsdf; float* weight; float* color;
+    void* mask;
     uint32_t cap_hash_log2, cap_blocks;
     float voxel_length, sdf_trunc;
 } gsr_tsdf_sparse;
-/* One frame.  extrinsic = world->camera, pose = camera->world (both [12] HOST, row-major 3x4); `frame` must be a fresh non-zero
- * number per call.  Synchronises the stream once (reads the number of units to integrate); *n_touched_host receives it. */
-int gsr_tsdf_sparse_integrate(const gsr_tsdf_sparse* vol, int32_t W, int32_t H, const float* depth /*[H,W]*/, const float* rgb /*[3,H,W]*/,
-                              float fx, float fy, float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc,
-                              int32_t stride, uint32_t frame, uint32_t* n_touched_host, void* stream);
-/* ABI 7.  The same frame, MI355X-shaped (csrc/gsr_tsdf_sparse.hip): rgb [3,H,W] as rendered; quant 0 = store as given, 1 = clamp to [0,1] and scale to
+/* One frame (ABI 7; the round-2 entry point gsr_tsdf_sparse_integrate with its host read in front of the voxel pass is gone since ABI 8).
+ * extrinsic = world->camera, pose = camera->world (both [12] HOST, row-major 3x4); `frame` must be a fresh non-zero number per call.
+ * rgb [3,H,W] as rendered; quant 0 = store as given, 1 = clamp to [0,1] and scale to
  * 0..255, 2 = additionally truncate to an integer (the uint8 conversion of mesh_utils.py:170) -- done on the device while the planes are interleaved into
- * `texels` [H*W*4] (caller-owned scratch); the voxel pass reads the length of its work list on the device, so nothing waits for the host in front of it.
+ * `texels` [H*W*4] floats (caller-owned scratch; quant 2 uses half of it: 8-byte texels (depth, rgb bytes)); the voxel pass reads the length of its work
+ * list on the device, so nothing waits for the host in front of it.
  * status_host [4] (may be NULL without GSR_TSDF_NO_SYNC) receives {units allocated, units integrated by this frame, capacity exhausted, sample out of range}.
- * Default: synchronises once at the end and reports the two error conditions like gsr_tsdf_sparse_integrate (in either case NOTHING of the frame has been
+ * Default: synchronises once at the end and reports the two error conditions (in either case NOTHING of the frame has been
  * integrated: grow the volume and run it again with a new frame number).  GSR_TSDF_NO_SYNC: returns after enqueuing; status_host must be pinned and stay
  * alive; the caller waits for an event of its own and passes the words to gsr_tsdf_sparse_status. */
 #define GSR_TSDF_NO_SYNC 1u
@@ -240,10 +245,16 @@ int gsr_tsdf_sparse_status(const gsr_tsdf_sparse* vol, const int32_t* status_hos
 /* After the caller re-allocated a volume's arrays (growth): keys all -1, coord / stamp / pool contents of units [0, n_units) copied, counters[0] = n_units --
  * gives every unit its key back with the slot it had.  No voxel is touched. */
 int gsr_tsdf_sparse_rehash(const gsr_tsdf_sparse* vol, int32_t n_units, void* stream);
-/* vol <- weighted merge with n_units units given as (coords [n,3] int32, tsdf/weight [n,4096], color [n,4096,3]): the fusion step of
- * extract_mesh_split.py when every GPU integrated its own tile's frames (running averages are associative in (sum w*tsdf, sum w)). */
+/* vol <- weighted merge with n_units units given as plain arrays in LOGICAL voxel order (coords [n,3] int32, tsdf/weight [n,16,16,16] x-major,
+ * color [n,16,16,16,3]; weight 0 = no data): the fusion step of extract_mesh_split.py when every GPU integrated its own tile's frames (running averages are
+ * associative in (sum w*tsdf, sum w)); the lists other ranks send. */
 int gsr_tsdf_sparse_merge(const gsr_tsdf_sparse* vol, int32_t n_units, const int32_t* coords, const float* tsdf, const float* weight,
                           const float* color, void* stream);
+/* ABI 8.  vol <- weighted merge with units [0, n_units) of another volume on the same device, read where they lie (storage order, written-group words):
+ * the per-tile volumes of one GPU.  Synchronises once (capacity check). */
+int gsr_tsdf_sparse_merge_volume(const gsr_tsdf_sparse* vol, const gsr_tsdf_sparse* other, int32_t n_units, void* stream);
+/* ABI 8.  Zero-fills the never-written groups of units [0, n_units) and marks them written: afterwards the pools are plain arrays (still in brick order). */
+int gsr_tsdf_sparse_materialize(const gsr_tsdf_sparse* vol, int32_t n_units, void* stream);
 /* Fused image-side loss right behind the rasterizer (the L1 term of gssr/scene/vanilla_scene.py:63-69
  * plus a linear functional of the auxiliary maps): loss = mean|color - gt| + sum(aux * waux); one streaming pass
  * writes dL/dcolor = sign(color-gt)/n and accumulates the scalar into *loss_out (device, caller zero-fills).

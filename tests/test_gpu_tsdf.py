@@ -14,8 +14,9 @@ VL, TR, DT = 0.02, 0.1, 6.0
 
 
 def _poison(vol):
-    """The pools are not zero-filled by the library any more (ABI 7): whatever a unit's 80 KB held before must never show."""
-    vol.tsdf.fill_(float("nan")); vol.weight.fill_(float("nan")); vol.color.fill_(float("nan"))
+    """The pools are not zero-filled by the library any more (ABI 7): whatever a unit's 80 KB held before must never show.  ABI 8: the written-group words
+    are not initialised either -- all-ones here, so that a kernel trusting a never-written unit's words would read the NaNs."""
+    vol.tsdf.fill_(float("nan")); vol.weight.fill_(float("nan")); vol.color.fill_(float("nan")); vol.mask.fill_(-1)
     return vol
 
 
@@ -133,18 +134,66 @@ def test_deferred_frames_equal_the_synchronous_ones_also_through_a_pool_growth()
         assert not torch.isnan(vol.units()[1]).any()
 
 
-def test_round4_frame_path_kept_for_ab_builds_the_same_volume(monkeypatch):
-    """GSR_TSDF_V1=1: the round-2..4 frame (colour conversion as torch ops, a host read of the work-list length in front of the voxel pass, one workgroup per unit with
-    4-byte accesses) through the ABI <= 6 entry point gsr_tsdf_sparse_integrate -- on the ABI-7 volume (uninitialised pools, colour planes).  Same units, same voxels."""
-    frs = tsdf_cases.frames(3)
-    ref = _hip_volume(frs, cap=8192)
-    monkeypatch.setenv("GSR_TSDF_V1", "1")
-    old = _hip_volume(frs, cap=8192)
-    assert old.num_units == ref.num_units
+def _same_volume(vol, ref):
     kr = {tuple(k): i for i, k in enumerate(ref.units()[0].tolist())}
-    order = torch.tensor([kr[tuple(k)] for k in old.units()[0].tolist()], device="cuda")
-    for a, b in zip(old.units()[1:], ref.units()[1:]):
+    assert vol.num_units == ref.num_units and set(kr) == set(map(tuple, vol.units()[0].tolist()))
+    order = torch.tensor([kr[tuple(k)] for k in vol.units()[0].tolist()], device="cuda")
+    for a, b in zip(vol.units()[1:], ref.units()[1:]):
         assert torch.equal(a, b[order])
+
+
+def test_many_frames_in_flight_also_through_a_refused_frame():
+    """Up to MAX_IN_FLIGHT deferred frames wait without the host looking at them; a frame that runs out of pool slots integrates nothing, neither do the
+    frames enqueued behind it, and finish() grows the pool and runs them all again in order: bit-identical to the synchronous volume."""
+    from gsrast.tsdf import ScalableTSDFVolume
+    frs = tsdf_cases.frames(11, seed=5)
+    ref = _hip_volume(frs, cap=16384)
+    for cap in (16384, 128):
+        vol = _hip_volume(frs, cap=cap, defer=True)
+        assert 1 <= len(vol._queue) <= ScalableTSDFVolume.MAX_IN_FLIGHT
+        _same_volume(vol, ref)
+        assert not vol._queue and (cap == 16384 or vol.cap > 128)
+
+
+def test_only_written_groups_exist_until_somebody_reads_the_pools():
+    """ABI 8: a frame writes only the 16-byte groups it updates (bit set in `mask`), also in a unit it opens; everything else keeps whatever the pool held
+    (NaN here) until units() / to_dense() materialise the volume.  The written groups, re-ordered from brick to x-major order, are the oracle's voxels."""
+    frs = tsdf_cases.frames(2)
+    vol = _hip_volume(frs)
+    vol.finish()
+    n = int(vol.counters[0].item())
+    bits = ((vol.mask[:n].view(n, 16, 1) >> torch.arange(64, device="cuda").view(1, 1, 64)) & 1).bool().view(n, 1024)       # [unit, group]
+    stamped = vol.stamp[:n] != 0
+    w = vol.weight[:n].view(n, 1024, 4)
+    assert torch.isnan(w[stamped][~bits[stamped]]).all()                   # never written: still the poison
+    assert not torch.isnan(w[stamped][bits[stamped]]).any()
+    assert 0.2 < bits[stamped].float().mean().item() < 0.95                  # a band through the units, not whole units
+    assert (vol.tsdf[:n].view(n, 1024, 4)[stamped][bits[stamped]].abs() <= 1).all()
+    _compare(vol, _oracle_units(frs))                                      # materialises
+    assert not torch.isnan(vol.weight[:n]).any() and (vol.mask[:n] == -1).all()
+
+
+def test_merge_reads_the_other_volumes_pools_in_place():
+    """merge_from on one device (gsr_tsdf_sparse_merge_volume: storage order, written groups only) == merge_units_ with the exported plain arrays
+    (gsr_tsdf_sparse_merge: what other ranks send), bit for bit, into an empty and into a populated volume."""
+    from gsrast.tsdf import ScalableTSDFVolume
+    frs = tsdf_cases.frames(6, seed=7)
+    for base in (0, 2):
+        a1 = _hip_volume(frs[:base], cap=8192); a2 = _hip_volume(frs[:base], cap=8192)
+        b1 = _hip_volume(frs[base:], cap=8192); b2 = _hip_volume(frs[base:], cap=8192)
+        a1.merge_from(b1)                                                  # pools in place (b1 never materialised)
+        co, t, w, c = b2.units()
+        a2.merge_units_(co, t, w, c, assume_unique=True)
+        _same_volume(a1, a2)
+    small = _poison(ScalableTSDFVolume(VL, TR, capacity_units=32))         # merging grows the pool like a frame does
+    small.merge_from(b1)
+    _same_volume(small, b2)
+    fixed = ScalableTSDFVolume(VL, TR, capacity_units=32, auto_grow=False)
+    with pytest.raises(RuntimeError, match="capacity exhausted"):
+        fixed.merge_from(b1)
+    assert fixed.num_units <= 32 and not fixed.units()[2].any()            # ADVICE r5: usable afterwards, no uninitialised pool memory on show
+    with pytest.raises(RuntimeError, match="capacity exhausted"):          # ... and the failure flag does not stick
+        fixed.merge_from(b1)
 
 
 def test_capacity_overflow_raises_or_grows():
@@ -156,7 +205,9 @@ def test_capacity_overflow_raises_or_grows():
     vol = _poison(ScalableTSDFVolume(VL, TR, capacity_units=16, auto_grow=False))
     with pytest.raises(RuntimeError, match="capacity exhausted"):
         vol.integrate(*args, depth_trunc=DT)
-    assert not torch.isnan(vol.units()[2]).any() and not vol.units()[2].any()      # the units the failed frame allocated: explicit empty units, not pool garbage
+    assert vol.num_units <= 16 and not torch.isnan(vol.units()[2]).any() and not vol.units()[2].any()      # the units the failed frame allocated: explicit empty units, not pool garbage
+    with pytest.raises(RuntimeError, match="capacity exhausted"):          # the volume stays usable: the next frame is refused for the same reason, not for a stale flag
+        vol.integrate(*args, depth_trunc=DT)
     small = _poison(ScalableTSDFVolume(VL, TR, capacity_units=16))
     small.integrate(*args, depth_trunc=DT)
     big = ScalableTSDFVolume(VL, TR, capacity_units=8192)

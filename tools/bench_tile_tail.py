@@ -62,12 +62,12 @@ def main():
                     depth = tile_tail.surf_depth_torch(allmap, 0.0)
                 e1.record()
                 if count:
-                    n0 = vol.num_units; w0 = float(vol.weight[:n0].double().sum()) if n0 else 0.0
+                    w0 = vol.weight_sum()
                 vol.integrate(color, depth, fx, fy, cx, cy, E, depth_trunc=a.depth_trunc, defer=not a.sync_frames and not count)
                 e2.record()
                 evs.append((e0, e1, e2, vol))
                 if count:
-                    updated.append(float(vol.weight[:vol.num_units].double().sum()) - w0); touched.append(vol.last_touched)
+                    updated.append(vol.weight_sum() - w0); touched.append(vol.last_touched)
             vol.finish()
             vols.append(vol); n_units.append(vol.num_units)
         torch.cuda.synchronize()

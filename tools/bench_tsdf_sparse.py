@@ -29,15 +29,14 @@ def main():
     f = 0.8 * W
     touched, ms, upd = [], [], []
     for i, (rgb, depth, E) in enumerate(frames):
-        n0 = vol.num_units
-        w0 = float(vol.weight[:n0].double().sum()) if n0 else 0.0
+        w0 = vol.weight_sum()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); t0 = time.perf_counter(); e0.record()
         vol.integrate(rgb, depth, f, f, W / 2, H / 2, E, depth_trunc=depth_trunc)
         e1.record(); torch.cuda.synchronize()
         if i >= 2:
             touched.append(vol.last_touched); ms.append((e0.elapsed_time(e1), 1e3 * (time.perf_counter() - t0)))
-            upd.append(float(vol.weight[:vol.num_units].double().sum()) - w0)      # every updated voxel gained exactly one unit of weight
+            upd.append(vol.weight_sum() - w0)      # every updated voxel gained exactly one unit of weight
     units = float(np.mean(touched)); gpu = float(np.mean([a for a, _ in ms])); wall = float(np.mean([b for _, b in ms]))
     # the same frames once more, only ENQUEUED (integrate(defer=True): no host wait between the frames, the status of a frame is read when the next one starts)
     vol2 = ScalableTSDFVolume(vl, 5 * vl, capacity_units=1 << 17)
