@@ -34,6 +34,7 @@
 #define TS_VOX (TS_RES * TS_RES * TS_RES)
 static constexpr unsigned long long TS_EMPTY = ~0ull;
 
+#define TS_UNIT_FLOATS (5 * TS_VOX)      // a unit's record: tsdf plane, weight plane, three colour planes (80 KB)
 struct SparseTsdf {
     unsigned long long* keys;      // [cap_hash] packed unit coordinate, TS_EMPTY when free
     int32_t* slot;                 // [cap_hash] pool index of the unit
@@ -41,10 +42,18 @@ struct SparseTsdf {
     uint32_t* stamp;               // [cap_blocks] last frame that touched the unit
     int32_t* list;                 // [cap_blocks] units touched by the current frame
     int32_t* counters;             // [0] = units allocated, [1] = units in `list`, [2] = pool/hash overflow flag
-    float* tsdf; float* weight; float* color;      // pools: [cap_blocks][4096], [..][4096], [..][3][4096] (colour PLANES per unit since ABI 7; brick order since ABI 8)
     unsigned long long* mask;      // [cap_blocks][16] written-group bits (ABI 8)
-    uint32_t cap_hash_log2, cap_blocks;
+    float* chunk[GSR_TSDF_MAX_CHUNKS];      // unit records in chunks of doubling size (ABI 8): growing a volume allocates a chunk, it never copies a voxel
+    uint32_t chunk0_log2, cap_hash_log2, cap_blocks;
 };
+// unit b's record: chunk 0 holds units [0, 2^chunk0_log2), chunk c >= 1 the units [2^(chunk0_log2 + c - 1), 2^(chunk0_log2 + c))
+__device__ __forceinline__ float* ts_unit(const SparseTsdf& v, int b)
+{
+    const uint32_t hi = (uint32_t)b >> v.chunk0_log2;
+    const int c = hi ? 32 - __clz((int)hi) : 0;
+    const uint32_t base = c ? (1u << (v.chunk0_log2 + c - 1)) : 0u;
+    return v.chunk[c] + (size_t)((uint32_t)b - base) * TS_UNIT_FLOATS;
+}
 
 __host__ __device__ __forceinline__ unsigned long long ts_pack(int x, int y, int z)
 {
@@ -325,12 +334,13 @@ __device__ __forceinline__ void ts_integrate_col(const SparseTsdf& v, const IntP
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
         const int e = v.list[k];
         const bool fresh = e < 0;
-        const int b = fresh ? ~e : e;
+        const int b = __builtin_amdgcn_readfirstlane(fresh ? ~e : e);
         const float ox = (float)v.coord[3 * b] * p.unit_len, oy = (float)v.coord[3 * b + 1] * p.unit_len, oz = (float)v.coord[3 * b + 2] * p.unit_len;
         const float y = oy + p.vl * ((float)L.iy + 0.5f);
-        float4* W4 = reinterpret_cast<float4*>(v.weight + (size_t)b * TS_VOX);
-        float4* S4 = reinterpret_cast<float4*>(v.tsdf + (size_t)b * TS_VOX);
-        float4* C4 = reinterpret_cast<float4*>(v.color + (size_t)b * TS_VOX * 3);      // three planes of 4096 floats: [channel][voxel]
+        float* rec = ts_unit(v, b);
+        float4* S4 = reinterpret_cast<float4*>(rec);
+        float4* W4 = reinterpret_cast<float4*>(rec + TS_VOX);
+        float4* C4 = reinterpret_cast<float4*>(rec + 2 * TS_VOX);      // three planes of 4096 floats: [channel][voxel]
         unsigned long long* M = v.mask + (size_t)b * 16;
         unsigned long long had[4];      // wave-uniform: the written-group words of this wave's four rounds (a fresh unit's words hold whatever the pool held)
 #pragma unroll
@@ -434,9 +444,10 @@ __global__ void __launch_bounds__(256) k_ts_materialize(SparseTsdf v, int n)
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         const bool fresh = v.stamp[b] == 0u;
         unsigned long long* M = v.mask + (size_t)b * 16;
-        float4* W4 = reinterpret_cast<float4*>(v.weight + (size_t)b * TS_VOX);
-        float4* S4 = reinterpret_cast<float4*>(v.tsdf + (size_t)b * TS_VOX);
-        float4* C4 = reinterpret_cast<float4*>(v.color + (size_t)b * TS_VOX * 3);
+        float* rec = ts_unit(v, b);
+        float4* S4 = reinterpret_cast<float4*>(rec);
+        float4* W4 = reinterpret_cast<float4*>(rec + TS_VOX);
+        float4* C4 = reinterpret_cast<float4*>(rec + 2 * TS_VOX);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -480,9 +491,11 @@ __global__ void __launch_bounds__(256) k_ts_insert_list(SparseTsdf v, const int3
 // SRC 1: they are the pools of another volume (storage order, colour planes, written-group words, stamps): merge_from() on one device, nothing is copied or
 // re-ordered in between and what the source never wrote is never read.
 template <int SRC>
-__global__ void __launch_bounds__(256) k_ts_merge(SparseTsdf v, const int32_t* __restrict__ coords, const float* __restrict__ o_tsdf, const float* __restrict__ o_weight,
-                                                  const float* __restrict__ o_color, const unsigned long long* __restrict__ o_mask, const uint32_t* __restrict__ o_stamp, int n)
+__global__ void __launch_bounds__(256) k_ts_merge(SparseTsdf v, SparseTsdf o, const int32_t* __restrict__ coords, const float* __restrict__ o_tsdf, const float* __restrict__ o_weight,
+                                                  const float* __restrict__ o_color, int n)
 {
+    const unsigned long long* __restrict__ o_mask = o.mask;
+    const uint32_t* __restrict__ o_stamp = o.stamp;
     const TsLane L = ts_lane((int)threadIdx.x);
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
     for (int k = blockIdx.x; k < n; k += gridDim.x) {
@@ -491,10 +504,14 @@ __global__ void __launch_bounds__(256) k_ts_merge(SparseTsdf v, const int32_t* _
         if (b < 0) continue;
         const bool fresh = v.stamp[b] == 0u;      // a unit this call (or an aborted frame) allocated: its pool memory and mask words are uninitialised
         unsigned long long* M = v.mask + (size_t)b * 16;
-        float4* W4 = reinterpret_cast<float4*>(v.weight + (size_t)b * TS_VOX);
-        float4* S4 = reinterpret_cast<float4*>(v.tsdf + (size_t)b * TS_VOX);
-        float4* C4 = reinterpret_cast<float4*>(v.color + (size_t)b * TS_VOX * 3);
-        const float* ot = o_tsdf + (size_t)k * TS_VOX; const float* ow = o_weight + (size_t)k * TS_VOX; const float* oc = o_color + (size_t)k * TS_VOX * 3;
+        float* rec = ts_unit(v, b);
+        float4* S4 = reinterpret_cast<float4*>(rec);
+        float4* W4 = reinterpret_cast<float4*>(rec + TS_VOX);
+        float4* C4 = reinterpret_cast<float4*>(rec + 2 * TS_VOX);
+        const float* orec = SRC == 1 ? ts_unit(o, k) : nullptr;
+        const float* ot = SRC == 1 ? orec : o_tsdf + (size_t)k * TS_VOX;
+        const float* ow = SRC == 1 ? orec + TS_VOX : o_weight + (size_t)k * TS_VOX;
+        const float* oc = SRC == 1 ? orec + 2 * TS_VOX : o_color + (size_t)k * TS_VOX * 3;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const unsigned long long had = fresh ? 0ull : ts_uniform64(M[wv + 4 * r]);
@@ -517,9 +534,9 @@ __global__ void __launch_bounds__(256) k_ts_merge(SparseTsdf v, const int32_t* _
                 for (int j = 0; j < 4; j++) { c1[0][j] = a[3 * j]; c1[1][j] = a[3 * j + 1]; c1[2][j] = a[3 * j + 2]; }
             }
             const bool any = w1[0] > 0.f || w1[1] > 0.f || w1[2] > 0.f || w1[3] > 0.f;
-            const unsigned long long now = __ballot(any);
+            const unsigned long long now = ts_complete_runs(__ballot(any));      // whole 128-byte lines are written back, as in the voxel pass
             if (lane == 0 && (fresh || (now & ~had) != 0ull)) M[wv + 4 * r] = had | now;
-            if (!any) continue;
+            if (!((now >> lane) & 1ull)) continue;
             float w0[4] = { 0.f, 0.f, 0.f, 0.f }, t0[4] = { 0.f, 0.f, 0.f, 0.f }, c0[3][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
             if ((had >> lane) & 1ull) {
                 ts_unpack4(W4[g], w0); ts_unpack4(S4[g], t0);
@@ -555,14 +572,21 @@ static SparseTsdf make_view(const gsr_tsdf_sparse* s)
 {
     SparseTsdf v;
     v.keys = (unsigned long long*)s->keys; v.slot = s->slot; v.coord = s->coord; v.stamp = s->stamp; v.list = s->list; v.counters = s->counters;
-    v.tsdf = s->tsdf; v.weight = s->weight; v.color = s->color; v.mask = (unsigned long long*)s->mask; v.cap_hash_log2 = s->cap_hash_log2; v.cap_blocks = s->cap_blocks;
+    v.mask = (unsigned long long*)s->mask; v.cap_hash_log2 = s->cap_hash_log2; v.cap_blocks = s->cap_blocks; v.chunk0_log2 = s->chunk0_log2;
+    for (int c = 0; c < GSR_TSDF_MAX_CHUNKS; c++) v.chunk[c] = c < (int)s->n_chunks ? s->chunk[c] : nullptr;
     return v;
 }
 static int check_vol(const gsr_tsdf_sparse* s)
 {
-    if (!s || !s->keys || !s->slot || !s->coord || !s->stamp || !s->list || !s->counters || !s->tsdf || !s->weight || !s->color || !s->mask) {
+    if (!s || !s->keys || !s->slot || !s->coord || !s->stamp || !s->list || !s->counters || !s->mask) {
         gsr_set_error("tsdf_sparse: null volume buffers"); return 1;
     }
+    if (s->n_chunks < 1 || s->n_chunks > GSR_TSDF_MAX_CHUNKS || s->chunk0_log2 > 27 || s->cap_blocks != (1u << (s->chunk0_log2 + s->n_chunks - 1))) {
+        gsr_set_error("tsdf_sparse: %u chunks of first size 2^%u do not make a pool of %u units (chunk c >= 1 holds 2^(chunk0_log2 + c - 1) units)", s->n_chunks, s->chunk0_log2,
+                      s->cap_blocks); return 1;
+    }
+    for (uint32_t c = 0; c < s->n_chunks; c++)
+        if (!s->chunk[c]) { gsr_set_error("tsdf_sparse: null chunk %u", c); return 1; }
     if (s->cap_hash_log2 < 4 || s->cap_hash_log2 > 30 || s->cap_blocks == 0 || (1ull << s->cap_hash_log2) < 2ull * s->cap_blocks) {
         gsr_set_error("tsdf_sparse: hash table must hold at least twice the unit capacity"); return 1;
     }
@@ -636,7 +660,7 @@ extern "C" int gsr_tsdf_sparse_status(const gsr_tsdf_sparse* s, const int32_t* s
     return frame_errors(s, status_host, (hipStream_t)stream);
 }
 
-// after the caller re-allocated the arrays of a volume (growth: larger pools, coord / stamp / pool contents of units [0, n) copied, keys all-ones,
+// after the caller re-allocated the arrays of a volume (growth: a further chunk, coord / stamp / mask of units [0, n) copied into larger arrays, keys all-ones,
 // counters[0] = n): every unit gets its key back with the slot it had.  No voxel is touched.
 extern "C" int gsr_tsdf_sparse_rehash(const gsr_tsdf_sparse* s, int32_t n_units, void* stream)
 {
@@ -667,8 +691,7 @@ extern "C" int gsr_tsdf_sparse_merge(const gsr_tsdf_sparse* s, int32_t n_units, 
     hipStream_t st = (hipStream_t)stream;
     SparseTsdf v = make_view(s);
     if (merge_insert(s, v, coords, n_units, st)) return 1;
-    hipLaunchKernelGGL(k_ts_merge<0>, dim3((uint32_t)std::min(n_units, 8 * TS_GRID)), dim3(256), 0, st, v, coords, tsdf, weight, color, (const unsigned long long*)nullptr,
-                       (const uint32_t*)nullptr, (int)n_units);
+    hipLaunchKernelGGL(k_ts_merge<0>, dim3((uint32_t)std::min(n_units, 8 * TS_GRID)), dim3(256), 0, st, v, v, coords, tsdf, weight, color, (int)n_units);
     return gsr_check_launch("tsdf_sparse_merge", st, false);
 }
 // ABI 8.  vol <- weighted merge with the first n_units units of another volume ON THE SAME DEVICE, read where they lie (pools in storage order, written-group
@@ -679,12 +702,12 @@ extern "C" int gsr_tsdf_sparse_merge_volume(const gsr_tsdf_sparse* s, const gsr_
     if (n_units <= 0) return 0;
     if ((uint32_t)n_units > other->cap_blocks) { gsr_set_error("tsdf_sparse_merge_volume: %d units exceed the source's capacity", n_units); return 1; }
     if (s->voxel_length != other->voxel_length || s->sdf_trunc != other->sdf_trunc) { gsr_set_error("tsdf_sparse_merge_volume: volumes must share voxel_length and sdf_trunc"); return 1; }
-    if (s->tsdf == other->tsdf) { gsr_set_error("tsdf_sparse_merge_volume: a volume cannot be merged into itself"); return 1; }
+    if (s->chunk[0] == other->chunk[0]) { gsr_set_error("tsdf_sparse_merge_volume: a volume cannot be merged into itself"); return 1; }
     hipStream_t st = (hipStream_t)stream;
     SparseTsdf v = make_view(s);
     if (merge_insert(s, v, other->coord, n_units, st)) return 1;
-    hipLaunchKernelGGL(k_ts_merge<1>, dim3((uint32_t)std::min(n_units, 8 * TS_GRID)), dim3(256), 0, st, v, (const int32_t*)other->coord, (const float*)other->tsdf,
-                       (const float*)other->weight, (const float*)other->color, (const unsigned long long*)other->mask, (const uint32_t*)other->stamp, (int)n_units);
+    hipLaunchKernelGGL(k_ts_merge<1>, dim3((uint32_t)std::min(n_units, 8 * TS_GRID)), dim3(256), 0, st, v, make_view(other), (const int32_t*)other->coord, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (int)n_units);
     return gsr_check_launch("tsdf_sparse_merge_volume", st, false);
 }
 // ABI 8.  Makes units [0, n_units) plain arrays: groups that were never written are zero-filled and marked written (see k_ts_materialize).  What a reader of

@@ -54,8 +54,10 @@ class MvCfg(C.Structure):
 
 class TsdfSparse(C.Structure):
     """gsr_tsdf_sparse (include/gsrast.h)."""
-    _fields_ = [("keys", _vp), ("slot", _vp), ("coord", _vp), ("stamp", _vp), ("list", _vp), ("counters", _vp), ("tsdf", _vp), ("weight", _vp),
-                ("color", _vp), ("mask", _vp), ("cap_hash_log2", C.c_uint32), ("cap_blocks", C.c_uint32), ("voxel_length", C.c_float), ("sdf_trunc", C.c_float)]
+    MAX_CHUNKS = 24
+    _fields_ = [("keys", _vp), ("slot", _vp), ("coord", _vp), ("stamp", _vp), ("list", _vp), ("counters", _vp), ("mask", _vp), ("chunk", _vp * 24),
+                ("chunk0_log2", C.c_uint32), ("n_chunks", C.c_uint32), ("cap_hash_log2", C.c_uint32), ("cap_blocks", C.c_uint32),
+                ("voxel_length", C.c_float), ("sdf_trunc", C.c_float)]
 
 
 class LodCfg(C.Structure):

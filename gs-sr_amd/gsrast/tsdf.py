@@ -96,8 +96,9 @@ class ScalableTSDFVolume:
     csrc/gsr_tsdf_sparse.hip); tests pin the HIP volume against a plain-C restatement on the CPU and, unit by unit, against
     DenseTSDFVolume.
 
-    capacity_units is the INITIAL number of 16^3 units (80 KB each: tsdf + weight + 3 colour floats per voxel); a frame that needs more doubles
-    the pool unless auto_grow=False, in which case it raises.
+    capacity_units is the INITIAL number of 16^3 units (80 KB each: tsdf + weight + 3 colour floats per voxel; rounded up to a power of two); a frame
+    that needs more doubles the pool -- one more chunk of records, no voxel copied -- unless auto_grow=False, in which case it raises.  With auto_grow the pool
+    also grows ahead of need (once more than half of it is allocated), so that a render -> integrate loop rarely sees a refused frame.
     Colours are stored on the 0..255 scale whether or not they are quantised to integers first (quantize_rgb8).
     The pools hold a unit in brick order and only the 16-byte groups a frame or merge has written (`mask`, ABI 8): read them through `units()` /
     `to_dense()`, which hand out plain x-major arrays.
@@ -118,9 +119,10 @@ class ScalableTSDFVolume:
         if self.device.type != "cuda":
             raise RuntimeError("ScalableTSDFVolume lives on a HIP device; there is no CPU path")
         self.stride = int(depth_sampling_stride)
-        self._alloc(int(capacity_units))
+        self._alloc(1 << max(4, (int(capacity_units) - 1).bit_length()))              # chunk addressing wants powers of two
         self.frame = 0
         self.last_touched = 0
+        self._allocated = 0           # units allocated as of the last frame whose status words have been read
         self._tex = None              # texel scratch of the last frame size (frames of one stream run in order: one buffer serves every frame in flight)
         self._queue = []              # frames enqueued with defer=True whose status words have not been looked at yet, oldest first
         self._status = None           # pinned int32[MAX_IN_FLIGHT, 4]
@@ -130,9 +132,11 @@ class ScalableTSDFVolume:
         """The newest frame still in flight (None when the volume is settled)."""
         return self._queue[-1] if self._queue else None
 
-    def _alloc(self, cap):
-        """The volume's arrays for `cap` units.  Neither the pools (80 KB per unit) nor the written-group words are initialised: a unit whose stamp is 0 has
-        never been written, and a clear mask bit means "zero" whatever the pool holds -- a 131 072-unit volume used to start with a 10.7 GB memset."""
+    def _alloc(self, cap, chunks=None):
+        """The volume's arrays for `cap` units (a power of two).  Voxels live in unit records of 5 x 4096 floats (planes tsdf, weight, r, g, b) held in chunks
+        of doubling size -- `chunks` keeps the existing ones, the rest is allocated.  Nothing is initialised, neither the records (80 KB per unit) nor the
+        written-group words: a unit whose stamp is 0 has never been written, and a clear mask bit means "zero" whatever the record holds -- a 131 072-unit
+        volume used to start with a 10.7 GB memset."""
         d = self.device
         self.cap = int(cap)
         self.log2 = max(4, (2 * self.cap - 1).bit_length())
@@ -142,15 +146,34 @@ class ScalableTSDFVolume:
         self.stamp = torch.zeros((self.cap,), dtype=torch.int32, device=d)
         self.list = torch.zeros((self.cap,), dtype=torch.int32, device=d)
         self.counters = torch.zeros((4,), dtype=torch.int32, device=d)
-        V = self.RES ** 3
-        self.tsdf = torch.empty((self.cap, V), dtype=torch.float32, device=d)
-        self.weight = torch.empty((self.cap, V), dtype=torch.float32, device=d)
-        self.color = torch.empty((self.cap, 3, V), dtype=torch.float32, device=d)      # three colour planes per unit (ABI 7), brick order (ABI 8)
         self.mask = torch.empty((self.cap, 16), dtype=torch.int64, device=d)           # written-group bits (ABI 8)
+        self.chunks = list(chunks or [])
+        have = sum(int(c.shape[0]) for c in self.chunks)
+        while have < self.cap:
+            k = self.cap if not self.chunks else have                                  # chunk 0: the initial capacity; every further chunk doubles the pool
+            if len(self.chunks) >= TsdfSparse.MAX_CHUNKS:
+                raise RuntimeError("ScalableTSDFVolume: chunk table full")
+            self.chunks.append(torch.empty((k, 5, self.RES ** 3), dtype=torch.float32, device=d))
+            have += k
+        self.chunk0_log2 = int(self.chunks[0].shape[0]).bit_length() - 1
 
     def _struct(self):
-        return TsdfSparse(ptr(self.keys), ptr(self.slot), ptr(self.coord), ptr(self.stamp), ptr(self.list), ptr(self.counters), ptr(self.tsdf),
-                          ptr(self.weight), ptr(self.color), ptr(self.mask), self.log2, self.cap, self.voxel_length, self.sdf_trunc)
+        import ctypes as C
+        arr = (C.c_void_p * TsdfSparse.MAX_CHUNKS)(*[c.data_ptr() for c in self.chunks])
+        return TsdfSparse(ptr(self.keys), ptr(self.slot), ptr(self.coord), ptr(self.stamp), ptr(self.list), ptr(self.counters), ptr(self.mask), arr,
+                          self.chunk0_log2, len(self.chunks), self.log2, self.cap, self.voxel_length, self.sdf_trunc)
+
+    def records(self, n=None):
+        """[n, 5, 4096] the raw unit records of units [0, n) (planes tsdf, weight, r, g, b in brick order; a view when they live in one chunk, else a
+        concatenation): test / export helper -- unwritten groups hold whatever the memory held unless the volume has been materialised."""
+        n = self.num_units if n is None else int(n)
+        parts, s = [], 0
+        for c in self.chunks:
+            k = min(int(c.shape[0]), n - s)
+            if k <= 0:
+                break
+            parts.append(c[:k]); s += k
+        return parts[0] if len(parts) == 1 else torch.cat(parts, 0) if parts else self.chunks[0][:0]
 
     def integrate(self, rgb, depth, fx, fy, cx, cy, extrinsic, depth_trunc=float("inf"), quantize_rgb8=True, defer=False):
         """rgb [3,H,W] in [0,1], depth [1,H,W] or [H,W] (0 = invalid, as mesh_utils.py:165-166 writes for masked pixels),
@@ -175,6 +198,12 @@ class ScalableTSDFVolume:
             self.finish()
         elif self._queue and self._queue[0]["event"].query():
             self._settle_done()
+        if self.auto_grow and 2 * self._allocated > self.cap and self.cap < (1 << 27):
+            # grow ahead of need: with chunked records that costs an allocation and a re-key of the (small) table, not a copy -- a refused frame costs its
+            # touch passes twice and stalls every frame queued behind it
+            self.finish()
+            while 2 * self._allocated > self.cap and self.cap < (1 << 27):
+                self._grow()
         if self._status is None:
             self._status = torch.zeros((self.MAX_IN_FLIGHT, 4), dtype=torch.int32).pin_memory()
         frame = dict(d=d, c=c, W=W, H=H, intr=(float(fx), float(fy), float(cx), float(cy)), Ea=Ea, Pa=Pa, dt=float(min(depth_trunc, 3.0e38)),
@@ -233,7 +262,7 @@ class ScalableTSDFVolume:
                 msg = last_error()
                 self._after_failure()
                 raise RuntimeError(f"tsdf_sparse_integrate: {msg}")
-            self.last_touched = int(self._status[f["slot"], 1])
+            self.last_touched = int(self._status[f["slot"], 1]); self._allocated = int(self._status[f["slot"], 0])
             frames.pop(0)
 
     def _settle_done(self):
@@ -242,7 +271,7 @@ class ScalableTSDFVolume:
             f = self._queue[0]
             if self._frame_rc(f) != 0:
                 return self.finish()
-            self.last_touched = int(self._status[f["slot"], 1])
+            self.last_touched = int(self._status[f["slot"], 1]); self._allocated = int(self._status[f["slot"], 0])
             self._queue.pop(0)
 
     def finish(self):
@@ -262,13 +291,13 @@ class ScalableTSDFVolume:
         self.counters[2] = 0
 
     def _grow(self):
-        """Doubles the unit pool: new arrays of twice the capacity, the allocated units' coordinates, stamps, mask words and voxels copied (device-to-device,
-        no arithmetic, and no fill of the part that is not in use), the hash table re-keyed with every unit in its old slot."""
+        """Doubles the unit pool: ONE MORE CHUNK of records (no voxel is copied, the volume never holds old and new pools side by side), larger coord / stamp /
+        list / mask arrays with the allocated units' entries copied (140 B per unit), the hash table re-keyed with every unit in its old slot."""
         import ctypes as C
         n = min(int(self.counters[0].item()), self.cap)
-        old = (self.coord, self.stamp, self.tsdf, self.weight, self.color, self.mask)
-        self._alloc(2 * self.cap)
-        for dst, src in zip((self.coord, self.stamp, self.tsdf, self.weight, self.color, self.mask), old):
+        old = (self.coord, self.stamp, self.mask)
+        self._alloc(2 * self.cap, chunks=self.chunks)
+        for dst, src in zip((self.coord, self.stamp, self.mask), old):
             dst[:n].copy_(src[:n])
         self.counters[0] = n
         st = self._struct()
@@ -286,12 +315,15 @@ class ScalableTSDFVolume:
         n = self.num_units
         if n == 0:
             return 0.0
-        tot = 0.0
-        for s in range(0, n, 16384):
-            e = min(n, s + 16384)
-            bits = ((self.mask[s:e].view(e - s, 16, 1) >> torch.arange(64, device=self.device).view(1, 1, 64)) & 1).bool().view(e - s, 1024)
-            bits &= (self.stamp[s:e] != 0).view(-1, 1)
-            tot += float(torch.where(bits.unsqueeze(-1), self.weight[s:e].view(e - s, 1024, 4), torch.zeros((), device=self.device)).double().sum())
+        tot, s0 = 0.0, 0
+        for ch in self.chunks:
+            for s in range(s0, min(n, s0 + int(ch.shape[0])), 16384):
+                e = min(n, s0 + int(ch.shape[0]), s + 16384)
+                bits = ((self.mask[s:e].view(e - s, 16, 1) >> torch.arange(64, device=self.device).view(1, 1, 64)) & 1).bool().view(e - s, 1024)
+                bits &= (self.stamp[s:e] != 0).view(-1, 1)
+                w = ch[s - s0:e - s0, 1].view(e - s, 1024, 4)
+                tot += float(torch.where(bits.unsqueeze(-1), w, torch.zeros((), device=self.device)).double().sum())
+            s0 += int(ch.shape[0])
         return tot
 
     def units(self):
@@ -304,9 +336,10 @@ class ScalableTSDFVolume:
         with torch.cuda.device(self.device):
             check(lib().gsr_tsdf_sparse_materialize(C.byref(st), n, stream_ptr(self.device)), "tsdf_sparse_materialize")
         # storage index bits, high to low: bx by bz (2 each) | x1 y1 x0 y0 | z (2)
-        plane = lambda a: a.view(n, 4, 4, 4, 2, 2, 2, 2, 4).permute(0, 1, 4, 6, 2, 5, 7, 3, 8).reshape(n, 16, 16, 16)
-        col = self.color[:n].view(n, 3, 4, 4, 4, 2, 2, 2, 2, 4).permute(0, 2, 5, 7, 3, 6, 8, 4, 9, 1).reshape(n, 16, 16, 16, 3)
-        return self.coord[:n], plane(self.tsdf[:n]), plane(self.weight[:n]), col
+        rec = self.records(n)
+        plane = lambda a: a.reshape(n, 4, 4, 4, 2, 2, 2, 2, 4).permute(0, 1, 4, 6, 2, 5, 7, 3, 8).reshape(n, 16, 16, 16)
+        col = rec[:, 2:5].reshape(n, 3, 4, 4, 4, 2, 2, 2, 2, 4).permute(0, 2, 5, 7, 3, 6, 8, 4, 9, 1).reshape(n, 16, 16, 16, 3)
+        return self.coord[:n], plane(rec[:, 0]), plane(rec[:, 1]), col
 
     def merge_units_(self, coords, tsdf, weight, color, assume_unique=False):
         """self <- weighted merge with the given units (plain arrays shaped like `units()`, on this device).  The merge kernel runs one workgroup per
@@ -340,6 +373,7 @@ class ScalableTSDFVolume:
                 msg = last_error()
                 self._after_failure()
                 raise RuntimeError(f"{what}: {msg}")
+            self._allocated = min(int(self.counters[0].item()), self.cap)
             return
 
     def merge_from(self, other):

@@ -210,20 +210,25 @@ int gsr_tsdf_integrate_dense(int32_t nx, int32_t ny, int32_t nz, const float* or
  * coordinate floor(p / (16 * voxel_length)); a frame opens every unit overlapping [p - sdf_trunc, p + sdf_trunc] for every
  * `stride`-th valid depth pixel's world point p and applies the gsr_tsdf_integrate_dense voxel rule to each opened unit once.
  * All buffers are caller-owned device memory: keys [2^cap_hash_log2] int64 filled with -1, slot [2^cap_hash_log2] int32,
- * coord [cap_blocks,3] int32, stamp/list [cap_blocks], counters [4] int32 zero-filled, pools tsdf/weight [cap_blocks,4096] and
- * color [cap_blocks,3,4096] float32 (ABI 7: three colour PLANES per unit, so that every plane is read and written in coalesced 16-byte groups; ABI <= 6:
- * [cap_blocks,4096,3]) -- since ABI 7 the pools need NOT be initialised (80 KB per unit of capacity): a unit whose stamp is 0 has never been
- * written and is written, without being read, by the first frame / merge that touches it.  counters[0] = units allocated so far.
- * ABI 8: (1) mask [cap_blocks,16] uint64, uninitialised like the pools: bit g of a unit's 1024 says that 16-byte group g (four consecutive z) has ever been
- * written.  A clear bit means (tsdf 0, weight 0, colour 0) whatever the pool holds there: the kernels never read such a group and a unit's first frame writes
- * only the groups it observed.  A reader of the raw pools calls gsr_tsdf_sparse_materialize first.  (2) A unit plane is stored in bricks, not x-major:
- * voxel (x,y,z) of a unit lives at float index 4*g + (z & 3) with
- *   g = (x>>2)<<8 | (y>>2)<<6 | (z>>2)<<4 | ((x>>1)&1)<<3 | ((y>>1)&1)<<2 | (x&1)<<1 | (y&1)
- * (4x4x4 bricks of 256 B, 64-byte sectors of 2x2x4 voxels: the surface shell a frame updates cuts compact sectors less often than 1x1x16 columns). */
+ * coord [cap_blocks,3] int32, stamp/list [cap_blocks], counters [4] int32 zero-filled; counters[0] = units allocated so far.
+ * ABI 8, the voxel storage:
+ * (1) unit RECORDS of 5 x 4096 float32 (planes tsdf, weight, r, g, b: every plane is read and written in coalesced 16-byte groups) in up to
+ *     GSR_TSDF_MAX_CHUNKS chunks of doubling size: chunk[0] holds units [0, 2^chunk0_log2), chunk[c >= 1] the units [2^(chunk0_log2+c-1), 2^(chunk0_log2+c));
+ *     cap_blocks = 2^(chunk0_log2 + n_chunks - 1).  Growing a volume = one more chunk + larger small arrays + gsr_tsdf_sparse_rehash: no voxel is copied.
+ * (2) NOTHING is initialised: a unit whose stamp is 0 has never been written, and mask [cap_blocks,16] uint64 (uninitialised as well) says per unit which of its
+ *     1024 16-byte groups (four consecutive z) have ever been written.  A clear bit means (tsdf 0, weight 0, colour 0) whatever the record holds there: the
+ *     kernels never read such a group and a unit's first frame writes only the 128-byte lines it observed.  A reader of the raw records calls
+ *     gsr_tsdf_sparse_materialize first.  (ABI <= 6 zero-filled 80 KB per unit of capacity, ABI 7 wrote a unit's first frame in full.)
+ * (3) A plane is stored in bricks, not x-major: voxel (x,y,z) of a unit lives at float index 4*g + (z & 3) of its plane with
+ *       g = (x>>2)<<8 | (y>>2)<<6 | (z>>2)<<4 | ((x>>1)&1)<<3 | ((y>>1)&1)<<2 | (x&1)<<1 | (y&1)
+ *     (4x4x4 bricks of 256 B, 128-byte lines of 2x4x4 voxels, 64-byte sectors of 2x2x4: the surface shell a frame updates cuts compact lines less often than
+ *     the 1x1x16 columns of an x-major plane). */
+#define GSR_TSDF_MAX_CHUNKS 24
 typedef struct gsr_tsdf_sparse {
     void* keys; int32_t* slot; int32_t* coord; uint32_t* stamp; int32_t* list; int32_t* counters;
-    float* tsdf; float* weight; float* color;
     void* mask;
+    float* chunk[GSR_TSDF_MAX_CHUNKS];
+    uint32_t chunk0_log2, n_chunks;
     uint32_t cap_hash_log2, cap_blocks;
     float voxel_length, sdf_trunc;
 } gsr_tsdf_sparse;
@@ -242,7 +247,7 @@ int gsr_tsdf_sparse_integrate2(const gsr_tsdf_sparse* vol, int32_t W, int32_t H,
                                float fx, float fy, float cx, float cy, const float* extrinsic, const float* pose, float depth_trunc, int32_t stride,
                                uint32_t frame, float* texels, int32_t* status_host, uint32_t flags, void* stream);
 int gsr_tsdf_sparse_status(const gsr_tsdf_sparse* vol, const int32_t* status_host, void* stream);
-/* After the caller re-allocated a volume's arrays (growth): keys all -1, coord / stamp / pool contents of units [0, n_units) copied, counters[0] = n_units --
+/* After the caller re-allocated a volume's arrays (growth: a further chunk, larger coord / stamp / list / mask with units [0, n_units) copied, keys all -1), counters[0] = n_units --
  * gives every unit its key back with the slot it had.  No voxel is touched. */
 int gsr_tsdf_sparse_rehash(const gsr_tsdf_sparse* vol, int32_t n_units, void* stream);
 /* vol <- weighted merge with n_units units given as plain arrays in LOGICAL voxel order (coords [n,3] int32, tsdf/weight [n,16,16,16] x-major,

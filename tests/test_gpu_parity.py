@@ -569,6 +569,26 @@ def test_full_size_oracle_parity(variant, cm, seed, pose):
         assert not rep["hip_grads"]["dL_dshs"][:, (int(deg) + 1) ** 2:].any()
 
 
+# BASELINE size on a NON-UNIFORM scene: scenes.concentrate pulls a fraction of the gaussians towards the optical axis, so that a few hundred tiles carry
+# lists of 1 500 ... 12 000 entries.  The paths only long lists take -- chunk halving and longest-first launch order in the splat-parallel backward
+# (csrc/gsr_blend_sp.hip), k_tile_order / the global-order feedback, the bitonic and radix fallbacks of the per-tile depth sort (csrc/gsr_tile_sort.h) -- meet the
+# float64 truth and the float32-geometry floor here, with the nominal bars of tests/parity_truth.py, not only the integer-list checks.
+# (surfel/backward.cu:143-447, rasterizer_impl.cu:300-308 are what the long lists restate.)
+SKEW_CASES = [("surfel", 0.6, 0.12), ("ewa", 0.7, 0.05)]
+
+
+@pytest.mark.parametrize("variant,frac,scale", SKEW_CASES)
+def test_full_size_oracle_parity_on_long_tile_lists(variant, frac, scale):
+    hr = _hiprun()
+    P, W, H = 300000, 1920, 1080
+    sc = scenes.concentrate(scenes.make_scene(variant, P, W, H, seed=0), frac, scale)
+    og = scenes.random_out_grads(variant, W, H, seed=0)
+    rep = _check_against_truth(hr, variant, "precomp", sc, og)
+    ln = np.diff(hr.run_raw(variant, sc)["ranges"].astype(np.int64), axis=1)[:, 0]
+    assert ln.max() >= 1500 and (ln > 1024).sum() >= 50, (int(ln.max()), int((ln > 1024).sum()))      # the long-list paths were taken
+    assert rep["robust_pixel_fraction"] > 0.9
+
+
 @pytest.mark.parametrize("variant,cm,P,W,H,pose", CASES)
 def test_small_cases_against_the_float64_truth(variant, cm, P, W, H, pose):
     hr = _hiprun()

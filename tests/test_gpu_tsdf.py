@@ -16,7 +16,9 @@ VL, TR, DT = 0.02, 0.1, 6.0
 def _poison(vol):
     """The pools are not zero-filled by the library any more (ABI 7): whatever a unit's 80 KB held before must never show.  ABI 8: the written-group words
     are not initialised either -- all-ones here, so that a kernel trusting a never-written unit's words would read the NaNs."""
-    vol.tsdf.fill_(float("nan")); vol.weight.fill_(float("nan")); vol.color.fill_(float("nan")); vol.mask.fill_(-1)
+    for ch in vol.chunks:
+        ch.fill_(float("nan"))
+    vol.mask.fill_(-1)
     return vol
 
 
@@ -156,21 +158,26 @@ def test_many_frames_in_flight_also_through_a_refused_frame():
 
 
 def test_only_written_groups_exist_until_somebody_reads_the_pools():
-    """ABI 8: a frame writes only the 16-byte groups it updates (bit set in `mask`), also in a unit it opens; everything else keeps whatever the pool held
-    (NaN here) until units() / to_dense() materialise the volume.  The written groups, re-ordered from brick to x-major order, are the oracle's voxels."""
+    """ABI 8: a frame writes only the 128-byte lines it updates a group of (bits set in `mask`), also in a unit it opens; everything else keeps whatever the
+    record held (NaN here) until units() / to_dense() materialise the volume.  The written groups, re-ordered from brick to x-major order, are the oracle's
+    voxels.  Growth adds a chunk of records and copies no voxel: chunk 0 is the same memory before and after."""
     frs = tsdf_cases.frames(2)
-    vol = _hip_volume(frs)
+    vol = _hip_volume(frs, cap=256)
     vol.finish()
     n = int(vol.counters[0].item())
+    assert len(vol.chunks) > 1 and vol.chunks[0].shape[0] == 256 and sum(c.shape[0] for c in vol.chunks) == vol.cap >= n
     bits = ((vol.mask[:n].view(n, 16, 1) >> torch.arange(64, device="cuda").view(1, 1, 64)) & 1).bool().view(n, 1024)       # [unit, group]
     stamped = vol.stamp[:n] != 0
-    w = vol.weight[:n].view(n, 1024, 4)
-    assert torch.isnan(w[stamped][~bits[stamped]]).all()                   # never written: still the poison
+    w = vol.records(n)[:, 1].view(n, 1024, 4)
+    first = stamped & (torch.arange(n, device="cuda") < 256)              # chunk 0 was poisoned before use (later chunks are fresh allocations)
+    assert first.sum() > 100 and torch.isnan(w[first][~bits[first]]).all()      # never written: still the poison
     assert not torch.isnan(w[stamped][bits[stamped]]).any()
     assert 0.2 < bits[stamped].float().mean().item() < 0.95                  # a band through the units, not whole units
-    assert (vol.tsdf[:n].view(n, 1024, 4)[stamped][bits[stamped]].abs() <= 1).all()
+    runs = bits.view(n, 128, 8)
+    assert (runs.all(-1) | ~runs.any(-1)).all()                            # whole 128-byte lines: eight groups written together (full-line write-back)
+    assert (vol.records(n)[:, 0].view(n, 1024, 4)[stamped][bits[stamped]].abs() <= 1).all()
     _compare(vol, _oracle_units(frs))                                      # materialises
-    assert not torch.isnan(vol.weight[:n]).any() and (vol.mask[:n] == -1).all()
+    assert not torch.isnan(vol.records(n)).any() and (vol.mask[:n] == -1).all()
 
 
 def test_merge_reads_the_other_volumes_pools_in_place():
