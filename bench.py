@@ -401,13 +401,49 @@ def launch_ranks(args, ndev):
     """`python bench.py --gpus N` with no RANK in the environment: start the N ranks (the job train_split.py:24-38 runs one tile after the
     other, and train.py:78-80 refuses on more than one GPU) and return the job's exit code; rank 0 prints the JSON line."""
     from gsrast import launch_tiles
+    if getattr(args, "dry_run", False):
+        ndev = args.gpus                    # no device is touched: pretend one per rank, so that the pinning of an N-GPU node is what gets exercised
     if args.gpus > ndev and not args.oversubscribe:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible; pass --oversubscribe to let ranks share devices")
     shared = args.gpus > ndev
-    env = {"GSR_BENCH_BACKEND": "gloo" if shared else "nccl"}
+    env = {"GSR_BENCH_BACKEND": "gloo" if (shared or getattr(args, "dry_run", False)) else "nccl"}
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     port = int(os.environ.get("MASTER_PORT", "0")) or launch_tiles.free_port()
     return launch_tiles.spawn_ranks(lambda r: cmd, args.gpus, min(args.gpus, ndev), port, pin_gpus=not args.no_pin, extra_env=env)
+
+
+def dry_run(args):
+    """`--dry-run`: everything of a multi-rank run EXCEPT the device -- the environment contract (RANK / WORLD_SIZE / MASTER_*), the per-rank
+    HIP_VISIBLE_DEVICES pinning, the process group, the all-gathered rank identities, W untimed + K timed 'steps' (a 1 ms sleep) between barriers, the
+    max-over-ranks / sum-over-ranks reduction and ONE JSON line from rank 0.  The line cannot be mistaken for a measurement: value null, metric 'DRY RUN'."""
+    import torch.distributed as dist
+    from gsrast import tiles
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N (see --help)")
+    ranks_seen = None
+    if world > 1 or "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, {"rank": rank, "pid": os.getpid(), "visible": os.environ.get("HIP_VISIBLE_DEVICES"), "local_rank": os.environ.get("LOCAL_RANK")})
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    tiles.barrier(None)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    tiles.barrier(None)
+    elapsed, total = tiles.reduce_job(time.perf_counter() - t0, args.steps, None)
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN -- no device work, not a measurement", "value": None, "unit": "iters/s", "dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "backend": "gloo", "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1, "ranks": ranks_seen,
+                          "total_steps_over_ranks": total, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "data": "none", "config": {"workload": "none (dry run of the launch path)", "parallelism": f"{world} ranks, 1 per GPU, no collective"}}),
+              flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -417,6 +453,9 @@ def main():
                          "(one pinned process per GPU, RCCL); under torch.distributed.run it is one of them")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow --gpus N > visible devices: ranks share devices (rank r on device r %% devices), control collectives over gloo")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="NO device work, NO measurement: the N ranks are started, pinned and joined exactly as for a real run (gloo), 'step' is a 1 ms sleep, "
+                         "rank 0 prints a line whose value is null and whose metric says DRY RUN.  Runs without a GPU: how the CPU test suite covers --gpus 8")
     ap.add_argument("--no-pin", action="store_true", help="self-launch without HIP_VISIBLE_DEVICES / NUMA pinning (LOCAL_RANK selects the device)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
@@ -441,6 +480,10 @@ def main():
                     help="skip the extra 'method_iteration' measurement (full scaffold-2dgs iteration incl. decode, real losses, statistics)")
     args = ap.parse_args()
 
+    if args.dry_run:
+        if "RANK" not in os.environ and args.gpus > 1:
+            sys.exit(launch_ranks(args, 0))
+        return dry_run(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the product has no CPU path")
     ndev = torch.cuda.device_count()
@@ -503,7 +546,7 @@ def main():
     # one independent tile-scene per rank (train_split.py trains tiles independently; seed = tile index)
     sc = scenes.make_scene(args.variant, args.P, args.W, args.H, seed=rank, color_mode=args.color_mode)
     if args.skew_frac > 0:      # side experiment (not the BASELINE workload): a fraction of the gaussians pulled towards the image centre -> a few very long tile lists
-        concentrate(sc, args.skew_frac, args.skew_scale)
+        scenes.concentrate(sc, args.skew_frac, args.skew_scale)
     step, state = make_step(args.variant, sc, device)
 
     from gsrast import tiles

@@ -106,7 +106,9 @@ __global__ void __launch_bounds__(1024) k_scan_lookback(uint32_t* __restrict__ d
     }
     __syncthreads();
     const uint32_t prev = s_prev;
-    if (i < n) data[i] = prev + base + incl - v;
+    // a workgroup that gave up writes an IN-RANGE sentinel (position 0), not POISON + offset: the kernels queued behind the scan (k_scatter_idx, the stage-2
+    // emitters: `out[pos[i]]`, `row_offset[i]`) run before any host could look at the total, and must stay inside their buffers
+    if (i < n) data[i] = (prev == GSD_SCAN_POISON) ? 0u : prev + base + incl - v;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = (prev == GSD_SCAN_POISON) ? GSD_SCAN_POISON : prev + all;
 }
 // data[0..n) -> exclusive prefix in place, *total_dev = sum.  flags: >= div_up(n,1024) words, zeroed by the kernel in front (k_flags).
@@ -843,7 +845,8 @@ extern "C" int gsd_compact_visible(const uint8_t* mask, int32_t Na, int32_t* vis
 
 // The same compaction WITHOUT the host synchronisation: vis_idx gets all Na entries, the visible anchors' indices first (ascending) and -1
 // behind them; the caller runs the decode with Nv = Na and the kernels skip the padding rows.  *count_dev (device, may be NULL) receives
-// the number of visible anchors.
+// the number of visible anchors -- or 0xFFFFFFFF when the scan's bounded look-back timed out (no host is in the loop to raise: vis_idx then holds
+// in-range indices and -1 only, and a caller that later reads the count sees the poison).
 extern "C" int gsd_compact_visible_padded(const uint8_t* mask, int32_t Na, int32_t* vis_idx, uint32_t* count_dev, void* scratch,
                                           size_t scratch_bytes, void* stream)
 {
@@ -952,13 +955,14 @@ extern "C" int gsd_forward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_p
 // Static-shape forward (round 3): no host synchronisation, so the call can be recorded into a HIP graph and replayed.  The outputs keep their
 // worst-case Nv*k rows; the rows behind the P emitted ones are PARKED at the camera centre with zero opacity, so that any rasterizer of this
 // library culls them in its preprocess (view depth 0 <= 0.2; radii 0, no tile instance, zero gradients) -- the caller passes all Nv*k rows on
-// and never learns P on the host.  *count_dev (DEVICE, optional) <- P.
+// and never learns P on the host.  *count_dev (DEVICE, optional) <- P, or 0xFFFFFFFF when the scan's bounded look-back timed out: ALL rows are parked then.
 __global__ void __launch_bounds__(256) k_park_tail(const uint32_t* __restrict__ total, uint32_t cap, const float* __restrict__ campos,
                                                    float* __restrict__ xyz, float* __restrict__ color, float* __restrict__ opacity,
                                                    float* __restrict__ scaling, float* __restrict__ rot, uint32_t* __restrict__ count_dev)
 {
-    const uint32_t P = *total;
-    if (count_dev && blockIdx.x == 0 && threadIdx.x == 0) *count_dev = P;
+    uint32_t P = *total;
+    if (count_dev && blockIdx.x == 0 && threadIdx.x == 0) *count_dev = P;      // GSD_SCAN_POISON (0xFFFFFFFF) when the scan timed out: then ...
+    if (P == GSD_SCAN_POISON) P = 0u;                                           // ... EVERY row is parked -- inert outputs, never rows at garbage offsets
     const float cx = campos[0], cy = campos[1], cz = campos[2];
     for (uint32_t i = P + blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
         xyz[3 * i] = cx; xyz[3 * i + 1] = cy; xyz[3 * i + 2] = cz;

@@ -265,12 +265,9 @@ static Mailbox* mailbox()
 // (tools/ab_tile_order.sh, profiles/r03_launch_order.txt).  So the order is used when it pays: every blend forward stores its tile's list length into a
 // mapped per-device word when it exceeds max(1024, 4 x mean) (BlendParams::long_word), and the forwards that follow a report -- the next 64 -- run
 // k_tile_order.  The decision costs the host one read of pinned memory; a stale decision is only a slower or faster launch order, never a wrong one
-// (the order's validity travels in the image arena, ImgView::tile_order[T]).  GSR_TILE_ORDER=0|1 forces it.
+// (the order's validity travels in the image arena, ImgView::tile_order[T]).  (GSR_TILE_ORDER=0|1 forced it for the round-3/4 A/B runs: removed in round 6.)
 bool gsr_tile_order_wanted()
 {
-    static int mode = -2;                       // -1 auto, 0 off, 1 on
-    if (mode == -2) { const char* e = getenv("GSR_TILE_ORDER"); mode = (!e || e[0] == 'a') ? -1 : (atoi(e) != 0 ? 1 : 0); }
-    if (mode >= 0) return mode != 0;
     Mailbox* mb = mailbox();
     return mb && mb->order_ttl.load(std::memory_order_relaxed) > 0;      // set by gsr_decide_depth_order, once per forward
 }
@@ -300,9 +297,7 @@ bool gsr_decide_depth_order(const gsr_cfg* cfg)
             t = mb->global_ttl.load(std::memory_order_relaxed);
             if (t > 0) mb->global_ttl.store(t - 1, std::memory_order_relaxed);
         }
-        static int fb = -1;
-        if (fb < 0) { const char* e = getenv("GSR_DEPTH_FEEDBACK"); fb = e ? (atoi(e) != 0) : 1; }
-        if (fb && !forced && mb->global_ttl.load(std::memory_order_relaxed) > 0) global = true;
+        if (!forced && mb->global_ttl.load(std::memory_order_relaxed) > 0) global = true;
     }
     return global;
 }
@@ -427,6 +422,14 @@ extern "C" int gsr_forward_stage2_ex(const gsr_cfg* cfg, const gsr_inputs* in, v
     if (mode == 0u) {
         GSR_CHECK(hipMemcpyAsync(&mode, g.counters + GSR_CNT_MODE, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read depth-order record");
         GSR_CHECK(hipStreamSynchronize(s), "stage2 sync");
+    }
+    else if (cfg->debug) {
+        // debug only (it synchronises anyway): the caller's word must be the record the preprocess kernel left -- a stale or mixed-up word would bin the
+        // arena in the wrong layout (which of sorted_idx / offsets / scan_tmp mean what) without any error
+        uint32_t rec = 0u;
+        GSR_CHECK(hipMemcpyAsync(&rec, g.counters + GSR_CNT_MODE, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read depth-order record");
+        GSR_CHECK(hipStreamSynchronize(s), "stage2 debug sync");
+        if (rec != mode) { gsr_set_error("gsr_forward_stage2_ex: depth_order 0x%08x is not the record stage 1 left in the geom buffer (0x%08x)", mode, rec); return 1; }
     }
     if (mode != GSR_MODE_TILE && mode != GSR_MODE_GLOBAL) {
         gsr_set_error("geom buffer carries no depth-order record (0x%08x): it must come from gsr_forward_stage1 / gsr_forward of this library, unmodified", mode);

@@ -26,11 +26,7 @@ __global__ void __launch_bounds__(256) k_blend_fwd(BlendParams p)
     // [wave][record quarter][candidate slot]: private to the wave, no barrier.  20 KB for every variant (SURFEL needs them; eight workgroups per CU --
     // the wave limit -- fit either way): the sort prologue borrows the buffer and takes lists of up to 2048 entries in LDS instead of sending EWA's
     // beyond 1024 to the global-memory radix path (EWA at P = 1.5 M: 624 -> 663 it/s; neutral at 300k: blend forward 0.2207 vs 0.2204 ms)
-#ifdef GSR_FWD_LDS_NOPAD      // A/B build only (make BLEND_EXTRA=-DGSR_FWD_LDS_NOPAD=1): every variant with just its own staging slots
-    __shared__ float4 s_rec[4 * ST * 64];
-#else
     __shared__ float4 s_rec[(4 * ST * 64 > 1280) ? 4 * ST * 64 : 1280];
-#endif
     const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order, p.static_map);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

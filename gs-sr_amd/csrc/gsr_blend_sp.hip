@@ -142,17 +142,11 @@ template <int I> __device__ __forceinline__ float bc_fresh(float x)
 // instructions less per pixel step in every variant.  The scalar moves and the s_nop are the wait states between the VALU write of a / b and their DPP read.
 template <int I> __device__ __forceinline__ void carry_put(float& Tc, float& Sc, float a, float b)
 {
-#ifndef SP_CARRY_TWO_STEP
     constexpr int M = (int)~(0x00010001u << I);
     asm volatile("s_mov_b32 vcc_lo, %4\n\ts_mov_b32 vcc_hi, %4\n\ts_nop 1\n\t"
                  "v_cndmask_b32_dpp %0, %2, %0, vcc row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
                  "v_cndmask_b32_dpp %1, %3, %1, vcc row_newbcast:15 row_mask:0xf bank_mask:0xf"
                  : "+v"(Tc), "+v"(Sc) : "v"(a), "v"(b), "n"(M) : "vcc");
-#else
-    const float nT = bc_fresh<15>(a), nS = bc_fresh<15>(b);
-    const bool mine = ((int)(lane_id() & 15u) == I);
-    Tc = mine ? nT : Tc; Sc = mine ? nS : Sc;
-#endif
 }
 
 // Opaque in-place use of the accumulators at the end of every pixel step.  The accumulations are pure arithmetic whose only reader is
@@ -187,7 +181,7 @@ template <> struct SpPix<GSR_SURFEL> {
 // The cancellation of px Tw against Tu happens once, in k0 / l0, as it does per pixel in the reference's form; the three cross products are formed
 // once per load and a pixel step evaluates p with <= 6 FMAs instead of 12 instructions.  The depth s . Tw.xy + Tw.z equals (p . Tw) / p.z and
 // p . Tw = det[Tu Tv Tw] =: D for every pixel (k, l differ from -Tu, -Tv by multiples of Tw), so depth = D / p.z with D from the record.
-struct SpSurf { float P0x, P0y, P0z, Pxx, Pxy, Pxz, Pyx, Pyy, Pyz, Tw0, Tw1, Tw2, D, cdx, cdy, oh; };      // EWA / PLANE use cdx, cdy (centre - block origin) and oh = -opacity / 2
+struct SpSurf { float P0x, P0y, P0z, Pxx, Pxy, Pxz, Pyx, Pyy, Pyz, Tw0, Tw1, Tw2, D, cdx, cdy, oh, rD, rTw2; };      // EWA / PLANE use cdx, cdy (centre - block origin) and oh = -opacity / 2
 __device__ __forceinline__ SpSurf sp_surf_setup(const float4& q0, const float4& q1, const float4& q2, const float4& q4, float x0, float y0)
 {
     SpSurf S;
@@ -198,6 +192,9 @@ __device__ __forceinline__ SpSurf sp_surf_setup(const float4& q0, const float4& 
     S.Pxx = Tw1 * lz - Tw2 * ly; S.Pxy = Tw2 * lx - Tw0 * lz; S.Pxz = Tw0 * ly - Tw1 * lx;        // Tw x l0
     S.Pyx = ky * Tw2 - kz * Tw1; S.Pyy = kz * Tw0 - kx * Tw2; S.Pyz = kx * Tw1 - ky * Tw0;        // k0 x Tw
     S.Tw0 = Tw0; S.Tw1 = Tw1; S.Tw2 = Tw2; S.D = q4.z;
+#ifdef SP_RCD_MUL      // A/B (VERDICT r5 #3 iii): 1 / c_d without a transcendental per step -- both reciprocals once per load
+    S.rD = rcp_(S.D); S.rTw2 = rcp_(S.Tw2);
+#endif
     S.cdx = q2.y - x0; S.cdy = q2.z - y0;
     return S;
 }
@@ -327,7 +324,11 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float r1a = rcp_(om);
         const float Tj = bc_fresh<I>(K.Tc) * row_scan_mul(r1a);
         const float w = al * Tj;
+#ifdef SP_RCD_MUL
+        const float rcd = ok ? (b3 ? ppz * S.rD : S.rTw2) : 1.0f;      // 1 / c_d: c_d = D / p.z or Tw.z
+#else
         const float rcd = rcp_(cd);
+#endif
         const float m_d = fmaf(-(FAR_N * NEAR_N) / (FAR_N - NEAR_N), rcd, FAR_N / (FAR_N - NEAR_N));      // far / (far - near) (1 - near / depth)
         const float dmd_dd = ((FAR_N * NEAR_N) / (FAR_N - NEAR_N)) * rcd * rcd;
         float u = bc_mul<I>(K.c2, m_d * m_d);
@@ -528,17 +529,10 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             const uint32_t id = s_ids[e];
             float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = make_float4(0.f, -1.f, 0.f, 0.f);
             if (v) { ca = p.cull[2 * (size_t)id]; cb = p.cull[2 * (size_t)id + 1]; }
-#ifndef SP_CULL_PER_BLOCK
             const uint32_t hit4 = cull_hit_quad4<V>(ca, cb, (float)qx, (float)qy);      // the four blocks share their bounding lines (gsr_blend_common.h)
-#endif
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-#ifndef SP_CULL_PER_BLOCK
                 const bool hit = v && (cbase + e < mlast_b[k]) && ((hit4 >> k) & 1u);
-#else
-                const bool hit = v && (cbase + e < mlast_b[k]) &&
-                                 cull_hit_rec<V>(ca, cb, (float)(qx + (k & 1) * 4), (float)(qy + (k >> 1) * 4), 3.f);
-#endif
                 const uint64_t bm = __ballot(hit);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
                 if (hit) s_queue[(wave * 4 + k) * SP_CH + cnt[k] + rank] = (uint8_t)e;

@@ -20,7 +20,7 @@ def cpu_deep_copy_tuple(input_tuple):
 
 
 # Expected number of tile instances per (device, variant, W, H): sizes the binning arena of the NEXT forward so that
-# stage 2 can be enqueued without waiting for the host to learn num_rendered (gsr_forward).  GSR_SPECULATIVE=0 disables.
+# stage 2 can be enqueued without waiting for the host to learn num_rendered (gsr_forward).
 # Policy (per key): the hint is a slowly decaying running maximum of the instance counts seen (max(R, 0.9 * previous hint)), so
 # alternating cameras / scenes with different counts at one resolution do not overflow on every other call; after two overflows
 # in a row the key falls back to the reference-shaped stage1 -> sync -> stage2 path for the next 8 calls.  `capacity_hint` lets a
@@ -28,7 +28,7 @@ def cpu_deep_copy_tuple(input_tuple):
 _R_HINT = {}
 _R_OVERFLOWS = {}     # key -> [consecutive overflows, calls left on the exact path]
 _HINT_LOCK = threading.Lock()
-_SPECULATIVE = os.environ.get("GSR_SPECULATIVE", "1") != "0"
+_SPECULATIVE = True           # (tests flip it to walk the exact stage1 -> sync -> stage2 path; it was the environment switch GSR_SPECULATIVE until round 6)
 
 
 def _bytes(n, device):
@@ -102,8 +102,8 @@ def async_status_reset():
 # ---- gradient-accumulator scratch of the backward, kept per (device, stream, variant) and left zeroed by the preprocess backward
 # (gsr_backward_ex GSR_BWD_SCRATCH_IS_ZERO | GSR_BWD_LEAVE_ZERO): no 24 MB memset + launch gap per iteration.  One buffer serves every P up to
 # its size (a call touches -- and clears -- rows [0, P) only; the decode's output row count changes from iteration to iteration), it is replaced
-# by a larger one when P outgrows it.  GSR_ACC_REUSE=0 disables.
-_ACC_REUSE = os.environ.get("GSR_ACC_REUSE", "1") != "0"
+# by a larger one when P outgrows it.
+_ACC_REUSE = True
 _ACC_CACHE = {}
 _ACC_LOCK = threading.Lock()
 

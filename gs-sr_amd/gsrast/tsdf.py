@@ -87,6 +87,16 @@ def merge_volumes_(tsdf, weight, color, group=None):
     return tsdf, weight, color
 
 
+def brick_to_xmajor(planes):
+    """[..., 4096] unit planes in the storage order of include/gsrast.h (ABI 8: float index 4 g + (z & 3),
+    g = (x>>2)<<8 | (y>>2)<<6 | (z>>2)<<4 | ((x>>1)&1)<<3 | ((y>>1)&1)<<2 | (x&1)<<1 | (y&1)) -> [..., 16, 16, 16] indexed [x, y, z].  Any device."""
+    lead = tuple(planes.shape[:-1])
+    k = len(lead)
+    # storage index bits, high to low: bx by bz (2 each) | x1 y1 x0 y0 | z (2)
+    v = planes.reshape(lead + (4, 4, 4, 2, 2, 2, 2, 4))
+    return v.permute(*range(k), k + 0, k + 3, k + 5, k + 1, k + 4, k + 6, k + 2, k + 7).reshape(lead + (16, 16, 16))
+
+
 class ScalableTSDFVolume:
     """Block-sparse TSDF volume with the call shape of o3d.pipelines.integration.ScalableTSDFVolume as GS-SR drives it
     (gssr/utils/mesh_utils.py:154-178: `ScalableTSDFVolume(voxel_length, sdf_trunc, RGB8)`, `integrate(rgbd, intrinsic, extrinsic)` with
@@ -336,10 +346,8 @@ class ScalableTSDFVolume:
         with torch.cuda.device(self.device):
             check(lib().gsr_tsdf_sparse_materialize(C.byref(st), n, stream_ptr(self.device)), "tsdf_sparse_materialize")
         # storage index bits, high to low: bx by bz (2 each) | x1 y1 x0 y0 | z (2)
-        rec = self.records(n)
-        plane = lambda a: a.reshape(n, 4, 4, 4, 2, 2, 2, 2, 4).permute(0, 1, 4, 6, 2, 5, 7, 3, 8).reshape(n, 16, 16, 16)
-        col = rec[:, 2:5].reshape(n, 3, 4, 4, 4, 2, 2, 2, 2, 4).permute(0, 2, 5, 7, 3, 6, 8, 4, 9, 1).reshape(n, 16, 16, 16, 3)
-        return self.coord[:n], plane(rec[:, 0]), plane(rec[:, 1]), col
+        rec = brick_to_xmajor(self.records(n))                      # [n, 5, 16, 16, 16]
+        return self.coord[:n], rec[:, 0], rec[:, 1], rec[:, 2:5].permute(0, 2, 3, 4, 1)
 
     def merge_units_(self, coords, tsdf, weight, color, assume_unique=False):
         """self <- weighted merge with the given units (plain arrays shaped like `units()`, on this device).  The merge kernel runs one workgroup per

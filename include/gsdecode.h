@@ -89,7 +89,8 @@ int gsd_compact_visible(const uint8_t* mask, int32_t Na, int32_t* vis_idx, uint3
                         void* stream);
 /* The same compaction without the host synchronisation: vis_idx has Na entries, the visible anchors' indices first (ascending) and -1 behind
  * them ("padding rows"); run the decode with cfg.Nv = Na -- every gsd_* kernel skips rows whose index is negative (they emit nothing, their
- * neural_opacity / mask rows are written as 0).  *count_dev (DEVICE, may be NULL) receives the number of visible anchors. */
+ * neural_opacity / mask rows are written as 0).  *count_dev (DEVICE, may be NULL) receives the number of visible anchors, or 0xFFFFFFFF when
+ * the compaction's bounded look-back timed out (vis_idx then holds in-range indices and -1 only; the synchronous entry points turn the same condition into an error). */
 int gsd_compact_visible_padded(const uint8_t* mask, int32_t Na, int32_t* vis_idx, uint32_t* count_dev, void* scratch, size_t scratch_bytes,
                                void* stream);
 
@@ -111,7 +112,7 @@ int gsd_forward(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, f
 /* static-shape forward (round 3): gsd_forward without its host synchronisation -- recordable into a HIP graph.  `out` keeps all Nv*k rows: the P
    emitted Gaussians first, the remaining rows PARKED at the camera centre (xyz = campos, opacity 0, scaling 0, rot identity, colour 0) so that the
    rasterizers of this library cull them in preprocess (radii 0, no tile instance, zero gradients); the caller hands all Nv*k rows on.
-   *count_dev (DEVICE word, may be NULL) <- P.  gsd_backward is unchanged: it never reads rows behind P. */
+   *count_dev (DEVICE word, may be NULL) <- P (0xFFFFFFFF: the scan timed out and ALL rows are parked).  gsd_backward is unchanged: it never reads rows behind P. */
 int gsd_forward_static(const gsd_cfg* cfg, const gsd_inputs* in, const gsd_params* p, float* neural_opacity, uint8_t* mask, uint32_t* row_offset,
                        const gsd_outputs* out, uint32_t* count_dev, void* scratch, size_t scratch_bytes, void* stream);
 

@@ -81,6 +81,43 @@ def test_self_launcher_refuses_shared_devices_unless_asked(monkeypatch):
     assert seen["world"] == 4 and seen["ndev"] == 2 and seen["env"] == {"GSR_BENCH_BACKEND": "gloo"}
 
 
+def _dry(cmd, env_extra=None, timeout=180):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GSR_BENCH_BACKEND", "HIP_VISIBLE_DEVICES")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable] + cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def test_eight_rank_launch_path_without_a_device():
+    """no 8-GPU node has ever run this repo.  `bench.py --gpus 8 --dry-run` walks the whole launch path of the 8-GPU command on CPU -- eight
+    processes with the torchrun environment contract, rank r pinned to device r (HIP_VISIBLE_DEVICES), one gloo group of 8, barrier-bracketed timed region,
+    max / sum reduction, exactly ONE JSON line from rank 0 with n_gpus 8 -- and its line says what it is (value null, 'DRY RUN').  Both ways of starting it:
+    self-launched, and under torch.distributed.run as the driver does for N > 1."""
+    import json
+    import sys
+    for how in ("self", "torchrun"):
+        if how == "self":
+            r = _dry([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "4", "--warmup", "1"], {"MASTER_PORT": "29731"})
+        else:
+            r = _dry(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29733",
+                      os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "4", "--warmup", "1"])
+        assert r.returncode == 0, (how, r.stdout[-1500:], r.stderr[-2500:])
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, (how, r.stdout[-2000:])
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 8 and d["dist_world_size"] == 8 and d["steps"] == 4 and d["total_steps_over_ranks"] == 32 and d["scaling"] == "weak"
+        assert d["dry_run"] is True and d["value"] is None and "DRY RUN" in d["metric"]
+        assert [q["rank"] for q in d["ranks"]] == list(range(8)) and len({q["pid"] for q in d["ranks"]}) == 8
+        if how == "self":          # the self-launcher pins: rank r sees exactly device r, as LOCAL_RANK 0 of its own one-device world
+            assert [q["visible"] for q in d["ranks"]] == [str(i) for i in range(8)] and all(q["local_rank"] == "0" for q in d["ranks"])
+        else:                      # torchrun does not pin: LOCAL_RANK selects the device inside bench.py
+            assert [q["local_rank"] for q in d["ranks"]] == [str(i) for i in range(8)]
+    # a rank count that does not match --gpus is refused in the dry run exactly as in a real one
+    r = _dry([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29735"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
 def test_committed_rocprof_summary_agrees_with_the_bench_line():
     """profiles/: the rocprofv3 --kernel-trace --stats average of the dominant kernel and the HIP-event average inside bench.py are two
     measurements of the same launches (different boxes of the pool: a few per cent apart at most), and the PMC traffic figure quoted in the

@@ -65,6 +65,23 @@ def test_bench_launches_its_own_ranks():
     assert d["backend"] == ("nccl" if nd >= 2 else "gloo") and d["distinct_devices"] == min(2, nd)
 
 
+def test_bench_eight_ranks_on_whatever_devices_there_are():
+    """The command the driver runs on an 8-GPU node, `bench.py --gpus 8`, at reduced size on THIS box: eight pinned processes, eight tile-scenes (seed = rank),
+    one JSON line with the whole-job rate.  With fewer than 8 devices the ranks share them (--oversubscribe, control collectives over gloo): every rank still
+    runs the product's forward + backward + Adam on its own scene."""
+    nd = torch.cuda.device_count()
+    r = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--P", "20000", "--W", "640", "--H", "368", "--no-cpu-baseline", "--no-method-iteration"] +
+               (["--oversubscribe"] if nd < 8 else []), timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["dist_world_size"] == 8 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and not d.get("dry_run")
+    assert [q["rank"] for q in d["ranks"]] == list(range(8)) and len({q["pid"] for q in d["ranks"]}) == 8
+    assert all(q["visible"] is not None and len(q["visible"].split(",")) == 1 for q in d["ranks"])
+    assert d["backend"] == ("nccl" if nd >= 8 else "gloo") and d["distinct_devices"] == min(8, nd)
+
+
 def test_bench_refuses_more_ranks_than_devices():
     nd = torch.cuda.device_count()
     r = _bench(["--gpus", str(nd + 1), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-method-iteration"], timeout=120)

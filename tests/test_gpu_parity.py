@@ -728,11 +728,10 @@ def test_launch_order_feedback_leaves_results_alone(P, frac, scale, longest):
     blend workgroups longest-list-first (k_tile_order; lists beyond max(1024, 4 x mean)) and, after a list beyond 6000 entries, take the GLOBAL depth
     order instead of the per-tile one.  Both are decided once per forward and change nothing in the results: every output of the later forwards
     stays bit-identical to the first one's (which ran before any report), and equal to the oracle's integer stages."""
-    import bench
     hr = _hiprun()
     W, H = 256, 256
     sc = scenes.make_scene("surfel", P, W, H, seed=13)
-    bench.concentrate(sc, frac, scale)
+    scenes.concentrate(sc, frac, scale)
     runs = [hr.run_raw("surfel", sc) for _ in range(4)]
     lens = runs[0]["ranges"][:, 1].astype(np.int64) - runs[0]["ranges"][:, 0].astype(np.int64)
     assert lens.max() > max(longest, 20 * P // (16 * 16))            # the scene does trigger the report (and, second case, the depth-order switch)
@@ -811,6 +810,15 @@ def test_stage2_refuses_a_geom_arena_without_its_depth_order_record():
                                   stream_ptr(geom.device)), "forward")
     torch.cuda.synchronize()
     assert torch.equal(color2, outs["color"]) and torch.equal(others2, outs["others"])
+    # cfg->debug: a word that is not the record stage 1 left (here: the other order's) is refused instead of binning the arena in the wrong layout
+    other = 0x47530001 if order.value == 0x47530002 else 0x47530002
+    cfg.debug = 1
+    with pytest.raises(RuntimeError, match="not the record stage 1 left"):
+        check(L.gsr_forward_stage2_ex(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(bin2), bin2.numel(), ptr(img), img.numel(), R, other, C.byref(o),
+                                      stream_ptr(geom.device)), "forward")
+    check(L.gsr_forward_stage2_ex(C.byref(cfg), C.byref(inp), ptr(geom), geom.numel(), ptr(bin2), bin2.numel(), ptr(img), img.numel(), R, order.value, C.byref(o),
+                                  stream_ptr(geom.device)), "forward")
+    cfg.debug = 0
     blank = torch.zeros_like(geom)                         # never seen by a preprocess kernel
     with pytest.raises(RuntimeError, match="depth-order record"):
         check(L.gsr_forward_stage2(C.byref(cfg), C.byref(inp), ptr(blank), blank.numel(), ptr(bin2), bin2.numel(), ptr(img), img.numel(), R, C.byref(o),

@@ -81,3 +81,24 @@ def test_merge_unit_lists_equals_joint_integration():
         assert np.array_equal(mw[i].numpy(), w[j].reshape(-1))
         assert np.abs(mt[i].numpy() - t[j].reshape(-1)).max() < 1e-5
         assert np.abs(mc[i].numpy() - c[j].reshape(-1, 3)).max() < 1e-2
+
+
+def test_brick_storage_order_is_the_formula_of_the_header():
+    """include/gsrast.h (ABI 8): voxel (x, y, z) of a unit lives at float index 4 g + (z & 3) of its plane,
+    g = (x>>2)<<8 | (y>>2)<<6 | (z>>2)<<4 | ((x>>1)&1)<<3 | ((y>>1)&1)<<2 | (x&1)<<1 | (y&1).  gsrast.tsdf.brick_to_xmajor -- what units() hands out -- inverts exactly
+    that; a 128-byte line (8 groups = 32 floats) is a 2 x 4 x 4 box of voxels and a 64-byte sector a 2 x 2 x 4 one (what the layout is for)."""
+    from gsrast.tsdf import brick_to_xmajor
+    x, y, z = np.meshgrid(np.arange(16), np.arange(16), np.arange(16), indexing="ij")
+    g = ((x >> 2) << 8) | ((y >> 2) << 6) | ((z >> 2) << 4) | (((x >> 1) & 1) << 3) | (((y >> 1) & 1) << 2) | ((x & 1) << 1) | (y & 1)
+    idx = 4 * g + (z & 3)
+    assert sorted(idx.ravel().tolist()) == list(range(4096))
+    plane = torch.arange(4096, dtype=torch.float32).reshape(1, 4096)          # the value of a float = its storage index
+    out = brick_to_xmajor(plane)[0].numpy().astype(np.int64)
+    assert np.array_equal(out, idx)
+    extent = lambda sel: tuple(int(a[sel].max() - a[sel].min() + 1) for a in (x, y, z))
+    for line in (0, 1, 77, 127):
+        assert extent(idx // 32 == line) == (2, 4, 4)
+    for sector in (0, 3, 200, 255):
+        assert extent(idx // 16 == sector) == (2, 2, 4)
+    planes = torch.arange(2 * 5 * 4096, dtype=torch.float32).reshape(2, 5, 4096)        # leading dimensions pass through
+    assert brick_to_xmajor(planes).shape == (2, 5, 16, 16, 16) and torch.equal(brick_to_xmajor(planes)[1, 3], brick_to_xmajor(planes[1, 3]))

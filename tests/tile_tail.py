@@ -13,13 +13,35 @@ import numpy as np
 import scenes
 
 
-def make_tiles(n_tiles=2, cams_per_tile=3, P=6000, W=320, H=208, seed=0, sigma_px=5.0):
+def lay_on_terrain(sc, seed=0):
+    """Moves a SURVEY 8d surfel scene onto ONE smooth surface: depth 4 + 0.6 sin(3 u) + 0.4 cos(2.5 v) (u, v = the surfel's position in the frustum, -1.1 .. 1.1)
+    with 2 mm of jitter, discs facing the camera up to a ~15 degree tilt.  The scene of SURVEY 8d is a cloud of independent surfels at depths 1 .. 20: its
+    rendered depth map is NOISE (neighbouring pixels blend different surfels at unrelated depths), the worst case for a TSDF volume -- the voxels a frame updates
+    are spatially independent.  A trained 2DGS scene renders surfaces; this is the stand-in for it."""
+    rng = np.random.default_rng(seed + 991)
+    V = sc["viewmatrix"].astype(np.float64)
+    pc = sc["means3D"].astype(np.float64) @ V[:3, :3] + V[3, :3]
+    u, v = pc[:, 0] / (pc[:, 2] * sc["tanfovx"]), pc[:, 1] / (pc[:, 2] * sc["tanfovy"])
+    z = 4.0 + 0.6 * np.sin(3.0 * u) + 0.4 * np.cos(2.5 * v) + rng.normal(0, 0.002, len(u))
+    scale = z / pc[:, 2]
+    pc = np.stack([u * z * sc["tanfovx"], v * z * sc["tanfovy"], z], -1)
+    sc["means3D"] = ((pc - V[3, :3]) @ np.linalg.inv(V[:3, :3])).astype(np.float32)
+    sc["scales"] = (sc["scales"] * scale[:, None]).astype(np.float32)          # the same footprint in pixels
+    q = np.concatenate([np.ones((len(u), 1)), rng.normal(0, 0.13, (len(u), 3))], 1)
+    sc["rotations"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    return sc
+
+
+def make_tiles(n_tiles=2, cams_per_tile=3, P=6000, W=320, H=208, seed=0, sigma_px=5.0, surface="cloud"):
     """-> list of tiles: dict(gauss = the tile's surfels (rasterizer kwargs without camera), cams = [camera dicts]).  Tile t's surfels sit in the
-    frustum of its first camera; its other cameras look at the same surfels from nearby poses.  Tiles are 8 world units apart along x."""
+    frustum of its first camera; its other cameras look at the same surfels from nearby poses.  Tiles are 8 world units apart along x.
+    surface: "cloud" = the SURVEY 8d distribution (independent surfels, depth maps of noise), "terrain" = the same surfels laid on one smooth surface."""
     tiles = []
     fx = W * (1600.0 / 1920.0)
     for t in range(n_tiles):
         sc = scenes.make_scene("surfel", P, W, H, fx=fx, seed=seed + 17 * t, sigma_px=sigma_px, bg=(0.0, 0.0, 0.0))
+        if surface == "terrain":
+            lay_on_terrain(sc, seed + 17 * t)
         off = np.array([8.0 * t, 0.0, 0.0], np.float32)
         gauss = {k: sc[k] for k in ("means3D", "scales", "rotations", "opacities", "colors_precomp", "bg", "scale_modifier", "sh_degree")}
         gauss["means3D"] = (sc["means3D"] + off).astype(np.float32)

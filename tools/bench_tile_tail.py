@@ -27,12 +27,15 @@ def main():
     ap.add_argument("--P", type=int, default=300000); ap.add_argument("--W", type=int, default=1920); ap.add_argument("--H", type=int, default=1080)
     ap.add_argument("--mesh-res", type=int, default=1024); ap.add_argument("--depth-trunc", type=float, default=8.0)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--capacity", type=int, default=65536, help="initial units per tile volume (the cloud scene needs ~88k: the pool grows on the way)")
     ap.add_argument("--count-updates", action="store_true", help="one extra (untimed) pass that counts the voxels every frame updates (from the weights)")
+    ap.add_argument("--surface", default="cloud", choices=["cloud", "terrain"], help="cloud: SURVEY 8d's independent surfels (depth maps of noise: every line of every listed "
+                    "unit is touched); terrain: the same surfels on one smooth surface (what a trained scene renders)")
     ap.add_argument("--sync-frames", action="store_true", help="integrate(defer=False): one host synchronisation per frame, as in rounds 2-4")
     a = ap.parse_args()
     import diff_surfel_rasterization as dsr
     from gsrast.tsdf import ScalableTSDFVolume
-    tiles = tile_tail.make_tiles(a.tiles, a.cams, a.P, a.W, a.H, seed=0, sigma_px=4.0)
+    tiles = tile_tail.make_tiles(a.tiles, a.cams, a.P, a.W, a.H, seed=0, sigma_px=4.0, surface=a.surface)
     vl = a.depth_trunc / a.mesh_res                     # extract_mesh_split.py:82-84: voxel = depth_trunc / mesh_res, sdf_trunc = 5 voxels
     tr = 5.0 * vl
     frames = []
@@ -52,7 +55,7 @@ def main():
         t_r = t_i = 0.0
         touched.clear(); updated.clear()
         for fr in frames:
-            vol = ScalableTSDFVolume(vl, tr, capacity_units=65536)
+            vol = ScalableTSDFVolume(vl, tr, capacity_units=a.capacity)
             for rs, t, (fx, fy, cx, cy, E) in fr:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
@@ -74,7 +77,7 @@ def main():
         for e0, e1, e2, _ in evs:
             t_r += e0.elapsed_time(e1); t_i += e1.elapsed_time(e2)
         t0 = time.perf_counter()
-        joint = ScalableTSDFVolume(vl, tr, capacity_units=max(65536, 2 * sum(n_units)))
+        joint = ScalableTSDFVolume(vl, tr, capacity_units=max(a.capacity, 2 * sum(n_units)))
         for v in vols:
             joint.merge_from(v)
         torch.cuda.synchronize()
@@ -96,15 +99,15 @@ def main():
         run(count=True)
         upd = sum(updated) / max(len(updated), 1); units = sum(touched) / max(len(touched), 1)
     print(json.dumps({"what": "config 5 tail: surfel render -> surface depth -> sparse TSDF integrate per frame, then merge of the tiles' volumes; device-resident images",
-                      "device": torch.cuda.get_device_name(0), "tiles": a.tiles, "cameras_per_tile": a.cams, "gaussians_per_tile": a.P, "image": [a.W, a.H],
+                      "device": torch.cuda.get_device_name(0), "surface": a.surface, "tiles": a.tiles, "cameras_per_tile": a.cams, "gaussians_per_tile": a.P, "image": [a.W, a.H],
                       "voxel_length": vl, "sdf_trunc": tr, "depth_trunc": a.depth_trunc, "frames": nf,
                       "render_ms_per_frame": round(t_r / nf, 4), "integrate_ms_per_frame": round(t_i / nf, 4),
                       "units_integrated_per_frame": None if units is None else round(units), "voxels_updated_per_frame": None if upd is None else round(upd),
                       "updated_fraction_of_the_listed_units": None if upd is None else round(upd / (units * 4096), 3),
                       "algorithmic_GB_per_frame": None if upd is None else round((upd * 40 + a.W * a.H * 16) / 1e9, 3),
                       "frames_deferred": not a.sync_frames,
-                      "integrate_note": "HIP events around ScalableTSDFVolume.integrate: texels, touch, stamp, voxel pass and any pool growth (capacity 65536 units per tile, ~88k needed); "
-                                        "deferred frames are only enqueued (their status is read when the next frame starts), --sync-frames restores the per-frame host wait",
+                      "integrate_note": "HIP events around ScalableTSDFVolume.integrate: texels, touch, stamp, voxel pass and any pool growth (--capacity units per tile at the start; "
+                                        "growth adds a chunk of records, no voxel is copied); deferred frames are only enqueued (up to 8 in flight), --sync-frames restores the per-frame host wait",
                       "frames_per_s_gpu": round(nf / ((t_r + t_i) * 1e-3), 1), "merge_ms": round(t_m, 3), "units_per_tile": n_units, "units_merged": n_joint,
                       "wall_ms_total": round(wall, 2), "frames_per_s_wall_incl_merge": round(nf / (wall * 1e-3), 1)}))
 

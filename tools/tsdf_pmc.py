@@ -5,7 +5,7 @@ import collections, csv, glob, json, os, sys
 
 d = sys.argv[1]
 out = {}
-for bench in ("tsdf_sparse", "tile_tail"):
+for bench in ("tsdf_sparse", "tile_tail", "tile_tail_terrain"):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(os.path.join(d, f"pmc_{bench}_{c}", "**", "*_counter_collection.csv"), recursive=True):
