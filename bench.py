@@ -628,7 +628,7 @@ def main():
         # measures the ceilings by operand kind: only VGPR-only fma / mul / add reach ~890 G/s; any DPP form, any SGPR operand and
         # v_min / v_max issue at ~575 G/s, transcendentals at ~300 G/s -- the instruction mix of these kernels caps them well below 1228.8.
         valu = None
-        pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")) if os.path.exists(q)), "")
+        pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")) if os.path.exists(q)), "")
         vidx = {"ewa": 0, "surfel": 1, "plane": 2}[args.variant]
         if os.path.exists(pj) and args.P == 300000 and (args.W, args.H) == (1920, 1080) and args.color_mode == "precomp":
             try:

@@ -333,155 +333,11 @@ int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
 }
 
 
-// ------------------------------------------------------------------------------------------------ one-sweep depth sort (round 6)
-// The global depth order of P >= 1.5 M gaussians used to be four LSD passes of two launches each (block histograms, then a scatter that re-derives every block's
-// base from them): eight launches, the keys read twice per pass, 0.25 ms for 3 M keys = 0.86 TB/s of its 216 MB.  One sweep instead:
-//   k_os_hist      all four digit histograms in one pass over the keys (12 MB);
-//   k_os_scatter   x 4: a workgroup takes the next 4096-key tile (a ticket: tiles start in index order whatever the dispatcher does, so a tile only ever waits for
-//                  tiles that are already running), ranks its keys by digit in LDS exactly as k_radix_scatter does, PUBLISHES its per-digit counts, and finds the
-//                  number of equal digits in front of it by DECOUPLED LOOK-BACK over the earlier tiles' state words (thread = digit; a word is flag | count,
-//                  aggregate -> inclusive prefix) instead of reading a histogram matrix a separate launch produced.  Keys and values are read once and written once.
-// Stable (ranks inside a tile follow the index order, tiles are laid down in index order): the same permutation as the LSD passes, bit for bit.
-#define OS_FLAG_AGG 0x40000000u
-#define OS_FLAG_INC 0x80000000u
-#define OS_COUNT 0x3FFFFFFFu
-__global__ void __launch_bounds__(GSR_SORT_THREADS) k_os_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ gh /*[4][256]*/)
-{
-    __shared__ uint32_t h[4][256];
-    for (uint32_t d = threadIdx.x; d < 1024u; d += GSR_SORT_THREADS) (&h[0][0])[d] = 0u;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * GSR_OS_KPB;
-#pragma unroll 4
-    for (uint32_t it = 0; it < GSR_OS_KPB / GSR_SORT_THREADS; it++) {
-        const uint32_t i = base + it * GSR_SORT_THREADS + threadIdx.x;
-        if (i < n) {
-            const uint32_t k = keys[i];
-            atomicAdd(&h[0][k & 255u], 1u); atomicAdd(&h[1][(k >> 8) & 255u], 1u); atomicAdd(&h[2][(k >> 16) & 255u], 1u); atomicAdd(&h[3][k >> 24], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t d = threadIdx.x; d < 1024u; d += GSR_SORT_THREADS) { const uint32_t c = (&h[0][0])[d]; if (c) atomicAdd(&gh[d], c); }
-}
-// one pass.  gh: the 256 digit counts of this pass; state: [tiles][256] words, zero; ticket: one word, zero.  vals_in == nullptr: value i for element i.
-__global__ void __launch_bounds__(GSR_SORT_THREADS) k_os_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n, int shift,
-                                                                 const uint32_t* __restrict__ gh, uint32_t* __restrict__ state, uint32_t* __restrict__ ticket)
-{
-    constexpr int ITEMS = GSR_OS_KPB / GSR_SORT_THREADS;      // 16
-    __shared__ uint32_t cnt[4][256];
-    __shared__ uint32_t gbase[256], lbase[256];
-    __shared__ uint32_t skey[GSR_OS_KPB], sval[GSR_OS_KPB];
-    __shared__ uint32_t lds[17];
-    __shared__ uint32_t s_tile;
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int i = threadIdx.x; i < 4 * 256; i += GSR_SORT_THREADS) (&cnt[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t base = tile * GSR_OS_KPB + wave * (GSR_WAVE * ITEMS);
-    uint32_t key[ITEMS], rank[ITEMS];
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t i = base + it * GSR_WAVE + lane;
-        key[it] = i < n ? keys_in[i] : 0xFFFFFFFFu;
-    }
-    const uint32_t dig_total = gh[threadIdx.x];      // thread = digit from here on
-    const uint64_t lt = lanemask_lt();
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t i = base + it * GSR_WAVE + lane;
-        const bool valid = i < n;
-        const uint32_t d = (key[it] >> shift) & 255u;
-        uint64_t peers = __ballot(valid);      // lanes of this wave holding the same digit (invalid lanes form their own group and are ignored)
-        if (!valid) peers = ~peers;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const uint32_t before = (uint32_t)__popcll(peers & lt);
-        uint32_t old = 0;
-        if (valid && before == 0) old = atomicAdd(&cnt[wave][d], (uint32_t)__popcll(peers));
-        const int leader = __ffsll((unsigned long long)peers) - 1;
-        old = __shfl(old, leader, 64);
-        rank[it] = old + before;
-    }
-    __syncthreads();
-    // this tile's count of digit d = threadIdx.x -> published at once (aggregate; tile 0: already its inclusive prefix), then the block-local layout
-    uint32_t mine = 0;
-    {
-        const uint32_t d = threadIdx.x;
-#pragma unroll
-        for (int w = 0; w < 4; w++) { const uint32_t t = cnt[w][d]; cnt[w][d] = mine; mine += t; }
-        __hip_atomic_store(&state[(size_t)tile * 256u + d], (tile == 0u ? OS_FLAG_INC : OS_FLAG_AGG) | mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t ex[1], tv[1] = { mine };
-        digit_excl_scan<256>(tv, ex, lds);
-        lbase[d] = ex[0];
-        uint32_t dv[1] = { dig_total }, dex[1];
-        digit_excl_scan<256>(dv, dex, lds);      // keys with a smaller digit, all tiles
-        gbase[d] = dex[0];
-    }
-    __syncthreads();
-    // stage the tile's keys / values in LDS in digit order (the look-back's round trips run underneath)
-    uint32_t val[ITEMS];
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t i = base + it * GSR_WAVE + lane;
-        val[it] = (vals_in && i < n) ? vals_in[i] : i;
-    }
-    // decoupled look-back, thread = digit: equal digits in the tiles in front of this one
-    {
-        const uint32_t d = threadIdx.x;
-        uint32_t excl = 0;
-        for (uint32_t t = tile; t-- > 0u;) {
-            uint32_t w;
-            while (((w = __hip_atomic_load(&state[(size_t)t * 256u + d], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) & (OS_FLAG_AGG | OS_FLAG_INC)) == 0u)
-                __builtin_amdgcn_s_sleep(1);
-            excl += w & OS_COUNT;
-            if (w & OS_FLAG_INC) break;
-        }
-        if (tile != 0u) __hip_atomic_store(&state[(size_t)tile * 256u + d], OS_FLAG_INC | (excl + mine), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        gbase[d] += excl;
-    }
-#pragma unroll
-    for (int it = 0; it < ITEMS; it++) {
-        const uint32_t i = base + it * GSR_WAVE + lane;
-        if (i < n) {
-            const uint32_t d = (key[it] >> shift) & 255u;
-            const uint32_t lp = lbase[d] + cnt[wave][d] + rank[it];
-            skey[lp] = key[it];
-            sval[lp] = val[it];
-        }
-    }
-    __syncthreads();
-    // each digit's run with consecutive lanes on consecutive addresses
-    const uint32_t nb = min(GSR_OS_KPB, n - min(n, tile * GSR_OS_KPB));
-    for (uint32_t q = threadIdx.x; q < nb; q += GSR_SORT_THREADS) {
-        const uint32_t k = skey[q];
-        const uint32_t d = (k >> shift) & 255u;
-        const uint32_t pos = gbase[d] + (q - lbase[d]);
-        keys_out[pos] = k;
-        vals_out[pos] = sval[q];
-    }
-}
-// keys_a (n 32-bit keys) -> vals_a = the stable ascending permutation (keys_a holds the sorted keys afterwards).  hist: >= gsr_os_zero_words(n) words, ZERO on entry.
-static int gsr_onesweep_sort_ids(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, hipStream_t s)
-{
-    const uint32_t tiles = gsr_os_tiles(n);
-    uint32_t* gh = hist; uint32_t* ticket = hist + 1024; uint32_t* state = hist + 1056;
-    hipLaunchKernelGGL(k_os_hist, dim3(tiles), dim3(GSR_SORT_THREADS), 0, s, (const uint32_t*)keys_a, n, gh);
-    // ids: identity -> vals_b -> vals_a -> vals_b -> vals_a
-    uint32_t *kin = keys_a, *kout = keys_b; uint32_t *vin = nullptr, *vout = vals_b;
-    for (int pass = 0; pass < 4; pass++) {
-        hipLaunchKernelGGL(k_os_scatter, dim3(tiles), dim3(GSR_SORT_THREADS), 0, s, (const uint32_t*)kin, (const uint32_t*)vin, kout, vout, n, 8 * pass,
-                           (const uint32_t*)(gh + 256 * pass), state + (size_t)pass * tiles * 256u, ticket + pass);
-        uint32_t* t = kin; kin = kout; kout = t;
-        if (pass == 0) { vin = vals_b; vout = vals_a; } else { t = vin; vin = vout; vout = t; }
-    }
-    return 0;
-}
-
+// (Round 6 built the one-sweep form of this sort -- all four digit histograms in one pass, then four scatter launches whose tiles find the equal digits in front of them
+// by decoupled look-back over per-tile state words, tickets for the tile order -- and measured it on 3 M keys: 0.80 ms PER PASS against 0.062 for hist + row scan +
+// scatter.  All 733 tiles of 4096 keys are resident at once on 256 CUs, none has an inclusive prefix to offer when the others look back, so the last tile walks ~700
+// aggregates at one L2 round trip (1.09 us) each: the chain is as long as the grid is wide.  A kernel boundary is the cheap grid barrier on this part (EXPERIMENTS.md (32),
+// (75)): the histogram launch in front of the scatter stays.)
 // ------------------------------------------------------------------------------------------------ depth order
 // offsets[i] = inclusive prefix of tiles_touched[sorted_idx[i]] (block-local), block_sums[blk] = block total
 __global__ void __launch_bounds__(GSR_SCAN_BLOCK) k_offsets_local(const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ tiles_touched,
@@ -535,10 +391,7 @@ int gsr_launch_depth_order(const gsr_cfg* cfg, GeomView g, uint32_t* host_word_d
     bool in_b = false;
     // Four 8-bit passes: keys depth_key (A) <-> keys_b end in A, ids: identity -> vals_b -> vals_a -> vals_b -> vals_a (= sorted_idx).
     // the preprocess kernel cleared the first group-histogram buffer (gsr_preprocess.hip: PreParams::zero_ptr)
-    // P >= 65536: the one-sweep sort (five launches, keys and ids moved once per pass); below, the LSD passes on their group histograms (the state words of the
-    // one-sweep sort would not fit the scratch, and nothing that small is sorted globally outside the tests' forced mode).  Same permutation either way.
-    if (P >= GSR_OS_MIN_KEYS) { if (gsr_onesweep_sort_ids(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, g.hist, s)) return 1; }
-    else if (gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, 8, true, g.hist, &in_b, s, false, true)) return 1;
+    if (gsr_radix_sort_pairs(g.depth_key, g.vals_a, g.keys_b, g.vals_b, P, nullptr, 0, 32, 8, true, g.hist, &in_b, s, false, true)) return 1;
     const uint32_t nblk = gsr_div_up(P, GSR_SCAN_BLOCK);
     hipLaunchKernelGGL(k_offsets_local, dim3(nblk), dim3(GSR_SCAN_BLOCK), 0, s, g.sorted_idx, g.tiles_touched, P, g.offsets, g.scan_tmp);
     // the single-block scan of the block sums also publishes num_rendered (device word + mapped pinned host word): k_duplicate adds the

@@ -181,7 +181,7 @@ template <> struct SpPix<GSR_SURFEL> {
 // The cancellation of px Tw against Tu happens once, in k0 / l0, as it does per pixel in the reference's form; the three cross products are formed
 // once per load and a pixel step evaluates p with <= 6 FMAs instead of 12 instructions.  The depth s . Tw.xy + Tw.z equals (p . Tw) / p.z and
 // p . Tw = det[Tu Tv Tw] =: D for every pixel (k, l differ from -Tu, -Tv by multiples of Tw), so depth = D / p.z with D from the record.
-struct SpSurf { float P0x, P0y, P0z, Pxx, Pxy, Pxz, Pyx, Pyy, Pyz, Tw0, Tw1, Tw2, D, cdx, cdy, oh, rD, rTw2; };      // EWA / PLANE use cdx, cdy (centre - block origin) and oh = -opacity / 2
+struct SpSurf { float P0x, P0y, P0z, Pxx, Pxy, Pxz, Pyx, Pyy, Pyz, Tw0, Tw1, Tw2, D, cdx, cdy, oh; };      // EWA / PLANE use cdx, cdy (centre - block origin) and oh = -opacity / 2
 __device__ __forceinline__ SpSurf sp_surf_setup(const float4& q0, const float4& q1, const float4& q2, const float4& q4, float x0, float y0)
 {
     SpSurf S;
@@ -192,9 +192,6 @@ __device__ __forceinline__ SpSurf sp_surf_setup(const float4& q0, const float4& 
     S.Pxx = Tw1 * lz - Tw2 * ly; S.Pxy = Tw2 * lx - Tw0 * lz; S.Pxz = Tw0 * ly - Tw1 * lx;        // Tw x l0
     S.Pyx = ky * Tw2 - kz * Tw1; S.Pyy = kz * Tw0 - kx * Tw2; S.Pyz = kx * Tw1 - ky * Tw0;        // k0 x Tw
     S.Tw0 = Tw0; S.Tw1 = Tw1; S.Tw2 = Tw2; S.D = q4.z;
-#ifdef SP_RCD_MUL      // A/B (VERDICT r5 #3 iii): 1 / c_d without a transcendental per step -- both reciprocals once per load
-    S.rD = rcp_(S.D); S.rTw2 = rcp_(S.Tw2);
-#endif
     S.cdx = q2.y - x0; S.cdy = q2.z - y0;
     return S;
 }
@@ -324,11 +321,9 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         const float r1a = rcp_(om);
         const float Tj = bc_fresh<I>(K.Tc) * row_scan_mul(r1a);
         const float w = al * Tj;
-#ifdef SP_RCD_MUL
-        const float rcd = ok ? (b3 ? ppz * S.rD : S.rTw2) : 1.0f;      // 1 / c_d: c_d = D / p.z or Tw.z
-#else
+        // (1 / c_d without a transcendental -- `ok ? (b3 ? ppz / D : 1 / Tw.z) : 1` with both reciprocals formed once per load -- was built and measured in round 6:
+        // 0.3843 ms against 0.3851 over three alternating runs, 128 VGPRs and 0 spills either way: noise.  EXPERIMENTS.md (76).)
         const float rcd = rcp_(cd);
-#endif
         const float m_d = fmaf(-(FAR_N * NEAR_N) / (FAR_N - NEAR_N), rcd, FAR_N / (FAR_N - NEAR_N));      // far / (far - near) (1 - near / depth)
         const float dmd_dd = ((FAR_N * NEAR_N) / (FAR_N - NEAR_N)) * rcd * rcd;
         float u = bc_mul<I>(K.c2, m_d * m_d);

@@ -164,12 +164,6 @@ int gsr_launch_preprocess_bwd(const gsr_cfg* cfg, const gsr_inputs* in, const in
 #endif
 static inline uint32_t gsr_sort_blocks(uint32_t n, bool big_blocks) { return gsr_div_up(n, GSR_SORT_THREADS * (big_blocks ? 16u : (uint32_t)GSR_SORT_ITEMS)); }
 static inline uint32_t gsr_sort_group_words(uint32_t n, bool big_blocks, uint32_t NB) { return NB * gsr_div_up(gsr_sort_blocks(n, big_blocks), GSR_SORT_GROUP); }
-// One-sweep depth sort (gsr_binning.hip, round 6): 4096-key tiles; in the sort's histogram scratch, from word 0 and ZERO when the sort starts (the preprocess kernel
-// clears them): [4 x 256 digit counts][32 words: one ticket counter per pass][4 passes x tiles x 256 look-back state words].  Fits gsr_sort_hist_words for P >= 65536.
-#define GSR_OS_KPB 4096u
-#define GSR_OS_MIN_KEYS 65536u
-static inline uint32_t gsr_os_tiles(uint32_t n) { return (n + GSR_OS_KPB - 1u) / GSR_OS_KPB; }
-static inline uint32_t gsr_os_zero_words(uint32_t n) { return 1024u + 32u + 4u * 256u * gsr_os_tiles(n); }
 static inline size_t gsr_sort_hist_words(uint32_t nblk_1024, uint32_t NB) { return (size_t)NB * nblk_1024 + 2 * (size_t)NB * (nblk_1024 / GSR_SORT_GROUP + 1); }
 int gsr_radix_sort_pairs(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* n_dev,
                          int begin_bit, int end_bit, int bits_per_pass, bool identity_vals, uint32_t* hist,

@@ -414,8 +414,7 @@ int gsr_launch_preprocess(const gsr_cfg* cfg, const gsr_inputs* in, GeomView g, 
 {
     PreParams p = make_params(cfg, in, g, radii);
     p.prefiltered_err = cfg->prefiltered ? prefiltered_err : nullptr;
-    // what the global depth sort that follows needs zeroed: the one-sweep sort's digit counts, tickets and look-back state, or the LSD passes' first group histogram
-    p.zero_ptr = g.hist; p.zero_n = !global_order ? 0u : ((uint32_t)cfg->P >= GSR_OS_MIN_KEYS ? gsr_os_zero_words((uint32_t)cfg->P) : gsr_sort_group_words((uint32_t)cfg->P, false, 256));
+    p.zero_ptr = g.hist; p.zero_n = global_order ? gsr_sort_group_words((uint32_t)cfg->P, false, 256) : 0u;      // first group histogram of the global depth sort
     p.mode_word = g.counters + GSR_CNT_MODE; p.mode = global_order ? GSR_MODE_GLOBAL : GSR_MODE_TILE;
     // per-tile depth order: instances are emitted in id order, the block-local prefix of tiles_touched is written here (256-gaussian blocks)
     if (!global_order) { p.scan_offsets = g.offsets; p.scan_sums = g.scan_tmp; }
