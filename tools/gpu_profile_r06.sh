@@ -49,4 +49,12 @@ done
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/it_losses -- python $R/tools/bench_losses.py > $O/bench_losses.json 2>/dev/null
 f=$(find $O/it_losses -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/loss_kernel_stats.csv; rm -rf $O/it_losses
 timeout 1500 python $R/tools/full_parity_report.py --big > $O/full_size_parity.jsonl 2> /dev/null; echo "parity report rc=$? (0 = every case inside its bars)"; wc -l $O/full_size_parity.jsonl
+# 7. the ordering chain where it is not launch-bound (VERDICT r5 #4 i): P = 3 M surfels, kernel stats + HBM traffic of preprocess / depth sort / duplicate / tile sort
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st3m -- $B --variant surfel --P 3000000 --steps 20 --warmup 3 > /dev/null 2>&1; echo "3M stats rc=$?"
+f=$(find $O/st3m -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/surfel_3m_kernel_stats.csv; rm -rf $O/st3m
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc3m_$c -- $B --variant surfel --P 3000000 --steps 6 --warmup 2 --stage-steps 1 > /dev/null 2>&1; echo "3M pmc $c rc=$?"
+done
+python $R/tools/chain_pmc.py $R/gpurun_out $O/surfel_3m_kernel_stats.csv > $O/chain_3m_pmc.json; rm -rf $R/gpurun_out/pmc3m_*
 ls -la $O | head -40

@@ -10,6 +10,7 @@ cp $O/timeline_surfel.json profiles/r06_timeline_surfel.json; cp $O/side_points.
 [ -s $O/tile_tail_terrain.json ] && cp $O/tile_tail_terrain.json profiles/r06_tile_tail_terrain.json
 [ -s $O/hbm_granule.json ] && cp $O/hbm_granule.json profiles/r06_hbm_granule.json
 for t in tsdf_sparse tile_tail tile_tail_terrain; do [ -s $O/${t}_kernel_stats.csv ] && cp $O/${t}_kernel_stats.csv profiles/r06_${t}_kernel_stats.csv; done
+[ -s $O/chain_3m_pmc.json ] && cp $O/chain_3m_pmc.json profiles/r06_chain_3m_pmc.json; [ -s $O/surfel_3m_kernel_stats.csv ] && cp $O/surfel_3m_kernel_stats.csv profiles/r06_surfel_3m_kernel_stats.csv
 [ -s $O/full_size_parity.jsonl ] && cp $O/full_size_parity.jsonl profiles/r06_full_size_parity.jsonl
 cp $O/scaffold-2dgs_iteration_kernel_stats.csv profiles/r06_scaffold2dgs_iteration_kernel_stats.csv; cp $O/octree-pgsr_iteration_kernel_stats.csv profiles/r06_octree_pgsr_iteration_kernel_stats.csv
 cp $O/loss_kernel_stats.csv profiles/r06_loss_kernel_stats.csv 2>/dev/null; cp $O/bench_losses.json profiles/r06_bench_losses.json 2>/dev/null
