@@ -45,15 +45,18 @@
 template <int V> struct SpOcc { static constexpr int WPE = (V == GSR_EWA) ? SP_WPE_EWA : (V == GSR_PLANE ? SP_WPE_PLANE : SP_WPE_SURFEL); };
 #define SP_OCC __attribute__((amdgpu_waves_per_eu(SpOcc<V>::WPE, SpOcc<V>::WPE)))
 #define SP_CH 256                 // tile-list entries per chunk (queues, masks); longer lists take several chunks
-#define SP_CAP 112                // rows of a wave's private accumulation table (entries of the chunk that reach the wave's quadrant)
+// rows of a wave's private accumulation table (entries of the chunk that reach the wave's quadrant), sized so that the variant keeps its workgroups per CU: EWA 6
+// (40-byte rows), PLANE 5 (64-byte rows), SURFEL 4 (72-byte rows, 4 KB of per-pixel constants beside the table).  The block queues hold one byte per row since round 6
+// (they were sized for a whole chunk), which is what pays for the surfel's constants.  More rows for EWA / PLANE (136 / 108: 27 072 / 32 400 B of LDS) measured SLOWER,
+// 0.272 vs 0.266 and 0.299 vs 0.272 ms: the allocation is rounded up and a workgroup per CU is lost (EXPERIMENTS.md (78)).
 #ifndef SP_CAP_EWA
-#define SP_CAP_EWA SP_CAP
+#define SP_CAP_EWA 112
 #endif
 #ifndef SP_CAP_SURFEL
-#define SP_CAP_SURFEL SP_CAP
+#define SP_CAP_SURFEL 111
 #endif
 #ifndef SP_CAP_PLANE
-#define SP_CAP_PLANE 96             // 96 rows x 16 floats x 4 waves + queues = 31.5 KB: five workgroups per CU (112 rows: four)
+#define SP_CAP_PLANE 96
 #endif
 
 template <int V> struct SpTraits;
@@ -66,9 +69,16 @@ template <int V> struct SpTraits;
 #ifndef SP_TS_PLANE
 #define SP_TS_PLANE 16
 #endif
-template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10, NREG = 10, NPIN = 9; };
-template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = SP_TS_PLANE, NREG = 16, NPIN = 16; };
-template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 18, NREG = 21, NPIN = 21; };
+// NC4: float4 slots per pixel of per-pixel constants kept in LDS instead of being broadcast from the owning lane's register (round 6, VERDICT r5 #3 i).  SURFEL: the four
+// pure multiplicands a step uses twice -- dL/dC (3) and dL/ddepth, once in u and once in an accumulator -- are written to LDS once per kernel and fetched per step
+// with one broadcast ds_read_b128 (the LDS pipe idles next to a saturated VALU), so that their eight consumers per step are VGPR-only fmas (2.6-3.0 issue cycles)
+// instead of DPP forms (4.2-4.4).  Measured on one box against the DPP form, backward kernel in ms (EXPERIMENTS.md (78)): 300k 0.3812 -> 0.3759, 1 M 1.0615 -> 1.0522,
+// 1600x900 0.3615 -> 0.3544, concentrated scene 0.3266 -> 0.3240, 600k 0.7163 -> 0.7218.  NOT for the rest: with the normal's gradients as well (two slots, 8 KB,
+// 97 table rows) the headline kernel is at 0.369 but 1 M / 1600x900 / concentrated lose 3-6 %; EWA (dL/dC) and PLANE (dL/dC + five all_map gradients) pay for the
+// LDS with a workgroup per CU (6 -> 5, 5 -> 4) or with table rows and lose 10-20 % either way.
+template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10, NREG = 10, NPIN = 9, NC4 = 0; };
+template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = SP_TS_PLANE, NREG = 16, NPIN = 16, NC4 = 0; };
+template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 18, NREG = 21, NPIN = 21, NC4 = 1; };
 
 // inclusive scans along the 16 lanes of each DPP row, lane 0 first, in place.  A lane whose source would lie outside the row is
 // disabled by the hardware (bound_ctrl off) and keeps its value -- exactly the Hillis-Steele step.  s_nop 1 = the two wait states
@@ -136,6 +146,9 @@ template <int I> __device__ __forceinline__ float bc_fresh(float x)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + I, 0xf, 0xf, true));
 }
+
+// acc + c * x with c either broadcast from lane I's register (fused DPP form) or already fetched from LDS by this lane
+template <int I, bool L> __device__ __forceinline__ float pc_fmac(float acc, float kc, float lc, float x) { if constexpr (L) return fmaf(lc, x, acc); else return bc_fmac<I>(acc, kc, x); }
 
 // New carry of pixel I: lane I of every row <- lane 15's value, every other lane keeps its own.  One v_cndmask_b32_dpp per carry (D = vcc ? src1 :
 // dpp(src0), vcc = the constant mask "lane != I of its row", written by two scalar moves) instead of a DPP move and a v_cndmask each -- two VALU
@@ -223,10 +236,13 @@ __device__ __forceinline__ void sp_surf_finish(const float4& t0, const float4& t
 
 // one pixel step of a row: pixel I of the block against the 16 splats held by the row's lanes
 template <int V, int I, int NACC>
-__device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4, const SpSurf& S,
+__device__ __forceinline__ void sp_step(SpPix<V>& K, const float4* __restrict__ pcrow, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4, const SpSurf& S,
                                         bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc, uint32_t& okbits)
 {
     const uint32_t last = bc_movu<I>(K.last);
+    constexpr bool L = SpTraits<V>::NC4 > 0;
+    float4 pc0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (L) pc0 = pcrow[I];      // (dL/dC, dL/ddepth) of pixel I of this row's block: one address for the row's 16 lanes
     if constexpr (V != GSR_SURFEL) {
         constexpr int DX = I & 3, DY = I >> 2;
         // centre - pixel.  EWA: from the block-relative centre of the load, squares shared by the exponent and the conic gradients.  PLANE keeps the
@@ -329,8 +345,8 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         float u = bc_mul<I>(K.c2, m_d * m_d);
         u = bc_fmac<I>(u, K.c1, m_d);
         u = bc_add<I>(K.c0, u);
-        u = bc_fmac<I>(u, K.dLd, cd);
-        u = bc_fmac<I>(u, K.dLp0, q3.w); u = bc_fmac<I>(u, K.dLp1, q4.x); u = bc_fmac<I>(u, K.dLp2, q4.y);
+        u = pc_fmac<I, L>(u, K.dLd, pc0.w, cd);
+        u = pc_fmac<I, L>(u, K.dLp0, pc0.x, q3.w); u = pc_fmac<I, L>(u, K.dLp1, pc0.y, q4.x); u = pc_fmac<I, L>(u, K.dLp2, pc0.z, q4.y);
         u = bc_fmac<I>(u, K.dN0, q3.x); u = bc_fmac<I>(u, K.dN1, q3.y); u = bc_fmac<I>(u, K.dN2, q3.z);
         const float wu = w * u;
         const float si = row_scan_add(wu);
@@ -346,14 +362,14 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4& q0, const flo
         // dL_dmd = 2 w (m A - M1) dL_dreg
         const float dL_dmd = w * bc_add<I>(K.c1, bc_mul<I>(K.c2, m_d + m_d));      // 2 w (m A - M1) dL_dreg
         dL_dz += dL_dmd * dmd_dd;
-        dL_dz = bc_fmac<I>(dL_dz, K.dLd, w);
+        dL_dz = pc_fmac<I, L>(dL_dz, K.dLd, pc0.w, w);
         const float dL_dG = opa * dL_dalpha;
         const float dL_dG3 = b3 ? dL_dG : 0.0f, dL_dG2 = b3 ? 0.0f : dL_dG, dL_dz3 = b3 ? dL_dz : 0.0f;
         const float dL_dsx = dL_dG3 * -G * sx + dL_dz3 * S.Tw0;
         const float dL_dsy = dL_dG3 * -G * sy + dL_dz3 * S.Tw1;
         const float dpx = dL_dsx * rpz, dpy = dL_dsy * rpz, dpz = -(dpx * sx + dpy * sy);
         // register accumulators (SURFEL): 0-2 colour, 3 opacity, 4-6 normal, 7-9 M0, 10-12 Mx, 13-15 My, 16-17 mean2D, 18-20 Z (sp_surf_finish)
-        acc[0] = bc_fmac<I>(acc[0], K.dLp0, w); acc[1] = bc_fmac<I>(acc[1], K.dLp1, w); acc[2] = bc_fmac<I>(acc[2], K.dLp2, w);
+        acc[0] = pc_fmac<I, L>(acc[0], K.dLp0, pc0.x, w); acc[1] = pc_fmac<I, L>(acc[1], K.dLp1, pc0.y, w); acc[2] = pc_fmac<I, L>(acc[2], K.dLp2, pc0.z, w);
         acc[3] += G * dL_dalpha;
         acc[4] = bc_fmac<I>(acc[4], K.dN0, w); acc[5] = bc_fmac<I>(acc[5], K.dN1, w); acc[6] = bc_fmac<I>(acc[6], K.dN2, w);
         acc[7] += dpx; acc[8] += dpy; acc[9] += dpz;
@@ -399,11 +415,13 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     __shared__ float2 s_wtab[4 * CAPV * (TS / 2)];        // [wave][compact entry][component pair]: PRIVATE to the wave, plain read-add-write
     __shared__ uint8_t s_cidx[4 * SP_CH];                   // [wave][entry] -> row of the wave's table, 0xFF: the entry does not reach the quadrant
     __shared__ uint32_t s_ids[SP_CH];
-    __shared__ uint32_t s_over;
+    __shared__ uint32_t s_lo[4];                            // per wave: the first entry of the chunk whose rows still fit its table
     __shared__ uint16_t s_mask[SP_CH];                      // bit q: entry reaches 8x8 quadrant q of the tile
     __shared__ uint8_t s_cent[4 * CAPV];                  // [wave][table row] -> chunk-local entry
-    __shared__ uint8_t s_queue[4 * 4 * SP_CH];              // [wave][block][position] -> chunk-local entry, list order
+    __shared__ uint8_t s_queue[4 * 4 * CAPV];               // [wave][block][position] -> chunk-local entry, list order (a block's queue is a subset of its wave's <= CAPV rows)
     __shared__ uint32_t s_wmax[4];
+    constexpr int NC4 = TR::NC4;
+    __shared__ float4 s_pc[NC4 > 0 ? 4 * 64 * NC4 : 1];     // [wave][pixel = lane]: the per-pixel multiplicands the steps fetch from LDS (SpTraits::NC4)
 
     const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order, p.static_map);
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -458,6 +476,8 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             K.c0 = fmaf(dLr, fD2, dLa); K.c1 = -2.0f * dLr * fD; K.c2 = dLr * (1.f - T_final);
         }
     }
+    if constexpr (V == GSR_SURFEL) s_pc[threadIdx.x] = make_float4(K.dLp0, K.dLp1, K.dLp2, K.dLd);
+    const float4* pcrow = s_pc + (NC4 > 0 ? (threadIdx.x & ~15) : 0);      // the row's 16 pixels (written by the row's own lanes; the __syncthreads below orders the stores)
     bool mn_live = false;
     if constexpr (V == GSR_SURFEL) mn_live = __ballot((K.dMN0 != 0.f) | (K.dMN1 != 0.f) | (K.dMN2 != 0.f)) != 0ull;
     const uint32_t mlast_row = row_max_u32(K.last);                                 // deepest contributor of this 4x4 block
@@ -470,18 +490,18 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     const uint32_t tile_max = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     if (tile_max == 0) return;                              // block-uniform
 
-    const uint8_t* myqueue = s_queue + (wave * 4 + b) * SP_CH;
+    const uint8_t* myqueue = s_queue + (wave * 4 + b) * CAPV;
     const float ddelx_dx = 0.5f * p.W, ddely_dy = 0.5f * p.H;
 
-    // The tile list is consumed from its deep end in chunks of <= SP_CH entries [lo, hi).  A chunk whose entries overflow a wave's
-    // SP_CAP-row table (dense scenes) is re-staged at half the length: 112 rows always hold a 112-entry chunk.
+    // The tile list is consumed from its deep end in chunks of <= SP_CH entries [cbase, hi).  A chunk whose entries would overflow a wave's SP_CAP-row table
+    // (dense scenes) is TRIMMED at its shallow end to the longest suffix that fits all four tables (the entries in front of it are staged again with the
+    // next chunk); rounds 2-5 re-staged the whole chunk at half its length (1600x900, lists of 157: 0.425 ms against 0.361 once the table had 88 rows).
     float2* mytab = s_wtab + wave * CAPV * (TS / 2);
     uint8_t* mycidx = s_cidx + wave * SP_CH;
     uint8_t* mycent = s_cent + wave * CAPV;
-    uint32_t hi = tile_max, want = SP_CH;
-    if (threadIdx.x == 0) s_over = 0;
+    uint32_t hi = tile_max;
     while (hi > 0) {
-        const uint32_t n = min(want, hi);
+        const uint32_t n = min((uint32_t)SP_CH, hi);
         const uint32_t cbase = hi - n;
         // ------------------------------------------------------------ stage: ids + which 8x8 QUADRANTS of the tile each entry reaches
         {
@@ -502,11 +522,29 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             }
         }
         __syncthreads();
+        // ------------------------------------------------------------ per wave: how much of the chunk fits its table, counted from the deep end (scalar work)
+        {
+            uint32_t run = 0, first = 0;
+            for (int e0 = (int)((n - 1u) & ~63u); e0 >= 0; e0 -= 64) {
+                const uint32_t e = (uint32_t)e0 + lane;
+                uint64_t am = __ballot((e < n) && (((uint32_t)s_mask[e] >> wave) & 1u) && (cbase + e < wmax));
+                const uint32_t c = (uint32_t)__popcll(am);
+                if (run + c > (uint32_t)CAPV) {                  // keep the CAPV - run highest entries of this group
+                    while ((uint32_t)__popcll(am) > (uint32_t)CAPV - run) am &= am - 1ull;
+                    first = (uint32_t)e0 + (am ? (uint32_t)__ffsll((unsigned long long)am) - 1u : 64u);
+                    break;
+                }
+                run += c;
+            }
+            if (lane == 0) s_lo[wave] = first;
+        }
+        __syncthreads();
+        const uint32_t lo_e = max(max(s_lo[0], s_lo[1]), max(s_lo[2], s_lo[3]));      // entries [lo_e, n) are this chunk; block-uniform
         // ------------------------------------------------------------ per wave: entries that reach ITS quadrant -> table rows (list order) ...
         uint32_t cany = 0;
         for (uint32_t e0 = 0; e0 < n; e0 += 64) {
             const uint32_t e = e0 + lane;
-            const bool any = (e < n) && (((uint32_t)s_mask[e] >> wave) & 1u) && (cbase + e < wmax);
+            const bool any = (e >= lo_e) && (e < n) && (((uint32_t)s_mask[e] >> wave) & 1u) && (cbase + e < wmax);
             const uint64_t am = __ballot(any);
             const uint32_t arank = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
             if (e < n) mycidx[e] = any ? (uint8_t)min(cany + arank, 255u) : (uint8_t)0xFF;
@@ -530,18 +568,9 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
                 const bool hit = v && (cbase + e < mlast_b[k]) && ((hit4 >> k) & 1u);
                 const uint64_t bm = __ballot(hit);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                if (hit) s_queue[(wave * 4 + k) * SP_CH + cnt[k] + rank] = (uint8_t)e;
+                if (hit) s_queue[(wave * 4 + k) * CAPV + cnt[k] + rank] = (uint8_t)e;
                 cnt[k] += (uint32_t)__popcll(bm);
             }
-        }
-        if (cany > CAPV && lane == 0) s_over = 1;
-        __syncthreads();
-        if (s_over) {                                       // block-uniform: redo this chunk shorter (n > CAPV here, so it terminates)
-            __syncthreads();
-            if (threadIdx.x == 0) s_over = 0;
-            want = (n + 1) / 2;
-            __syncthreads();
-            continue;
         }
         for (uint32_t q = lane; q < cany * (TS / 2); q += 64) mytab[q] = make_float2(0.f, 0.f);
         const int Qmine = (int)(b == 0 ? cnt[0] : (b == 1 ? cnt[1] : (b == 2 ? cnt[2] : cnt[3])));
@@ -575,7 +604,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             // the basic block, so the 16 unrolled steps are scheduled one at a time -- as ONE block the scheduler overlaps them and the
             // kernel needs 280+ VGPRs (one wave per SIMD); split, every step's temporaries die inside the step.
             const bool never = p.gx == 0x7fffffff;
-#define SP_STEP(I) sp_step<V, I, NACC>(K, q0, q1, q2, q3, q4, S, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc, okbits); sp_pin<TR::NPIN>(acc); if (never) asm volatile("s_nop 0");
+#define SP_STEP(I) sp_step<V, I, NACC>(K, pcrow, q0, q1, q2, q3, q4, S, valid, idx0, j, geo, ddelx_dx, ddely_dy, acc, okbits); sp_pin<TR::NPIN>(acc); if (never) asm volatile("s_nop 0");
 #ifndef SP_DIAG_NO_STEPS      // diagnostic build only (make BLEND_EXTRA=-DSP_DIAG_NO_STEPS): what the kernel costs without its pixel steps (results are then wrong)
             SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6) SP_STEP(7)
             SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11)
@@ -620,7 +649,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
         __syncthreads();
         // ------------------------------------------------------------ combine the four waves' tables; one 16-lane atomic per entry that received anything
         // (measured alternative: every wave flushing its own rows without this barrier -- 1.35 x the accumulator line operations -- 0.499 vs 0.506 ms)
-        for (uint32_t e = threadIdx.x >> 4; e < n; e += 16) {
+        for (uint32_t e = lo_e + (threadIdx.x >> 4); e < n; e += 16) {
             const uint32_t c = threadIdx.x & 15u;
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
@@ -640,8 +669,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             if (v0 == 123.456f && v1 == 1.f) dst[c] = v0;
 #endif
         }
-        hi = cbase;
-        want = SP_CH;
+        hi = cbase + lo_e;
         if (hi > 0) __syncthreads();
     }
 }

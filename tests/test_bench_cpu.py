@@ -18,7 +18,7 @@ def test_algorithmic_bytes_follow_the_survey_table():
         assert bwd == R * (rec + grad) + N * pix_b + 8 * T
     # the headline kernel's figure in the committed bench line is this model at the R that run measured
     import json
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_default.json")).read().strip().splitlines()[-1])
     fwd, bwd = bench.algorithmic_bytes("surfel", line["config"]["tile_instances_R"], N, T)
     assert line["roofline"]["algorithmic_bytes_per_launch"] == bwd
     assert abs(line["roofline"]["achieved"] - bwd / (line["roofline"]["avg_launch_ms"] * 1e-3) / 1e9) < 0.5
@@ -125,12 +125,12 @@ def test_committed_rocprof_summary_agrees_with_the_bench_line():
     import csv
     import json
     prof = os.path.join(ROOT, "profiles")
-    line = json.loads(open(os.path.join(prof, "r05_bench_default.json")).read().strip().splitlines()[-1])
-    rows = [r for r in csv.DictReader(open(os.path.join(prof, "r05_surfel_kernel_stats.csv"))) if "k_blend_bwd_sp<1>" in r["Name"]]
+    line = json.loads(open(os.path.join(prof, "r06_bench_default.json")).read().strip().splitlines()[-1])
+    rows = [r for r in csv.DictReader(open(os.path.join(prof, "r06_surfel_kernel_stats.csv"))) if "k_blend_bwd_sp<1>" in r["Name"]]
     assert len(rows) == 1
     rocprof_ms = float(rows[0]["AverageNs"]) * 1e-6
     assert abs(rocprof_ms - line["roofline"]["avg_launch_ms"]) < 0.03 * line["roofline"]["avg_launch_ms"]
-    pmc = json.load(open(os.path.join(prof, "r05_pmc_summary.json")))
+    pmc = json.load(open(os.path.join(prof, "r06_pmc_summary.json")))
     assert abs(pmc["k_blend_bwd_sp<1>"]["hbm_bytes_per_launch"] - line["roofline"]["traffic"]) < 0.02 * line["roofline"]["traffic"]
     assert line["roofline"]["traffic"] >= line["roofline"]["algorithmic_bytes_per_launch"]
     assert line["metric"].startswith("train iters/sec") and line["unit"] == "iters/s" and line["n_gpus"] == 1 and line["scaling"] == "weak"
