@@ -276,7 +276,7 @@ bool gsr_tile_order_wanted()
 // launch order for 64 forwards after a list beyond max(1024, 4 x mean); GLOBAL depth order for 64 forwards after a list beyond 6000 entries, where
 // the prologue's global-memory radix path loses to it (816 vs 780 it/s at 12 633 entries, a tie at 3800: profiles/r03_skewed_density.txt) --
 // and return the depth order of THIS forward.  The caller hands it to every stage launcher; the preprocess kernel records it in the geom arena
-// (GeomView::counters[GSR_CNT_MODE]) for later calls on that arena (gsr_forward_stage2).  GSR_DEPTH_FEEDBACK=0: the static rule only.
+// (GeomView::counters[GSR_CNT_MODE]) for later calls on that arena (gsr_forward_stage2).
 bool gsr_decide_depth_order(const gsr_cfg* cfg)
 {
     const int T = ((cfg->W + GSR_TILE - 1) / GSR_TILE) * ((cfg->H + GSR_TILE - 1) / GSR_TILE);

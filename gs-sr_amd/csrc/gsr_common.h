@@ -148,7 +148,7 @@ static inline size_t gsr_tile_bucket_words(uint32_t cap, size_t T)
 #define GSR_TB_GROUPS_MAX (GSR_TB_TILES_MAX / 64)       // behind the table (BinView::tile_tab + gsr_tile_bucket_words(cap, T)): per chunk, the exclusive prefix of its
                                                         // instances over the groups of 64 tiles, [GSR_TB_ROWS_MAX][GSR_TB_GROUPS_MAX]
 bool gsr_tile_sort_is_fused();        // GSR_TILE_SORT=fused|kernel: who orders a tile's list by depth when the depth order is per tile (gsr_binning.hip)
-bool gsr_tile_order_wanted();         // GSR_TILE_ORDER=0|1, default auto: on while recent forwards reported long tile lists (gsr_api.hip); once per forward
+bool gsr_tile_order_wanted();         // on while recent forwards reported long tile lists (gsr_api.hip); once per forward
 const uint32_t* gsr_static_tile_map(int gx, int gy, hipStream_t s);     // device [gx*gy] blockIdx -> tile, block-cyclic over the XCDs; cached per device and grid; nullptr if unavailable (gsr_api.hip)
 uint32_t* gsr_long_list_word();       // device pointer of the per-device feedback word the blend forward reports long lists into, or nullptr (gsr_api.hip)
 int gsr_memset_async(void* p, int byte_value, size_t nbytes, hipStream_t s);
