@@ -456,6 +456,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="NO device work, NO measurement: the N ranks are started, pinned and joined exactly as for a real run (gloo), 'step' is a 1 ms sleep, "
                          "rank 0 prints a line whose value is null and whose metric says DRY RUN.  Runs without a GPU: how the CPU test suite covers --gpus 8")
+    ap.add_argument("--sync-free", action="store_true",
+                    help="experiment: the timed steps run inside gsrast.rasterize.static_capacity() -- the rasterizer forward never reads num_rendered back (an arena overflow is "
+                         "flagged, checked after the timed region, instead of repaired), so the host can run ahead of the device by more than one iteration")
     ap.add_argument("--no-pin", action="store_true", help="self-launch without HIP_VISIBLE_DEVICES / NUMA pinning (LOCAL_RANK selects the device)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
@@ -555,23 +558,50 @@ def main():
         tiles.barrier(device)
 
     prewarm_ms = clock_prewarm(device, args.clock_prewarm_ms)
+    import contextlib
+    from gsrast import rasterize as rz
     for _ in range(args.warmup):
         step()
     barrier()
+    sync_free = rz.static_capacity() if args.sync_free else contextlib.nullcontext()      # (capacity: 1.25 x the running maximum of the warm-up forwards + 16384)
+    rz.async_status_reset()
     # Inside the timed region only the DOMINANT kernel's stage carries HIP events (the live duration behind `roofline`): every timed stage
     # costs two event records = ~10 us of stream idle time per launch (profiles/r03_timeline.json: 82 us of gaps per 1043 us iteration with all
     # seven stages timed).  The other stages are timed in a second, untimed pass of --stage-steps iterations right after.
     gsrast.profile_enable(True, stages=None if args.profile_all_stages_in_timed_region else ["blend_bwd"])
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    with sync_free:
+        for _ in range(args.steps):
+            step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.sync_free:
+        st_async = rz.async_status(reset=True)
+        if len(st_async) != args.steps or any(o for _, o, _ in st_async):
+            raise SystemExit(f"bench.py --sync-free: {sum(1 for _, o, _ in st_async if o)} of {len(st_async)} forwards overflowed their arena")
     prof_timed = gsrast.profile_read()
     gsrast.profile_enable(False)
     reduce_dev = device if os.environ.get("GSR_BENCH_BACKEND", "nccl") == "nccl" else None
     elapsed, total_iters = tiles.reduce_job(elapsed, args.steps, reduce_dev)
     prof = prof_timed
+    sync_free_info = None
+    if rank == 0 and world == 1 and not args.sync_free:
+        # informational: the same K steps with the rasterizer forward sync-free (gsrast.rasterize.static_capacity: num_rendered stays on the device, an arena overflow is
+        # flagged instead of repaired) -- the host may then run ahead of the device by more than one iteration, so the figure does not depend on how promptly a shared
+        # host reacts to the forward's mailbox word.  `value` above stays the default drop-in call (one host read of num_rendered per forward, as the reference's
+        # cudaMemcpy at rasterizer_impl.cu:281).
+        rz.async_status_reset()
+        barrier()
+        ts = time.perf_counter()
+        with rz.static_capacity():
+            for _ in range(args.steps):
+                step()
+        barrier()
+        ts = time.perf_counter() - ts
+        st_async = rz.async_status(reset=True)
+        sync_free_info = {"iters_per_s": round(args.steps / ts, 3), "ms_per_step": round(1e3 * ts / args.steps, 4), "steps": args.steps,
+                          "arena_overflows": sum(1 for _, o, _ in st_async if o),
+                          "what": "the step of `value` with the forward's host read of num_rendered removed (gsr_forward_async inside gsrast.rasterize.static_capacity())"}
     if rank == 0 and not args.profile_all_stages_in_timed_region:
         gsrast.profile_enable(True)
         for _ in range(max(1, args.stage_steps)):
@@ -647,7 +677,7 @@ def main():
             "metric": "train iters/sec @300k Gaussians 1080p (rasterize fwd+bwd ms and HBM GB/s vs roofline alongside)",
             "value": round(total_iters / elapsed, 3), "unit": "iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "backend": backend, "dist_world_size": (dist.get_world_size() if dist is not None else 1), "ranks": ranks_seen,
+            "sync_free_forward": bool(args.sync_free), "sync_free": sync_free_info, "backend": backend, "dist_world_size": (dist.get_world_size() if dist is not None else 1), "ranks": ranks_seen,
             "distinct_devices": (len({(r["uuid"], r["pci"]) for r in ranks_seen}) if ranks_seen else 1),
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -421,7 +421,10 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
     __shared__ uint8_t s_queue[4 * 4 * CAPV];               // [wave][block][position] -> chunk-local entry, list order (a block's queue is a subset of its wave's <= CAPV rows)
     __shared__ uint32_t s_wmax[4];
     constexpr int NC4 = TR::NC4;
-    __shared__ float4 s_pc[NC4 > 0 ? 4 * 64 * NC4 : 1];     // [wave][pixel = lane]: the per-pixel multiplicands the steps fetch from LDS (SpTraits::NC4)
+    // (the four rows' broadcast reads of a step fall on the same banks: rows 17 slots apart instead of 16 remove the conflicts -- 22 % of the kernel's LDS cycles -- and
+    // change nothing, 0.3741 vs 0.3743 ms: the kernel does not wait for the LDS.  EXPERIMENTS.md (78).)
+    constexpr int PCW = 64, PCR = 16;
+    __shared__ float4 s_pc[NC4 > 0 ? 4 * PCW * NC4 : 1];    // [wave][row][pixel]: the per-pixel multiplicands the steps fetch from LDS (SpTraits::NC4)
 
     const int tile = tile_of_block(blockIdx.x, p.gx * p.gy, p.xcd_remap, p.tile_order, p.static_map);
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -476,8 +479,8 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
             K.c0 = fmaf(dLr, fD2, dLa); K.c1 = -2.0f * dLr * fD; K.c2 = dLr * (1.f - T_final);
         }
     }
-    if constexpr (V == GSR_SURFEL) s_pc[threadIdx.x] = make_float4(K.dLp0, K.dLp1, K.dLp2, K.dLd);
-    const float4* pcrow = s_pc + (NC4 > 0 ? (threadIdx.x & ~15) : 0);      // the row's 16 pixels (written by the row's own lanes; the __syncthreads below orders the stores)
+    if constexpr (V == GSR_SURFEL) s_pc[wave * PCW + b * PCR + j] = make_float4(K.dLp0, K.dLp1, K.dLp2, K.dLd);
+    const float4* pcrow = s_pc + (NC4 > 0 ? wave * PCW + b * PCR : 0);      // the row's 16 pixels (written by the row's own lanes; the __syncthreads below orders the stores)
     bool mn_live = false;
     if constexpr (V == GSR_SURFEL) mn_live = __ballot((K.dMN0 != 0.f) | (K.dMN1 != 0.f) | (K.dMN2 != 0.f)) != 0ull;
     const uint32_t mlast_row = row_max_u32(K.last);                                 // deepest contributor of this 4x4 block
