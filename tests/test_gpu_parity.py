@@ -569,6 +569,16 @@ def test_full_size_oracle_parity(variant, cm, seed, pose):
         assert not rep["hip_grads"]["dL_dshs"][:, (int(deg) + 1) ** 2:].any()
 
 
+@pytest.mark.parametrize("variant,cm,seed,pose", FULL_CASES_REPORT[len(FULL_CASES):])
+def test_full_size_oracle_parity_remaining_report_cases(variant, cm, seed, pose):
+    """The other eight BASELINE-size cases (seeds 1 / 2, both poses, degree-3 SH) with the suite's own assertion: 15-28 s of oracle time each, so they run when
+    GSR_FULL_PARITY=1 is set -- and, in any case, in tools/full_parity_report.py, which exits non-zero on a violated bar and is step 6 of tools/gpu_profile_r06.sh
+    (profiles/r06_full_size_parity.jsonl holds all 17 cases of this round)."""
+    if os.environ.get("GSR_FULL_PARITY") != "1":
+        pytest.skip("set GSR_FULL_PARITY=1 (or run tools/full_parity_report.py) for the remaining BASELINE-size cases")
+    test_full_size_oracle_parity(variant, cm, seed, pose)
+
+
 # BASELINE size on a NON-UNIFORM scene (VERDICT r5 #2): scenes.concentrate pulls a fraction of the gaussians towards the optical axis, so that a few hundred tiles carry
 # lists of 1 500 ... 12 000 entries.  The paths only long lists take -- chunk halving and longest-first launch order in the splat-parallel backward
 # (csrc/gsr_blend_sp.hip), k_tile_order / the global-order feedback, the bitonic and radix fallbacks of the per-tile depth sort (csrc/gsr_tile_sort.h) -- meet the
