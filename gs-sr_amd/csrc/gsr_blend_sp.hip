@@ -46,7 +46,7 @@ template <int V> struct SpOcc { static constexpr int WPE = (V == GSR_EWA) ? SP_W
 #define SP_OCC __attribute__((amdgpu_waves_per_eu(SpOcc<V>::WPE, SpOcc<V>::WPE)))
 #define SP_CH 256                 // tile-list entries per chunk (queues, masks); longer lists take several chunks
 // rows of a wave's private accumulation table (entries of the chunk that reach the wave's quadrant), sized so that the variant keeps its workgroups per CU: EWA 6
-// (40-byte rows), PLANE 5 (64-byte rows), SURFEL 4 (72-byte rows, 4 KB of per-pixel constants beside the table).  The block queues hold one byte per row since round 6
+// (40-byte rows), PLANE 5 (64-byte rows), SURFEL 4 (72-byte rows); 4 KB of per-pixel constants beside the table in all three.  The block queues hold one byte per row since round 6
 // (they were sized for a whole chunk), which is what pays for the surfel's constants.  More rows for EWA / PLANE (136 / 108: 27 072 / 32 400 B of LDS) measured SLOWER,
 // 0.272 vs 0.266 and 0.299 vs 0.272 ms: the allocation is rounded up and a workgroup per CU is lost (EXPERIMENTS.md (78)).
 #ifndef SP_CAP_EWA
@@ -56,7 +56,7 @@ template <int V> struct SpOcc { static constexpr int WPE = (V == GSR_EWA) ? SP_W
 #define SP_CAP_SURFEL 111
 #endif
 #ifndef SP_CAP_PLANE
-#define SP_CAP_PLANE 96
+#define SP_CAP_PLANE 91
 #endif
 
 template <int V> struct SpTraits;
@@ -69,15 +69,22 @@ template <int V> struct SpTraits;
 #ifndef SP_TS_PLANE
 #define SP_TS_PLANE 16
 #endif
-// NC4: float4 slots per pixel of per-pixel constants kept in LDS instead of being broadcast from the owning lane's register (round 6, VERDICT r5 #3 i).  SURFEL: the four
-// pure multiplicands a step uses twice -- dL/dC (3) and dL/ddepth, once in u and once in an accumulator -- are written to LDS once per kernel and fetched per step
-// with one broadcast ds_read_b128 (the LDS pipe idles next to a saturated VALU), so that their eight consumers per step are VGPR-only fmas (2.6-3.0 issue cycles)
-// instead of DPP forms (4.2-4.4).  Measured on one box against the DPP form, backward kernel in ms (EXPERIMENTS.md (78)): 300k 0.3812 -> 0.3759, 1 M 1.0615 -> 1.0522,
-// 1600x900 0.3615 -> 0.3544, concentrated scene 0.3266 -> 0.3240, 600k 0.7163 -> 0.7218.  NOT for the rest: with the normal's gradients as well (two slots, 8 KB,
-// 97 table rows) the headline kernel is at 0.369 but 1 M / 1600x900 / concentrated lose 3-6 %; EWA (dL/dC) and PLANE (dL/dC + five all_map gradients) pay for the
-// LDS with a workgroup per CU (6 -> 5, 5 -> 4) or with table rows and lose 10-20 % either way.
-template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10, NREG = 10, NPIN = 9, NC4 = 0; };
-template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = SP_TS_PLANE, NREG = 16, NPIN = 16, NC4 = 0; };
+// NC4: float4 slots per pixel of per-pixel constants kept in LDS instead of being broadcast from the owning lane's register (round 6, VERDICT r5 #3 i).  The pure
+// multiplicands a step uses twice -- once in u, once in an accumulator -- are written to LDS once per kernel and fetched per step with one broadcast ds_read_b128 (the LDS
+// pipe idles next to a saturated VALU), so that their consumers are VGPR-only fmas (2.6-3.0 issue cycles) instead of DPP forms (4.2-4.4).  ONE slot per variant, paid for by
+// the block queues (one byte per table row since round 6): SURFEL dL/dC + dL/ddepth (8 consumers), EWA dL/dC (6), PLANE dL/dC + the first all_map gradient (8, and 91 table
+// rows instead of 96).  Backward kernel in ms, DPP form -> LDS form, same box (EXPERIMENTS.md (78)): SURFEL 300k 0.3812 -> 0.3759, 1 M 1.0615 -> 1.0522, 1600x900
+// 0.3615 -> 0.3544; EWA 0.2659 -> 0.2608, 0.4328 -> 0.4239, 0.2711 -> 0.2650; PLANE 0.2718 -> 0.2672, 0.7743 -> 0.7590, 0.2839 -> 0.2839.  MORE does not pay: two slots for
+// the surfel (the normal's gradients too: 8 KB, 97 rows) win 3 % at 300k and lose 3-6 % at 1 M / 1600x900 / on concentrated scenes; two slots for PLANE or one slot at the
+// price of a workgroup per CU lose 10-20 %.
+#ifndef SP_NC4_EWA
+#define SP_NC4_EWA 1
+#endif
+#ifndef SP_NC4_PLANE
+#define SP_NC4_PLANE 1
+#endif
+template <> struct SpTraits<GSR_EWA> { static constexpr int NACC = 9, TS = 10, NREG = 10, NPIN = 9, NC4 = SP_NC4_EWA; };
+template <> struct SpTraits<GSR_PLANE> { static constexpr int NACC = 16, TS = SP_TS_PLANE, NREG = 16, NPIN = 16, NC4 = SP_NC4_PLANE; };
 template <> struct SpTraits<GSR_SURFEL> { static constexpr int NACC = 18, TS = 18, NREG = 21, NPIN = 21, NC4 = 1; };
 
 // inclusive scans along the 16 lanes of each DPP row, lane 0 first, in place.  A lane whose source would lie outside the row is
@@ -267,12 +274,12 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4* __restrict__ 
         const float r1a = rcp_(om);
         const float Tj = bc_fresh<I>(K.Tc) * row_scan_mul(r1a);
         const float w = al * Tj;
-        float u = bc_mul<I>(K.dLp0, q1.z);
-        u = bc_fmac<I>(u, K.dLp1, q1.w);
-        u = bc_fmac<I>(u, K.dLp2, q2.x);
+        float u = L ? pc0.x * q1.z : bc_mul<I>(K.dLp0, q1.z);
+        u = pc_fmac<I, L>(u, K.dLp1, pc0.y, q1.w);
+        u = pc_fmac<I, L>(u, K.dLp2, pc0.z, q2.x);
         if constexpr (V == GSR_PLANE) {
             if (geo) {
-                u = bc_fmac<I>(u, K.dA0, q2.y); u = bc_fmac<I>(u, K.dA1, q2.z); u = bc_fmac<I>(u, K.dA2, q2.w);
+                u = pc_fmac<I, L>(u, K.dA0, pc0.w, q2.y); u = bc_fmac<I>(u, K.dA1, q2.z); u = bc_fmac<I>(u, K.dA2, q2.w);
                 u = bc_fmac<I>(u, K.dA3, q3.x); u = bc_fmac<I>(u, K.dA4, q3.y);
             }
         }
@@ -286,7 +293,7 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4* __restrict__ 
         //   opacity += gG;  conic (xx, xy, yy) += h (dx^2, dx dy, dy^2);  mean2D.x += 2 h (A dx + B dy) W/2,  mean2D.y += 2 h (C dy + B dx) H/2.
         // EWA accumulates the two moments sum h dx, sum h dy and applies A, B, C and the NDC factors once per load (end of the load loop); PLANE needs
         // |mean2D term| per pixel (PLANE backward.cu:552-553) and keeps the literal per-pixel terms.
-        acc[0] = bc_fmac<I>(acc[0], K.dLp0, w); acc[1] = bc_fmac<I>(acc[1], K.dLp1, w); acc[2] = bc_fmac<I>(acc[2], K.dLp2, w);
+        acc[0] = pc_fmac<I, L>(acc[0], K.dLp0, pc0.x, w); acc[1] = pc_fmac<I, L>(acc[1], K.dLp1, pc0.y, w); acc[2] = pc_fmac<I, L>(acc[2], K.dLp2, pc0.z, w);
         if constexpr (V == GSR_EWA) {
             const float gG = Gm * dL_dalpha;
             const float h = gG * S.oh;
@@ -307,7 +314,7 @@ __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4* __restrict__ 
             acc[8] += -0.5f * gdy * dy * dL_dG;
             acc[9] += fabsf(g_mx); acc[10] += fabsf(g_my);
             if (geo) {
-                acc[11] = bc_fmac<I>(acc[11], K.dA0, w); acc[12] = bc_fmac<I>(acc[12], K.dA1, w); acc[13] = bc_fmac<I>(acc[13], K.dA2, w);
+                acc[11] = pc_fmac<I, L>(acc[11], K.dA0, pc0.w, w); acc[12] = bc_fmac<I>(acc[12], K.dA1, w); acc[13] = bc_fmac<I>(acc[13], K.dA2, w);
                 acc[14] = bc_fmac<I>(acc[14], K.dA3, w); acc[15] = bc_fmac<I>(acc[15], K.dA4, w);
             }
         }
@@ -480,6 +487,8 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
         }
     }
     if constexpr (V == GSR_SURFEL) s_pc[wave * PCW + b * PCR + j] = make_float4(K.dLp0, K.dLp1, K.dLp2, K.dLd);
+    if constexpr (V == GSR_EWA && NC4 > 0) s_pc[wave * PCW + b * PCR + j] = make_float4(K.dLp0, K.dLp1, K.dLp2, 0.f);
+    if constexpr (V == GSR_PLANE && NC4 > 0) s_pc[wave * PCW + b * PCR + j] = make_float4(K.dLp0, K.dLp1, K.dLp2, K.dA0);
     const float4* pcrow = s_pc + (NC4 > 0 ? wave * PCW + b * PCR : 0);      // the row's 16 pixels (written by the row's own lanes; the __syncthreads below orders the stores)
     bool mn_live = false;
     if constexpr (V == GSR_SURFEL) mn_live = __ballot((K.dMN0 != 0.f) | (K.dMN1 != 0.f) | (K.dMN2 != 0.f)) != 0ull;
