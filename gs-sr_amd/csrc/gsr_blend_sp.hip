@@ -246,10 +246,13 @@ template <int V, int I, int NACC>
 __device__ __forceinline__ void sp_step(SpPix<V>& K, const float4* __restrict__ pcrow, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4, const SpSurf& S,
                                         bool valid, uint32_t idx0, int j, bool geo, float ddelx_dx, float ddely_dy, float* acc, uint32_t& okbits)
 {
-    const uint32_t last = bc_movu<I>(K.last);
     constexpr bool L = SpTraits<V>::NC4 > 0;
     float4 pc0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (L) pc0 = pcrow[I];      // (dL/dC, dL/ddepth) of pixel I of this row's block: one address for the row's 16 lanes
+    if constexpr (L) pc0 = pcrow[I];      // (dL/dC, dL/ddepth | dA0 | last contributor) of pixel I of this row's block: one address for the row's 16 lanes
+    // EWA's slot has a word to spare: the pixel's last-contributor index rides in it (one DPP move less per step)
+    // (the surfel's (last, median) indices from a second, 8-byte slot -- 2 KB, 104 table rows -- : 300k 0.3760 -> 0.3721 ms, but 1600x900 +0.9 %, 1 M +1.6 %, concentrated
+    // scene +3.1 %: the table rows are worth more.  EXPERIMENTS.md (78).)
+    const uint32_t last = (V == GSR_EWA && L) ? __float_as_uint(pc0.w) : bc_movu<I>(K.last);
     if constexpr (V != GSR_SURFEL) {
         constexpr int DX = I & 3, DY = I >> 2;
         // centre - pixel.  EWA: from the block-relative centre of the load, squares shared by the exponent and the conic gradients.  PLANE keeps the
@@ -487,7 +490,7 @@ __global__ void __launch_bounds__(256) SP_OCC k_blend_bwd_sp(BlendParams p)
         }
     }
     if constexpr (V == GSR_SURFEL) s_pc[wave * PCW + b * PCR + j] = make_float4(K.dLp0, K.dLp1, K.dLp2, K.dLd);
-    if constexpr (V == GSR_EWA && NC4 > 0) s_pc[wave * PCW + b * PCR + j] = make_float4(K.dLp0, K.dLp1, K.dLp2, 0.f);
+    if constexpr (V == GSR_EWA && NC4 > 0) s_pc[wave * PCW + b * PCR + j] = make_float4(K.dLp0, K.dLp1, K.dLp2, __uint_as_float(K.last));
     if constexpr (V == GSR_PLANE && NC4 > 0) s_pc[wave * PCW + b * PCR + j] = make_float4(K.dLp0, K.dLp1, K.dLp2, K.dA0);
     const float4* pcrow = s_pc + (NC4 > 0 ? wave * PCW + b * PCR : 0);      // the row's 16 pixels (written by the row's own lanes; the __syncthreads below orders the stores)
     bool mn_live = false;
